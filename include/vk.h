@@ -1,0 +1,381 @@
+/*
+ * vk.h — C ABI of the MI355X-native fusion + raycast hot path (libvk_hip.so).
+ *
+ * This is the drop-in boundary. The reference (mkaspr/Vulcan) has no FFI: its
+ * boundary is the C++ class surface Volume / Integrator(+3) / Tracer / Frame /
+ * DepthTracker plus the free-function layer tracer.cuh:14-32 / frame.cuh.  Each
+ * entry point below replaces the body of one of those methods (cited as
+ * `ref: file:line`, paths relative to the reference tree); the C++ classes in
+ * vulcan_amd/host/ keep the reference's names and forward here.
+ *
+ * Conventions
+ *  - plain C: PODs, raw DEVICE pointers, ints, floats. No C++/torch types.
+ *  - every function returns 0 on success, a hipError_t value (>0) on a HIP
+ *    failure, or a negative VK_ERR_* code on bad arguments. Nothing throws.
+ *    vk_error_string() maps a code to text.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream). All
+ *    work is stream-ordered and asynchronous unless the function name ends in
+ *    `_sync` or the comment says "blocking".
+ *  - matrices are 4x4 column-major float[16], exactly the reference's
+ *    Matrix4f (matrix.h:320-333); vk_transform carries matrix + cached inverse
+ *    like Transform (transform.h:168-170). The inverse is never recomputed.
+ *  - counts that the reference reads back to the host between kernels
+ *    (visible-block count volume.cu:494, patch count tracer.cpp:67) stay in
+ *    device memory (vk_volume.counters); consumers read them on the device.
+ */
+#ifndef VK_H_
+#define VK_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- PODs -- */
+
+/* ref: include/vulcan/voxel.h:43-49 — 20 bytes, align 4 */
+typedef struct vk_voxel {
+  float   distance;
+  float   color[3];
+  int16_t distance_weight;
+  int16_t color_weight;
+} vk_voxel;
+
+/* ref: include/vulcan/block.h:81-85 — 8 bytes. `pad` is uninitialised in the
+ * reference; here it is always written as 0 in hash entries. */
+typedef struct vk_block {
+  int16_t origin[3];
+  int16_t pad;
+} vk_block;
+
+/* ref: include/vulcan/hash.h:51-55 — 16 bytes */
+typedef struct vk_hash_entry {
+  vk_block block;
+  int32_t  data;  /* voxel pool slot, -1 = unallocated */
+  int32_t  next;  /* entry index of next in chain, -1 = end */
+} vk_hash_entry;
+
+/* ref: include/vulcan/tracer.h:13-22 — 16 bytes */
+typedef struct vk_patch {
+  int16_t origin[2];
+  int16_t size[2];
+  float   bounds[2];
+} vk_patch;
+
+/* ref: include/vulcan/projection.h:111-113 — focal length then centre */
+typedef struct vk_projection {
+  float fx, fy, cx, cy;
+} vk_projection;
+
+/* ref: include/vulcan/transform.h:168-170 */
+typedef struct vk_transform {
+  float m[16];    /* matrix_, column-major */
+  float inv[16];  /* inv_matrix_ */
+} vk_transform;
+
+/* ref: include/vulcan/light.h:62-66 */
+typedef struct vk_light {
+  float intensity;
+  float position[3];
+} vk_light;
+
+/* ref: include/vulcan/types.h:6-18 */
+enum { VK_VISIBILITY_UNKNOWN = 0, VK_VISIBILITY_FALSE = 1, VK_VISIBILITY_TRUE = 2 };
+enum { VK_ALLOC_NONE = 0, VK_ALLOC_MAIN = 1, VK_ALLOC_EXCESS = 2 };
+
+enum {
+  VK_BLOCK_RESOLUTION = 8,    /* block.h:13 */
+  VK_BLOCK_VOXELS     = 512,  /* block.h:15 */
+  VK_PATCH_MAX_SIZE   = 16    /* tracer.h:15 */
+};
+
+/* Per-volume device counters. The reference keeps these as file-scope
+ * __device__ symbols shared by every Volume (volume.cu:17-21); here each
+ * volume owns an int[VK_CTR_COUNT] in device memory. */
+enum {
+  VK_CTR_VISIBLE    = 0,  /* buffer_size: number of entries in visible_blocks */
+  VK_CTR_VOXEL_PTR  = 1,  /* voxel_pointer: top of the free-slot stack */
+  VK_CTR_EXCESS_PTR = 2,  /* excess_pointer: next free excess entry */
+  VK_CTR_PATCHES    = 3,  /* tracer patch count (tracer.h buffer_size_) */
+  VK_CTR_REQUESTS   = 4,  /* requests committed by the last handle pass */
+  VK_CTR_DROPPED    = 5,  /* requests dropped: pool or excess list exhausted */
+  VK_CTR_COUNT      = 8
+};
+
+enum {
+  VK_OK              =  0,
+  VK_ERR_ARGUMENT    = -1,  /* null pointer / non-positive size */
+  VK_ERR_UNSUPPORTED = -2,
+  VK_ERR_NO_DEVICE   = -3
+};
+
+/* Device-memory view of a Volume (ref: include/vulcan/volume.h:89-116).
+ * The caller owns every buffer; the library never allocates or frees them. */
+typedef struct vk_volume {
+  vk_voxel*      voxels;             /* [max_block_count * 512]      voxels_            */
+  vk_hash_entry* hash_entries;       /* [max_block_count]            hash_entries_      */
+  int32_t*       free_voxel_blocks;  /* [max_block_count]            free_voxel_blocks_ */
+  uint8_t*       allocation_types;   /* [main_block_count]           allocation_types_  */
+  vk_block*      allocation_blocks;  /* [main_block_count], 8-byte aligned  allocation_blocks_ */
+  uint8_t*       block_visibility;   /* [max_block_count]            block_visibility_  */
+  int32_t*       visible_blocks;     /* [max_block_count]            visible_blocks_    */
+  int32_t*       counters;           /* [VK_CTR_COUNT]               (volume.cu:17-21)  */
+  int32_t        main_block_count;
+  int32_t        excess_block_count;
+  float          voxel_length;       /* volume.cu:376 default 0.008 */
+  float          truncation_length;  /* volume.cu:375 default 0.04  */
+  float          min_depth;          /* volume.cu:374 default 0.1   */
+  float          max_depth;          /*               default 5.0   */
+} vk_volume;
+
+/* Depth / colour / normal images of a Frame (ref: include/vulcan/frame.h:11-32)
+ * row-major, no pitch; colour and normals are packed 12-byte float3. */
+typedef struct vk_frame {
+  const float*  depth;        /* [height*width]   */
+  const float*  color;        /* [height*width*3] or NULL */
+  const float*  normals;      /* [height*width*3] or NULL */
+  int32_t       width;
+  int32_t       height;
+  vk_projection depth_projection;
+  vk_projection color_projection;
+  vk_transform  depth_to_world;   /* Twd */
+  vk_transform  depth_to_color;   /* Tcd */
+} vk_frame;
+
+/* ------------------------------------------------------ library / device -- */
+
+VK_API const char* vk_error_string(int code);
+VK_API int vk_version(void);                       /* 100*major + minor */
+VK_API int vk_device_count(int* count);
+VK_API int vk_set_device(int device);
+VK_API int vk_device_name(char* out, size_t bytes);
+
+VK_API int vk_stream_create(void** stream);
+VK_API int vk_stream_destroy(void* stream);
+VK_API int vk_stream_synchronize(void* stream);   /* blocking */
+
+/* Device memory for the host classes (ref: buffer.h:64-103, image.h:85-97). */
+VK_API int vk_malloc(void** ptr, size_t bytes);
+VK_API int vk_free(void* ptr);
+VK_API int vk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);  /* blocking */
+VK_API int vk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);  /* blocking */
+VK_API int vk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+VK_API int vk_memset(void* dst, int value, size_t bytes, void* stream);
+
+/* Timing helpers (hipEvent) so hosts without HIP headers can time kernels. */
+VK_API int vk_event_create(void** event);
+VK_API int vk_event_destroy(void* event);
+VK_API int vk_event_record(void* event, void* stream);
+VK_API int vk_event_elapsed_ms(void* start, void* stop, float* ms);  /* blocking on stop */
+
+/* ----------------------------------------------------------------- volume -- */
+
+/* ref: src/volume.cu:552-627 Volume::Initialize + 9 Create* — fills voxels
+ * with Voxel::Empty(), entries with HashEntry(), free list with 0..N-1,
+ * types NONE, visibility FALSE; counters: visible=0, voxel_ptr=N-1,
+ * excess_ptr=main. */
+VK_API int vk_volume_initialize(const vk_volume* v, void* stream);
+
+/* ref: src/volume.cu:465-471 Volume::ResetBlockVisibility — TRUE -> UNKNOWN */
+VK_API int vk_volume_reset_block_visibility(const vk_volume* v, void* stream);
+
+/* ref: src/volume.cu:87-301,497-518 Volume::CreateAllocationRequests.
+ * One request per main bucket per call, as in the reference; where the
+ * reference lets racing threads overwrite each other (last writer wins,
+ * volume.cu:200,237) the winner here is the request with the largest packed
+ * (pad=type,z,y,x) 64-bit key, chosen with one 64-bit atomic max, so a request
+ * cannot tear and the outcome does not depend on timing. */
+VK_API int vk_volume_create_allocation_requests(const vk_volume* v,
+    const float* depth, int width, int height, const vk_projection* projection,
+    const vk_transform* Twd, void* stream);
+
+/* ref: src/volume.cu:304-368,520-535 Volume::HandleAllocationRequests.
+ * Pool slots and excess indices are handed out in ascending bucket order
+ * (an exclusive scan instead of the reference's atomicAdd/atomicSub order,
+ * volume.cu:337,352), i.e. the outcome of running the reference's threads
+ * serially; slot numbers are therefore reproducible. */
+VK_API int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream);
+
+/* ref: src/volume.cu:25-84,473-495 Volume::UpdateBlockVisibility. Leaves the
+ * count in counters[VK_CTR_VISIBLE]; does NOT read it back. The order of
+ * visible_blocks is unspecified (as in the reference). */
+VK_API int vk_volume_update_block_visibility(const vk_volume* v, int width,
+    int height, const vk_projection* projection, const vk_transform* Tdw,
+    void* stream);
+
+/* ref: src/volume.cu:430-437 Volume::SetView = the four calls above. */
+VK_API int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream);
+
+/* ref: src/volume.cu:537-543 Volume::GetBufferSize — blocking readback of all
+ * VK_CTR_COUNT counters into host memory. */
+VK_API int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream);
+
+/* ------------------------------------------------------------- integrators -- */
+
+/* Integrator parameters (ref: include/vulcan/integrator.h:38-44, integrator.cu:7-13) */
+typedef struct vk_integrator {
+  float min_depth;            /* depth_range_[0] = 0.1 */
+  float max_depth;            /* depth_range_[1] = 5.0 */
+  float max_distance_weight;  /* 16 */
+  float max_color_weight;     /* 16 */
+} vk_integrator;
+
+/* ref: src/depth_integrator.cu:17-80,89-115 DepthIntegrator::Integrate
+ * (= ColorIntegrator::IntegrateDepth color_integrator.cu:18-80,150-176
+ *  = LightIntegrator::IntegrateDepth light_integrator.cu:106-168,295-321).
+ * Visible blocks and their count are read from the volume on the device. */
+VK_API int vk_integrate_depth(const vk_volume* v, const vk_integrator* p,
+    const vk_frame* frame, void* stream);
+
+/* ref: src/color_integrator.cu:83-135,178-204 ColorIntegrator::IntegrateColor */
+VK_API int vk_integrate_color(const vk_volume* v, const vk_integrator* p,
+    const vk_frame* frame, void* stream);
+
+/* ref: src/color_integrator.cu:144-148 ColorIntegrator::Integrate — depth then
+ * colour in ONE pass over the voxels (same values as the two reference passes:
+ * the colour update reads the distance the depth update just wrote). */
+VK_API int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p,
+    const vk_frame* frame, void* stream);
+
+/* ref: src/light_integrator.cu:17-103,277-293 LightIntegrator::ComputeFrameMask
+ * (keeps the reference's asymmetric window). mask: [h*w] floats. */
+VK_API int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold,
+    float* mask, void* stream);
+
+/* ref: src/light_integrator.cu:170-250,323-354 LightIntegrator::IntegrateColor */
+VK_API int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p,
+    const vk_light* light, const float* mask, const vk_frame* frame, void* stream);
+
+/* ref: src/light_integrator.cu:270-275 LightIntegrator::Integrate minus the
+ * mask kernel: depth + light-colour update in one pass. */
+VK_API int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p,
+    const vk_light* light, const float* mask, const vk_frame* frame, void* stream);
+
+/* ------------------------------------------------------------------ tracer -- */
+
+/* ref: include/vulcan/tracer.cuh:14-18, src/tracer.cu:13-87,453-466
+ * vulcan::ComputePatches. `block_count_dev` (device int*, may be NULL): when
+ * non-NULL the number of visible blocks is read from it on the device and
+ * `block_count` is only the upper bound used to size the grid. patch_count is
+ * a device int the caller has zeroed (tracer.cpp:102-108). Patches are not
+ * written past `patch_capacity`. Blocks with no valid depth interval emit no
+ * patch (the reference writes patches[-1] there). */
+VK_API int vk_trace_compute_patches(const int32_t* indices,
+    const vk_hash_entry* entries, const vk_transform* Tcw,
+    const vk_projection* projection, float block_length, float min_depth,
+    float max_depth, int block_count, const int32_t* block_count_dev,
+    int image_width, int image_height, int bounds_width, int bounds_height,
+    vk_patch* patches, int patch_capacity, int32_t* patch_count, void* stream);
+
+/* ref: tracer.cuh:20-21, src/tracer.cu:89-112,468-476 vulcan::ComputeBounds.
+ * bounds: [bounds_h*bounds_w] float2 (near,far). patch_count_dev as above. */
+VK_API int vk_trace_compute_bounds(const vk_patch* patches, float* bounds,
+    int bounds_width, int patch_count, const int32_t* patch_count_dev, void* stream);
+
+/* ref: tracer.cuh:32, src/tracer.cu:494-500 vulcan::ResetBoundsBuffer */
+VK_API int vk_trace_reset_bounds(float* bounds, int count, void* stream);
+
+/* Fused patches+bounds: every visible block rasterises its cell rectangle
+ * straight into `bounds` (min/max are order independent, so the result is
+ * bit-identical to ComputePatches + ComputeBounds). Resets bounds first. */
+VK_API int vk_trace_compute_block_bounds(const int32_t* indices,
+    const vk_hash_entry* entries, const vk_transform* Tcw,
+    const vk_projection* projection, float block_length, float min_depth,
+    float max_depth, int block_count, const int32_t* block_count_dev,
+    int image_width, int image_height, int bounds_width, int bounds_height,
+    float* bounds, void* stream);
+
+/* ref: tracer.cuh:23-27, src/tracer.cu:114-451,478-492 vulcan::ComputePoints.
+ * block_count = MAIN block count (the hash modulus K, tracer.cpp:85).
+ * depths [h*w], colors [h*w*3]. */
+VK_API int vk_trace_compute_points(const vk_hash_entry* entries,
+    const vk_voxel* voxels, const float* bounds, int block_count,
+    float block_length, float voxel_length, float trunc_length,
+    const vk_transform* Twc, const vk_projection* projection, float* depths,
+    float* colors, int image_width, int image_height, int bounds_width,
+    int bounds_height, void* stream);
+
+/* ref: tracer.cuh:29-30, src/frame.cu:9-122,183-192 vulcan::ComputeNormals
+ * (= Frame::ComputeNormals frame.cpp:21-36). normals [h*w*3]. */
+VK_API int vk_frame_compute_normals(const float* depths,
+    const vk_projection* projection, float* normals, int image_width,
+    int image_height, void* stream);
+
+/* ref: src/frame.cu:126-181,194-203 vulcan::FilterDepths (7x7 bilateral). */
+VK_API int vk_frame_filter_depths(int image_width, int image_height,
+    const float* src, float* dst, void* stream);
+
+/* ref: src/tracer.cpp:41-47 Tracer::Trace — bounds (fused), points, normals.
+ * `frame` supplies pose + intrinsics; outputs go to depth/color/normals
+ * (all non-const device pointers owned by the caller). `bounds` is the
+ * tracer's 80x60 float2 scratch (tracer.cpp:140). */
+VK_API int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth,
+    float max_depth, float* bounds, int bounds_width, int bounds_height,
+    float* out_depth, float* out_color, float* out_normals, void* stream);
+
+/* ------------------------------------------------------------------- image -- */
+
+/* ref: src/image.cu:101-165,183-211 Image::Downsample (nearest or 2x2 box) */
+VK_API int vk_image_downsample(int src_w, int src_h, const float* src,
+    float* dst, int nearest, void* stream);
+
+/* ref: src/image.cu:133-165,234-262 ColorImage::Downsample */
+VK_API int vk_color_image_downsample(int src_w, int src_h, const float* src,
+    float* dst, int nearest, void* stream);
+
+/* --------------------------------------------------------------------- ICP -- */
+
+/* One side of the ICP problem (keyframe or frame). */
+typedef struct vk_icp_view {
+  const float*  depths;      /* [h*w]   */
+  const float*  normals;     /* [h*w*3] */
+  int32_t       width;
+  int32_t       height;
+  vk_projection projection;
+} vk_icp_view;
+
+/* ref: src/depth_tracker.cu:97-118,272-300 DepthTracker::ComputeResiduals */
+VK_API int vk_icp_compute_residuals(const vk_icp_view* keyframe,
+    const vk_transform* Twm, const vk_icp_view* frame, const vk_transform* Twc,
+    float* residuals, void* stream);
+
+/* ref: src/depth_tracker.cu:120-141,302-336 DepthTracker::ComputeJacobian.
+ * jacobian: [h*w*6] floats; columns 3..5 are 0 when !translation_enabled. */
+VK_API int vk_icp_compute_jacobian(const vk_icp_view* keyframe,
+    const vk_transform* Twm, const vk_icp_view* frame, const vk_transform* Twc,
+    int translation_enabled, float* jacobian, void* stream);
+
+/* ref: src/depth_tracker.cu:144-268,338-378 DepthTracker::ComputeSystem.
+ * hessian: device float[36] — the first 21 (6 when !translation_enabled) hold
+ * the packed lower triangle, row-major (r, c<=r), rest zero; gradient: device
+ * float[6]. Both are overwritten (the reference zero-fills then atomically
+ * accumulates; this is a two-stage fixed-order reduction, so the sums are
+ * reproducible). `workspace`: device float[vk_icp_workspace_floats(w,h)].
+ * `Twc_dev`: optional DEVICE pointer to a vk_transform that overrides Twc
+ * (lets a device-side Gauss-Newton loop run without host round trips). */
+VK_API size_t vk_icp_workspace_floats(int width, int height);
+VK_API int vk_icp_compute_system(const vk_icp_view* keyframe,
+    const vk_transform* Twm, const vk_icp_view* frame, const vk_transform* Twc,
+    const vk_transform* Twc_dev, int translation_enabled, float* workspace,
+    float* hessian, float* gradient, void* stream);
+
+/* ref: src/tracker.cpp:124-163 Tracker::ComputeUpdate + src/depth_tracker.cpp:
+ * 22-86 DepthTracker::ApplyUpdate, on the device: unpack the packed lower
+ * triangle, LDLT-solve x = -H^-1 g, compose Tinc*Twc, re-orthonormalise, write
+ * the new transform to *Twc_dev. state_dev: device int[2] = {iteration, done};
+ * once ||x|| < 1e-6 (tracker.cpp:162) `done` is set and later calls (and
+ * vk_icp_compute_system calls given the same state) become no-ops.
+ * update_dev (optional): device float[6] receiving x. */
+VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
+    int translation_enabled, vk_transform* Twc_dev, int32_t* state_dev,
+    float* update_dev, void* stream);
+
+#ifdef __cplusplus
+}  /* extern "C" */
+#endif
+
+#endif  /* VK_H_ */

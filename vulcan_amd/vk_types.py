@@ -1,0 +1,146 @@
+"""ctypes / numpy mirrors of the PODs declared in include/vk.h.
+
+Layouts follow the reference's types (sizes verified against the reference
+headers): Voxel 20 B (voxel.h:43-49), Block 8 B (block.h:81-85),
+HashEntry 16 B (hash.h:51-55), Patch 16 B (tracer.h:13-22), Projection 16 B
+(projection.h:111-113), Transform 128 B (transform.h:168-170), Light 16 B.
+"""
+import ctypes as C
+
+import numpy as np
+
+VK_CTR_VISIBLE, VK_CTR_VOXEL_PTR, VK_CTR_EXCESS_PTR, VK_CTR_PATCHES = 0, 1, 2, 3
+VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_COUNT = 4, 5, 8
+VISIBILITY_UNKNOWN, VISIBILITY_FALSE, VISIBILITY_TRUE = 0, 1, 2
+ALLOC_NONE, ALLOC_MAIN, ALLOC_EXCESS = 0, 1, 2
+BLOCK_RESOLUTION, BLOCK_VOXELS, PATCH_MAX_SIZE = 8, 512, 16
+
+voxel_dtype = np.dtype([("distance", "<f4"), ("color", "<f4", (3,)),
+                        ("distance_weight", "<i2"), ("color_weight", "<i2")])
+block_dtype = np.dtype([("origin", "<i2", (3,)), ("pad", "<i2")])
+hash_entry_dtype = np.dtype([("block", block_dtype), ("data", "<i4"), ("next", "<i4")])
+patch_dtype = np.dtype([("origin", "<i2", (2,)), ("size", "<i2", (2,)), ("bounds", "<f4", (2,))])
+assert voxel_dtype.itemsize == 20 and block_dtype.itemsize == 8
+assert hash_entry_dtype.itemsize == 16 and patch_dtype.itemsize == 16
+
+
+class Projection(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+    @staticmethod
+    def make(fx, fy, cx, cy):
+        return Projection(np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy))
+
+
+class Transform(C.Structure):
+    """4x4 column-major matrix + cached inverse (transform.h). Host-side helpers
+    follow the reference's float32 arithmetic (transform.h:62-159)."""
+    _fields_ = [("m", C.c_float * 16), ("inv", C.c_float * 16)]
+
+    @staticmethod
+    def from_matrices(m, inv):
+        t = Transform()
+        mm = np.asarray(m, dtype=np.float32).reshape(4, 4)
+        ii = np.asarray(inv, dtype=np.float32).reshape(4, 4)
+        t.m[:] = mm.T.reshape(-1).tolist()     # column-major storage
+        t.inv[:] = ii.T.reshape(-1).tolist()
+        return t
+
+    def matrix(self):
+        return np.array(self.m[:], dtype=np.float32).reshape(4, 4).T.copy()
+
+    def inverse_matrix(self):
+        return np.array(self.inv[:], dtype=np.float32).reshape(4, 4).T.copy()
+
+    @staticmethod
+    def identity():
+        return Transform.from_matrices(np.eye(4), np.eye(4))
+
+    @staticmethod
+    def translate(x, y, z):
+        m = np.eye(4, dtype=np.float32)
+        i = np.eye(4, dtype=np.float32)
+        m[:3, 3] = np.array([x, y, z], dtype=np.float32)
+        i[:3, 3] = -np.array([x, y, z], dtype=np.float32)
+        return Transform.from_matrices(m, i)
+
+    @staticmethod
+    def rotate(w, x, y, z):
+        """transform.h:108-136 Rotate(w, x, y, z), float32, same expression order."""
+        f = np.float32
+        w, x, y, z = f(w), f(x), f(y), f(z)
+        m = np.zeros((4, 4), dtype=np.float32)
+        m[0, 0] = f(1) - f(2) * (y * y + z * z)
+        m[0, 1] = f(2) * (x * y - w * z)
+        m[0, 2] = f(2) * (x * z + w * y)
+        m[1, 0] = f(2) * (x * y + w * z)
+        m[1, 1] = f(1) - f(2) * (x * x + z * z)
+        m[1, 2] = f(2) * (y * z - w * x)
+        m[2, 0] = f(2) * (x * z - w * y)
+        m[2, 1] = f(2) * (y * z + w * x)
+        m[2, 2] = f(1) - f(2) * (x * x + y * y)
+        m[3, 3] = f(1)
+        return Transform.from_matrices(m, m.T)
+
+    @staticmethod
+    def _matmul(a, b):
+        # matrix.h:297-318: result(m,p) = 0; result += A(m,n) * B(n,p), n ascending
+        out = np.zeros((4, 4), dtype=np.float32)
+        for p in range(4):
+            for m in range(4):
+                acc = np.float32(0)
+                for n in range(4):
+                    acc = np.float32(acc + np.float32(a[m, n] * b[n, p]))
+                out[m, p] = acc
+        return out
+
+    def __mul__(self, other):
+        """transform.h:62-66: (A*B).m = A.m*B.m, (A*B).inv = B.inv*A.inv"""
+        return Transform.from_matrices(
+            Transform._matmul(self.matrix(), other.matrix()),
+            Transform._matmul(other.inverse_matrix(), self.inverse_matrix()))
+
+    def inverse(self):
+        return Transform.from_matrices(self.inverse_matrix(), self.matrix())
+
+
+class Light(C.Structure):
+    _fields_ = [("intensity", C.c_float), ("position", C.c_float * 3)]
+
+    @staticmethod
+    def make(intensity, position):
+        l = Light()
+        l.intensity = intensity
+        l.position[:] = [float(p) for p in position]
+        return l
+
+
+class Volume(C.Structure):
+    _fields_ = [("voxels", C.c_void_p), ("hash_entries", C.c_void_p),
+                ("free_voxel_blocks", C.c_void_p), ("allocation_types", C.c_void_p),
+                ("allocation_blocks", C.c_void_p), ("block_visibility", C.c_void_p),
+                ("visible_blocks", C.c_void_p), ("counters", C.c_void_p),
+                ("main_block_count", C.c_int32), ("excess_block_count", C.c_int32),
+                ("voxel_length", C.c_float), ("truncation_length", C.c_float),
+                ("min_depth", C.c_float), ("max_depth", C.c_float)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("normals", C.c_void_p),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("depth_projection", Projection), ("color_projection", Projection),
+                ("depth_to_world", Transform), ("depth_to_color", Transform)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("min_depth", C.c_float), ("max_depth", C.c_float),
+                ("max_distance_weight", C.c_float), ("max_color_weight", C.c_float)]
+
+    @staticmethod
+    def default():
+        return Integrator(0.1, 5.0, 16.0, 16.0)   # integrator.cu:7-13
+
+
+class IcpView(C.Structure):
+    _fields_ = [("depths", C.c_void_p), ("normals", C.c_void_p),
+                ("width", C.c_int32), ("height", C.c_int32), ("projection", Projection)]
