@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the fusion + raycast hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): a 640x480 depth-only sequence fused into a
+5 mm hashed volume, Volume(65024, 8192) (apps/vulcan/vulcan.cu:12-13). One
+"step" = one frame = Volume::SetView -> DepthIntegrator::Integrate ->
+Tracer::Trace through the C ABI (include/vk.h). The camera sits at the centre of
+a 2 m sphere and yaws 0.5 deg per frame, so the depth image (resident in HBM) is
+the same closed form every frame while new blocks are allocated every frame.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, every rank owns a replica volume and its own frame
+sequence (weak scaling, no data-path collective: SURVEY.md §8e); value = frames
+of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with `roofline` (integrate kernel, HBM bound)
+and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same frames).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 640, 480
+VOXEL, TRUNC = 0.005, 0.04
+MAIN, EXCESS = 65024, 8192
+RADIUS, YAW_STEP = 2.0, 0.5
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_BLOCK = 4 + 16 + 2 * 512 * 20   # index + entry + voxel read + write
+
+
+def sphere_room_depth(k):
+    """Depth seen from the centre of a sphere of radius RADIUS: z = R / |unproject(u,v)|
+    (identical for every camera rotation about the centre)."""
+    y, x = np.mgrid[0:H, 0:W]
+    rx = (x + 0.5 - k.cx) / k.fx
+    ry = (y + 0.5 - k.cy) / k.fy
+    return (RADIUS / np.sqrt(rx * rx + ry * ry + 1.0)).astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    from vulcan_amd import api, dist as vd, vk_types as T
+    import scenes
+
+    rank, local_rank, world = vd.init()
+    assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    lib = api.lib()
+
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth_np = sphere_room_depth(k)
+    total_frames = args.warmup + args.steps
+    # every rank walks the same arc, offset so ranks do not share poses
+    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total_frames)]
+
+    def fresh():
+        vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+        frame = api.Frame(depth_np, k, poses[0])
+        out = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
+                        color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
+                        normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
+        return vol, frame, out, api.DepthIntegrator(vol), api.Tracer(vol)
+
+    vol, frame, out, integ, tracer = fresh()
+    stream = api.stream()
+
+    def step(i, ev=None):
+        frame.depth_to_world = poses[i]
+        out.depth_to_world = poses[i]
+        vol.set_view(frame)                      # volume.cu:430-437
+        if ev:
+            lib.vk_event_record(ev[0], stream)
+        integ.integrate(frame)                   # depth_integrator.cu:89-115
+        if ev:
+            lib.vk_event_record(ev[1], stream)
+        tracer.trace(out)                        # tracer.cpp:41-47
+
+    def make_event():
+        e = C.c_void_p()
+        api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
+        return e
+
+    events = [(make_event(), make_event()) for _ in range(args.steps)]
+
+    for i in range(args.warmup):
+        step(i)
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i, events[i])
+    torch.cuda.synchronize()
+    vd.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = vd.max_over_ranks(elapsed, device="cuda")
+
+    # integrate kernel time from the HIP events recorded inside the timed region
+    kernel_ms = []
+    for e0, e1 in events:
+        ms = C.c_float()
+        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
+        kernel_ms.append(ms.value)
+    ctr = vol.read_counters()
+
+    # Allocation is deterministic, so an untimed replay of the same poses gives the
+    # visible-block count the integrate launch of every timed frame saw.
+    del vol, frame, out, integ, tracer
+    vol, frame, out, integ, tracer = fresh()
+    nvis = []
+    for i in range(total_frames):
+        frame.depth_to_world = poses[i]
+        vol.set_view(frame)
+        integ.integrate(frame)
+        if i >= args.warmup:
+            nvis.append(vol.visible_count)
+    nvis = np.array(nvis, dtype=np.float64)
+    alg_bytes = nvis * BYTES_PER_BLOCK + W * H * 4
+    achieved = float(alg_bytes.sum() / (np.sum(kernel_ms) * 1e-3) / 1e9)
+
+    frames_all = vd.sum_over_ranks(args.steps, device="cuda")
+    result = {
+        "metric": "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels",
+        "value": frames_all / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: 640x480 depth-only sequence, SetView + DepthIntegrator + Tracer, "
+                        "5 mm voxels, Volume(65024,8192), camera at the centre of a 2 m sphere yawing 0.5 deg/frame",
+            "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL,
+            "truncation_length": TRUNC, "visible_blocks_mean": float(nvis.mean()),
+            "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
+            "dropped_requests": int(ctr[T.VK_CTR_DROPPED]), "parallelism": f"replica volume per GPU x{world}",
+        },
+        "roofline": {
+            "kernel": "integrate_kernel<depth> (vk_integrate_depth)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
+            "avg_launch_us": float(np.mean(kernel_ms) * 1e3),
+        },
+    }
+
+    if rank == 0 and args.cpu_frames > 0:
+        result["cpu_baseline"] = cpu_baseline(depth_np, k, poses, args.cpu_frames)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    vd.shutdown()
+
+
+def cpu_baseline(depth_np, k, poses, frames):
+    """The CPU oracle (oracle/, the restated reference kernels) on the first `frames`
+    poses of the same sequence; OpenMP over blocks / pixels where the reference's
+    threads are independent, allocation serial."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_threads(cores)
+    hv = orc.HostVolume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+    hf = orc.HostFrame(depth_np, k, poses[0])
+    t0 = time.perf_counter()
+    for i in range(frames):
+        hf.depth_to_world = poses[i]
+        hv.set_view(hf, orc.POLICY_SERIAL)
+        orc.integrate_depth(hv, hf)
+        orc.trace(hv, hf)
+    dt = time.perf_counter() - t0
+    orc.set_threads(1)
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"first {frames} frames of the same sequence (cold volume: every frame allocates), "
+                      f"SetView serial, integrate/raycast/normals OpenMP x{cores}"}
+
+
+if __name__ == "__main__":
+    main()

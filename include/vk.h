@@ -367,8 +367,9 @@ VK_API int vk_icp_compute_system(const vk_icp_view* keyframe,
  * 22-86 DepthTracker::ApplyUpdate, on the device: unpack the packed lower
  * triangle, LDLT-solve x = -H^-1 g, compose Tinc*Twc, re-orthonormalise, write
  * the new transform to *Twc_dev. state_dev: device int[2] = {iteration, done};
- * once ||x|| < 1e-6 (tracker.cpp:162) `done` is set and later calls (and
- * vk_icp_compute_system calls given the same state) become no-ops.
+ * once ||x|| < 1e-6 (tracker.cpp:162) `done` is set and later calls become
+ * no-ops (the pose stops changing), so a fixed-length device-side loop gives
+ * the same pose as the reference's early exit.
  * update_dev (optional): device float[6] receiving x. */
 VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
     int translation_enabled, vk_transform* Twc_dev, int32_t* state_dev,

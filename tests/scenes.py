@@ -88,3 +88,22 @@ def block_map(entries, voxels=None):
         o = entries["block"]["origin"][i]
         out[(int(o[0]), int(o[1]), int(o[2]))] = int(i)
     return out
+
+
+def tracer_patch_kat():
+    """tracer_test.cu:22-66: five blocks placed by unprojecting image points at
+    known depths through Tcw^-1; returns (entries, Tcw, projection)."""
+    F = np.float32
+    block_length = F(0.008)
+    tcw = T.Transform.translate(0.3, -1.3, 3.7) * T.Transform.rotate(0.7474, 0.3438, -0.3884, 0.4152)
+    k = T.Projection.make(346.723, 353.914, 321.294, 239.052)
+    points = [(320.0, 240.0, 2.5), (120.0, 340.0, 1.5), (420.0, 240.0, 0.6),
+              (-20.0, -40.0, 1.0), (720.0, 580.0, 1.0)]
+    entries = np.zeros(len(points), dtype=T.hash_entry_dtype)
+    for i, (u, v, d) in enumerate(points):
+        ifx, ify = F(1) / F(k.fx), F(1) / F(k.fy)
+        xcp = np.array([ifx * F(u) - F(k.cx) * ifx, ify * F(v) - F(k.cy) * ify, F(1)], np.float32) * F(d)
+        xwp = (tcw.inverse_matrix() @ np.append(xcp, F(1)).astype(np.float32)).astype(np.float32)
+        entries["block"]["origin"][i] = [np.int16(int(F(c) / block_length)) for c in xwp[:3]]
+        entries["data"][i], entries["next"][i] = 0, -1
+    return entries, tcw, k

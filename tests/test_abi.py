@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: libvk_hip.so loads without a GPU,
+exports exactly what include/vk.h declares, the Python bindings cover every
+entry point, argument validation works without touching a device, and the
+product never reaches into oracle/."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vk.h")
+
+
+def declared():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"VK_API\s+[\w\s\*]+?\b(vk_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vulcan_amd import api
+    lib = api.lib()
+    names = declared()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in vk.h but not exported"
+    assert sorted(api.EXPORTS) == names, "python bindings out of sync with vk.h"
+    out = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T vk_" in l)
+    assert exported == names, "library exports symbols vk.h does not declare"
+
+
+def test_every_entry_point_cites_the_reference():
+    text = open(HEADER).read()
+    for name in declared():
+        if re.match(r"vk_(error_string|version|device_|set_device|stream_|malloc|free|memcpy|memset|event_|"
+                    r"icp_workspace|trace_compute_block_bounds)", name):
+            continue
+        head = text[:text.index(name + "(")]
+        comment = head[head.rindex("/*"):]
+        assert "ref:" in comment, f"{name} has no reference citation"
+
+
+def test_version_and_errors_without_gpu():
+    from vulcan_amd import api
+    lib = api.lib()
+    assert lib.vk_version() == 100
+    assert b"invalid argument" in lib.vk_error_string(-1)
+    assert lib.vk_volume_initialize(None, None) == -1              # VK_ERR_ARGUMENT, no device touched
+    assert lib.vk_integrate_depth(None, None, None, None) == -1
+    assert lib.vk_trace_compute_points(None, None, None, 0, 0.0, 0.0, 0.0, None, None, None, None, 0, 0, 0, 0, None) == -1
+    assert lib.vk_icp_workspace_floats(640, 480) == 300 * 32
+    n = C.c_int(-5)
+    lib.vk_device_count(C.byref(n))
+    assert n.value >= 0
+
+
+def test_pod_layouts_match_header():
+    from vulcan_amd import vk_types as T
+    assert C.sizeof(T.Volume) == 8 * 8 + 2 * 4 + 4 * 4
+    assert C.sizeof(T.Frame) == 3 * 8 + 2 * 4 + 2 * 16 + 2 * 128
+    assert C.sizeof(T.Integrator) == 16 and C.sizeof(T.IcpView) == 2 * 8 + 2 * 4 + 16
+
+
+def test_product_does_not_use_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "vulcan_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c")) or f == "Makefile":
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"import\s+oracle|from\s+oracle|from\s+\.+\s*oracle|oracle[/.]\w|liboracle|\borc_\w+\s*\(|"
+                             r"#\s*include[^\n]*oracle", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+    out = subprocess.run(["ldd", os.path.join(ROOT, "vulcan_amd", "lib", "libvk_hip.so")],
+                         stdout=subprocess.PIPE, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from vulcan_amd import api
+    monkeypatch.setattr(api, "_LIB", None)
+    monkeypatch.setattr(api, "LIB_PATH", str(tmp_path / "libvk_hip.so"))
+    try:
+        api.lib()
+    except api.VkError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("expected VkError")

@@ -1,0 +1,522 @@
+"""ctypes bindings of libvk_hip.so (include/vk.h) and thin host classes that mirror
+the reference's Volume / Integrator / Tracer / Frame surface for tests and
+bench.py. Device memory lives in torch tensors (plumbing only): every compute
+call goes through the C ABI on the HIP stream torch is currently using.
+
+There is NO CPU fallback: loading fails loudly when the library is missing, and
+every wrapper raises VkError on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import vk_types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvk_hip.so")
+_LIB = None
+
+# name -> argtypes, in the order of include/vk.h (restype is int unless noted)
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_PP = C.POINTER(C.c_void_p)
+_SIGNATURES = {
+    "vk_error_string": ([_I], C.c_char_p),
+    "vk_version": ([], _I),
+    "vk_device_count": ([C.POINTER(_I)], _I),
+    "vk_set_device": ([_I], _I),
+    "vk_device_name": ([C.c_char_p, _SZ], _I),
+    "vk_stream_create": ([_PP], _I),
+    "vk_stream_destroy": ([_P], _I),
+    "vk_stream_synchronize": ([_P], _I),
+    "vk_malloc": ([_PP, _SZ], _I),
+    "vk_free": ([_P], _I),
+    "vk_memcpy_h2d": ([_P, _P, _SZ, _P], _I),
+    "vk_memcpy_d2h": ([_P, _P, _SZ, _P], _I),
+    "vk_memcpy_d2d": ([_P, _P, _SZ, _P], _I),
+    "vk_memset": ([_P, _I, _SZ, _P], _I),
+    "vk_event_create": ([_PP], _I),
+    "vk_event_destroy": ([_P], _I),
+    "vk_event_record": ([_P, _P], _I),
+    "vk_event_elapsed_ms": ([_P, _P, C.POINTER(_F)], _I),
+    "vk_volume_initialize": ([_P, _P], _I),
+    "vk_volume_reset_block_visibility": ([_P, _P], _I),
+    "vk_volume_create_allocation_requests": ([_P, _P, _I, _I, _P, _P, _P], _I),
+    "vk_volume_handle_allocation_requests": ([_P, _P], _I),
+    "vk_volume_update_block_visibility": ([_P, _I, _I, _P, _P, _P], _I),
+    "vk_volume_set_view": ([_P, _P, _P], _I),
+    "vk_volume_read_counters_sync": ([_P, _P, _P], _I),
+    "vk_integrate_depth": ([_P, _P, _P, _P], _I),
+    "vk_integrate_color": ([_P, _P, _P, _P], _I),
+    "vk_integrate_depth_color": ([_P, _P, _P, _P], _I),
+    "vk_light_compute_frame_mask": ([_P, _F, _P, _P], _I),
+    "vk_integrate_light_color": ([_P, _P, _P, _P, _P, _P], _I),
+    "vk_integrate_depth_light": ([_P, _P, _P, _P, _P, _P], _I),
+    "vk_trace_compute_patches": ([_P, _P, _P, _P, _F, _F, _F, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P], _I),
+    "vk_trace_compute_bounds": ([_P, _P, _I, _I, _P, _P], _I),
+    "vk_trace_reset_bounds": ([_P, _I, _P], _I),
+    "vk_trace_compute_block_bounds": ([_P, _P, _P, _P, _F, _F, _F, _I, _P, _I, _I, _I, _I, _P, _P], _I),
+    "vk_trace_compute_points": ([_P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
+    "vk_frame_compute_normals": ([_P, _P, _P, _I, _I, _P], _I),
+    "vk_frame_filter_depths": ([_I, _I, _P, _P, _P], _I),
+    "vk_trace": ([_P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P], _I),
+    "vk_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
+    "vk_color_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
+    "vk_icp_compute_residuals": ([_P, _P, _P, _P, _P, _P], _I),
+    "vk_icp_compute_jacobian": ([_P, _P, _P, _P, _I, _P, _P], _I),
+    "vk_icp_workspace_floats": ([_I, _I], _SZ),
+    "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+class VkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvk_hip.so. torch is imported first so the HIP runtime it bundles
+    (libamdhip64.so.7) is the one the library binds to."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise VkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+        import torch  # noqa: F401  (loads the HIP runtime)
+        handle = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes, fn.restype = argtypes, restype
+        _LIB = handle
+    return _LIB
+
+
+def check(code, what=""):
+    if code != 0:
+        raise VkError(f"{what}: {lib().vk_error_string(code).decode()} [{code}]")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _ref(s):
+    return C.byref(s)
+
+
+def stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_bytes(n, device):
+    import torch
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+def to_numpy(t, dtype):
+    """Device byte tensor -> numpy structured array."""
+    return np.frombuffer(t.cpu().numpy().tobytes(), dtype=dtype).copy()
+
+
+class Frame:
+    """vulcan::Frame (frame.h:11-32) with images in device memory."""
+
+    def __init__(self, depth, depth_projection, depth_to_world=None, color=None, normals=None,
+                 color_projection=None, depth_to_color=None, device="cuda"):
+        import torch
+        self.device = device
+        self.depth = torch.as_tensor(np.ascontiguousarray(depth, dtype=np.float32)).to(device) \
+            if not hasattr(depth, "data_ptr") else depth
+        self.height, self.width = self.depth.shape
+        self.color = None
+        self.normals = None
+        if color is not None:
+            self.color = torch.as_tensor(np.ascontiguousarray(color, dtype=np.float32)).to(device) \
+                if not hasattr(color, "data_ptr") else color
+        if normals is not None:
+            self.normals = torch.as_tensor(np.ascontiguousarray(normals, dtype=np.float32)).to(device) \
+                if not hasattr(normals, "data_ptr") else normals
+        self.depth_projection = depth_projection
+        self.color_projection = color_projection or depth_projection
+        self.depth_to_world = depth_to_world or T.Transform.identity()
+        self.depth_to_color = depth_to_color or T.Transform.identity()
+
+    def desc(self):
+        d = T.Frame()
+        d.depth = self.depth.data_ptr()
+        d.color = None if self.color is None else self.color.data_ptr()
+        d.normals = None if self.normals is None else self.normals.data_ptr()
+        d.width, d.height = self.width, self.height
+        d.depth_projection, d.color_projection = self.depth_projection, self.color_projection
+        d.depth_to_world, d.depth_to_color = self.depth_to_world, self.depth_to_color
+        return d
+
+    def compute_normals(self):
+        """Frame::ComputeNormals (frame.cpp:21-36)"""
+        import torch
+        if self.normals is None:
+            self.normals = torch.empty((self.height, self.width, 3), dtype=torch.float32, device=self.device)
+        k = self.depth_projection
+        check(lib().vk_frame_compute_normals(_ptr(self.depth), _ref(k), _ptr(self.normals),
+                                             self.width, self.height, stream()), "vk_frame_compute_normals")
+        return self.normals
+
+    def filter_depths(self):
+        """Frame::FilterDepths (frame.cpp:8-19)"""
+        import torch
+        tmp = torch.empty_like(self.depth)
+        check(lib().vk_frame_filter_depths(self.width, self.height, _ptr(self.depth), _ptr(tmp), stream()),
+              "vk_frame_filter_depths")
+        self.depth.copy_(tmp)
+
+    def downsample(self):
+        """Frame::Downsample (frame.cpp:38-58): nearest depth/normals, box colour,
+        intrinsics halved."""
+        import torch
+        w2, h2 = self.width // 2, self.height // 2
+        depth = torch.empty((h2, w2), dtype=torch.float32, device=self.device)
+        check(lib().vk_image_downsample(self.width, self.height, _ptr(self.depth), _ptr(depth), 1, stream()),
+              "vk_image_downsample")
+        color = normals = None
+        if self.color is not None:
+            color = torch.empty((h2, w2, 3), dtype=torch.float32, device=self.device)
+            check(lib().vk_color_image_downsample(self.width, self.height, _ptr(self.color), _ptr(color), 0,
+                                                  stream()), "vk_color_image_downsample")
+        if self.normals is not None:
+            normals = torch.empty((h2, w2, 3), dtype=torch.float32, device=self.device)
+            check(lib().vk_color_image_downsample(self.width, self.height, _ptr(self.normals), _ptr(normals), 1,
+                                                  stream()), "vk_color_image_downsample")
+        f32 = np.float32
+
+        def half(k):  # Vector2f / 2 multiplies by 1/2 (matrix.h:279-295)
+            return T.Projection.make(f32(k.fx) * f32(0.5), f32(k.fy) * f32(0.5),
+                                     f32(k.cx) * f32(0.5), f32(k.cy) * f32(0.5))
+        return Frame(depth, half(self.depth_projection), self.depth_to_world, color, normals,
+                     half(self.color_projection), self.depth_to_color, self.device)
+
+
+class Volume:
+    """vulcan::Volume (volume.h:16-117): owns the device buffers, forwards to vk_volume_*."""
+
+    def __init__(self, main_block_count, excess_block_count, voxel_length=0.008,
+                 truncation_length=0.04, depth_range=(0.1, 5.0), device="cuda"):
+        import torch
+        self.device = device
+        n = main_block_count + excess_block_count
+        self.main, self.excess, self.max = main_block_count, excess_block_count, n
+        self.voxels = _dev_bytes(n * 512 * 20, device)
+        self.hash_entries = _dev_bytes(n * 16, device)
+        self.free_voxel_blocks = torch.empty(n, dtype=torch.int32, device=device)
+        self.allocation_types = _dev_bytes(main_block_count, device)
+        self.allocation_blocks = _dev_bytes(main_block_count * 8, device)
+        self.block_visibility = _dev_bytes(n, device)
+        self.visible_blocks = torch.empty(n, dtype=torch.int32, device=device)
+        self.counters = torch.zeros(T.VK_CTR_COUNT, dtype=torch.int32, device=device)
+        self.voxel_length = voxel_length
+        self.truncation_length = truncation_length
+        self.depth_range = depth_range
+        check(lib().vk_volume_initialize(_ref(self.desc()), stream()), "vk_volume_initialize")
+
+    def desc(self):
+        d = T.Volume()
+        d.voxels = self.voxels.data_ptr()
+        d.hash_entries = self.hash_entries.data_ptr()
+        d.free_voxel_blocks = self.free_voxel_blocks.data_ptr()
+        d.allocation_types = self.allocation_types.data_ptr()
+        d.allocation_blocks = self.allocation_blocks.data_ptr()
+        d.block_visibility = self.block_visibility.data_ptr()
+        d.visible_blocks = self.visible_blocks.data_ptr()
+        d.counters = self.counters.data_ptr()
+        d.main_block_count, d.excess_block_count = self.main, self.excess
+        d.voxel_length, d.truncation_length = self.voxel_length, self.truncation_length
+        d.min_depth, d.max_depth = self.depth_range
+        return d
+
+    # -- Volume::SetView and its four protected stages (volume.cu:430-535)
+    def set_view(self, frame):
+        check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
+
+    def reset_block_visibility(self):
+        check(lib().vk_volume_reset_block_visibility(_ref(self.desc()), stream()), "reset_block_visibility")
+
+    def create_allocation_requests(self, frame):
+        check(lib().vk_volume_create_allocation_requests(
+            _ref(self.desc()), _ptr(frame.depth), frame.width, frame.height,
+            _ref(frame.depth_projection), _ref(frame.depth_to_world), stream()), "create_allocation_requests")
+
+    def handle_allocation_requests(self):
+        check(lib().vk_volume_handle_allocation_requests(_ref(self.desc()), stream()), "handle_allocation_requests")
+
+    def update_block_visibility(self, frame):
+        tdw = frame.depth_to_world.inverse()
+        check(lib().vk_volume_update_block_visibility(
+            _ref(self.desc()), frame.width, frame.height, _ref(frame.depth_projection), _ref(tdw), stream()),
+            "update_block_visibility")
+
+    # -- host views (blocking)
+    def read_counters(self):
+        out = (C.c_int32 * T.VK_CTR_COUNT)()
+        check(lib().vk_volume_read_counters_sync(_ref(self.desc()), out, stream()), "read_counters")
+        return np.array(out[:], dtype=np.int32)
+
+    @property
+    def visible_count(self):
+        return int(self.read_counters()[T.VK_CTR_VISIBLE])
+
+    def visible(self):
+        return self.visible_blocks[:self.visible_count].cpu().numpy()
+
+    def host_voxels(self):
+        return to_numpy(self.voxels, T.voxel_dtype)
+
+    def host_entries(self):
+        return to_numpy(self.hash_entries, T.hash_entry_dtype)
+
+    def host_visibility(self):
+        return self.block_visibility.cpu().numpy()
+
+    def host_allocation_types(self):
+        return self.allocation_types.cpu().numpy()
+
+    def host_allocation_blocks(self):
+        return to_numpy(self.allocation_blocks, T.block_dtype)
+
+    def upload(self, host):
+        """Copy an oracle HostVolume (same sizes) into this volume's buffers — lets a
+        test start the device path from an exactly known state."""
+        import torch
+        assert host.main == self.main and host.excess == self.excess
+        for name in ("voxels", "hash_entries", "allocation_types", "allocation_blocks", "block_visibility"):
+            src = torch.from_numpy(np.frombuffer(getattr(host, name).tobytes(), dtype=np.uint8).copy())
+            getattr(self, name).copy_(src.to(self.device))
+        self.free_voxel_blocks.copy_(torch.from_numpy(host.free_voxel_blocks).to(self.device))
+        self.visible_blocks.copy_(torch.from_numpy(host.visible_blocks).to(self.device))
+        self.counters.copy_(torch.from_numpy(host.counters).to(self.device))
+        self.voxel_length, self.truncation_length = host.voxel_length, host.truncation_length
+        self.depth_range = host.depth_range
+
+
+class Integrator:
+    """vulcan::Integrator (integrator.h:12-45): depth range (0.1,5), max weights 16."""
+
+    def __init__(self, volume):
+        self.volume = volume
+        self.params = T.Integrator.default()
+
+    def _call(self, fn, frame, *extra):
+        check(getattr(lib(), fn)(_ref(self.volume.desc()), _ref(self.params), *extra,
+                                 _ref(frame.desc()), stream()), fn)
+
+
+class DepthIntegrator(Integrator):
+    def integrate(self, frame):                      # depth_integrator.cu:89-115
+        self._call("vk_integrate_depth", frame)
+
+
+class ColorIntegrator(Integrator):
+    def integrate(self, frame):                      # color_integrator.cu:144-148, one pass
+        self._call("vk_integrate_depth_color", frame)
+
+    def integrate_depth(self, frame):                # color_integrator.cu:150-176
+        self._call("vk_integrate_depth", frame)
+
+    def integrate_color(self, frame):                # color_integrator.cu:178-204
+        self._call("vk_integrate_color", frame)
+
+
+class LightIntegrator(Integrator):
+    def __init__(self, volume):
+        super().__init__(volume)
+        self.light = T.Light.make(1.0, (0, 0, 0))    # light.h:14-18
+        self.depth_threshold = 0.2                   # light_integrator.cu:256
+        self.frame_mask = None
+
+    def compute_frame_mask(self, frame):             # light_integrator.cu:277-293
+        import torch
+        if self.frame_mask is None or tuple(self.frame_mask.shape) != (frame.height, frame.width):
+            self.frame_mask = torch.empty((frame.height, frame.width), dtype=torch.float32, device=frame.device)
+        check(lib().vk_light_compute_frame_mask(_ref(frame.desc()), self.depth_threshold,
+                                                _ptr(self.frame_mask), stream()), "vk_light_compute_frame_mask")
+        return self.frame_mask
+
+    def integrate(self, frame):                      # light_integrator.cu:270-275
+        self.compute_frame_mask(frame)
+        self._call("vk_integrate_depth_light", frame, _ref(self.light), _ptr(self.frame_mask))
+
+    def integrate_depth(self, frame):
+        self._call("vk_integrate_depth", frame)
+
+    def integrate_color(self, frame):                # light_integrator.cu:323-354
+        self._call("vk_integrate_light_color", frame, _ref(self.light), _ptr(self.frame_mask))
+
+
+class Tracer:
+    """vulcan::Tracer (tracer.h:24-77): 80x60 bounds grid, 262144 patch capacity."""
+
+    BOUNDS_W, BOUNDS_H, PATCH_CAPACITY = 80, 60, 262144   # tracer.cpp:56-57,134
+
+    def __init__(self, volume):
+        import torch
+        self.volume = volume
+        self.depth_range = (0.1, 5.0)
+        dev = volume.device
+        self.bounds = torch.empty((self.BOUNDS_H, self.BOUNDS_W, 2), dtype=torch.float32, device=dev)
+        self.patches = _dev_bytes(self.PATCH_CAPACITY * 16, dev)
+        self.patch_count = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def trace(self, frame):
+        """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals."""
+        import torch
+        if frame.color is None:
+            frame.color = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
+        if frame.normals is None:
+            frame.normals = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
+        check(lib().vk_trace(_ref(self.volume.desc()), _ref(frame.desc()), self.depth_range[0], self.depth_range[1],
+                             _ptr(self.bounds), self.BOUNDS_W, self.BOUNDS_H, _ptr(frame.depth), _ptr(frame.color),
+                             _ptr(frame.normals), stream()), "vk_trace")
+
+    # the tracer.cuh free functions, for the stage-by-stage tests
+    def compute_patches(self, frame, block_count=None):
+        v = self.volume
+        self.patch_count.zero_()
+        tcw = frame.depth_to_world.inverse()
+        n = v.max if block_count is None else block_count
+        dev_count = C.c_void_p(v.counters.data_ptr()) if block_count is None else None
+        check(lib().vk_trace_compute_patches(
+            _ptr(v.visible_blocks), _ptr(v.hash_entries), _ref(tcw), _ref(frame.depth_projection),
+            np.float32(8) * np.float32(v.voxel_length), self.depth_range[0], self.depth_range[1], n, dev_count,
+            frame.width, frame.height, self.BOUNDS_W, self.BOUNDS_H, _ptr(self.patches), self.PATCH_CAPACITY,
+            _ptr(self.patch_count), stream()), "vk_trace_compute_patches")
+
+    def compute_bounds(self):
+        check(lib().vk_trace_reset_bounds(_ptr(self.bounds), self.BOUNDS_W * self.BOUNDS_H, stream()),
+              "vk_trace_reset_bounds")
+        check(lib().vk_trace_compute_bounds(_ptr(self.patches), _ptr(self.bounds), self.BOUNDS_W,
+                                            self.PATCH_CAPACITY, _ptr(self.patch_count), stream()),
+              "vk_trace_compute_bounds")
+
+    def compute_block_bounds(self, frame):
+        v = self.volume
+        tcw = frame.depth_to_world.inverse()
+        check(lib().vk_trace_compute_block_bounds(
+            _ptr(v.visible_blocks), _ptr(v.hash_entries), _ref(tcw), _ref(frame.depth_projection),
+            np.float32(8) * np.float32(v.voxel_length), self.depth_range[0], self.depth_range[1], v.max,
+            C.c_void_p(v.counters.data_ptr()), frame.width, frame.height, self.BOUNDS_W, self.BOUNDS_H,
+            _ptr(self.bounds), stream()), "vk_trace_compute_block_bounds")
+
+    def compute_points(self, frame, depth_out, color_out):
+        v = self.volume
+        check(lib().vk_trace_compute_points(
+            _ptr(v.hash_entries), _ptr(v.voxels), _ptr(self.bounds), v.main,
+            np.float32(8) * np.float32(v.voxel_length), v.voxel_length, v.truncation_length,
+            _ref(frame.depth_to_world), _ref(frame.depth_projection), _ptr(depth_out), _ptr(color_out),
+            frame.width, frame.height, self.BOUNDS_W, self.BOUNDS_H, stream()), "vk_trace_compute_points")
+
+    def host_patches(self):
+        n = min(int(self.patch_count.cpu()[0]), self.PATCH_CAPACITY)
+        return to_numpy(self.patches[:n * 16], T.patch_dtype)
+
+
+class DepthTracker:
+    """vulcan::DepthTracker (depth_tracker.h, tracker.h): Gauss-Newton ICP against a
+    keyframe; the pose, the 27-float system and the solve stay on the device."""
+
+    def __init__(self, device="cuda"):
+        import torch
+        self.device = device
+        self.translation_enabled = True      # tracker.cpp:11
+        self.max_iterations = 20             # tracker.cpp:12
+        self.keyframe = None
+        # one 48-float buffer = 36 hessian + 6 gradient + pad, so a multi-GPU rig
+        # needs ONE all-reduce per Gauss-Newton iteration
+        self.system = torch.zeros(48, dtype=torch.float32, device=device)
+        self.hessian = self.system[:36]
+        self.gradient = self.system[36:42]
+        self.pose = _dev_bytes(128, device)
+        self.state = torch.zeros(2, dtype=torch.int32, device=device)
+        self.update = torch.zeros(6, dtype=torch.float32, device=device)
+        self.workspace = None
+        self.reduce_hook = None              # e.g. an all-reduce over ranks
+
+    @staticmethod
+    def _view(frame):
+        v = T.IcpView()
+        v.depths, v.normals = frame.depth.data_ptr(), frame.normals.data_ptr()
+        v.width, v.height = frame.width, frame.height
+        v.projection = frame.depth_projection
+        return v
+
+    def _workspace(self, frame):
+        import torch
+        n = int(lib().vk_icp_workspace_floats(frame.width, frame.height))
+        if self.workspace is None or self.workspace.numel() < n:
+            self.workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self.workspace
+
+    def compute_residuals(self, frame):      # depth_tracker.cu:272-300
+        import torch
+        out = torch.empty((frame.height, frame.width), dtype=torch.float32, device=self.device)
+        check(lib().vk_icp_compute_residuals(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
+                                             _ref(self._view(frame)), _ref(frame.depth_to_world), _ptr(out),
+                                             stream()), "vk_icp_compute_residuals")
+        return out
+
+    def compute_jacobian(self, frame):       # depth_tracker.cu:302-336
+        import torch
+        out = torch.empty((frame.height, frame.width, 6), dtype=torch.float32, device=self.device)
+        check(lib().vk_icp_compute_jacobian(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
+                                            _ref(self._view(frame)), _ref(frame.depth_to_world),
+                                            int(self.translation_enabled), _ptr(out), stream()),
+              "vk_icp_compute_jacobian")
+        return out
+
+    def compute_system(self, frame, pose_on_device=False):   # depth_tracker.cu:338-378
+        ws = self._workspace(frame)
+        check(lib().vk_icp_compute_system(
+            _ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world), _ref(self._view(frame)),
+            _ref(frame.depth_to_world), _ptr(self.pose) if pose_on_device else None,
+            int(self.translation_enabled), _ptr(ws), _ptr(self.hessian), _ptr(self.gradient), stream()),
+            "vk_icp_compute_system")
+
+    def track(self, frame):
+        """Tracker::Track (tracker.cpp:53-63): <= max_iterations Gauss-Newton steps,
+        all enqueued without a host sync; one 128-byte readback of the pose at the end."""
+        import torch
+        host = np.frombuffer(bytes(frame.depth_to_world), dtype=np.uint8).copy()
+        self.pose.copy_(torch.from_numpy(host).to(self.device))
+        self.state.zero_()
+        for _ in range(self.max_iterations):
+            self.compute_system(frame, pose_on_device=True)
+            if self.reduce_hook is not None:
+                self.reduce_hook(self.system)
+            check(lib().vk_icp_solve_update(_ptr(self.hessian), _ptr(self.gradient), int(self.translation_enabled),
+                                            _ptr(self.pose), _ptr(self.state), _ptr(self.update), stream()),
+                  "vk_icp_solve_update")
+        out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
+        frame.depth_to_world = out
+        return out
+
+
+class PyramidTracker:
+    """vulcan::PyramidTracker<DepthTracker> (pyramid_tracker.cpp:52-90): half
+    resolution (15 iterations) then full resolution (20)."""
+
+    def __init__(self, tracker=None, device="cuda"):
+        self.tracker = tracker or DepthTracker(device)
+        self.keyframe = None
+
+    def track(self, frame):
+        half_frame = frame.downsample()
+        half_key = self.keyframe.downsample()
+        t = self.tracker
+        t.max_iterations, t.translation_enabled = 15, True
+        t.keyframe = half_key
+        t.track(half_frame)
+        t.max_iterations = 20
+        frame.depth_to_world = half_frame.depth_to_world
+        t.keyframe = self.keyframe
+        return t.track(frame)

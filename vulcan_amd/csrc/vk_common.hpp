@@ -1,0 +1,177 @@
+// vk_common.hpp — shared host/device helpers for libvk_hip.so (gfx950 only).
+//
+// Device arithmetic follows the reference's operation order exactly and the
+// library is built with -ffp-contract=off, so results do not depend on where
+// the compiler would have fused a multiply-add.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#include "../../include/vk.h"
+
+#define VK_CHECK(expr)                                  \
+  do {                                                  \
+    const hipError_t vk_e__ = (expr);                   \
+    if (vk_e__ != hipSuccess) return (int)vk_e__;       \
+  } while (0)
+
+#define VK_REQUIRE(cond)                                \
+  do {                                                  \
+    if (!(cond)) return VK_ERR_ARGUMENT;                \
+  } while (0)
+
+// Launch errors are picked up with hipGetLastError (no device sync).
+#define VK_LAUNCH_CHECK() VK_CHECK(hipGetLastError())
+
+static inline hipStream_t vk_s(void* stream) { return reinterpret_cast<hipStream_t>(stream); }
+
+namespace vk
+{
+
+constexpr int kWave = 64;       // CDNA4 wavefront
+constexpr int kCUs = 256;       // MI355X compute units
+
+// ---- float3 in the reference's operation order (matrix.h) ------------------
+
+struct f3 { float x, y, z; };
+
+__device__ __forceinline__ f3 make3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+// matrix.h:157-169 Dot: starts from 0, adds in index order
+__device__ __forceinline__ float dot3(f3 a, f3 b)
+{
+  float r = 0.0f;
+  r += a.x * b.x;
+  r += a.y * b.y;
+  r += a.z * b.z;
+  return r;
+}
+__device__ __forceinline__ float sqnorm3(f3 a) { return dot3(a, a); }
+// matrix.h:131-154 Normalize(d): multiply by 1/sqrt(dot)
+__device__ __forceinline__ f3 normalized3(f3 a)
+{
+  const float inv = 1.0f / sqrtf(sqnorm3(a));
+  return scale3(a, inv);
+}
+// matrix.h:279-295 operator/ multiplies by the reciprocal
+__device__ __forceinline__ f3 div3(f3 a, float s) { return scale3(a, 1.0f / s); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+  return f3{(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)};
+}
+
+// math.h:9-32 (operand order of the comparisons matters for NaN)
+__device__ __forceinline__ float vmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float vmax(float a, float b) { return (b > a) ? b : a; }
+__device__ __forceinline__ int vmini(int a, int b) { return (b < a) ? b : a; }
+__device__ __forceinline__ int vmaxi(int a, int b) { return (b > a) ? b : a; }
+__device__ __forceinline__ float vclamp(float v, float lo, float hi) { return vmin(hi, vmax(lo, v)); }
+__device__ __forceinline__ int vclampi(int v, int lo, int hi) { return vmini(hi, vmaxi(lo, v)); }
+
+// float -> int / short: saturating, NaN -> 0 (what the reference gets from the
+// GPU's cvt instruction where C leaves the conversion undefined).
+__device__ __forceinline__ int f2i(float x)
+{
+  if (x != x) return 0;
+  if (x >= 2147483648.0f) return INT32_MAX;
+  if (x <= -2147483648.0f) return INT32_MIN;
+  return (int)x;
+}
+__device__ __forceinline__ int f2s(float x)
+{
+  if (x != x) return 0;
+  if (x >= 32767.0f) return 32767;
+  if (x <= -32768.0f) return -32768;
+  return (int)x;
+}
+
+// Rigid transform rows as kernel arguments: 12 floats, row-major 3x4.
+struct Rt
+{
+  float r[12];
+};
+
+// column-major 4x4 -> row-major 3x4
+static inline Rt make_rt(const float* m)
+{
+  Rt t;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) t.r[r * 4 + c] = m[c * 4 + r];
+  return t;
+}
+
+// transform.h:43-60 Transform::operator*(Vector4f) with w = 1 / w = 0
+__device__ __forceinline__ f3 xform_point(const Rt& t, f3 p)
+{
+  return f3{t.r[0] * p.x + t.r[1] * p.y + t.r[2] * p.z + t.r[3] * 1.0f,
+            t.r[4] * p.x + t.r[5] * p.y + t.r[6] * p.z + t.r[7] * 1.0f,
+            t.r[8] * p.x + t.r[9] * p.y + t.r[10] * p.z + t.r[11] * 1.0f};
+}
+__device__ __forceinline__ f3 xform_dir(const Rt& t, f3 p)
+{
+  return f3{t.r[0] * p.x + t.r[1] * p.y + t.r[2] * p.z + t.r[3] * 0.0f,
+            t.r[4] * p.x + t.r[5] * p.y + t.r[6] * p.z + t.r[7] * 0.0f,
+            t.r[8] * p.x + t.r[9] * p.y + t.r[10] * p.z + t.r[11] * 0.0f};
+}
+
+// projection.h:63-70
+__device__ __forceinline__ void project(const vk_projection& k, f3 X, float& u, float& v)
+{
+  const float inv_w = 1.0f / X.z;
+  u = inv_w * k.fx * X.x + k.cx;
+  v = inv_w * k.fy * X.y + k.cy;
+}
+// projection.h:78-88
+__device__ __forceinline__ f3 unproject(const vk_projection& k, float u, float v)
+{
+  const float ifx = 1.0f / k.fx;
+  const float ify = 1.0f / k.fy;
+  return f3{ifx * u - k.cx * ifx, ify * v - k.cy * ify, 1.0f};
+}
+// projection.h:96-100: d * Unproject(uv)
+__device__ __forceinline__ f3 unproject_d(const vk_projection& k, float u, float v, float d)
+{
+  return scale3(unproject(k, u, v), d);
+}
+
+// volume.cu:168-180, tracer.cu:151-155
+__device__ __forceinline__ uint32_t block_hash(int bx, int by, int bz, uint32_t K)
+{
+  return (((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349669u) ^ ((uint32_t)bz * 83492791u)) % K;
+}
+
+// 16-byte hash entry as one vector load
+struct Entry
+{
+  int16_t ox, oy, oz, pad;
+  int32_t data;
+  int32_t next;
+};
+static_assert(sizeof(Entry) == 16, "HashEntry layout");
+
+__device__ __forceinline__ Entry load_entry(const vk_hash_entry* entries, uint32_t index)
+{
+  const int4 raw = reinterpret_cast<const int4*>(entries)[index];
+  Entry e;
+  e.ox = (int16_t)(raw.x & 0xffff);
+  e.oy = (int16_t)((uint32_t)raw.x >> 16);
+  e.oz = (int16_t)(raw.y & 0xffff);
+  e.pad = (int16_t)((uint32_t)raw.y >> 16);
+  e.data = raw.z;
+  e.next = raw.w;
+  return e;
+}
+
+// Block(bx,by,bz) truncates to short (block.h:26) before the comparison
+__device__ __forceinline__ bool entry_is(const Entry& e, int bx, int by, int bz)
+{
+  return e.ox == (int16_t)bx && e.oy == (int16_t)by && e.oz == (int16_t)bz;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+}  // namespace vk

@@ -1,0 +1,532 @@
+// vk_icp.hip — projective point-to-plane ICP normal system, Gauss-Newton update
+// and the image pyramid for gfx950 (ref: src/depth_tracker.cu,
+// src/tracker.cpp:124-163, src/depth_tracker.cpp:22-86, src/image.cu:101-165).
+//
+// The reference reduces 27 sums with 9 rounds of three 256-wide LDS trees per
+// workgroup and 27 float atomicAdds per workgroup (order-nondeterministic), then
+// copies 42 floats to the host every Gauss-Newton iteration for an Eigen LDLT.
+// Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
+// summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
+// solve + SE(3) update can run on the device so an iteration needs no readback.
+#include "vk_common.hpp"
+
+using namespace vk;
+
+namespace
+{
+
+struct View
+{
+  const float* depths;
+  const float* normals;
+  int width, height;
+  vk_projection k;
+};
+
+struct IcpParams
+{
+  View key, frm;
+  Rt Twm, Tmw, Twc;
+  const vk_transform* Twc_dev;  // optional device override of Twc
+};
+
+__device__ __forceinline__ Rt rt_from_colmajor(const float* m)
+{
+  Rt t;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t.r[r * 4 + c] = m[c * 4 + r];
+  return t;
+}
+
+// ref: depth_tracker.cu:18-94 Evaluate<translation_enabled>; returns false when
+// the pixel contributes nothing (residual 0, Jacobian 0).
+template <bool TRANSLATION>
+__device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int frame_x, int frame_y,
+    float& residual, float J[6])
+{
+  residual = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) J[i] = 0.0f;
+
+  const View& frm = P.frm;
+  const View& key = P.key;
+  if (!(frame_x < frm.width && frame_y < frm.height)) return false;
+
+  const int frame_index = frame_y * frm.width + frame_x;
+  const float frame_depth = frm.depths[frame_index];
+  if (!(frame_depth > 0)) return false;
+
+  const f3 Xcp = unproject_d(frm.k, frame_x + 0.5f, frame_y + 0.5f, frame_depth);
+  const f3 Xwp = xform_point(Twc, Xcp);
+  const f3 Xmp = xform_point(P.Tmw, Xwp);
+  float ku, kv;
+  project(key.k, Xmp, ku, kv);
+  if (!(ku >= 0 && ku < key.width && kv >= 0 && kv < key.height)) return false;
+
+  const int keyframe_index = (int)kv * key.width + (int)ku;
+  const float keyframe_depth = key.depths[keyframe_index];
+  if (!(keyframe_depth > 0)) return false;
+
+  f3 frame_normal = make3(frm.normals[3 * frame_index + 0], frm.normals[3 * frame_index + 1],
+      frm.normals[3 * frame_index + 2]);
+  frame_normal = xform_dir(Twc, frame_normal);
+  f3 keyframe_normal = make3(key.normals[3 * keyframe_index + 0], key.normals[3 * keyframe_index + 1],
+      key.normals[3 * keyframe_index + 2]);
+  keyframe_normal = xform_dir(P.Twm, keyframe_normal);
+
+  if (!(sqnorm3(keyframe_normal) > 0.0f && dot3(frame_normal, keyframe_normal) > 0.5f)) return false;
+
+  const f3 Ymp = unproject_d(key.k, floorf(ku) + 0.5f, floorf(kv) + 0.5f, keyframe_depth);
+  const f3 Ywp = xform_point(P.Twm, Ymp);
+  const f3 delta = sub3(Xwp, Ywp);
+  if (!(sqnorm3(delta) < 0.05f)) return false;
+
+  residual = dot3(delta, keyframe_normal);
+  J[0] = keyframe_normal.z * Xwp.y - keyframe_normal.y * Xwp.z;
+  J[1] = keyframe_normal.x * Xwp.z - keyframe_normal.z * Xwp.x;
+  J[2] = keyframe_normal.y * Xwp.x - keyframe_normal.x * Xwp.y;
+  if (TRANSLATION)
+  {
+    J[3] = keyframe_normal.x;
+    J[4] = keyframe_normal.y;
+    J[5] = keyframe_normal.z;
+  }
+  return true;
+}
+
+// ref: depth_tracker.cu:97-118
+__global__ __launch_bounds__(256) void residuals_kernel(IcpParams P, float* __restrict__ residuals)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.frm.width || y >= P.frm.height) return;
+  float r, J[6];
+  evaluate<false>(P, P.Twc, x, y, r, J);
+  residuals[y * P.frm.width + x] = r;
+}
+
+// ref: depth_tracker.cu:120-141
+template <bool TRANSLATION>
+__global__ __launch_bounds__(256) void jacobian_kernel(IcpParams P, float* __restrict__ jacobian)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.frm.width || y >= P.frm.height) return;
+  float r, J[6];
+  evaluate<TRANSLATION>(P, P.Twc, x, y, r, J);
+  float* out = jacobian + 6 * (size_t)(y * P.frm.width + x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = J[i];
+}
+
+constexpr int kSysThreads = 256;
+constexpr int kSysPixelsPerThread = 4;
+constexpr int kSysStride = 32;  // floats per workgroup partial: 6 gradient + 21 hessian + pad
+
+// ref: depth_tracker.cu:144-268. Slot layout of a partial: [0,6) J^T r,
+// [6,27) packed lower triangle of J^T J in (r, c<=r) row-major order.
+template <bool TRANSLATION>
+__global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P, float* __restrict__ workspace)
+{
+  __shared__ float lds[kSysThreads / 64][kSysStride];
+
+  const Rt Twc = P.Twc_dev ? rt_from_colmajor(P.Twc_dev->m) : P.Twc;
+  const int total = P.frm.width * P.frm.height;
+  const int base = blockIdx.x * (kSysThreads * kSysPixelsPerThread);
+
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+
+#pragma unroll
+  for (int k = 0; k < kSysPixelsPerThread; ++k)
+  {
+    const int pixel = base + k * kSysThreads + threadIdx.x;
+    if (pixel >= total) continue;
+    float r, J[6];
+    if (!evaluate<TRANSLATION>(P, Twc, pixel % P.frm.width, pixel / P.frm.width, r, J)) continue;
+
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] += J[i] * r;
+    int counter = 6;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int c = 0; c <= rr; ++c, ++counter) acc[counter] += J[rr] * J[c];
+  }
+
+  // wave64 butterfly: after 6 xor steps every lane holds the wave's sum
+#pragma unroll
+  for (int i = 0; i < 27; ++i)
+  {
+    float v = acc[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    acc[i] = v;
+  }
+
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0)
+  {
+#pragma unroll
+    for (int i = 0; i < 27; ++i) lds[wave][i] = acc[i];
+  }
+  __syncthreads();
+
+  if (threadIdx.x < kSysStride)
+  {
+    float v = 0.0f;
+    if (threadIdx.x < 27)
+      v = ((lds[0][threadIdx.x] + lds[1][threadIdx.x]) + lds[2][threadIdx.x]) + lds[3][threadIdx.x];
+    workspace[(size_t)blockIdx.x * kSysStride + threadIdx.x] = v;
+  }
+}
+
+// Fixed-order sum of the partials: 8 slices x 32 components, then the slices in
+// order. Writes hessian[36] (packed lower triangle first, rest 0) and gradient[6].
+__global__ __launch_bounds__(256) void system_final_kernel(const float* __restrict__ workspace,
+    int partials, int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient)
+{
+  __shared__ float slices[8][kSysStride];
+  const int c = threadIdx.x & 31;
+  const int s = threadIdx.x >> 5;
+
+  float v = 0.0f;
+  for (int j = s; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
+  slices[s][c] = v;
+  __syncthreads();
+
+  if (threadIdx.x < 36 + 6)
+  {
+    if (threadIdx.x < 6)
+    {
+      float g = 0.0f;
+      const int n = translation_enabled ? 6 : 3;
+      if ((int)threadIdx.x < n)
+        for (int k = 0; k < 8; ++k) g += slices[k][threadIdx.x];
+      gradient[threadIdx.x] = g;
+    }
+    else
+    {
+      // depth_tracker.cu:199-214: with translation disabled the packed triangle
+      // is that of the 3x3 rotation block (6 values)
+      const int out = threadIdx.x - 6;
+      const int n = translation_enabled ? 21 : 6;
+      float h = 0.0f;
+      if (out < n)
+        for (int k = 0; k < 8; ++k) h += slices[k][6 + out];
+      hessian[out] = h;
+    }
+  }
+}
+
+// ---- 6x6 solve + pose update on the device -----------------------------------
+
+// LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
+// not vendored; agreement is to rounding).
+__device__ void ldlt_solve(int n, const float* A, const float* b, float* x)
+{
+  float L[36], D[6], y[6];
+  for (int i = 0; i < 36; ++i) L[i] = 0.0f;
+
+  for (int j = 0; j < n; ++j)
+  {
+    float d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k] * D[k];
+    D[j] = d;
+    L[j * n + j] = 1.0f;
+
+    for (int i = j + 1; i < n; ++i)
+    {
+      float s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k] * D[k];
+      L[i * n + j] = s / d;
+    }
+  }
+
+  for (int i = 0; i < n; ++i)
+  {
+    float s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k];
+    y[i] = s;
+  }
+
+  for (int i = 0; i < n; ++i) y[i] = y[i] / D[i];
+
+  for (int i = n - 1; i >= 0; --i)
+  {
+    float s = y[i];
+    for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+    x[i] = s;
+  }
+}
+
+__device__ void matmul4(const float* A, const float* B, float* C)  // matrix.h:297-318
+{
+  for (int p = 0; p < 4; ++p)
+    for (int m = 0; m < 4; ++m)
+    {
+      float r = 0.0f;
+      for (int n = 0; n < 4; ++n) r += A[n * 4 + m] * B[p * 4 + n];
+      C[p * 4 + m] = r;
+    }
+}
+
+// ref: tracker.cpp:124-163 + depth_tracker.cpp:22-86. One lane; 6x6 is too
+// small to spread.
+__global__ void solve_update_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state && state[1]) return;  // converged earlier: tracker.cpp:162
+
+  const int n = translation_enabled ? 6 : 3;
+  float H[36], x[6], update[6];
+
+  int index = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j)
+    {
+      H[i * n + j] = hessian[index];
+      H[j * n + i] = hessian[index];
+      ++index;
+    }
+
+  float g[6];
+  for (int i = 0; i < n; ++i) g[i] = gradient[i];
+  ldlt_solve(n, H, g, x);
+  for (int i = 0; i < 6; ++i) update[i] = 0.0f;
+  for (int i = 0; i < n; ++i) update[i] = -x[i];
+
+  // depth_tracker.cpp:33-53, including Tinc(1,2) = +update[0]
+  float Tinc[16];
+  Tinc[0] = 1.0f;        Tinc[4] = -update[2]; Tinc[8] = +update[1];  Tinc[12] = +update[3];
+  Tinc[1] = +update[2];  Tinc[5] = 1.0f;       Tinc[9] = +update[0];  Tinc[13] = +update[4];
+  Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
+  Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
+
+  float M[16];
+  matmul4(Tinc, Twc->m, M);
+
+  f3 x_axis = normalized3(make3(M[0], M[1], M[2]));
+  f3 y_axis = normalized3(make3(M[4], M[5], M[6]));
+  const f3 z_axis = cross3(x_axis, y_axis);
+  y_axis = cross3(z_axis, x_axis);
+
+  // Translate(t) * Rotate(R): transform.h:62-66,74-99,146-159
+  float Tm[16], Ti[16], Rm[16], Ri[16];
+  for (int i = 0; i < 16; ++i) { Tm[i] = Ti[i] = Rm[i] = 0.0f; }
+  for (int i = 0; i < 4; ++i) { Tm[5 * i] = Ti[5 * i] = Rm[5 * i] = 1.0f; }
+  Tm[12] = M[12];  Tm[13] = M[13];  Tm[14] = M[14];
+  Ti[12] = -M[12]; Ti[13] = -M[13]; Ti[14] = -M[14];
+  Rm[0] = x_axis.x; Rm[1] = x_axis.y; Rm[2] = x_axis.z;
+  Rm[4] = y_axis.x; Rm[5] = y_axis.y; Rm[6] = y_axis.z;
+  Rm[8] = z_axis.x; Rm[9] = z_axis.y; Rm[10] = z_axis.z;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) Ri[c * 4 + r] = Rm[r * 4 + c];
+
+  float out_m[16], out_i[16];
+  matmul4(Tm, Rm, out_m);
+  matmul4(Ri, Ti, out_i);
+  for (int i = 0; i < 16; ++i) { Twc->m[i] = out_m[i]; Twc->inv[i] = out_i[i]; }
+
+  float sq = 0.0f;
+  for (int i = 0; i < n; ++i) sq += update[i] * update[i];
+  if (update_out) for (int i = 0; i < 6; ++i) update_out[i] = update[i];
+  if (state)
+  {
+    state[0] += 1;
+    if (sqrtf(sq) < 1E-6f) state[1] = 1;
+  }
+}
+
+// ------------------------------------------------------------------ pyramid ----
+
+// ref: image.cu:101-131
+__global__ __launch_bounds__(256) void downsample_kernel(int src_w, int dst_w, int dst_h,
+    const float* __restrict__ src, float* __restrict__ dst, int nearest)
+{
+  const int dst_x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dst_y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dst_x >= dst_w || dst_y >= dst_h) return;
+
+  const int src_x = 2 * dst_x, src_y = 2 * dst_y;
+  float sample = 0;
+
+  if (nearest)
+  {
+    sample = src[src_y * src_w + src_x];
+  }
+  else
+  {
+    sample += src[(src_y + 0) * src_w + (src_x + 1)];
+    sample += src[(src_y + 0) * src_w + (src_x + 0)];
+    sample += src[(src_y + 1) * src_w + (src_x + 1)];
+    sample += src[(src_y + 1) * src_w + (src_x + 0)];
+    sample *= 0.25f;
+  }
+
+  dst[dst_y * dst_w + dst_x] = sample;
+}
+
+// ref: image.cu:133-165
+__global__ __launch_bounds__(256) void downsample3_kernel(int src_w, int dst_w, int dst_h,
+    const float* __restrict__ src, float* __restrict__ dst, int nearest)
+{
+  const int dst_x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dst_y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dst_x >= dst_w || dst_y >= dst_h) return;
+
+  const int src_x = 2 * dst_x, src_y = 2 * dst_y;
+
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+  {
+    float sample = 0;
+    if (nearest)
+    {
+      sample = src[3 * (src_y * src_w + src_x) + c];
+    }
+    else
+    {
+      sample += src[3 * ((src_y + 0) * src_w + (src_x + 1)) + c];
+      sample += src[3 * ((src_y + 0) * src_w + (src_x + 0)) + c];
+      sample += src[3 * ((src_y + 1) * src_w + (src_x + 1)) + c];
+      sample += src[3 * ((src_y + 1) * src_w + (src_x + 0)) + c];
+      sample *= 0.25f;
+    }
+    dst[3 * (dst_y * dst_w + dst_x) + c] = sample;
+  }
+}
+
+int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, const vk_transform* Twc)
+{
+  if (!keyframe || !Twm || !frame || !Twc) return VK_ERR_ARGUMENT;
+  if (!keyframe->depths || !keyframe->normals || !frame->depths || !frame->normals) return VK_ERR_ARGUMENT;
+  if (keyframe->width <= 0 || keyframe->height <= 0 || frame->width <= 0 || frame->height <= 0)
+    return VK_ERR_ARGUMENT;
+  P.key.depths = keyframe->depths;
+  P.key.normals = keyframe->normals;
+  P.key.width = keyframe->width;
+  P.key.height = keyframe->height;
+  P.key.k = keyframe->projection;
+  P.frm.depths = frame->depths;
+  P.frm.normals = frame->normals;
+  P.frm.width = frame->width;
+  P.frm.height = frame->height;
+  P.frm.k = frame->projection;
+  P.Twm = make_rt(Twm->m);
+  P.Tmw = make_rt(Twm->inv);
+  P.Twc = make_rt(Twc->m);
+  P.Twc_dev = nullptr;
+  return VK_OK;
+}
+
+int partial_count(int width, int height)
+{
+  const int per = kSysThreads * kSysPixelsPerThread;
+  return (width * height + per - 1) / per;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_icp_compute_residuals(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, const vk_transform* Twc, float* residuals, void* stream)
+{
+  IcpParams P;
+  const int rc = fill_icp(P, keyframe, Twm, frame, Twc);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(residuals);
+  const dim3 grid((frame->width + 63) / 64, (frame->height + 3) / 4);
+  hipLaunchKernelGGL(residuals_kernel, grid, dim3(256), 0, vk_s(stream), P, residuals);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_icp_compute_jacobian(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, const vk_transform* Twc, int translation_enabled, float* jacobian,
+    void* stream)
+{
+  IcpParams P;
+  const int rc = fill_icp(P, keyframe, Twm, frame, Twc);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(jacobian);
+  const dim3 grid((frame->width + 63) / 64, (frame->height + 3) / 4);
+  if (translation_enabled)
+    hipLaunchKernelGGL(jacobian_kernel<true>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
+  else
+    hipLaunchKernelGGL(jacobian_kernel<false>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+size_t vk_icp_workspace_floats(int width, int height)
+{
+  if (width <= 0 || height <= 0) return 0;
+  return (size_t)partial_count(width, height) * kSysStride;
+}
+
+int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, const vk_transform* Twc, const vk_transform* Twc_dev,
+    int translation_enabled, float* workspace, float* hessian, float* gradient, void* stream)
+{
+  IcpParams P;
+  vk_transform identity;
+  if (!Twc && Twc_dev)
+  {
+    for (int i = 0; i < 16; ++i) identity.m[i] = identity.inv[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    Twc = &identity;
+  }
+  const int rc = fill_icp(P, keyframe, Twm, frame, Twc);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(workspace && hessian && gradient);
+  P.Twc_dev = Twc_dev;
+  const int partials = partial_count(frame->width, frame->height);
+  if (translation_enabled)
+    hipLaunchKernelGGL(system_partial_kernel<true>, dim3(partials), dim3(kSysThreads), 0, vk_s(stream), P, workspace);
+  else
+    hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, vk_s(stream), P, workspace);
+  VK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
+      translation_enabled, hessian, gradient);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_icp_solve_update(const float* hessian, const float* gradient, int translation_enabled,
+    vk_transform* Twc_dev, int32_t* state_dev, float* update_dev, void* stream)
+{
+  VK_REQUIRE(hessian && gradient && Twc_dev);
+  hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
+      translation_enabled, Twc_dev, state_dev, update_dev);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_image_downsample(int src_w, int src_h, const float* src, float* dst, int nearest, void* stream)
+{
+  VK_REQUIRE(src && dst && src_w > 0 && src_h > 0 && (src_w % 2) == 0 && (src_h % 2) == 0);
+  const int dst_w = src_w / 2, dst_h = src_h / 2;
+  const dim3 grid((dst_w + 63) / 64, (dst_h + 3) / 4);
+  hipLaunchKernelGGL(downsample_kernel, grid, dim3(256), 0, vk_s(stream), src_w, dst_w, dst_h, src, dst, nearest);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_color_image_downsample(int src_w, int src_h, const float* src, float* dst, int nearest, void* stream)
+{
+  VK_REQUIRE(src && dst && src_w > 0 && src_h > 0 && (src_w % 2) == 0 && (src_h % 2) == 0);
+  const int dst_w = src_w / 2, dst_h = src_h / 2;
+  const dim3 grid((dst_w + 63) / 64, (dst_h + 3) / 4);
+  hipLaunchKernelGGL(downsample3_kernel, grid, dim3(256), 0, vk_s(stream), src_w, dst_w, dst_h, src, dst, nearest);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+}  // extern "C"

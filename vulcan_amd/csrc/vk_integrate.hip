@@ -1,0 +1,416 @@
+// vk_integrate.hip — TSDF / colour / light integration for gfx950
+// (ref: src/depth_integrator.cu, src/color_integrator.cu, src/light_integrator.cu).
+//
+// Layout: the 20-byte AoS Voxel is pinned by the API (Volume::GetVoxels), so a
+// block is 512*20 = 10 240 contiguous bytes = 640 float4. ONE WAVEFRONT owns one
+// visible block: it pulls the block into LDS with ten coalesced 1-KiB float4
+// loads, updates its eight z-slices (lane = y*8+x) out of LDS — a 5-dword
+// voxel stride is conflict-free on the 32-bank ds_read_b32 path — and streams
+// the tile back with ten float4 stores. The reference runs one 512-thread CUDA
+// block per voxel block with 5-dword-strided per-thread global accesses, and a
+// second full pass for colour; here depth+colour are one pass.
+//
+// HBM-bound: algorithmic bytes per visible block = 4 (index) + 16 (entry) +
+// 2*10240 (voxel read + write) = 20 500 B, plus the images once per frame
+// (SURVEY.md §8d).
+#include "vk_common.hpp"
+
+using namespace vk;
+
+namespace
+{
+
+enum { COLOR_NONE = 0, COLOR_PLAIN = 1, COLOR_LIGHT = 2 };
+
+struct IntegrateParams
+{
+  float4* voxels4;               // pool viewed as float4
+  const vk_hash_entry* entries;
+  const int32_t* visible;
+  const int32_t* counters;
+  const float* depth;
+  const float* color;
+  const float* normals;
+  const float* mask;
+  int width, height;
+  vk_projection kd, kc;
+  Rt Tdw, Tcw, Tcd;
+  vk_light light;
+  float voxel_length, block_length, truncation_length;
+  float min_depth, max_depth;
+  float max_distance_weight, max_color_weight;
+};
+
+constexpr int kWavesPerGroup = 4;
+constexpr int kTileF4 = 640;  // float4 per voxel block
+
+// light.h:53-60
+__device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 normal)
+{
+  const f3 delta = sub3(make3(l.position[0], l.position[1], l.position[2]), point);
+  const f3 direction = normalized3(delta);
+  const float distance_squared = sqnorm3(delta);
+  const float cos_theta = dot3(normal, direction);
+  return l.intensity * cos_theta / distance_squared;
+}
+
+template <bool DEPTH, int COLOR>
+__global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(IntegrateParams P)
+{
+  __shared__ float4 tiles[kWavesPerGroup][kTileF4];
+
+  const int lane = lane_id();
+  const int wave_in_group = threadIdx.x >> 6;
+  const int wave = blockIdx.x * kWavesPerGroup + wave_in_group;
+  const int total_waves = gridDim.x * kWavesPerGroup;
+  const int count = P.counters[VK_CTR_VISIBLE];
+
+  float4* tile4 = tiles[wave_in_group];
+  float* tile = reinterpret_cast<float*>(tile4);
+
+  const int vx = lane & 7;
+  const int vy = lane >> 3;
+
+  for (int i = wave; i < count; i += total_waves)
+  {
+    const int entry_index = __builtin_amdgcn_readfirstlane(P.visible[i]);
+    const Entry entry = load_entry(P.entries, (uint32_t)entry_index);
+    // never-allocated origin block marked visible by the reference's quirk
+    // (SURVEY §2.5-1): the reference would index voxels[-512..]; skipped.
+    if (entry.data < 0) continue;
+
+    float4* block4 = P.voxels4 + (size_t)entry.data * kTileF4;
+
+    // ---- stage: 10 x 1 KiB coalesced loads, all in flight before the first LDS write
+    float4 r[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) r[k] = block4[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) tile4[k * 64 + lane] = r[k];
+
+    // ---- update the eight z-slices
+    // depth_integrator.cu:35-39
+    const f3 block_offset = scale3(make3((float)entry.ox, (float)entry.oy, (float)entry.oz), P.block_length);
+    bool dirty = false;
+
+#pragma unroll
+    for (int vz = 0; vz < 8; ++vz)
+    {
+      const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+      const f3 Xwp = add3(block_offset, voxel_offset);
+      float* vox = tile + (vz * 64 + lane) * 5;  // 5 dwords per voxel
+
+      float distance_value = 0.0f;
+      bool have_distance = false;
+
+      f3 Xdp = make3(0, 0, 0);
+      float du = 0, dv = 0;
+      if (DEPTH || COLOR == COLOR_LIGHT)
+      {
+        Xdp = xform_point(P.Tdw, Xwp);
+        project(P.kd, Xdp, du, dv);
+      }
+
+      if (DEPTH)
+      {
+        // depth_integrator.cu:41-78
+        if (du >= 0 && du < P.width && dv >= 0 && dv < P.height)
+        {
+          const int image_index = (int)dv * P.width + (int)du;
+          const float depth = P.depth[image_index];
+
+          if (!(depth < P.min_depth || depth > P.max_depth))
+          {
+            const float distance = depth - Xdp.z;
+
+            if (distance > -P.truncation_length)
+            {
+              const float old_distance = vox[0];
+              const uint32_t weights = __float_as_uint(vox[4]);
+              const int16_t dw = (int16_t)(weights & 0xffff);
+
+              const float prev_dist = dw * old_distance;
+              const float curr_dist = vmin(1.0f, distance / P.truncation_length);
+              const float dist_weight = dw + 1;
+              const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
+              distance_value = (prev_dist + curr_dist) / dist_weight;
+              have_distance = true;
+
+              vox[0] = distance_value;
+              vox[4] = __uint_as_float((weights & 0xffff0000u) | (uint16_t)new_dw);
+              dirty = true;
+            }
+          }
+        }
+      }
+
+      if (COLOR == COLOR_PLAIN)
+      {
+        // color_integrator.cu:100-134
+        const f3 Xcp = xform_point(P.Tcw, Xwp);
+        float cu, cv;
+        project(P.kc, Xcp, cu, cv);
+
+        if (cu >= 0 && cu < P.width && cv >= 0 && cv < P.height)
+        {
+          const float dist = have_distance ? distance_value : vox[0];
+
+          if (fabsf(dist) < 1.0f)
+          {
+            const int image_index = (int)cv * P.width + (int)cu;
+            const uint32_t weights = __float_as_uint(vox[4]);
+            const int16_t cw = (int16_t)(weights >> 16);
+            const float cwf = cw;
+            const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+            const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
+                P.color[3 * image_index + 2]);
+            const float color_weight = cw + 1;
+            const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+            const f3 c = div3(add3(prev_color, curr_color), color_weight);
+            vox[1] = c.x;
+            vox[2] = c.y;
+            vox[3] = c.z;
+            vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+            dirty = true;
+          }
+        }
+      }
+
+      if (COLOR == COLOR_LIGHT)
+      {
+        // light_integrator.cu:197-248
+        const f3 Xcp = xform_point(P.Tcw, Xwp);
+        float cu, cv;
+        project(P.kc, Xcp, cu, cv);
+
+        if (du >= 0 && du < P.width && dv >= 0 && dv < P.height &&
+            cu >= 0 && cu < P.width && cv >= 0 && cv < P.height)
+        {
+          const int depth_index = (int)dv * P.width + (int)du;
+          const int color_index = (int)cv * P.width + (int)cu;
+
+          if (P.mask[depth_index] > 0.5f)
+          {
+            const float dist = have_distance ? distance_value : vox[0];
+
+            if (fabsf(dist) < 1.0f)
+            {
+              f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
+                  P.color[3 * color_index + 2]);
+              const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
+                  P.normals[3 * depth_index + 2]);
+              const f3 Xcn = xform_dir(P.Tcd, Xdn);
+              const float shading = light_shading(P.light, Xcp, Xcn);
+
+              if (shading > 0.05f)
+              {
+                curr_color = div3(curr_color, shading);
+                const uint32_t weights = __float_as_uint(vox[4]);
+                const int16_t cw = (int16_t)(weights >> 16);
+                const float color_weight = cw + 1;
+                const float cwf = cw;
+                const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+                const f3 c = div3(add3(prev_color, curr_color), color_weight);
+                const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+                vox[1] = c.x;
+                vox[2] = c.y;
+                vox[3] = c.z;
+                vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+                dirty = true;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- stream the tile back (skipped when no voxel of the block changed)
+    if (__any(dirty))
+    {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) r[k] = tile4[k * 64 + lane];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) block4[k * 64 + lane] = r[k];
+    }
+  }
+}
+
+int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, const vk_frame* f,
+    const vk_light* light, const float* mask, bool need_depth, bool need_color, bool need_light)
+{
+  if (!v || !p || !f) return VK_ERR_ARGUMENT;
+  if (!v->voxels || !v->hash_entries || !v->visible_blocks || !v->counters) return VK_ERR_ARGUMENT;
+  if (reinterpret_cast<uintptr_t>(v->voxels) & 15) return VK_ERR_ARGUMENT;
+  if (f->width <= 0 || f->height <= 0) return VK_ERR_ARGUMENT;
+  if (need_depth && !f->depth) return VK_ERR_ARGUMENT;
+  if (need_color && !f->color) return VK_ERR_ARGUMENT;
+  if (need_light && (!f->normals || !mask || !light)) return VK_ERR_ARGUMENT;
+
+  P.voxels4 = reinterpret_cast<float4*>(v->voxels);
+  P.entries = v->hash_entries;
+  P.visible = v->visible_blocks;
+  P.counters = v->counters;
+  P.depth = f->depth;
+  P.color = f->color;
+  P.normals = f->normals;
+  P.mask = mask;
+  P.width = f->width;
+  P.height = f->height;
+  P.kd = f->depth_projection;
+  P.kc = f->color_projection;
+  P.Tdw = make_rt(f->depth_to_world.inv);  // Twd.Inverse(), depth_integrator.cu:104
+
+  // Tcw = Tcd * Tdw (color_integrator.cu:192, light_integrator.cu:337-338),
+  // matrix.h:297-318 product order
+  float Tcw[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+    {
+      float acc = 0.0f;
+      for (int n = 0; n < 4; ++n) acc += f->depth_to_color.m[n * 4 + r] * f->depth_to_world.inv[c * 4 + n];
+      Tcw[c * 4 + r] = acc;
+    }
+  P.Tcw = make_rt(Tcw);
+  P.Tcd = make_rt(f->depth_to_color.m);
+  if (light) P.light = *light; else { P.light.intensity = 1.0f; P.light.position[0] = P.light.position[1] = P.light.position[2] = 0.0f; }
+  P.voxel_length = v->voxel_length;
+  P.block_length = VK_BLOCK_RESOLUTION * v->voxel_length;
+  P.truncation_length = v->truncation_length;
+  P.min_depth = p->min_depth;
+  P.max_depth = p->max_depth;
+  P.max_distance_weight = p->max_distance_weight;
+  P.max_color_weight = p->max_color_weight;
+  return VK_OK;
+}
+
+// Persistent grid: 4 workgroups of 4 waves per CU (40 KiB LDS each, 160 KiB/CU),
+// capped by the largest possible visible count so small volumes do not launch
+// idle workgroups.
+int grid_for(const vk_volume* v)
+{
+  const int max_count = v->main_block_count + v->excess_block_count;
+  const int want = (max_count + kWavesPerGroup - 1) / kWavesPerGroup;
+  const int cap = kCUs * 4;
+  return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
+template <bool DEPTH, int COLOR>
+int launch(const IntegrateParams& P, const vk_volume* v, hipStream_t s)
+{
+  hipLaunchKernelGGL((integrate_kernel<DEPTH, COLOR>), dim3(grid_for(v)), dim3(kWavesPerGroup * 64), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+// ---------------------------------------------------------------- frame mask ----
+
+// ref: light_integrator.cu:17-103 ComputeFrameMaskKernel<16,3>. The reference
+// stages a 22x22 tile with a -1 halo offset and reads it with a +3 centre, so
+// pixel (x,y) looks at [x-1,x+5] x [y-1,y+5]; kept as is.
+__global__ __launch_bounds__(256) void frame_mask_kernel(int width, int height,
+    const float* __restrict__ depths, const float* __restrict__ colors, float depth_threshold,
+    float* __restrict__ mask)
+{
+  constexpr int BD = 16, KS = 3, DIM = BD + 2 * KS;
+  __shared__ float buffer[DIM * DIM];
+
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int x = blockIdx.x * BD + tx;
+  const int y = blockIdx.y * BD + ty;
+
+  for (int sindex = threadIdx.x; sindex < DIM * DIM; sindex += 256)
+  {
+    float depth = 0;
+    const int vx = (blockIdx.x * BD - 1) + (sindex % DIM);
+    const int vy = (blockIdx.y * BD - 1) + (sindex / DIM);
+    if (vx >= 0 && vx < width && vy >= 0 && vy < height) depth = depths[vy * width + vx];
+    buffer[sindex] = depth;
+  }
+
+  __syncthreads();
+
+  if (x < width && y < height)
+  {
+    const int index = y * width + x;
+    const float c0 = colors[3 * index + 0], c1 = colors[3 * index + 1], c2 = colors[3 * index + 2];
+
+    if (c0 < 0.02f || c0 > 0.98f || c1 < 0.02f || c1 > 0.98f || c2 < 0.02f || c2 > 0.98f)
+    {
+      mask[index] = 0.0f;
+      return;
+    }
+
+    float dmin = +FLT_MAX;
+    float dmax = -FLT_MAX;
+    const int cx = tx + KS;
+    const int cy = ty + KS;
+
+    for (int i = -KS; i <= KS; ++i)
+      for (int j = -KS; j <= KS; ++j)
+      {
+        const float depth = buffer[(cy + i) * DIM + (cx + j)];
+        dmin = fminf(depth, dmin);
+        dmax = fmaxf(depth, dmax);
+      }
+
+    mask[index] = (dmax - dmin <= depth_threshold) ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_integrate_depth(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
+  if (rc != VK_OK) return rc;
+  return launch<true, COLOR_NONE>(P, v, vk_s(stream));
+}
+
+int vk_integrate_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, nullptr, nullptr, false, true, false);
+  if (rc != VK_OK) return rc;
+  return launch<false, COLOR_PLAIN>(P, v, vk_s(stream));
+}
+
+int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, true, false);
+  if (rc != VK_OK) return rc;
+  return launch<true, COLOR_PLAIN>(P, v, vk_s(stream));
+}
+
+int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold, float* mask, void* stream)
+{
+  VK_REQUIRE(frame && frame->depth && frame->color && mask && frame->width > 0 && frame->height > 0);
+  const dim3 grid((frame->width + 15) / 16, (frame->height + 15) / 16);
+  hipLaunchKernelGGL(frame_mask_kernel, grid, dim3(256), 0, vk_s(stream), frame->width, frame->height,
+      frame->depth, frame->color, depth_threshold, mask);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p, const vk_light* light,
+    const float* mask, const vk_frame* frame, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, light, mask, false, true, true);
+  if (rc != VK_OK) return rc;
+  return launch<false, COLOR_LIGHT>(P, v, vk_s(stream));
+}
+
+int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const vk_light* light,
+    const float* mask, const vk_frame* frame, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, light, mask, true, true, true);
+  if (rc != VK_OK) return rc;
+  return launch<true, COLOR_LIGHT>(P, v, vk_s(stream));
+}
+
+}  // extern "C"

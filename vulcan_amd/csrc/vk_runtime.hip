@@ -1,0 +1,154 @@
+// vk_runtime.hip — device, stream, memory and event entry points of vk.h.
+// These exist so that hosts built without HIP headers (the C++ class layer in
+// vulcan_amd/host, ctypes) can own device memory; ref: buffer.h:64-103,
+// image.h:85-97, device.h:14-54.
+#include "vk_common.hpp"
+
+#include <string.h>
+
+extern "C" {
+
+const char* vk_error_string(int code)
+{
+  switch (code)
+  {
+    case VK_OK: return "success";
+    case VK_ERR_ARGUMENT: return "invalid argument [vk error -1]";
+    case VK_ERR_UNSUPPORTED: return "unsupported [vk error -2]";
+    case VK_ERR_NO_DEVICE: return "no HIP device [vk error -3]";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown error";
+}
+
+int vk_version(void) { return 100; }
+
+int vk_device_count(int* count)
+{
+  VK_REQUIRE(count);
+  *count = 0;
+  const hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) { *count = 0; return (int)e; }
+  return VK_OK;
+}
+
+int vk_set_device(int device)
+{
+  VK_CHECK(hipSetDevice(device));
+  return VK_OK;
+}
+
+int vk_device_name(char* out, size_t bytes)
+{
+  VK_REQUIRE(out && bytes > 0);
+  int dev = 0;
+  VK_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  VK_CHECK(hipGetDeviceProperties(&prop, dev));
+  strncpy(out, prop.gcnArchName, bytes - 1);
+  out[bytes - 1] = 0;
+  return VK_OK;
+}
+
+int vk_stream_create(void** stream)
+{
+  VK_REQUIRE(stream);
+  hipStream_t s;
+  VK_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = s;
+  return VK_OK;
+}
+
+int vk_stream_destroy(void* stream)
+{
+  VK_CHECK(hipStreamDestroy(vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_stream_synchronize(void* stream)
+{
+  VK_CHECK(hipStreamSynchronize(vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_malloc(void** ptr, size_t bytes)
+{
+  VK_REQUIRE(ptr);
+  *ptr = nullptr;
+  if (bytes == 0) return VK_OK;
+  VK_CHECK(hipMalloc(ptr, bytes));
+  return VK_OK;
+}
+
+int vk_free(void* ptr)
+{
+  if (!ptr) return VK_OK;
+  VK_CHECK(hipFree(ptr));
+  return VK_OK;
+}
+
+int vk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+  if (bytes == 0) return VK_OK;
+  VK_REQUIRE(dst && src);
+  VK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, vk_s(stream)));
+  VK_CHECK(hipStreamSynchronize(vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+  if (bytes == 0) return VK_OK;
+  VK_REQUIRE(dst && src);
+  VK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, vk_s(stream)));
+  VK_CHECK(hipStreamSynchronize(vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+  if (bytes == 0) return VK_OK;
+  VK_REQUIRE(dst && src);
+  VK_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_memset(void* dst, int value, size_t bytes, void* stream)
+{
+  if (bytes == 0) return VK_OK;
+  VK_REQUIRE(dst);
+  VK_CHECK(hipMemsetAsync(dst, value, bytes, vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_event_create(void** event)
+{
+  VK_REQUIRE(event);
+  hipEvent_t e;
+  VK_CHECK(hipEventCreate(&e));
+  *event = e;
+  return VK_OK;
+}
+
+int vk_event_destroy(void* event)
+{
+  VK_CHECK(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+  return VK_OK;
+}
+
+int vk_event_record(void* event, void* stream)
+{
+  VK_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(event), vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+  VK_REQUIRE(ms);
+  VK_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+  VK_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return VK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,749 @@
+// vk_trace.hip — raycasting the hashed volume back to a depth/colour/normal
+// frame on gfx950 (ref: src/tracer.cu, src/tracer.cpp, src/frame.cu).
+//
+// The reference runs ComputePatches -> (host readback of the patch count) ->
+// ComputeBounds with float CAS atomics -> ComputePoints -> ComputeNormals. Here
+// the counts stay on the device, and the fused path (vk_trace /
+// vk_trace_compute_block_bounds) rasterises each visible block's cell rectangle
+// straight into the 80x60 bounds grid with native integer atomic min/max
+// (positive floats order like their bit patterns), skipping the patch list.
+#include "vk_common.hpp"
+
+using namespace vk;
+
+namespace
+{
+
+// ------------------------------------------------------------------ patches ----
+
+struct BlockRect
+{
+  int bmin_x, bmin_y, bmax_x, bmax_y;
+  float near_, far_;
+  int gx, gy, count;
+};
+
+// tracer.cu:23-71: project the 8 corners, running clamp of the cell rectangle
+// and of the depth interval, then the patch grid size.
+__device__ __forceinline__ BlockRect block_rect(const Entry& entry, const Rt& Tcw,
+    const vk_projection& k, float block_length, float min_depth, float max_depth,
+    int image_width, int image_height, int bounds_width, int bounds_height)
+{
+  int bmax_x = -1, bmax_y = -1;
+  int bmin_x = (int16_t)bounds_width, bmin_y = (int16_t)bounds_height;
+  float d0 = +FLT_MAX, d1 = -FLT_MAX;
+
+#pragma unroll
+  for (int z = 0; z <= 1; ++z)
+  {
+    const float wz = block_length * (z + entry.oz);
+#pragma unroll
+    for (int y = 0; y <= 1; ++y)
+    {
+      const float wy = block_length * (y + entry.oy);
+#pragma unroll
+      for (int x = 0; x <= 1; ++x)
+      {
+        const float wx = block_length * (x + entry.ox);
+        const f3 Xcp = xform_point(Tcw, make3(wx, wy, wz));
+        float u, v;
+        project(k, Xcp, u, v);
+        u = bounds_width * u / image_width;
+        v = bounds_height * v / image_height;
+
+        bmin_x = vclampi(vmini(f2s(floorf(u)), bmin_x), 0, bounds_width - 1);
+        bmin_y = vclampi(vmini(f2s(floorf(v)), bmin_y), 0, bounds_height - 1);
+        bmax_x = vclampi(vmaxi(f2s(ceilf(u)), bmax_x), 0, bounds_width - 1);
+        bmax_y = vclampi(vmaxi(f2s(ceilf(v)), bmax_y), 0, bounds_height - 1);
+
+        d0 = vclamp(vmin(Xcp.z, d0), min_depth, max_depth);
+        d1 = vclamp(vmax(Xcp.z, d1), min_depth, max_depth);
+      }
+    }
+  }
+
+  BlockRect r;
+  r.bmin_x = bmin_x; r.bmin_y = bmin_y; r.bmax_x = bmax_x; r.bmax_y = bmax_y;
+  r.near_ = d0; r.far_ = d1;
+  const int rx = bmax_x - bmin_x;
+  const int ry = bmax_y - bmin_y;
+  r.gx = (rx + VK_PATCH_MAX_SIZE - 1) / VK_PATCH_MAX_SIZE;
+  r.gy = (ry + VK_PATCH_MAX_SIZE - 1) / VK_PATCH_MAX_SIZE;
+  r.count = (d1 > d0) ? r.gx * r.gy : 0;
+  if (r.count < 0) r.count = 0;
+  return r;
+}
+
+struct PatchParams
+{
+  const int32_t* indices;
+  const vk_hash_entry* entries;
+  Rt Tcw;
+  vk_projection k;
+  float block_length, min_depth, max_depth;
+  int block_count;
+  const int32_t* block_count_dev;
+  int image_width, image_height, bounds_width, bounds_height;
+  vk_patch* patches;
+  int patch_capacity;
+  int32_t* patch_count;
+  float* bounds;
+};
+
+constexpr int kPatchThreads = 256;
+
+// ref: tracer.cu:13-87. Offsets: wave prefix (ballot-free integer scan with
+// shuffles) + one atomicAdd per workgroup; util.cuh:52-95 PrefixSum used a
+// 2*log2(512)-barrier LDS scan.
+__global__ __launch_bounds__(kPatchThreads) void compute_patches_kernel(PatchParams P)
+{
+  __shared__ int wave_total[kPatchThreads / 64];
+  __shared__ int block_base;
+
+  const int block_count = P.block_count_dev ? min(*P.block_count_dev, P.block_count) : P.block_count;
+  const int index = blockIdx.x * kPatchThreads + threadIdx.x;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+
+  BlockRect r;
+  r.count = 0;
+  r.gx = r.gy = 0;
+
+  if (index < block_count)
+  {
+    const Entry entry = load_entry(P.entries, (uint32_t)P.indices[index]);
+    r = block_rect(entry, P.Tcw, P.k, P.block_length, P.min_depth, P.max_depth, P.image_width,
+        P.image_height, P.bounds_width, P.bounds_height);
+  }
+
+  int incl = r.count;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+
+  if (threadIdx.x == 0)
+  {
+    int total = 0;
+    for (int w = 0; w < kPatchThreads / 64; ++w)
+    {
+      const int c = wave_total[w];
+      wave_total[w] = total;
+      total += c;
+    }
+    block_base = (total > 0) ? atomicAdd(P.patch_count, total) : 0;
+  }
+  __syncthreads();
+
+  if (r.count > 0)
+  {
+    const int offset = block_base + wave_total[wave] + incl - r.count;
+
+    for (int i = 0; i < r.gy; ++i)
+      for (int j = 0; j < r.gx; ++j)
+      {
+        const int output = offset + i * r.gx + j;
+        if (output >= P.patch_capacity) continue;
+        vk_patch patch;
+        patch.origin[0] = (int16_t)(r.bmin_x + VK_PATCH_MAX_SIZE * j);
+        patch.origin[1] = (int16_t)(r.bmin_y + VK_PATCH_MAX_SIZE * i);
+        patch.size[0] = (int16_t)vmini(VK_PATCH_MAX_SIZE, r.bmax_x - patch.origin[0] + 1);
+        patch.size[1] = (int16_t)vmini(VK_PATCH_MAX_SIZE, r.bmax_y - patch.origin[1] + 1);
+        patch.bounds[0] = r.near_;
+        patch.bounds[1] = r.far_;
+        P.patches[output] = patch;
+      }
+  }
+}
+
+// ------------------------------------------------------------------- bounds ----
+
+__global__ __launch_bounds__(256) void reset_bounds_kernel(float2* __restrict__ bounds, int count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) bounds[i] = make_float2(+FLT_MAX, -FLT_MAX);
+}
+
+// Every stored bound is a positive float (clamped to [min_depth, max_depth],
+// min_depth > 0) or the +-FLT_MAX initialiser, so signed-integer min/max on the
+// bit pattern equals float min/max: -FLT_MAX is a negative int, below every
+// positive pattern. One native atomic instead of util.cuh:20-50's CAS loop.
+__device__ __forceinline__ void bound_cell(float* bounds, int pixel, float near_, float far_)
+{
+  int* cell = reinterpret_cast<int*>(bounds) + 2 * pixel;
+  const int n = __float_as_int(near_), f = __float_as_int(far_);
+  if (n < __hip_atomic_load(cell + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(cell + 0, n);
+  if (f > __hip_atomic_load(cell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell + 1, f);
+}
+
+// ref: tracer.cu:89-112
+__global__ __launch_bounds__(256) void compute_bounds_kernel(const vk_patch* __restrict__ patches,
+    float* bounds, int bounds_width, int patch_count, const int32_t* patch_count_dev)
+{
+  const int count = patch_count_dev ? min(*patch_count_dev, patch_count) : patch_count;
+  const int index = blockIdx.x * blockDim.x + threadIdx.x;
+  if (index >= count) return;
+
+  const vk_patch patch = patches[index];
+
+  for (int i = 0; i < patch.size[1]; ++i)
+  {
+    const int y = patch.origin[1] + i;
+    for (int j = 0; j < patch.size[0]; ++j)
+    {
+      const int x = patch.origin[0] + j;
+      bound_cell(bounds, y * bounds_width + x, patch.bounds[0], patch.bounds[1]);
+    }
+  }
+}
+
+// Fused ComputePatches + ComputeBounds: the union of a block's patches is a
+// rectangle anchored at bmin, so rasterising that rectangle gives bit-identical
+// bounds (min/max commute) without materialising the patch list.
+__global__ __launch_bounds__(256) void block_bounds_kernel(PatchParams P)
+{
+  const int block_count = P.block_count_dev ? min(*P.block_count_dev, P.block_count) : P.block_count;
+  const int stride = gridDim.x * blockDim.x;
+
+  for (int index = blockIdx.x * blockDim.x + threadIdx.x; index < block_count; index += stride)
+  {
+    const Entry entry = load_entry(P.entries, (uint32_t)P.indices[index]);
+    const BlockRect r = block_rect(entry, P.Tcw, P.k, P.block_length, P.min_depth, P.max_depth,
+        P.image_width, P.image_height, P.bounds_width, P.bounds_height);
+    if (r.count <= 0) continue;
+
+    // The patches tile [bmin, bmin + 16*g) clipped to bmax (tracer.cu:67-82). With
+    // g = (bmax - bmin + 15) / 16 a span that is an exact multiple of 16 leaves
+    // its last column / row uncovered in the reference; reproduced here.
+    const int x_end = vmini(r.bmax_x, r.bmin_x + VK_PATCH_MAX_SIZE * r.gx - 1);
+    const int y_end = vmini(r.bmax_y, r.bmin_y + VK_PATCH_MAX_SIZE * r.gy - 1);
+    for (int y = r.bmin_y; y <= y_end; ++y)
+      for (int x = r.bmin_x; x <= x_end; ++x)
+        bound_cell(P.bounds, y * P.bounds_width + x, r.near_, r.far_);
+  }
+}
+
+// ------------------------------------------------------------------- points ----
+
+struct PointParams
+{
+  const vk_hash_entry* entries;
+  const vk_voxel* voxels;
+  const float* bounds;
+  uint32_t K;
+  float block_length, voxel_length, trunc_length;
+  Rt Twc, Tcw;
+  vk_projection k;
+  float* depths;
+  float* colors;
+  int image_width, image_height, bounds_width, bounds_height;
+};
+
+struct VoxelData
+{
+  float distance;
+  float r, g, b;
+  int color_weight;
+};
+
+__device__ __forceinline__ VoxelData load_voxel(const vk_voxel* voxels, int index)
+{
+  const float* p = reinterpret_cast<const float*>(voxels) + (size_t)index * 5;
+  VoxelData v;
+  v.distance = p[0];
+  v.r = p[1];
+  v.g = p[2];
+  v.b = p[3];
+  v.color_weight = (int)(int16_t)(__float_as_uint(p[4]) >> 16);
+  return v;
+}
+
+__device__ __forceinline__ VoxelData empty_voxel()
+{
+  VoxelData v;
+  v.distance = 1.0f;
+  v.r = v.g = v.b = 0.0f;
+  v.color_weight = 0;
+  return v;
+}
+
+// One-entry cache of the last hash lookup: consecutive march steps and the
+// eight trilinear corners mostly stay in one block, and the table is read-only
+// during the kernel, so the cached answer is the answer a fresh walk would give.
+struct BlockCache
+{
+  int bx, by, bz;
+  int data;    // pool slot of the block, -1 when absent / unallocated
+  bool valid;
+};
+
+// tracer.cu:364-371: walk the chain until the block matches or the chain ends;
+// a hit needs the match AND IsAllocated().
+__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int bx, int by, int bz)
+{
+  if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
+
+  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
+  while (!entry_is(entry, bx, by, bz) && entry.next != -1) entry = load_entry(P.entries, (uint32_t)entry.next);
+
+  const int data = (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
+  cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
+  return data;
+}
+
+// tracer.cu:114-188 GetVoxel
+__device__ __forceinline__ VoxelData get_voxel(const PointParams& P, BlockCache& cache,
+    int bx, int by, int bz, int vx, int vy, int vz)
+{
+  const int r = VK_BLOCK_RESOLUTION;
+  if (vx < 0) { --bx; vx = r + vx; } else if (vx >= r) { ++bx; vx = vx - r; }
+  if (vy < 0) { --by; vy = r + vy; } else if (vy >= r) { ++by; vy = vy - r; }
+  if (vz < 0) { --bz; vz = r + vz; } else if (vz >= r) { ++bz; vz = vz - r; }
+
+  const int data = find_block(P, cache, bx, by, bz);
+  if (data < 0) return empty_voxel();
+  return load_voxel(P.voxels, VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx);
+}
+
+// tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
+__device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& cache, int bx, int by,
+    int bz, int data, f3 p, float& sdf, f3& color)
+{
+  const float wx = (p.x - bx * P.block_length) / P.voxel_length;
+  const float wy = (p.y - by * P.block_length) / P.voxel_length;
+  const float wz = (p.z - bz * P.block_length) / P.voxel_length;
+
+  const int block_offset = VK_BLOCK_VOXELS * data;
+  const int i0x = f2i(floorf(wx - 0.5f));
+  const int i0y = f2i(floorf(wy - 0.5f));
+  const int i0z = f2i(floorf(wz - 0.5f));
+
+  VoxelData vv[8];  // index dz*4 + dy*2 + dx
+
+  if (i0x >= 0 && i0y >= 0 && i0z >= 0 && i0x < 7 && i0y < 7 && i0z < 7)
+  {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      vv[c] = load_voxel(P.voxels, block_offset + (i0z + ((c >> 2) & 1)) * 64 + (i0y + ((c >> 1) & 1)) * 8 + (i0x + (c & 1)));
+  }
+  else
+  {
+    // the neighbour lookups move away from (bx,by,bz); use a scratch cache so the
+    // march keeps its own
+    BlockCache scratch = cache;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      vv[c] = get_voxel(P, scratch, bx, by, bz, i0x + (c & 1), i0y + ((c >> 1) & 1), i0z + ((c >> 2) & 1));
+  }
+
+  const float w1x = wx - (i0x + 0.5f), w1y = wy - (i0y + 0.5f), w1z = wz - (i0z + 0.5f);
+  const float w0x = 1.0f - w1x, w0y = 1.0f - w1y, w0z = 1.0f - w1z;
+
+  const float n00 = vv[0].distance * w0x + vv[1].distance * w1x;
+  const float n01 = vv[2].distance * w0x + vv[3].distance * w1x;
+  const float n10 = vv[4].distance * w0x + vv[5].distance * w1x;
+  const float n11 = vv[6].distance * w0x + vv[7].distance * w1x;
+  const float n0 = n00 * w0y + n01 * w1y;
+  const float n1 = n10 * w0y + n11 * w1y;
+
+  // tracer.cu:282-289: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`
+  float total = 0.0f;
+  f3 acc = make3(0.0f, 0.0f, 0.0f);
+  float cwt[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+  {
+    const float fz = ((c >> 2) & 1) ? w1z : w0z;
+    const float fy = ((c >> 1) & 1) ? w1y : w0y;
+    const float fx = (c & 1) ? w1x : w0x;
+    const float prod = fz * fy * fx * (float)(vv[c].color_weight > 0 ? 1 : 0);
+    cwt[c] = (prod != 0.0f) ? 1.0f : 0.0f;   // NaN counts as true, as in C
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) total += cwt[c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc = add3(acc, scale3(make3(vv[c].r, vv[c].g, vv[c].b), cwt[c]));
+  if (total > 0) acc = div3(acc, total);
+
+  sdf = n0 * w0z + n1 * w1z;
+  color = acc;
+}
+
+// ref: tracer.cu:317-451
+__global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
+{
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= P.image_width || y >= P.image_height) return;
+
+  const int px = P.bounds_width * x / P.image_width;
+  const int py = P.bounds_height * y / P.image_height;
+  const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
+
+  float depth = 0;
+  float final_depth = 0;
+  f3 color = make3(0, 0, 0);
+
+  if (bound.x < bound.y)
+  {
+    const f3 Xcp = unproject_d(P.k, x + 0.5f, y + 0.5f, bound.x);
+    const f3 Xwp = xform_point(P.Twc, Xcp);
+    const f3 dir = normalized3(xform_dir(P.Twc, Xcp));
+
+    f3 p = Xwp;
+    depth = bound.x;
+    int iters = 0;
+    BlockCache cache;
+    cache.valid = false;
+    cache.bx = cache.by = cache.bz = 0;
+    cache.data = -1;
+
+    do
+    {
+      const int bx = f2i(floorf(p.x / P.block_length));
+      const int by = f2i(floorf(p.y / P.block_length));
+      const int bz = f2i(floorf(p.z / P.block_length));
+      const int data = find_block(P, cache, bx, by, bz);
+
+      if (data >= 0)
+      {
+        const float wx = (p.x - bx * P.block_length) / P.voxel_length;
+        const float wy = (p.y - by * P.block_length) / P.voxel_length;
+        const float wz = (p.z - bz * P.block_length) / P.voxel_length;
+
+        // int(w) can reach 8 on a block face: clamped, see DESIGN.md
+        const int vx = vmini(f2i(wx), 7);
+        const int vy = vmini(f2i(wy), 7);
+        const int vz = vmini(f2i(wz), 7);
+
+        float sdf = reinterpret_cast<const float*>(P.voxels)[(size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5];
+
+        if (sdf <= 0.1f && sdf >= -0.5f) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
+
+        if (sdf <= 0.0f)
+        {
+          p = add3(p, scale3(dir, P.trunc_length * sdf));
+
+          const int bx2 = f2i(floorf(p.x / P.block_length));
+          const int by2 = f2i(floorf(p.y / P.block_length));
+          const int bz2 = f2i(floorf(p.z / P.block_length));
+          const int data2 = find_block(P, cache, bx2, by2, bz2);
+
+          if (data2 >= 0)
+          {
+            interpolate(P, cache, bx2, by2, bz2, data2, p, sdf, color);
+            p = add3(p, scale3(dir, P.trunc_length * sdf));
+          }
+
+          final_depth = xform_point(P.Tcw, p).z;
+          break;
+        }
+        else
+        {
+          p = add3(p, scale3(dir, vmax(P.voxel_length, P.trunc_length * sdf)));
+        }
+      }
+      else
+      {
+        p = add3(p, scale3(dir, P.block_length));
+      }
+
+      depth = xform_point(P.Tcw, p).z;
+
+      if (++iters >= 500)
+      {
+        color = make3(1, 0, 0);
+        break;
+      }
+    }
+    while (depth < bound.y);
+  }
+
+  const int pixel = y * P.image_width + x;
+  P.depths[pixel] = final_depth;
+  P.colors[3 * pixel + 0] = color.x;
+  P.colors[3 * pixel + 1] = color.y;
+  P.colors[3 * pixel + 2] = color.z;
+}
+
+// ------------------------------------------------------------------ normals ----
+
+__device__ __forceinline__ float depth_at(const float* depths, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? depths[y * w + x] : 0.0f;
+}
+
+// ref: frame.cu:9-122. The +-2 px taps are read through L1/L2 (each depth value
+// is used by 5 pixels of neighbouring rows/columns) instead of a 20x20 LDS tile.
+__global__ __launch_bounds__(256) void compute_normals_kernel(const float* __restrict__ depths,
+    vk_projection k, float* __restrict__ normals, int image_width, int image_height)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= image_width || y >= image_height) return;
+
+  const int pad = 2;
+  const float depth = depths[y * image_width + x];
+  f3 normal = make3(0, 0, 0);
+
+  if (depth > 0)
+  {
+    const f3 z0 = unproject_d(k, (x + 0) + 0.5f, (y + 0) + 0.5f, depth);
+    float d;
+
+    d = depth_at(depths, image_width, image_height, x - pad, y);
+    const f3 x0 = (d == 0) ? z0 : scale3(unproject(k, (x - pad) + 0.5f, (y + 0) + 0.5f), d);
+    d = depth_at(depths, image_width, image_height, x + pad, y);
+    const f3 x1 = (d == 0) ? z0 : scale3(unproject(k, (x + pad) + 0.5f, (y + 0) + 0.5f), d);
+    d = depth_at(depths, image_width, image_height, x, y - pad);
+    const f3 y0 = (d == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y - pad) + 0.5f), d);
+    d = depth_at(depths, image_width, image_height, x, y + pad);
+    const f3 y1 = (d == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y + pad) + 0.5f), d);
+
+    const f3 dx = sub3(x0, x1);
+    const f3 dy = sub3(y0, y1);
+
+    if (sqnorm3(dx) > 0 && sqnorm3(dy) > 0) normal = normalized3(cross3(dy, dx));
+  }
+
+  const int output = y * image_width + x;
+  normals[3 * output + 0] = normal.x;
+  normals[3 * output + 1] = normal.y;
+  normals[3 * output + 2] = normal.z;
+}
+
+// ref: frame.cu:126-181 (7x7 bilateral; expf is not bit-reproducible across
+// libm implementations, parity is to 1e-6 relative)
+__global__ __launch_bounds__(256) void filter_depths_kernel(int image_width, int image_height,
+    const float* __restrict__ src, float* __restrict__ dst)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= image_width || y >= image_height) return;
+
+  const int pad = 3;
+  const float d0 = src[y * image_width + x];
+  float dn = 0;
+  float w = 0;
+
+  for (int i = -pad; i <= pad; ++i)
+    for (int j = -pad; j <= pad; ++j)
+    {
+      const float dk = depth_at(src, image_width, image_height, x + j, y + i);
+      const float delta = d0 - dk;
+      float sq = 0;
+      sq += (float)i * (float)i;
+      sq += (float)j * (float)j;
+      const float wr = expf(-sq / (pad * pad));
+      const float ws = expf(-(delta * delta) / 0.0004f);
+      const float ww = wr * ws;
+      dn += ww * dk;
+      w += ww;
+    }
+
+  dst[y * image_width + x] = dn / w;
+}
+
+int fill_patch_params(PatchParams& P, const int32_t* indices, const vk_hash_entry* entries,
+    const vk_transform* Tcw, const vk_projection* projection, float block_length, float min_depth,
+    float max_depth, int block_count, const int32_t* block_count_dev, int image_width,
+    int image_height, int bounds_width, int bounds_height)
+{
+  if (!indices || !entries || !Tcw || !projection) return VK_ERR_ARGUMENT;
+  if (block_count < 0 || image_width <= 0 || image_height <= 0 || bounds_width <= 0 ||
+      bounds_height <= 0 || bounds_width > 32767 || bounds_height > 32767)
+    return VK_ERR_ARGUMENT;
+  P.indices = indices;
+  P.entries = entries;
+  P.Tcw = make_rt(Tcw->m);
+  P.k = *projection;
+  P.block_length = block_length;
+  P.min_depth = min_depth;
+  P.max_depth = max_depth;
+  P.block_count = block_count;
+  P.block_count_dev = block_count_dev;
+  P.image_width = image_width;
+  P.image_height = image_height;
+  P.bounds_width = bounds_width;
+  P.bounds_height = bounds_height;
+  P.patches = nullptr;
+  P.patch_capacity = 0;
+  P.patch_count = nullptr;
+  P.bounds = nullptr;
+  return VK_OK;
+}
+
+int launch_block_bounds(PatchParams& P, float* bounds, hipStream_t s)
+{
+  const int cells = P.bounds_width * P.bounds_height;
+  hipLaunchKernelGGL(reset_bounds_kernel, dim3((cells + 255) / 256), dim3(256), 0, s,
+      reinterpret_cast<float2*>(bounds), cells);
+  VK_LAUNCH_CHECK();
+  if (P.block_count == 0) return VK_OK;
+  P.bounds = bounds;
+  int blocks = (P.block_count + 255) / 256;
+  if (blocks > kCUs * 4) blocks = kCUs * 4;
+  hipLaunchKernelGGL(block_bounds_kernel, dim3(blocks), dim3(256), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length,
+    const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
+    int image_width, int image_height, int bounds_width, int bounds_height, hipStream_t s)
+{
+  PointParams P;
+  P.entries = entries;
+  P.voxels = voxels;
+  P.bounds = bounds;
+  P.K = (uint32_t)block_count;
+  P.block_length = block_length;
+  P.voxel_length = voxel_length;
+  P.trunc_length = trunc_length;
+  P.Twc = make_rt(Twc->m);
+  P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
+  P.k = *projection;
+  P.depths = depths;
+  P.colors = colors;
+  P.image_width = image_width;
+  P.image_height = image_height;
+  P.bounds_width = bounds_width;
+  P.bounds_height = bounds_height;
+  const dim3 grid((image_width + 15) / 16, (image_height + 15) / 16);
+  hipLaunchKernelGGL(compute_points_kernel, grid, dim3(256), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int launch_normals(const float* depths, const vk_projection* projection, float* normals,
+    int image_width, int image_height, hipStream_t s)
+{
+  const dim3 grid((image_width + 63) / 64, (image_height + 3) / 4);
+  hipLaunchKernelGGL(compute_normals_kernel, grid, dim3(256), 0, s, depths, *projection, normals,
+      image_width, image_height);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_trace_compute_patches(const int32_t* indices, const vk_hash_entry* entries,
+    const vk_transform* Tcw, const vk_projection* projection, float block_length, float min_depth,
+    float max_depth, int block_count, const int32_t* block_count_dev, int image_width,
+    int image_height, int bounds_width, int bounds_height, vk_patch* patches, int patch_capacity,
+    int32_t* patch_count, void* stream)
+{
+  PatchParams P;
+  const int rc = fill_patch_params(P, indices, entries, Tcw, projection, block_length, min_depth,
+      max_depth, block_count, block_count_dev, image_width, image_height, bounds_width, bounds_height);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(patches && patch_count && patch_capacity > 0);
+  if (block_count == 0) return VK_OK;
+  P.patches = patches;
+  P.patch_capacity = patch_capacity;
+  P.patch_count = patch_count;
+  hipLaunchKernelGGL(compute_patches_kernel, dim3((block_count + kPatchThreads - 1) / kPatchThreads),
+      dim3(kPatchThreads), 0, vk_s(stream), P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_trace_compute_bounds(const vk_patch* patches, float* bounds, int bounds_width,
+    int patch_count, const int32_t* patch_count_dev, void* stream)
+{
+  VK_REQUIRE(patches && bounds && bounds_width > 0 && patch_count >= 0);
+  if (patch_count == 0) return VK_OK;
+  hipLaunchKernelGGL(compute_bounds_kernel, dim3((patch_count + 255) / 256), dim3(256), 0,
+      vk_s(stream), patches, bounds, bounds_width, patch_count, patch_count_dev);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_trace_reset_bounds(float* bounds, int count, void* stream)
+{
+  VK_REQUIRE(bounds && count > 0);
+  hipLaunchKernelGGL(reset_bounds_kernel, dim3((count + 255) / 256), dim3(256), 0, vk_s(stream),
+      reinterpret_cast<float2*>(bounds), count);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_trace_compute_block_bounds(const int32_t* indices, const vk_hash_entry* entries,
+    const vk_transform* Tcw, const vk_projection* projection, float block_length, float min_depth,
+    float max_depth, int block_count, const int32_t* block_count_dev, int image_width,
+    int image_height, int bounds_width, int bounds_height, float* bounds, void* stream)
+{
+  PatchParams P;
+  const int rc = fill_patch_params(P, indices, entries, Tcw, projection, block_length, min_depth,
+      max_depth, block_count, block_count_dev, image_width, image_height, bounds_width, bounds_height);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(bounds);
+  return launch_block_bounds(P, bounds, vk_s(stream));
+}
+
+int vk_trace_compute_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length,
+    const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
+    int image_width, int image_height, int bounds_width, int bounds_height, void* stream)
+{
+  VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors);
+  VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
+  VK_REQUIRE(block_length > 0 && voxel_length > 0);
+  return launch_points(entries, voxels, bounds, block_count, block_length, voxel_length, trunc_length,
+      Twc, projection, depths, colors, image_width, image_height, bounds_width, bounds_height, vk_s(stream));
+}
+
+int vk_frame_compute_normals(const float* depths, const vk_projection* projection, float* normals,
+    int image_width, int image_height, void* stream)
+{
+  VK_REQUIRE(depths && projection && normals && image_width > 0 && image_height > 0);
+  return launch_normals(depths, projection, normals, image_width, image_height, vk_s(stream));
+}
+
+int vk_frame_filter_depths(int image_width, int image_height, const float* src, float* dst, void* stream)
+{
+  VK_REQUIRE(src && dst && src != dst && image_width > 0 && image_height > 0);
+  const dim3 grid((image_width + 63) / 64, (image_height + 3) / 4);
+  hipLaunchKernelGGL(filter_depths_kernel, grid, dim3(256), 0, vk_s(stream), image_width, image_height, src, dst);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float max_depth,
+    float* bounds, int bounds_width, int bounds_height, float* out_depth, float* out_color,
+    float* out_normals, void* stream)
+{
+  VK_REQUIRE(v && frame && bounds && out_depth && out_color && out_normals);
+  VK_REQUIRE(v->hash_entries && v->voxels && v->visible_blocks && v->counters);
+  hipStream_t s = vk_s(stream);
+  const float block_length = VK_BLOCK_RESOLUTION * v->voxel_length;
+  const int max_count = v->main_block_count + v->excess_block_count;
+
+  // tracer.cpp:49-76 ComputePatches + ComputeBounds, fused, count read on device
+  vk_transform Tcw;
+  for (int i = 0; i < 16; ++i) { Tcw.m[i] = frame->depth_to_world.inv[i]; Tcw.inv[i] = frame->depth_to_world.m[i]; }
+  PatchParams P;
+  int rc = fill_patch_params(P, v->visible_blocks, v->hash_entries, &Tcw, &frame->depth_projection,
+      block_length, min_depth, max_depth, max_count, v->counters + VK_CTR_VISIBLE, frame->width,
+      frame->height, bounds_width, bounds_height);
+  if (rc != VK_OK) return rc;
+  if ((rc = launch_block_bounds(P, bounds, s)) != VK_OK) return rc;
+
+  // tracer.cpp:78-95 ComputePoints
+  if ((rc = launch_points(v->hash_entries, v->voxels, bounds, v->main_block_count, block_length,
+           v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
+           out_depth, out_color, frame->width, frame->height, bounds_width, bounds_height, s)) != VK_OK)
+    return rc;
+
+  // tracer.cpp:97-100 ComputeNormals
+  return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
+}
+
+}  // extern "C"

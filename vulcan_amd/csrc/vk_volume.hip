@@ -1,0 +1,635 @@
+// vk_volume.hip — hashed voxel volume: initialisation, block allocation and
+// visible-block compaction for gfx950 (ref: src/volume.cu).
+//
+// Per SetView the reference issues thrust::replace + 3 kernels and reads the
+// visible count back to the host (volume.cu:494). Here the count stays in
+// v.counters[VK_CTR_VISIBLE]; every consumer reads it on the device.
+#include "vk_common.hpp"
+
+using namespace vk;
+
+namespace
+{
+
+// ------------------------------------------------------------------ init ----
+
+// Voxel::Empty() = {1.0f, 0, 0, 0, (short)0, (short)0}: a 5-dword pattern.
+__global__ __launch_bounds__(256) void fill_voxels_kernel(float4* __restrict__ voxels4, size_t n4)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += stride)
+  {
+    const size_t d = j * 4;  // first dword index of this float4
+    float4 v;
+    v.x = ((d + 0) % 5 == 0) ? 1.0f : 0.0f;
+    v.y = ((d + 1) % 5 == 0) ? 1.0f : 0.0f;
+    v.z = ((d + 2) % 5 == 0) ? 1.0f : 0.0f;
+    v.w = ((d + 3) % 5 == 0) ? 1.0f : 0.0f;
+    voxels4[j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void init_tables_kernel(vk_volume v)
+{
+  const int max_count = v.main_block_count + v.excess_block_count;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+
+  if (i < max_count)
+  {
+    reinterpret_cast<int4*>(v.hash_entries)[i] = make_int4(0, 0, -1, -1);  // HashEntry()
+    v.free_voxel_blocks[i] = i;
+    v.block_visibility[i] = VK_VISIBILITY_FALSE;
+  }
+
+  if (i < v.main_block_count)
+  {
+    v.allocation_types[i] = VK_ALLOC_NONE;
+    reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+  }
+
+  if (i < VK_CTR_COUNT)
+  {
+    int value = 0;
+    if (i == VK_CTR_EXCESS_PTR) value = v.main_block_count;  // volume.cu:581-586
+    if (i == VK_CTR_VOXEL_PTR) value = max_count - 1;        // volume.cu:596-601
+    v.counters[i] = value;
+  }
+}
+
+// ------------------------------------------------------- reset visibility ----
+
+// TRUE (2) -> UNKNOWN (0), FALSE (1) stays (volume.cu:469); 4 entries per lane.
+__global__ __launch_bounds__(256) void reset_visibility_kernel(uint8_t* __restrict__ vis, int count)
+{
+  const int words = count >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+
+  if (i < words)
+  {
+    uint32_t w = reinterpret_cast<uint32_t*>(vis)[i];
+    // a byte is 2 exactly when bit 1 is set (values are 0, 1, 2)
+    const uint32_t is_true = (w >> 1) & 0x01010101u;
+    w &= ~(is_true * 0x3u);
+    reinterpret_cast<uint32_t*>(vis)[i] = w;
+  }
+
+  if (i < (count & 3))
+  {
+    const int j = (words << 2) + i;
+    if (vis[j] == VK_VISIBILITY_TRUE) vis[j] = VK_VISIBILITY_UNKNOWN;
+  }
+}
+
+// ------------------------------------------------------ allocation requests ----
+
+__device__ __forceinline__ unsigned long long request_key(int type, int bx, int by, int bz)
+{
+  return ((unsigned long long)(uint16_t)type << 48) | ((unsigned long long)(uint16_t)(int16_t)bz << 32) |
+         ((unsigned long long)(uint16_t)(int16_t)by << 16) | (unsigned long long)(uint16_t)(int16_t)bx;
+}
+
+__device__ __forceinline__ void mark_visible(uint8_t* vis, uint32_t index)
+{
+  // the reference stores unconditionally (volume.cu:190); reading first keeps
+  // hundreds of rays that cross the same block from all storing the same byte
+  if (vis[index] != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
+}
+
+__device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz)
+{
+  unsigned long long* slot = reinterpret_cast<unsigned long long*>(v.allocation_blocks) + h;
+  const unsigned long long key = request_key(type, bx, by, bz);
+  // monotonic max: skip the atomic when the slot already holds a key >= ours
+  if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key)
+    atomicMax(slot, key);
+  if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
+}
+
+struct RequestParams
+{
+  vk_volume v;
+  const float* depth;
+  int width, height;
+  vk_projection k;
+  Rt Twd;
+};
+
+// ref: volume.cu:87-301. One lane per depth pixel; the lanes of a wave cover a
+// 64x1 run of a row so the depth read is one coalesced 256-byte load.
+__global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.width || y >= P.height) return;
+
+  const vk_volume& v = P.v;
+  const uint32_t K = (uint32_t)v.main_block_count;
+  const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
+  const float truncation_length = v.truncation_length;
+
+  f3 direction = unproject(P.k, x + 0.5f, y + 0.5f);
+  direction = xform_dir(P.Twd, direction);
+  const f3 origin = make3(P.Twd.r[3], P.Twd.r[7], P.Twd.r[11]);
+
+  const float depth = P.depth[y * P.width + x];
+  if (depth < v.min_depth || depth > v.max_depth) return;
+
+  const f3 Xwp = add3(origin, scale3(direction, depth));
+  direction = normalized3(direction);
+  const f3 begin = sub3(Xwp, scale3(direction, truncation_length));
+  const f3 end = add3(Xwp, scale3(direction, truncation_length));
+
+  const int step_x = (direction.x < 0) ? -1 : 1;
+  const int step_y = (direction.y < 0) ? -1 : 1;
+  const int step_z = (direction.z < 0) ? -1 : 1;
+
+  const float inv_block_length = 1.0f / block_length;
+  int bx = f2i(floorf(begin.x * inv_block_length));
+  int by = f2i(floorf(begin.y * inv_block_length));
+  int bz = f2i(floorf(begin.z * inv_block_length));
+  const int ex = f2i(floorf(end.x * inv_block_length));
+  const int ey = f2i(floorf(end.y * inv_block_length));
+  const int ez = f2i(floorf(end.z * inv_block_length));
+
+  const float ox = block_length * (bx + vmaxi(0, step_x)) - begin.x;
+  const float oy = block_length * (by + vmaxi(0, step_y)) - begin.y;
+  const float oz = block_length * (bz + vmaxi(0, step_z)) - begin.z;
+
+  float tmax_x = ox / direction.x;
+  float tmax_y = oy / direction.y;
+  float tmax_z = oz / direction.z;
+  if (direction.x == 0) tmax_x = (float)1E20;
+  if (direction.y == 0) tmax_y = (float)1E20;
+  if (direction.z == 0) tmax_z = (float)1E20;
+
+  const float tdelta_x = (step_x * block_length) / direction.x;
+  const float tdelta_y = (step_y * block_length) / direction.y;
+  const float tdelta_z = (step_z * block_length) / direction.z;
+
+  // A segment of 2*trunc crosses a bounded number of blocks; the cap only
+  // guarantees that every wave exits on NaN / degenerate input.
+  for (int guard = 0; guard < 4096; ++guard)
+  {
+    const uint32_t hash_code = block_hash(bx, by, bz, K);
+    Entry entry = load_entry(v.hash_entries, hash_code);
+
+    if (entry_is(entry, bx, by, bz))
+    {
+      mark_visible(v.block_visibility, hash_code);
+    }
+    else if (entry.data == -1)
+    {
+      mark_visible(v.block_visibility, hash_code);
+      post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz);
+    }
+    else
+    {
+      bool found = false;
+      uint32_t index = hash_code;
+
+      while (entry.next != -1)
+      {
+        index = (uint32_t)entry.next;
+        entry = load_entry(v.hash_entries, index);
+
+        if (entry_is(entry, bx, by, bz))
+        {
+          mark_visible(v.block_visibility, index);
+          found = true;
+          break;
+        }
+      }
+
+      if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz);
+    }
+
+    if (tmax_x < tmax_y)
+    {
+      if (tmax_x < tmax_z)
+      {
+        bx += step_x;
+        if (bx == ex + step_x) break;
+        tmax_x += tdelta_x;
+      }
+      else
+      {
+        bz += step_z;
+        if (bz == ez + step_z) break;
+        tmax_z += tdelta_z;
+      }
+    }
+    else
+    {
+      if (tmax_y < tmax_z)
+      {
+        by += step_y;
+        if (by == ey + step_y) break;
+        tmax_y += tdelta_y;
+      }
+      else
+      {
+        bz += step_z;
+        if (bz == ez + step_z) break;
+        tmax_z += tdelta_z;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------- handle requests ----
+
+constexpr int kHandleThreads = 1024;
+constexpr int kHandlePerThread = 32;                              // buckets per thread per tile
+constexpr int kHandleTile = kHandleThreads * kHandlePerThread;    // 32768 buckets = 32 KB of LDS
+
+// Inclusive block-wide scan of two packed 16-bit-safe counters kept as two ints.
+__device__ __forceinline__ void block_exclusive_scan2(int& a, int& b, int* lds_a, int* lds_b,
+    int& total_a, int& total_b)
+{
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  int ia = a, ib = b;
+
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int ta = __shfl_up(ia, d);
+    const int tb = __shfl_up(ib, d);
+    if (lane >= d) { ia += ta; ib += tb; }
+  }
+
+  if (lane == 63) { lds_a[wave] = ia; lds_b[wave] = ib; }
+  __syncthreads();
+
+  int base_a = 0, base_b = 0;
+  total_a = 0;
+  total_b = 0;
+  for (int w = 0; w < kHandleThreads / 64; ++w)
+  {
+    const int wa = lds_a[w], wb = lds_b[w];
+    if (w < wave) { base_a += wa; base_b += wb; }
+    total_a += wa;
+    total_b += wb;
+  }
+  __syncthreads();
+
+  a = base_a + ia - a;  // exclusive
+  b = base_b + ib - b;
+}
+
+// ref: volume.cu:304-368. ONE workgroup walks the main buckets in ascending
+// order; pool slots and excess indices come from an exclusive scan over the
+// request flags, i.e. exactly what the reference's threads would obtain from
+// atomicSub(voxel_pointer)/atomicAdd(excess_pointer) (volume.cu:337,352) if
+// they ran in index order. Requests are sparse (a few hundred per frame in
+// steady state), so one CU is enough and no inter-workgroup hand-off is needed.
+__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible)
+{
+  __shared__ uint32_t types_lds[kHandleTile / 4];
+  __shared__ int scan_a[kHandleThreads / 64];
+  __shared__ int scan_b[kHandleThreads / 64];
+
+  const int count = v.main_block_count;
+  const int max_count = v.main_block_count + v.excess_block_count;
+  const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
+  const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
+  int done_all = 0, done_excess = 0, committed = 0;
+
+  for (int tile = 0; tile < count; tile += kHandleTile)
+  {
+    const int tile_count = min(kHandleTile, count - tile);
+    const int tile_words = (tile_count + 3) >> 2;
+
+    // stage the request flags: coalesced dword loads (tile is 4-byte aligned)
+    for (int wi = threadIdx.x; wi < kHandleTile / 4; wi += kHandleThreads)
+    {
+      uint32_t w = 0;
+      if (wi < tile_words)
+      {
+        if (wi * 4 + 4 <= tile_count)
+          w = reinterpret_cast<const uint32_t*>(v.allocation_types + tile)[wi];
+        else
+          for (int b = 0; b < tile_count - wi * 4; ++b)
+            w |= (uint32_t)v.allocation_types[tile + wi * 4 + b] << (8 * b);
+      }
+      types_lds[wi] = w;
+    }
+    __syncthreads();
+
+    // count this thread's requests (all) and EXCESS requests
+    int n_all = 0, n_excess = 0;
+    const int first_word = threadIdx.x * (kHandlePerThread / 4);
+#pragma unroll
+    for (int k = 0; k < kHandlePerThread / 4; ++k)
+    {
+      const uint32_t w = types_lds[first_word + k];
+      // byte != 0  <=>  bit0 | bit1 ; byte == 2  <=>  bit1
+      n_all += __popc((w | (w >> 1)) & 0x01010101u);
+      n_excess += __popc((w >> 1) & 0x01010101u);
+    }
+
+    int rank_all = n_all, rank_excess = n_excess, tile_all, tile_excess;
+    block_exclusive_scan2(rank_all, rank_excess, scan_a, scan_b, tile_all, tile_excess);
+    rank_all += done_all;
+    rank_excess += done_excess;
+
+    if (n_all > 0)
+    {
+      for (int k = 0; k < kHandlePerThread; ++k)
+      {
+        const int local = threadIdx.x * kHandlePerThread + k;
+        const int type = (types_lds[local >> 2] >> (8 * (local & 3))) & 0xff;
+        if (type == VK_ALLOC_NONE) continue;
+
+        const int index = tile + local;
+        const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[index];
+        int entry_index = index;
+
+        if (type == VK_ALLOC_EXCESS)
+        {
+          int other_index = index;
+          int next = v.hash_entries[other_index].next;
+          for (int guard = 0; next != -1 && guard < max_count; ++guard)
+          {
+            other_index = next;
+            next = v.hash_entries[other_index].next;
+          }
+
+          entry_index = excess_ptr0 + rank_excess;
+          ++rank_excess;
+
+          if (entry_index < max_count)
+          {
+            v.hash_entries[other_index].next = entry_index;
+            v.block_visibility[entry_index] = VK_VISIBILITY_TRUE;
+          }
+        }
+
+        const int voxel_index = voxel_ptr0 - rank_all;
+        ++rank_all;
+
+        if (entry_index < max_count && voxel_index >= 0)
+        {
+          // entry = {block (pad cleared), data = free slot, next = -1}
+          const int lo = (int)(packed & 0xffffffffull);
+          const int hi = (int)((packed >> 32) & 0xffffull);
+          reinterpret_cast<int4*>(v.hash_entries)[entry_index] =
+              make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
+          ++committed;
+        }
+
+        v.allocation_types[index] = VK_ALLOC_NONE;
+        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[index] = 0ull;
+      }
+    }
+
+    done_all += tile_all;
+    done_excess += tile_excess;
+    __syncthreads();
+  }
+
+  // committed count: block reduce through the scan scratch
+  {
+    int c = committed;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane_id() == 0) scan_a[threadIdx.x >> 6] = c;
+    __syncthreads();
+  }
+
+  if (threadIdx.x == 0)
+  {
+    int c = 0;
+    for (int w = 0; w < kHandleThreads / 64; ++w) c += scan_a[w];
+    v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - done_all;
+    v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + done_excess;
+    v.counters[VK_CTR_REQUESTS] = c;
+    v.counters[VK_CTR_DROPPED] += done_all - c;
+    // volume.cu:488 ResetBufferSize for the visibility pass that follows in SetView
+    if (zero_visible) v.counters[VK_CTR_VISIBLE] = 0;
+  }
+}
+
+// -------------------------------------------------------- update visibility ----
+
+struct VisibilityParams
+{
+  vk_volume v;
+  int width, height;
+  vk_projection k;
+  Rt Tdw;
+};
+
+constexpr int kVisThreads = 1024;
+
+// ref: volume.cu:25-84. Frustum test of UNKNOWN entries + compaction of the
+// visible ones. Compaction: wave ballot -> per-wave count in LDS -> ONE atomic
+// per 1024-entry workgroup (72 atomics for 73 216 entries, instead of the
+// reference's 10-step LDS scan + atomic per 512).
+__global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(VisibilityParams P)
+{
+  __shared__ int wave_count[kVisThreads / 64];
+  __shared__ int block_base;
+
+  const vk_volume& v = P.v;
+  const int count = v.main_block_count + v.excess_block_count;
+  const int index = blockIdx.x * kVisThreads + threadIdx.x;
+  const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
+  bool visible = false;
+
+  if (index < count)
+  {
+    const int visibility = v.block_visibility[index];
+    visible = (visibility == VK_VISIBILITY_TRUE);
+
+    if (visibility == VK_VISIBILITY_UNKNOWN)
+    {
+      const Entry e = load_entry(v.hash_entries, index);
+
+      for (int i = 0; i < 8; ++i)
+      {
+        f3 Xwp;
+        Xwp.x = block_length * (e.ox + ((i & 1) >> 0));
+        Xwp.y = block_length * (e.oy + ((i & 2) >> 1));
+        Xwp.z = block_length * (e.oz + ((i & 4) >> 2));
+        const f3 Xdp = xform_point(P.Tdw, Xwp);
+        if (Xdp.z < 0) continue;
+
+        float u, w;
+        project(P.k, Xdp, u, w);
+
+        if (u >= 0 && u <= P.width && w >= 0 && w <= P.height)
+        {
+          visible = true;
+          break;
+        }
+      }
+
+      if (!visible) v.block_visibility[index] = VK_VISIBILITY_FALSE;
+    }
+  }
+
+  const unsigned long long mask = __ballot(visible);
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0) wave_count[wave] = __popcll(mask);
+  __syncthreads();
+
+  if (threadIdx.x == 0)
+  {
+    int total = 0;
+    for (int w = 0; w < kVisThreads / 64; ++w)
+    {
+      const int c = wave_count[w];
+      wave_count[w] = total;
+      total += c;
+    }
+    block_base = (total > 0) ? atomicAdd(&v.counters[VK_CTR_VISIBLE], total) : 0;
+  }
+  __syncthreads();
+
+  if (visible)
+  {
+    const int offset = block_base + wave_count[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+    v.visible_blocks[offset] = index;
+  }
+}
+
+int check_volume(const vk_volume* v)
+{
+  if (!v) return VK_ERR_ARGUMENT;
+  if (!v->voxels || !v->hash_entries || !v->free_voxel_blocks || !v->allocation_types ||
+      !v->allocation_blocks || !v->block_visibility || !v->visible_blocks || !v->counters)
+    return VK_ERR_ARGUMENT;
+  if (v->main_block_count <= 0 || v->excess_block_count < 0) return VK_ERR_ARGUMENT;
+  if (!(v->voxel_length > 0) || !(v->truncation_length > 0)) return VK_ERR_ARGUMENT;
+  if ((reinterpret_cast<uintptr_t>(v->allocation_blocks) & 7) || (reinterpret_cast<uintptr_t>(v->hash_entries) & 15) ||
+      (reinterpret_cast<uintptr_t>(v->voxels) & 15) || (reinterpret_cast<uintptr_t>(v->block_visibility) & 3) ||
+      (reinterpret_cast<uintptr_t>(v->allocation_types) & 3))
+    return VK_ERR_ARGUMENT;
+  return VK_OK;
+}
+
+int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
+    const vk_projection* projection, const vk_transform* Twd, hipStream_t s)
+{
+  RequestParams P;
+  P.v = *v;
+  P.depth = depth;
+  P.width = width;
+  P.height = height;
+  P.k = *projection;
+  P.Twd = make_rt(Twd->m);
+  const dim3 grid((width + 63) / 64, (height + 3) / 4);
+  hipLaunchKernelGGL(create_requests_kernel, grid, dim3(256), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int launch_update_visibility(const vk_volume* v, int width, int height,
+    const vk_projection* projection, const float* Tdw_m, hipStream_t s)
+{
+  VisibilityParams P;
+  P.v = *v;
+  P.width = width;
+  P.height = height;
+  P.k = *projection;
+  P.Tdw = make_rt(Tdw_m);
+  const int count = v->main_block_count + v->excess_block_count;
+  hipLaunchKernelGGL(update_visibility_kernel, dim3((count + kVisThreads - 1) / kVisThreads),
+      dim3(kVisThreads), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int launch_reset_visibility(const vk_volume* v, hipStream_t s)
+{
+  const int count = v->main_block_count + v->excess_block_count;
+  const int threads = (count >> 2) > 4 ? (count >> 2) : 4;
+  hipLaunchKernelGGL(reset_visibility_kernel, dim3((threads + 255) / 256), dim3(256), 0, s,
+      v->block_visibility, count);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_volume_initialize(const vk_volume* v, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  const int max_count = v->main_block_count + v->excess_block_count;
+  const size_t n4 = (size_t)max_count * VK_BLOCK_VOXELS * sizeof(vk_voxel) / 16;
+  const int blocks = (int)((n4 + 255) / 256 < (size_t)(kCUs * 16) ? (n4 + 255) / 256 : (size_t)(kCUs * 16));
+  hipLaunchKernelGGL(fill_voxels_kernel, dim3(blocks), dim3(256), 0, vk_s(stream),
+      reinterpret_cast<float4*>(v->voxels), n4);
+  VK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(init_tables_kernel, dim3((max_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_volume_reset_block_visibility(const vk_volume* v, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  return launch_reset_visibility(v, vk_s(stream));
+}
+
+int vk_volume_create_allocation_requests(const vk_volume* v, const float* depth, int width,
+    int height, const vk_projection* projection, const vk_transform* Twd, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(depth && projection && Twd && width > 0 && height > 0);
+  return launch_create_requests(v, depth, width, height, projection, Twd, vk_s(stream));
+}
+
+int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  hipLaunchKernelGGL(handle_requests_kernel, dim3(1), dim3(kHandleThreads), 0, vk_s(stream), *v, 0);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
+    const vk_projection* projection, const vk_transform* Tdw, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(projection && Tdw && width > 0 && height > 0);
+  // volume.cu:488 ResetBufferSize
+  VK_CHECK(hipMemsetAsync(v->counters + VK_CTR_VISIBLE, 0, sizeof(int32_t), vk_s(stream)));
+  return launch_update_visibility(v, width, height, projection, Tdw->m, vk_s(stream));
+}
+
+int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0);
+  hipStream_t s = vk_s(stream);
+  int r;
+  if ((r = launch_reset_visibility(v, s)) != VK_OK) return r;
+  if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
+           &frame->depth_projection, &frame->depth_to_world, s)) != VK_OK) return r;
+  hipLaunchKernelGGL(handle_requests_kernel, dim3(1), dim3(kHandleThreads), 0, s, *v, 1);
+  VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]
+  return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
+      frame->depth_to_world.inv, s);
+}
+
+int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)
+{
+  VK_REQUIRE(v && v->counters && host_out);
+  VK_CHECK(hipMemcpyAsync(host_out, v->counters, sizeof(int32_t) * VK_CTR_COUNT,
+      hipMemcpyDeviceToHost, vk_s(stream)));
+  VK_CHECK(hipStreamSynchronize(vk_s(stream)));
+  return VK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend
+"nccl" on ROCm) — or gloo on CPU for the tests.
+
+The fusion + raycast path shards by frame / camera: every rank owns a replica
+volume and its own frames, and no voxel data ever crosses xGMI. The only
+exchange step the path has is the ICP normal system of a rigid multi-camera rig
+(SURVEY.md §8e): 27 useful floats, summed over ranks once per Gauss-Newton
+iteration, after which every rank solves the same 6x6 system. At 192 bytes the
+collective is latency bound, so it is issued as ONE all-reduce of the packed
+48-float buffer on the compute stream, straight from device memory.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
+        int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+    Returns (rank, local_rank, world_size); a single process needs no group."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def shard(items, rank, world):
+    """Frames / views owned by `rank`: item i goes to rank i % world."""
+    return [x for i, x in enumerate(items) if i % world == rank]
+
+
+def allreduce_system(system):
+    """Sum the packed ICP system (api.DepthTracker.system, 48 floats) over ranks, in
+    place. No-op for a single process."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(system, op=dist.ReduceOp.SUM)
+    return system
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """Max of a python float over ranks (bench timing contract)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
