@@ -101,8 +101,10 @@ enum {
   VK_CTR_VOXEL_PTR  = 1,  /* voxel_pointer: top of the free-slot stack */
   VK_CTR_EXCESS_PTR = 2,  /* excess_pointer: next free excess entry */
   VK_CTR_PATCHES    = 3,  /* tracer patch count (tracer.h buffer_size_) */
-  VK_CTR_REQUESTS   = 4,  /* requests committed by the last handle pass */
-  VK_CTR_DROPPED    = 5,  /* requests dropped: pool or excess list exhausted */
+  VK_CTR_REQUESTS   = 4,  /* requests seen by the last handle pass */
+  VK_CTR_DROPPED    = 5,  /* requests dropped so far: pool or excess list exhausted */
+  VK_CTR_PENDING_ALL    = 6,  /* internal: pointer updates of a handle pass, not yet folded in */
+  VK_CTR_PENDING_EXCESS = 7,
   VK_CTR_COUNT      = 8
 };
 
@@ -309,10 +311,16 @@ VK_API int vk_frame_compute_normals(const float* depths,
 VK_API int vk_frame_filter_depths(int image_width, int image_height,
     const float* src, float* dst, void* stream);
 
+/* Floats the `bounds` scratch of vk_trace must hold: the bounds grid itself
+ * (tracer.cpp:140: 80*60 float2) followed by the per-workgroup private copies
+ * the fused bounds pass reduces into. */
+VK_API size_t vk_trace_bounds_floats(int bounds_width, int bounds_height);
+
 /* ref: src/tracer.cpp:41-47 Tracer::Trace — bounds (fused), points, normals.
  * `frame` supplies pose + intrinsics; outputs go to depth/color/normals
  * (all non-const device pointers owned by the caller). `bounds` is the
- * tracer's 80x60 float2 scratch (tracer.cpp:140). */
+ * tracer's scratch, vk_trace_bounds_floats(w, h) floats; on return its first
+ * w*h float2 hold the (near, far) grid of Tracer::bounds_. */
 VK_API int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth,
     float max_depth, float* bounds, int bounds_width, int bounds_height,
     float* out_depth, float* out_color, float* out_normals, void* stream);

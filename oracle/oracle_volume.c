@@ -278,7 +278,7 @@ void orc_volume_handle_allocation_requests(const vk_volume* v)
     memset(&v->allocation_blocks[index], 0, sizeof(vk_block));
   }
 
-  v->counters[VK_CTR_REQUESTS] = committed;
+  v->counters[VK_CTR_REQUESTS] = committed + dropped;
   v->counters[VK_CTR_DROPPED] += dropped;
 }
 

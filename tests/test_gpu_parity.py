@@ -341,9 +341,11 @@ def test_trace_matches_oracle(api, orc, traced):
     odepth, ocolor, onormals, obounds, steps = orc.trace(hv, hf, want_steps=True)
     out = api.Frame(torch.zeros((hf.height, hf.width), dtype=torch.float32, device="cuda"),
                     hf.depth_projection, hf.depth_to_world)
-    api.Tracer(dv).trace(out)
+    tracer = api.Tracer(dv)
+    tracer.trace(out)
     sync()
     d, c, n = out.depth.cpu().numpy(), out.color.cpu().numpy(), out.normals.cpu().numpy()
+    assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)     # Tracer::bounds_ after Trace
     assert (odepth > 0).sum() > 100000 and steps.max() < 500
     assert np.array_equal(d, odepth)                        # bit-exact raycast depth
     assert np.array_equal(c, ocolor)

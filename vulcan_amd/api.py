@@ -59,6 +59,7 @@ _SIGNATURES = {
     "vk_trace_compute_points": ([_P, _P, _P, _I, _F, _F, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P], _I),
     "vk_frame_compute_normals": ([_P, _P, _P, _I, _I, _P], _I),
     "vk_frame_filter_depths": ([_I, _I, _P, _P, _P], _I),
+    "vk_trace_bounds_floats": ([_I, _I], _SZ),
     "vk_trace": ([_P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P], _I),
     "vk_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
     "vk_color_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
@@ -364,7 +365,9 @@ class Tracer:
         self.volume = volume
         self.depth_range = (0.1, 5.0)
         dev = volume.device
-        self.bounds = torch.empty((self.BOUNDS_H, self.BOUNDS_W, 2), dtype=torch.float32, device=dev)
+        n = int(lib().vk_trace_bounds_floats(self.BOUNDS_W, self.BOUNDS_H))
+        self.bounds_scratch = torch.empty(n, dtype=torch.float32, device=dev)
+        self.bounds = self.bounds_scratch[:self.BOUNDS_W * self.BOUNDS_H * 2].view(self.BOUNDS_H, self.BOUNDS_W, 2)
         self.patches = _dev_bytes(self.PATCH_CAPACITY * 16, dev)
         self.patch_count = torch.zeros(1, dtype=torch.int32, device=dev)
 

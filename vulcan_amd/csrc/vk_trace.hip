@@ -227,13 +227,85 @@ __global__ __launch_bounds__(256) void block_bounds_kernel(PatchParams P)
   }
 }
 
+// Fast path of the fused bounds pass. Global float atomics on 9600 words from
+// ~7k blocks x ~10 cells ran at ~1.5 atomics/ns (77 us per frame, r01 profile):
+// instead each of kBoundsGroups workgroups folds its share of the visible blocks
+// into a PRIVATE copy of the grid in LDS (ds_min/ds_max_i32), then stores the
+// copy with plain coalesced writes. The consumer takes min/max over the
+// kBoundsGroups copies (compute_points_kernel, or merge_bounds_kernel for the
+// stand-alone API). No global atomics, no reset pass, no inter-workgroup order.
+constexpr int kBoundsGroups = 8;
+constexpr int kBoundsThreads = 1024;
+constexpr int kBoundsMaxCells = 8192;  // 64 KiB of LDS
+
+__global__ __launch_bounds__(kBoundsThreads) void block_bounds_partial_kernel(PatchParams P, float2* __restrict__ partials)
+{
+  __shared__ int grid[2 * kBoundsMaxCells];
+
+  const int cells = P.bounds_width * P.bounds_height;
+  const int block_count = P.block_count_dev ? min(*P.block_count_dev, P.block_count) : P.block_count;
+
+  for (int c = threadIdx.x; c < cells; c += kBoundsThreads)
+  {
+    grid[2 * c + 0] = __float_as_int(+FLT_MAX);
+    grid[2 * c + 1] = __float_as_int(-FLT_MAX);
+  }
+  __syncthreads();
+
+  for (int index = blockIdx.x * kBoundsThreads + threadIdx.x; index < block_count; index += kBoundsGroups * kBoundsThreads)
+  {
+    const Entry entry = load_entry(P.entries, (uint32_t)P.indices[index]);
+    const BlockRect r = block_rect(entry, P.Tcw, P.k, P.block_length, P.min_depth, P.max_depth,
+        P.image_width, P.image_height, P.bounds_width, P.bounds_height);
+    if (r.count <= 0) continue;
+
+    const int x_end = vmini(r.bmax_x, r.bmin_x + VK_PATCH_MAX_SIZE * r.gx - 1);
+    const int y_end = vmini(r.bmax_y, r.bmin_y + VK_PATCH_MAX_SIZE * r.gy - 1);
+    const int n = __float_as_int(r.near_), f = __float_as_int(r.far_);
+    for (int y = r.bmin_y; y <= y_end; ++y)
+      for (int x = r.bmin_x; x <= x_end; ++x)
+      {
+        const int c = y * P.bounds_width + x;
+        atomicMin(&grid[2 * c + 0], n);
+        atomicMax(&grid[2 * c + 1], f);
+      }
+  }
+  __syncthreads();
+
+  float2* out = partials + (size_t)blockIdx.x * cells;
+  for (int c = threadIdx.x; c < cells; c += kBoundsThreads)
+    out[c] = make_float2(__int_as_float(grid[2 * c + 0]), __int_as_float(grid[2 * c + 1]));
+}
+
+__device__ __forceinline__ float2 merged_bound(const float2* __restrict__ partials, int cells, int cell)
+{
+  float2 b = partials[cell];
+#pragma unroll
+  for (int g = 1; g < kBoundsGroups; ++g)
+  {
+    const float2 o = partials[(size_t)g * cells + cell];
+    b.x = vmin(o.x, b.x);
+    b.y = vmax(o.y, b.y);
+  }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void merge_bounds_kernel(const float2* __restrict__ partials,
+    float2* __restrict__ bounds, int cells)
+{
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < cells) bounds[c] = merged_bound(partials, cells, c);
+}
+
 // ------------------------------------------------------------------- points ----
 
 struct PointParams
 {
   const vk_hash_entry* entries;
   const vk_voxel* voxels;
-  const float* bounds;
+  const float* bounds;        // merged grid (read when partials == nullptr)
+  const float2* partials;     // kBoundsGroups private grids (fused path), or nullptr
+  float2* bounds_out;         // fused path: the merged grid is written back here
   uint32_t K;
   float block_length, voxel_length, trunc_length;
   Rt Twc, Tcw;
@@ -243,32 +315,72 @@ struct PointParams
   int image_width, image_height, bounds_width, bounds_height;
 };
 
-struct VoxelData
+// A voxel is 5 dwords {distance, r, g, b, (cw << 16 | dw)} at a 4-byte aligned
+// address; gfx950 global loads only need dword alignment, so a voxel is read as
+// dwordx4 + dword, and the x-adjacent pair of a trilinear row as 10 contiguous
+// dwords, instead of the reference's five scalar loads per voxel.
+typedef float vf2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float vf3 __attribute__((ext_vector_type(3), aligned(4)));
+
+struct Corner
 {
   float distance;
   float r, g, b;
   int color_weight;
 };
 
-__device__ __forceinline__ VoxelData load_voxel(const vk_voxel* voxels, int index)
+__device__ __forceinline__ Corner empty_corner()   // Voxel::Empty(), voxel.h:31-39
 {
-  const float* p = reinterpret_cast<const float*>(voxels) + (size_t)index * 5;
-  VoxelData v;
-  v.distance = p[0];
-  v.r = p[1];
-  v.g = p[2];
-  v.b = p[3];
-  v.color_weight = (int)(int16_t)(__float_as_uint(p[4]) >> 16);
-  return v;
+  Corner c;
+  c.distance = 1.0f;
+  c.r = c.g = c.b = 0.0f;
+  c.color_weight = 0;
+  return c;
 }
 
-__device__ __forceinline__ VoxelData empty_voxel()
+__device__ __forceinline__ int color_weight_of(float packed)
 {
-  VoxelData v;
-  v.distance = 1.0f;
-  v.r = v.g = v.b = 0.0f;
-  v.color_weight = 0;
-  return v;
+  return (int)(int16_t)(__float_as_uint(packed) >> 16);
+}
+
+// A voxel whose colour weight is 0 has never had its colour written (every
+// colour update increments the weight), so its colour is the initial (0,0,0):
+// the 12 colour bytes are only fetched when the weight is positive.
+__device__ __forceinline__ Corner load_corner(const float* __restrict__ vox)
+{
+  Corner c;
+  c.distance = vox[0];
+  c.color_weight = color_weight_of(vox[4]);
+  c.r = c.g = c.b = 0.0f;
+  if (c.color_weight > 0)
+  {
+    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 1);
+    c.r = rgb.x; c.g = rgb.y; c.b = rgb.z;
+  }
+  return c;
+}
+
+// two x-adjacent voxels: d0 | (w0, d1) | w1 as dword, dwordx2, dword
+__device__ __forceinline__ void load_corner_pair(const float* __restrict__ vox, Corner& c0, Corner& c1)
+{
+  c0.distance = vox[0];
+  const vf2 mid = *reinterpret_cast<const vf2*>(vox + 4);
+  const float w1 = vox[9];
+  c0.color_weight = color_weight_of(mid.x);
+  c1.distance = mid.y;
+  c1.color_weight = color_weight_of(w1);
+  c0.r = c0.g = c0.b = 0.0f;
+  c1.r = c1.g = c1.b = 0.0f;
+  if (c0.color_weight > 0)
+  {
+    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 1);
+    c0.r = rgb.x; c0.g = rgb.y; c0.b = rgb.z;
+  }
+  if (c1.color_weight > 0)
+  {
+    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 6);
+    c1.r = rgb.x; c1.g = rgb.y; c1.b = rgb.z;
+  }
 }
 
 // One-entry cache of the last hash lookup: consecutive march steps and the
@@ -296,7 +408,7 @@ __device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cach
 }
 
 // tracer.cu:114-188 GetVoxel
-__device__ __forceinline__ VoxelData get_voxel(const PointParams& P, BlockCache& cache,
+__device__ __forceinline__ Corner get_voxel(const PointParams& P, BlockCache& cache,
     int bx, int by, int bz, int vx, int vy, int vz)
 {
   const int r = VK_BLOCK_RESOLUTION;
@@ -305,8 +417,8 @@ __device__ __forceinline__ VoxelData get_voxel(const PointParams& P, BlockCache&
   if (vz < 0) { --bz; vz = r + vz; } else if (vz >= r) { ++bz; vz = vz - r; }
 
   const int data = find_block(P, cache, bx, by, bz);
-  if (data < 0) return empty_voxel();
-  return load_voxel(P.voxels, VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx);
+  if (data < 0) return empty_corner();
+  return load_corner(reinterpret_cast<const float*>(P.voxels) + (size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5);
 }
 
 // tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
@@ -322,13 +434,16 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   const int i0y = f2i(floorf(wy - 0.5f));
   const int i0z = f2i(floorf(wz - 0.5f));
 
-  VoxelData vv[8];  // index dz*4 + dy*2 + dx
+  Corner vv[8];  // index dz*4 + dy*2 + dx
 
   if (i0x >= 0 && i0y >= 0 && i0z >= 0 && i0x < 7 && i0y < 7 && i0z < 7)
   {
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      vv[c] = load_voxel(P.voxels, block_offset + (i0z + ((c >> 2) & 1)) * 64 + (i0y + ((c >> 1) & 1)) * 8 + (i0x + (c & 1)));
+    // all eight corners in this block: four x-adjacent pairs
+    const float* base = reinterpret_cast<const float*>(P.voxels) + (size_t)(block_offset + i0z * 64 + i0y * 8 + i0x) * 5;
+    load_corner_pair(base, vv[0], vv[1]);
+    load_corner_pair(base + 8 * 5, vv[2], vv[3]);
+    load_corner_pair(base + 64 * 5, vv[4], vv[5]);
+    load_corner_pair(base + 72 * 5, vv[6], vv[7]);
   }
   else
   {
@@ -373,16 +488,35 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   color = acc;
 }
 
-// ref: tracer.cu:317-451
+// ref: tracer.cu:317-451. One lane per pixel; a wave covers an 8x8 pixel tile
+// (one bounds cell at 640x480 / 80x60) so its rays start at the same depth, run
+// a similar number of steps and walk the same few blocks; a workgroup is 2x2
+// such tiles.
 __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
 {
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
   if (x >= P.image_width || y >= P.image_height) return;
 
   const int px = P.bounds_width * x / P.image_width;
   const int py = P.bounds_height * y / P.image_height;
-  const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
+  const int cell = py * P.bounds_width + px;
+  float2 bound;
+
+  if (P.partials)
+  {
+    bound = merged_bound(P.partials, P.bounds_width * P.bounds_height, cell);
+    // the first pixel that maps to a cell publishes the merged value (Tracer::bounds_)
+    const bool first_x = (x == 0) || (P.bounds_width * (x - 1) / P.image_width != px);
+    const bool first_y = (y == 0) || (P.bounds_height * (y - 1) / P.image_height != py);
+    if (first_x && first_y) P.bounds_out[cell] = bound;
+  }
+  else
+  {
+    bound = reinterpret_cast<const float2*>(P.bounds)[cell];
+  }
 
   float depth = 0;
   float final_depth = 0;
@@ -577,9 +711,26 @@ int fill_patch_params(PatchParams& P, const int32_t* indices, const vk_hash_entr
   return VK_OK;
 }
 
-int launch_block_bounds(PatchParams& P, float* bounds, hipStream_t s)
+// Fused patches+bounds. `partials` (device, kBoundsGroups grids) selects the
+// LDS-privatised path; with merge == true the merged grid is also written to
+// `bounds` by a small kernel (stand-alone API), otherwise the consumer merges.
+int launch_block_bounds(PatchParams& P, float* bounds, float2* partials, bool merge, hipStream_t s)
 {
   const int cells = P.bounds_width * P.bounds_height;
+
+  if (partials && cells <= kBoundsMaxCells)
+  {
+    hipLaunchKernelGGL(block_bounds_partial_kernel, dim3(kBoundsGroups), dim3(kBoundsThreads), 0, s, P, partials);
+    VK_LAUNCH_CHECK();
+    if (merge)
+    {
+      hipLaunchKernelGGL(merge_bounds_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, partials,
+          reinterpret_cast<float2*>(bounds), cells);
+      VK_LAUNCH_CHECK();
+    }
+    return VK_OK;
+  }
+
   hipLaunchKernelGGL(reset_bounds_kernel, dim3((cells + 255) / 256), dim3(256), 0, s,
       reinterpret_cast<float2*>(bounds), cells);
   VK_LAUNCH_CHECK();
@@ -593,7 +744,7 @@ int launch_block_bounds(PatchParams& P, float* bounds, hipStream_t s)
 }
 
 int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
-    int block_count, float block_length, float voxel_length, float trunc_length,
+    const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
     int image_width, int image_height, int bounds_width, int bounds_height, hipStream_t s)
 {
@@ -601,6 +752,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.entries = entries;
   P.voxels = voxels;
   P.bounds = bounds;
+  P.partials = partials;
+  P.bounds_out = reinterpret_cast<float2*>(const_cast<float*>(bounds));
   P.K = (uint32_t)block_count;
   P.block_length = block_length;
   P.voxel_length = voxel_length;
@@ -685,7 +838,7 @@ int vk_trace_compute_block_bounds(const int32_t* indices, const vk_hash_entry* e
       max_depth, block_count, block_count_dev, image_width, image_height, bounds_width, bounds_height);
   if (rc != VK_OK) return rc;
   VK_REQUIRE(bounds);
-  return launch_block_bounds(P, bounds, vk_s(stream));
+  return launch_block_bounds(P, bounds, nullptr, false, vk_s(stream));
 }
 
 int vk_trace_compute_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
@@ -696,7 +849,7 @@ int vk_trace_compute_points(const vk_hash_entry* entries, const vk_voxel* voxels
   VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors);
   VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
   VK_REQUIRE(block_length > 0 && voxel_length > 0);
-  return launch_points(entries, voxels, bounds, block_count, block_length, voxel_length, trunc_length,
+  return launch_points(entries, voxels, bounds, nullptr, block_count, block_length, voxel_length, trunc_length,
       Twc, projection, depths, colors, image_width, image_height, bounds_width, bounds_height, vk_s(stream));
 }
 
@@ -714,6 +867,13 @@ int vk_frame_filter_depths(int image_width, int image_height, const float* src, 
   hipLaunchKernelGGL(filter_depths_kernel, grid, dim3(256), 0, vk_s(stream), image_width, image_height, src, dst);
   VK_LAUNCH_CHECK();
   return VK_OK;
+}
+
+size_t vk_trace_bounds_floats(int bounds_width, int bounds_height)
+{
+  if (bounds_width <= 0 || bounds_height <= 0) return 0;
+  const size_t cells = (size_t)bounds_width * bounds_height;
+  return 2 * cells * (cells <= (size_t)kBoundsMaxCells ? 1 + kBoundsGroups : 1);
 }
 
 int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float max_depth,
@@ -734,10 +894,13 @@ int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float m
       block_length, min_depth, max_depth, max_count, v->counters + VK_CTR_VISIBLE, frame->width,
       frame->height, bounds_width, bounds_height);
   if (rc != VK_OK) return rc;
-  if ((rc = launch_block_bounds(P, bounds, s)) != VK_OK) return rc;
+  // `bounds` = merged grid followed by kBoundsGroups private grids (vk_trace_bounds_floats)
+  const int cells = bounds_width * bounds_height;
+  float2* partials = (cells <= kBoundsMaxCells) ? reinterpret_cast<float2*>(bounds) + cells : nullptr;
+  if ((rc = launch_block_bounds(P, bounds, partials, false, s)) != VK_OK) return rc;
 
-  // tracer.cpp:78-95 ComputePoints
-  if ((rc = launch_points(v->hash_entries, v->voxels, bounds, v->main_block_count, block_length,
+  // tracer.cpp:78-95 ComputePoints (merges the private grids on the fly)
+  if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
            out_depth, out_color, frame->width, frame->height, bounds_width, bounds_height, s)) != VK_OK)
     return rc;

@@ -238,176 +238,197 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
 
 // --------------------------------------------------------- handle requests ----
 
-constexpr int kHandleThreads = 1024;
-constexpr int kHandlePerThread = 32;                              // buckets per thread per tile
-constexpr int kHandleTile = kHandleThreads * kHandlePerThread;    // 32768 buckets = 32 KB of LDS
+constexpr int kHandleThreads = 256;
+constexpr int kHandlePerGroup = 4 * kHandleThreads;   // 1024 buckets per workgroup, one dword of flags per lane
 
-// Inclusive block-wide scan of two packed 16-bit-safe counters kept as two ints.
-__device__ __forceinline__ void block_exclusive_scan2(int& a, int& b, int* lds_a, int* lds_b,
-    int& total_a, int& total_b)
+// sums two ints over the workgroup; every lane gets the totals
+__device__ __forceinline__ void block_sum2(int& a, int& b, int* lds)
 {
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  int ia = a, ib = b;
-
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
+  for (int d = 32; d >= 1; d >>= 1)
   {
-    const int ta = __shfl_up(ia, d);
-    const int tb = __shfl_up(ib, d);
-    if (lane >= d) { ia += ta; ib += tb; }
+    a += __shfl_xor(a, d);
+    b += __shfl_xor(b, d);
   }
-
-  if (lane == 63) { lds_a[wave] = ia; lds_b[wave] = ib; }
+  const int wave = threadIdx.x >> 6;
+  if (lane_id() == 0) { lds[2 * wave] = a; lds[2 * wave + 1] = b; }
   __syncthreads();
-
-  int base_a = 0, base_b = 0;
-  total_a = 0;
-  total_b = 0;
-  for (int w = 0; w < kHandleThreads / 64; ++w)
-  {
-    const int wa = lds_a[w], wb = lds_b[w];
-    if (w < wave) { base_a += wa; base_b += wb; }
-    total_a += wa;
-    total_b += wb;
-  }
+  a = 0;
+  b = 0;
+#pragma unroll
+  for (int w = 0; w < kHandleThreads / 64; ++w) { a += lds[2 * w]; b += lds[2 * w + 1]; }
   __syncthreads();
-
-  a = base_a + ia - a;  // exclusive
-  b = base_b + ib - b;
 }
 
-// ref: volume.cu:304-368. ONE workgroup walks the main buckets in ascending
-// order; pool slots and excess indices come from an exclusive scan over the
-// request flags, i.e. exactly what the reference's threads would obtain from
-// atomicSub(voxel_pointer)/atomicAdd(excess_pointer) (volume.cu:337,352) if
-// they ran in index order. Requests are sparse (a few hundred per frame in
-// steady state), so one CU is enough and no inter-workgroup hand-off is needed.
+// byte != 0 <=> bit0 | bit1 ; byte == EXCESS(2) <=> bit1  (values are 0, 1, 2)
+__device__ __forceinline__ void count_flags(uint32_t w, int& n_all, int& n_excess)
+{
+  n_all += __popc((w | (w >> 1)) & 0x01010101u);
+  n_excess += __popc((w >> 1) & 0x01010101u);
+}
+
+// ref: volume.cu:304-368. Pool slots and excess indices must come out as if the
+// reference's threads ran in ascending bucket order (reproducible allocation):
+// request r (in bucket order) takes free slot voxel_pointer - r, EXCESS request
+// e takes entry excess_pointer + e. Each 1024-bucket workgroup obtains its base
+// ranks by counting the request flags of ALL buckets before it (a few KB of
+// bytes, L2-resident) — redundant work instead of an inter-workgroup scan, so
+// there is no cross-workgroup hand-off at all. Neither the counters nor the
+// request flags are modified here (other workgroups still read them): the last
+// workgroup publishes the totals in VK_CTR_PENDING_*, and finish_handle() —
+// run by the kernel that follows — folds them in and clears the flags
+// (volume.cu:365).
 __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible)
 {
-  __shared__ uint32_t types_lds[kHandleTile / 4];
-  __shared__ int scan_a[kHandleThreads / 64];
-  __shared__ int scan_b[kHandleThreads / 64];
+  __shared__ int red[2 * (kHandleThreads / 64)];
+  __shared__ int wave_a[kHandleThreads / 64], wave_b[kHandleThreads / 64];
 
   const int count = v.main_block_count;
   const int max_count = v.main_block_count + v.excess_block_count;
   const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
   const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
-  int done_all = 0, done_excess = 0, committed = 0;
+  const int first = blockIdx.x * kHandlePerGroup;
 
-  for (int tile = 0; tile < count; tile += kHandleTile)
+  // (1) requests in buckets [0, first): 16 bytes per load, first is a multiple of 1024
+  int base_all = 0, base_excess = 0;
+  const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
+  for (int j = threadIdx.x; j < first / 16; j += kHandleThreads)
   {
-    const int tile_count = min(kHandleTile, count - tile);
-    const int tile_words = (tile_count + 3) >> 2;
+    const uint4 q = flags16[j];
+    count_flags(q.x, base_all, base_excess);
+    count_flags(q.y, base_all, base_excess);
+    count_flags(q.z, base_all, base_excess);
+    count_flags(q.w, base_all, base_excess);
+  }
+  block_sum2(base_all, base_excess, red);
 
-    // stage the request flags: coalesced dword loads (tile is 4-byte aligned)
-    for (int wi = threadIdx.x; wi < kHandleTile / 4; wi += kHandleThreads)
-    {
-      uint32_t w = 0;
-      if (wi < tile_words)
-      {
-        if (wi * 4 + 4 <= tile_count)
-          w = reinterpret_cast<const uint32_t*>(v.allocation_types + tile)[wi];
-        else
-          for (int b = 0; b < tile_count - wi * 4; ++b)
-            w |= (uint32_t)v.allocation_types[tile + wi * 4 + b] << (8 * b);
-      }
-      types_lds[wi] = w;
-    }
-    __syncthreads();
+  // (2) this lane's four buckets
+  const int bucket0 = first + 4 * threadIdx.x;
+  uint32_t w = 0;
+  if (bucket0 + 4 <= count)
+    w = reinterpret_cast<const uint32_t*>(v.allocation_types)[bucket0 >> 2];
+  else
+    for (int b = 0; b < count - bucket0; ++b) w |= (uint32_t)v.allocation_types[bucket0 + b] << (8 * b);
 
-    // count this thread's requests (all) and EXCESS requests
-    int n_all = 0, n_excess = 0;
-    const int first_word = threadIdx.x * (kHandlePerThread / 4);
+  int n_all = 0, n_excess = 0;
+  count_flags(w, n_all, n_excess);
+
+  // exclusive scan over the workgroup (wave shuffle scan + 4 wave totals)
+  int incl_a = n_all, incl_b = n_excess;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < kHandlePerThread / 4; ++k)
-    {
-      const uint32_t w = types_lds[first_word + k];
-      // byte != 0  <=>  bit0 | bit1 ; byte == 2  <=>  bit1
-      n_all += __popc((w | (w >> 1)) & 0x01010101u);
-      n_excess += __popc((w >> 1) & 0x01010101u);
-    }
-
-    int rank_all = n_all, rank_excess = n_excess, tile_all, tile_excess;
-    block_exclusive_scan2(rank_all, rank_excess, scan_a, scan_b, tile_all, tile_excess);
-    rank_all += done_all;
-    rank_excess += done_excess;
-
-    if (n_all > 0)
-    {
-      for (int k = 0; k < kHandlePerThread; ++k)
-      {
-        const int local = threadIdx.x * kHandlePerThread + k;
-        const int type = (types_lds[local >> 2] >> (8 * (local & 3))) & 0xff;
-        if (type == VK_ALLOC_NONE) continue;
-
-        const int index = tile + local;
-        const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[index];
-        int entry_index = index;
-
-        if (type == VK_ALLOC_EXCESS)
-        {
-          int other_index = index;
-          int next = v.hash_entries[other_index].next;
-          for (int guard = 0; next != -1 && guard < max_count; ++guard)
-          {
-            other_index = next;
-            next = v.hash_entries[other_index].next;
-          }
-
-          entry_index = excess_ptr0 + rank_excess;
-          ++rank_excess;
-
-          if (entry_index < max_count)
-          {
-            v.hash_entries[other_index].next = entry_index;
-            v.block_visibility[entry_index] = VK_VISIBILITY_TRUE;
-          }
-        }
-
-        const int voxel_index = voxel_ptr0 - rank_all;
-        ++rank_all;
-
-        if (entry_index < max_count && voxel_index >= 0)
-        {
-          // entry = {block (pad cleared), data = free slot, next = -1}
-          const int lo = (int)(packed & 0xffffffffull);
-          const int hi = (int)((packed >> 32) & 0xffffull);
-          reinterpret_cast<int4*>(v.hash_entries)[entry_index] =
-              make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
-          ++committed;
-        }
-
-        v.allocation_types[index] = VK_ALLOC_NONE;
-        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[index] = 0ull;
-      }
-    }
-
-    done_all += tile_all;
-    done_excess += tile_excess;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int ta = __shfl_up(incl_a, d);
+    const int tb = __shfl_up(incl_b, d);
+    if (lane >= d) { incl_a += ta; incl_b += tb; }
+  }
+  if (lane == 63) { wave_a[wave] = incl_a; wave_b[wave] = incl_b; }
+  __syncthreads();
+  int group_all = 0, group_excess = 0;
+  int rank_all = base_all + incl_a - n_all, rank_excess = base_excess + incl_b - n_excess;
+#pragma unroll
+  for (int k = 0; k < kHandleThreads / 64; ++k)
+  {
+    if (k < wave) { rank_all += wave_a[k]; rank_excess += wave_b[k]; }
+    group_all += wave_a[k];
+    group_excess += wave_b[k];
   }
 
-  // committed count: block reduce through the scan scratch
+  // (3) commit this lane's requests in bucket order
+  int dropped = 0;
+  if (n_all > 0)
   {
-    int c = committed;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if (lane_id() == 0) scan_a[threadIdx.x >> 6] = c;
-    __syncthreads();
+    for (int k = 0; k < 4; ++k)
+    {
+      const int type = (w >> (8 * k)) & 0xff;
+      if (type == VK_ALLOC_NONE) continue;
+
+      const int index = bucket0 + k;
+      const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[index];
+      int entry_index = index;
+
+      if (type == VK_ALLOC_EXCESS)
+      {
+        int other_index = index;
+        int next = v.hash_entries[other_index].next;
+        for (int guard = 0; next != -1 && guard < max_count; ++guard)
+        {
+          other_index = next;
+          next = v.hash_entries[other_index].next;
+        }
+
+        entry_index = excess_ptr0 + rank_excess;
+        ++rank_excess;
+
+        if (entry_index < max_count)
+        {
+          v.hash_entries[other_index].next = entry_index;
+          v.block_visibility[entry_index] = VK_VISIBILITY_TRUE;
+        }
+      }
+
+      const int voxel_index = voxel_ptr0 - rank_all;
+      ++rank_all;
+
+      if (entry_index < max_count && voxel_index >= 0)
+      {
+        // entry = {block (pad cleared), data = free slot, next = -1}
+        const int lo = (int)(packed & 0xffffffffull);
+        const int hi = (int)((packed >> 32) & 0xffffull);
+        reinterpret_cast<int4*>(v.hash_entries)[entry_index] =
+            make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
+      }
+      else
+      {
+        ++dropped;
+      }
+      // the request flag is cleared by finish_handle(), not here: later
+      // workgroups are still counting the flags of these buckets
+    }
   }
 
-  if (threadIdx.x == 0)
+  if (dropped) atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
+
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
   {
-    int c = 0;
-    for (int w = 0; w < kHandleThreads / 64; ++w) c += scan_a[w];
-    v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - done_all;
-    v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + done_excess;
-    v.counters[VK_CTR_REQUESTS] = c;
-    v.counters[VK_CTR_DROPPED] += done_all - c;
+    v.counters[VK_CTR_PENDING_ALL] = base_all + group_all;
+    v.counters[VK_CTR_PENDING_EXCESS] = base_excess + group_excess;
+    v.counters[VK_CTR_REQUESTS] = base_all + group_all;
     // volume.cu:488 ResetBufferSize for the visibility pass that follows in SetView
     if (zero_visible) v.counters[VK_CTR_VISIBLE] = 0;
   }
+}
+
+// Second half of the handle pass, one lane per main bucket: clear the request
+// (volume.cu:365) and, once, apply the pointer updates the reference does with
+// atomics (volume.cu:337,352).
+__device__ __forceinline__ void finish_handle(const vk_volume& v, int index)
+{
+  if (index < v.main_block_count && v.allocation_types[index] != VK_ALLOC_NONE)
+  {
+    v.allocation_types[index] = VK_ALLOC_NONE;
+    reinterpret_cast<unsigned long long*>(v.allocation_blocks)[index] = 0ull;
+  }
+
+  if (index == 0)
+  {
+    const int all = v.counters[VK_CTR_PENDING_ALL];
+    const int excess = v.counters[VK_CTR_PENDING_EXCESS];
+    if (all | excess)
+    {
+      v.counters[VK_CTR_VOXEL_PTR] -= all;
+      v.counters[VK_CTR_EXCESS_PTR] += excess;
+      v.counters[VK_CTR_PENDING_ALL] = 0;
+      v.counters[VK_CTR_PENDING_EXCESS] = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void finish_handle_kernel(vk_volume v)
+{
+  finish_handle(v, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // -------------------------------------------------------- update visibility ----
@@ -415,6 +436,7 @@ __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volu
 struct VisibilityParams
 {
   vk_volume v;
+  int finish_handle;   // SetView: this kernel also completes the handle pass before it
   int width, height;
   vk_projection k;
   Rt Tdw;
@@ -436,6 +458,8 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
   const int index = blockIdx.x * kVisThreads + threadIdx.x;
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
   bool visible = false;
+
+  if (P.finish_handle) finish_handle(v, index);
 
   if (index < count)
   {
@@ -505,7 +529,7 @@ int check_volume(const vk_volume* v)
   if (!(v->voxel_length > 0) || !(v->truncation_length > 0)) return VK_ERR_ARGUMENT;
   if ((reinterpret_cast<uintptr_t>(v->allocation_blocks) & 7) || (reinterpret_cast<uintptr_t>(v->hash_entries) & 15) ||
       (reinterpret_cast<uintptr_t>(v->voxels) & 15) || (reinterpret_cast<uintptr_t>(v->block_visibility) & 3) ||
-      (reinterpret_cast<uintptr_t>(v->allocation_types) & 3))
+      (reinterpret_cast<uintptr_t>(v->allocation_types) & 15))
     return VK_ERR_ARGUMENT;
   return VK_OK;
 }
@@ -527,10 +551,11 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
 }
 
 int launch_update_visibility(const vk_volume* v, int width, int height,
-    const vk_projection* projection, const float* Tdw_m, hipStream_t s)
+    const vk_projection* projection, const float* Tdw_m, bool finish, hipStream_t s)
 {
   VisibilityParams P;
   P.v = *v;
+  P.finish_handle = finish ? 1 : 0;
   P.width = width;
   P.height = height;
   P.k = *projection;
@@ -591,7 +616,10 @@ int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
 {
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
-  hipLaunchKernelGGL(handle_requests_kernel, dim3(1), dim3(kHandleThreads), 0, vk_s(stream), *v, 0);
+  hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
+      dim3(kHandleThreads), 0, vk_s(stream), *v, 0);
+  VK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(finish_handle_kernel, dim3((v->main_block_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -604,7 +632,7 @@ int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
   VK_REQUIRE(projection && Tdw && width > 0 && height > 0);
   // volume.cu:488 ResetBufferSize
   VK_CHECK(hipMemsetAsync(v->counters + VK_CTR_VISIBLE, 0, sizeof(int32_t), vk_s(stream)));
-  return launch_update_visibility(v, width, height, projection, Tdw->m, vk_s(stream));
+  return launch_update_visibility(v, width, height, projection, Tdw->m, false, vk_s(stream));
 }
 
 int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
@@ -617,10 +645,11 @@ int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
   if ((r = launch_reset_visibility(v, s)) != VK_OK) return r;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
            &frame->depth_projection, &frame->depth_to_world, s)) != VK_OK) return r;
-  hipLaunchKernelGGL(handle_requests_kernel, dim3(1), dim3(kHandleThreads), 0, s, *v, 1);
-  VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]
+  hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
+      dim3(kHandleThreads), 0, s, *v, 1);
+  VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
   return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
-      frame->depth_to_world.inv, s);
+      frame->depth_to_world.inv, true, s);
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)
