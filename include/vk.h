@@ -383,6 +383,19 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
     int translation_enabled, vk_transform* Twc_dev, int32_t* state_dev,
     float* update_dev, void* stream);
 
+/* ------------------------------------------------------------------ probes -- */
+
+/* Measurement aids, no reference counterpart (the reference has no benchmarks,
+ * SURVEY.md §6): a float4 device copy and the integrate kernel's access pattern
+ * (read + write back every visible block) with the arithmetic removed. bench.py
+ * reports the integrate kernel's GB/s against both. */
+VK_API int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
+VK_API int vk_probe_block_rmw(const vk_volume* v, void* stream);
+/* Timing-only ablations of the depth integrate kernel (variant 1..3 produce WRONG
+ * voxels on purpose: 1 = no depth gather, 2 = no update, 3 = no LDS staging). */
+VK_API int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame,
+    int variant, void* stream);
+
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif

@@ -68,6 +68,9 @@ _SIGNATURES = {
     "vk_icp_workspace_floats": ([_I, _I], _SZ),
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_probe_stream_copy": ([_P, _P, _SZ, _P], _I),
+    "vk_probe_block_rmw": ([_P, _P], _I),
+    "vk_probe_integrate": ([_P, _P, _P, _I, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -73,13 +73,14 @@ __device__ __forceinline__ float vclamp(float v, float lo, float hi) { return vm
 __device__ __forceinline__ int vclampi(int v, int lo, int hi) { return vmini(hi, vmaxi(lo, v)); }
 
 // float -> int / short: saturating, NaN -> 0 (what the reference gets from the
-// GPU's cvt instruction where C leaves the conversion undefined).
+// GPU's cvt instruction where C leaves the conversion undefined). v_cvt_i32_f32
+// has exactly these semantics; inline asm keeps the out-of-range case out of
+// the optimiser's hands.
 __device__ __forceinline__ int f2i(float x)
 {
-  if (x != x) return 0;
-  if (x >= 2147483648.0f) return INT32_MAX;
-  if (x <= -2147483648.0f) return INT32_MIN;
-  return (int)x;
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
 }
 __device__ __forceinline__ int f2s(float x)
 {

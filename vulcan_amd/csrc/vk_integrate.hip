@@ -54,13 +54,24 @@ __device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 n
   return l.intensity * cos_theta / distance_squared;
 }
 
-template <bool DEPTH, int COLOR>
+// Per-voxel depth sample gathered before the voxel tile arrives.
+struct DepthSample
+{
+  float depth;   // depth image value at the voxel's pixel (0 when not sampled)
+  float z;       // Xdp.z
+  bool valid;    // projects inside the image (depth_integrator.cu:46)
+};
+
+// VARIANT != 0 are timing-only ablations reached through vk_probe_integrate (their
+// results are wrong on purpose): 1 = no depth gather (depth = z + 1 cm), 2 = no per-voxel update,
+// 3 = no LDS staging either (load + store).
+template <bool DEPTH, int COLOR, int VARIANT = 0>
 __global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(IntegrateParams P)
 {
   __shared__ float4 tiles[kWavesPerGroup][kTileF4];
 
   const int lane = lane_id();
-  const int wave_in_group = threadIdx.x >> 6;
+  const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wave = blockIdx.x * kWavesPerGroup + wave_in_group;
   const int total_waves = gridDim.x * kWavesPerGroup;
   const int count = P.counters[VK_CTR_VISIBLE];
@@ -71,152 +82,203 @@ __global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(Integrat
   const int vx = lane & 7;
   const int vy = lane >> 3;
 
-  for (int i = wave; i < count; i += total_waves)
+  // This wave owns blocks wave, wave + W, wave + 2W, ... Lane j fetches the hash
+  // entry of the j-th of them up front (two gathers per 64 blocks), so the block
+  // loop itself never waits on the visible list or the hash table: each
+  // iteration broadcasts its entry out of lane j with v_readlane.
+  for (int first = wave; first < count; first += 64 * total_waves)
   {
-    const int entry_index = __builtin_amdgcn_readfirstlane(P.visible[i]);
-    const Entry entry = load_entry(P.entries, (uint32_t)entry_index);
-    // never-allocated origin block marked visible by the reference's quirk
-    // (SURVEY §2.5-1): the reference would index voxels[-512..]; skipped.
-    if (entry.data < 0) continue;
+    const int mine = first + lane * total_waves;
+    int4 my_entry = make_int4(0, 0, -1, -1);
+    if (mine < count) my_entry = reinterpret_cast<const int4*>(P.entries)[P.visible[mine]];
 
-    float4* block4 = P.voxels4 + (size_t)entry.data * kTileF4;
+    for (int j = 0; j < 64; ++j)
+    {
+      const int i = first + j * total_waves;
+      if (i >= count) break;
 
-    // ---- stage: 10 x 1 KiB coalesced loads, all in flight before the first LDS write
+      const int e0 = __builtin_amdgcn_readlane(my_entry.x, j);
+      const int e1 = __builtin_amdgcn_readlane(my_entry.y, j);
+      const int data = __builtin_amdgcn_readlane(my_entry.z, j);
+      const int ox = (int16_t)(e0 & 0xffff), oy = (int16_t)((uint32_t)e0 >> 16), oz = (int16_t)(e1 & 0xffff);
+
+      // never-allocated origin block marked visible by the reference's quirk
+      // (SURVEY §2.5-1): the reference would index voxels[-512..]; skipped.
+      if (data < 0) continue;
+
+      float4* block4 = P.voxels4 + (size_t)data * kTileF4;
+
+    // ---- 1. project the lane's eight voxels and gather their depth pixels. This
+    // depends on the hash entry only, so the gathers fly together with the ten
+    // tile loads below instead of after them. The gather is unconditional (lanes
+    // that project outside the image read pixel 0 and ignore it): a branch
+    // around each load would force a wait at every merge point.
+    // depth_integrator.cu:35-52
+    const f3 block_offset = scale3(make3((float)ox, (float)oy, (float)oz), P.block_length);
+    DepthSample ds[8];
+    float du[8], dv[8];
+    if (DEPTH || COLOR == COLOR_LIGHT)
+    {
+#pragma unroll
+      for (int vz = 0; vz < 8; ++vz)
+      {
+        const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+        const f3 Xdp = xform_point(P.Tdw, add3(block_offset, voxel_offset));
+        project(P.kd, Xdp, du[vz], dv[vz]);
+        ds[vz].z = Xdp.z;
+        ds[vz].valid = du[vz] >= 0 && du[vz] < P.width && dv[vz] >= 0 && dv[vz] < P.height;
+        ds[vz].depth = 0.0f;
+        if (DEPTH)
+        {
+          const int pixel = ds[vz].valid ? (int)dv[vz] * P.width + (int)du[vz] : 0;
+          ds[vz].depth = (VARIANT == 4) ? P.depth[(i & 1023) * 256 + vz * 64 + lane]   // coalesced stand-in
+                       : (VARIANT >= 1) ? ds[vz].z + 0.01f : P.depth[pixel];
+        }
+      }
+    }
+
+    // ---- 2. stage the tile: 10 x 1 KiB coalesced loads, then LDS
     float4 r[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) r[k] = block4[k * 64 + lane];
+    if (VARIANT == 3)
+    {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) block4[k * 64 + lane] = r[k];
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < 10; ++k) tile4[k * 64 + lane] = r[k];
 
-    // ---- update the eight z-slices
-    // depth_integrator.cu:35-39
-    const f3 block_offset = scale3(make3((float)entry.ox, (float)entry.oy, (float)entry.oz), P.block_length);
+    // ---- 3. update the eight z-slices. All sixteen LDS reads (distance +
+    // weight word per voxel) are issued before the first update so their latency
+    // overlaps instead of serialising behind eight branches.
     bool dirty = false;
+    float old_d[8];
+    uint32_t old_w[8];
+#pragma unroll
+    for (int vz = 0; vz < 8; ++vz)
+    {
+      const float* vox = tile + (vz * 64 + lane) * 5;
+      old_d[vz] = vox[0];
+      old_w[vz] = __float_as_uint(vox[4]);
+    }
 
 #pragma unroll
     for (int vz = 0; vz < 8; ++vz)
     {
-      const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
-      const f3 Xwp = add3(block_offset, voxel_offset);
       float* vox = tile + (vz * 64 + lane) * 5;  // 5 dwords per voxel
-
       float distance_value = 0.0f;
       bool have_distance = false;
 
-      f3 Xdp = make3(0, 0, 0);
-      float du = 0, dv = 0;
-      if (DEPTH || COLOR == COLOR_LIGHT)
+      if (VARIANT == 2)
       {
-        Xdp = xform_point(P.Tdw, Xwp);
-        project(P.kd, Xdp, du, dv);
+        vox[0] = old_d[vz] + 0.0f;   // ablation: LDS round trip only
+        dirty = true;
       }
-
-      if (DEPTH)
+      else if (DEPTH)
       {
-        // depth_integrator.cu:41-78
-        if (du >= 0 && du < P.width && dv >= 0 && dv < P.height)
+        // depth_integrator.cu:54-78
+        const float depth = ds[vz].depth;
+        if (ds[vz].valid && !(depth < P.min_depth || depth > P.max_depth))
         {
-          const int image_index = (int)dv * P.width + (int)du;
-          const float depth = P.depth[image_index];
+          const float distance = depth - ds[vz].z;
 
-          if (!(depth < P.min_depth || depth > P.max_depth))
+          if (distance > -P.truncation_length)
           {
-            const float distance = depth - Xdp.z;
+            const float old_distance = old_d[vz];
+            const uint32_t weights = old_w[vz];
+            const int16_t dw = (int16_t)(weights & 0xffff);
 
-            if (distance > -P.truncation_length)
-            {
-              const float old_distance = vox[0];
-              const uint32_t weights = __float_as_uint(vox[4]);
-              const int16_t dw = (int16_t)(weights & 0xffff);
+            const float prev_dist = dw * old_distance;
+            const float curr_dist = vmin(1.0f, distance / P.truncation_length);
+            const float dist_weight = dw + 1;
+            const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
+            distance_value = (prev_dist + curr_dist) / dist_weight;
+            have_distance = true;
 
-              const float prev_dist = dw * old_distance;
-              const float curr_dist = vmin(1.0f, distance / P.truncation_length);
-              const float dist_weight = dw + 1;
-              const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
-              distance_value = (prev_dist + curr_dist) / dist_weight;
-              have_distance = true;
-
-              vox[0] = distance_value;
-              vox[4] = __uint_as_float((weights & 0xffff0000u) | (uint16_t)new_dw);
-              dirty = true;
-            }
-          }
-        }
-      }
-
-      if (COLOR == COLOR_PLAIN)
-      {
-        // color_integrator.cu:100-134
-        const f3 Xcp = xform_point(P.Tcw, Xwp);
-        float cu, cv;
-        project(P.kc, Xcp, cu, cv);
-
-        if (cu >= 0 && cu < P.width && cv >= 0 && cv < P.height)
-        {
-          const float dist = have_distance ? distance_value : vox[0];
-
-          if (fabsf(dist) < 1.0f)
-          {
-            const int image_index = (int)cv * P.width + (int)cu;
-            const uint32_t weights = __float_as_uint(vox[4]);
-            const int16_t cw = (int16_t)(weights >> 16);
-            const float cwf = cw;
-            const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-            const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
-                P.color[3 * image_index + 2]);
-            const float color_weight = cw + 1;
-            const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-            const f3 c = div3(add3(prev_color, curr_color), color_weight);
-            vox[1] = c.x;
-            vox[2] = c.y;
-            vox[3] = c.z;
-            vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+            vox[0] = distance_value;
+            old_w[vz] = (weights & 0xffff0000u) | (uint16_t)new_dw;
+            vox[4] = __uint_as_float(old_w[vz]);
             dirty = true;
           }
         }
       }
 
-      if (COLOR == COLOR_LIGHT)
+      if (COLOR != COLOR_NONE)
       {
-        // light_integrator.cu:197-248
+        const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+        const f3 Xwp = add3(block_offset, voxel_offset);
         const f3 Xcp = xform_point(P.Tcw, Xwp);
         float cu, cv;
         project(P.kc, Xcp, cu, cv);
+        const bool color_valid = cu >= 0 && cu < P.width && cv >= 0 && cv < P.height;
 
-        if (du >= 0 && du < P.width && dv >= 0 && dv < P.height &&
-            cu >= 0 && cu < P.width && cv >= 0 && cv < P.height)
+        if (COLOR == COLOR_PLAIN)
         {
-          const int depth_index = (int)dv * P.width + (int)du;
-          const int color_index = (int)cv * P.width + (int)cu;
-
-          if (P.mask[depth_index] > 0.5f)
+          // color_integrator.cu:100-134
+          if (color_valid)
           {
-            const float dist = have_distance ? distance_value : vox[0];
+            const float dist = have_distance ? distance_value : old_d[vz];
 
             if (fabsf(dist) < 1.0f)
             {
-              f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
-                  P.color[3 * color_index + 2]);
-              const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
-                  P.normals[3 * depth_index + 2]);
-              const f3 Xcn = xform_dir(P.Tcd, Xdn);
-              const float shading = light_shading(P.light, Xcp, Xcn);
+              const int image_index = (int)cv * P.width + (int)cu;
+              const uint32_t weights = old_w[vz];
+              const int16_t cw = (int16_t)(weights >> 16);
+              const float cwf = cw;
+              const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+              const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
+                  P.color[3 * image_index + 2]);
+              const float color_weight = cw + 1;
+              const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+              const f3 c = div3(add3(prev_color, curr_color), color_weight);
+              vox[1] = c.x;
+              vox[2] = c.y;
+              vox[3] = c.z;
+              vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+              dirty = true;
+            }
+          }
+        }
 
-              if (shading > 0.05f)
+        if (COLOR == COLOR_LIGHT)
+        {
+          // light_integrator.cu:197-248
+          if (ds[vz].valid && color_valid)
+          {
+            const int depth_index = (int)dv[vz] * P.width + (int)du[vz];
+            const int color_index = (int)cv * P.width + (int)cu;
+
+            if (P.mask[depth_index] > 0.5f)
+            {
+              const float dist = have_distance ? distance_value : old_d[vz];
+
+              if (fabsf(dist) < 1.0f)
               {
-                curr_color = div3(curr_color, shading);
-                const uint32_t weights = __float_as_uint(vox[4]);
-                const int16_t cw = (int16_t)(weights >> 16);
-                const float color_weight = cw + 1;
-                const float cwf = cw;
-                const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-                const f3 c = div3(add3(prev_color, curr_color), color_weight);
-                const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-                vox[1] = c.x;
-                vox[2] = c.y;
-                vox[3] = c.z;
-                vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-                dirty = true;
+                f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
+                    P.color[3 * color_index + 2]);
+                const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
+                    P.normals[3 * depth_index + 2]);
+                const f3 Xcn = xform_dir(P.Tcd, Xdn);
+                const float shading = light_shading(P.light, Xcp, Xcn);
+
+                if (shading > 0.05f)
+                {
+                  curr_color = div3(curr_color, shading);
+                  const uint32_t weights = old_w[vz];
+                  const int16_t cw = (int16_t)(weights >> 16);
+                  const float color_weight = cw + 1;
+                  const float cwf = cw;
+                  const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+                  const f3 c = div3(add3(prev_color, curr_color), color_weight);
+                  const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+                  vox[1] = c.x;
+                  vox[2] = c.y;
+                  vox[3] = c.z;
+                  vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+                  dirty = true;
+                }
               }
             }
           }
@@ -224,7 +286,7 @@ __global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(Integrat
       }
     }
 
-    // ---- stream the tile back (skipped when no voxel of the block changed)
+    // ---- 4. stream the tile back (skipped when no voxel of the block changed)
     if (__any(dirty))
     {
 #pragma unroll
@@ -232,7 +294,8 @@ __global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(Integrat
 #pragma unroll
       for (int k = 0; k < 10; ++k) block4[k * 64 + lane] = r[k];
     }
-  }
+    }  // blocks of this wave
+  }    // 64-block groups
 }
 
 int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, const vk_frame* f,
@@ -411,6 +474,24 @@ int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const v
   const int rc = fill_params(P, v, p, frame, light, mask, true, true, true);
   if (rc != VK_OK) return rc;
   return launch<true, COLOR_LIGHT>(P, v, vk_s(stream));
+}
+
+int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int variant, void* stream)
+{
+  IntegrateParams P;
+  const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
+  if (rc != VK_OK) return rc;
+  const dim3 grid(grid_for(v)), block(kWavesPerGroup * 64);
+  switch (variant)
+  {
+    case 1: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 1>), grid, block, 0, vk_s(stream), P); break;
+    case 2: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 2>), grid, block, 0, vk_s(stream), P); break;
+    case 3: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 3>), grid, block, 0, vk_s(stream), P); break;
+    case 4: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 4>), grid, block, 0, vk_s(stream), P); break;
+    default: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 0>), grid, block, 0, vk_s(stream), P); break;
+  }
+  VK_LAUNCH_CHECK();
+  return VK_OK;
 }
 
 }  // extern "C"

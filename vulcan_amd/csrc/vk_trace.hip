@@ -407,18 +407,12 @@ __device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cach
   return data;
 }
 
-// tracer.cu:114-188 GetVoxel
-__device__ __forceinline__ Corner get_voxel(const PointParams& P, BlockCache& cache,
-    int bx, int by, int bz, int vx, int vy, int vz)
+// tracer.cu:114-188 GetVoxel: a corner index outside [0,8) moves one block over
+// along that axis (a single wrap, as in the reference)
+__device__ __forceinline__ void wrap_axis(int v, int& local, int& shift)
 {
-  const int r = VK_BLOCK_RESOLUTION;
-  if (vx < 0) { --bx; vx = r + vx; } else if (vx >= r) { ++bx; vx = vx - r; }
-  if (vy < 0) { --by; vy = r + vy; } else if (vy >= r) { ++by; vy = vy - r; }
-  if (vz < 0) { --bz; vz = r + vz; } else if (vz >= r) { ++bz; vz = vz - r; }
-
-  const int data = find_block(P, cache, bx, by, bz);
-  if (data < 0) return empty_corner();
-  return load_corner(reinterpret_cast<const float*>(P.voxels) + (size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5);
+  shift = (v < 0) ? -1 : ((v >= VK_BLOCK_RESOLUTION) ? 1 : 0);
+  local = v - VK_BLOCK_RESOLUTION * shift;
 }
 
 // tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
@@ -435,11 +429,12 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   const int i0z = f2i(floorf(wz - 0.5f));
 
   Corner vv[8];  // index dz*4 + dy*2 + dx
+  const float* voxf = reinterpret_cast<const float*>(P.voxels);
 
   if (i0x >= 0 && i0y >= 0 && i0z >= 0 && i0x < 7 && i0y < 7 && i0z < 7)
   {
     // all eight corners in this block: four x-adjacent pairs
-    const float* base = reinterpret_cast<const float*>(P.voxels) + (size_t)(block_offset + i0z * 64 + i0y * 8 + i0x) * 5;
+    const float* base = voxf + (size_t)(block_offset + i0z * 64 + i0y * 8 + i0x) * 5;
     load_corner_pair(base, vv[0], vv[1]);
     load_corner_pair(base + 8 * 5, vv[2], vv[3]);
     load_corner_pair(base + 64 * 5, vv[4], vv[5]);
@@ -447,12 +442,38 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   }
   else
   {
-    // the neighbour lookups move away from (bx,by,bz); use a scratch cache so the
-    // march keeps its own
-    BlockCache scratch = cache;
+    // The eight corners touch at most 2x2x2 blocks. The reference walks the hash
+    // table once per corner (GetVoxel x8); here every DISTINCT neighbour block is
+    // looked up once: sx/sy/sz say which way each of the two corners per axis
+    // leaves the block (0 = stays), and corner (dx,dy,dz) lives in block
+    // b + (sx[dx], sy[dy], sz[dz]).
+    int lx[2], ly[2], lz[2], sx[2], sy[2], sz[2];
+    wrap_axis(i0x, lx[0], sx[0]); wrap_axis(i0x + 1, lx[1], sx[1]);
+    wrap_axis(i0y, ly[0], sy[0]); wrap_axis(i0y + 1, ly[1], sy[1]);
+    wrap_axis(i0z, lz[0], sz[0]); wrap_axis(i0z + 1, lz[1], sz[1]);
+
+    int slot[8];  // pool slot of the block holding corner c, -1 = absent
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      vv[c] = get_voxel(P, scratch, bx, by, bz, i0x + (c & 1), i0y + ((c >> 1) & 1), i0z + ((c >> 2) & 1));
+    {
+      const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+      // reuse the answer of the corner that differs only in an axis along which both corners share a block
+      if (dx && sx[1] == sx[0]) { slot[c] = slot[c ^ 1]; continue; }
+      if (dy && sy[1] == sy[0]) { slot[c] = slot[c ^ 2]; continue; }
+      if (dz && sz[1] == sz[0]) { slot[c] = slot[c ^ 4]; continue; }
+      if ((sx[dx] | sy[dy] | sz[dz]) == 0) { slot[c] = data; continue; }
+      BlockCache scratch;
+      scratch.valid = false;
+      slot[c] = find_block(P, scratch, bx + sx[dx], by + sy[dy], bz + sz[dz]);
+    }
+
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+      const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+      vv[c] = (slot[c] < 0) ? empty_corner()
+                            : load_corner(voxf + (size_t)(VK_BLOCK_VOXELS * slot[c] + lz[dz] * 64 + ly[dy] * 8 + lx[dx]) * 5);
+    }
   }
 
   const float w1x = wx - (i0x + 0.5f), w1y = wy - (i0y + 0.5f), w1z = wz - (i0z + 0.5f);
@@ -518,7 +539,6 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
     bound = reinterpret_cast<const float2*>(P.bounds)[cell];
   }
 
-  float depth = 0;
   float final_depth = 0;
   f3 color = make3(0, 0, 0);
 
@@ -529,72 +549,90 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
     const f3 dir = normalized3(xform_dir(P.Twc, Xcp));
 
     f3 p = Xwp;
-    depth = bound.x;
     int iters = 0;
     BlockCache cache;
     cache.valid = false;
     cache.bx = cache.by = cache.bz = 0;
     cache.data = -1;
 
-    do
+    // The reference's loop body (tracer.cu:358-444) contains a second, nested
+    // lookup + interpolation for the step that follows the first sample behind
+    // the surface (:395-423). Here that step is one more trip through the same
+    // loop body with `refine` set, so the lanes of a wave share ONE lookup site
+    // and ONE interpolation site whatever phase each ray is in.
+    bool refine = false;
+
+    for (;;)
     {
       const int bx = f2i(floorf(p.x / P.block_length));
       const int by = f2i(floorf(p.y / P.block_length));
       const int bz = f2i(floorf(p.z / P.block_length));
       const int data = find_block(P, cache, bx, by, bz);
+      bool done = false;
 
       if (data >= 0)
       {
-        const float wx = (p.x - bx * P.block_length) / P.voxel_length;
-        const float wy = (p.y - by * P.block_length) / P.voxel_length;
-        const float wz = (p.z - bz * P.block_length) / P.voxel_length;
+        float sdf;
+        bool sample = refine;
 
-        // int(w) can reach 8 on a block face: clamped, see DESIGN.md
-        const int vx = vmini(f2i(wx), 7);
-        const int vy = vmini(f2i(wy), 7);
-        const int vz = vmini(f2i(wz), 7);
-
-        float sdf = reinterpret_cast<const float*>(P.voxels)[(size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5];
-
-        if (sdf <= 0.1f && sdf >= -0.5f) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
-
-        if (sdf <= 0.0f)
+        if (!refine)
         {
-          p = add3(p, scale3(dir, P.trunc_length * sdf));
+          const float wx = (p.x - bx * P.block_length) / P.voxel_length;
+          const float wy = (p.y - by * P.block_length) / P.voxel_length;
+          const float wz = (p.z - bz * P.block_length) / P.voxel_length;
 
-          const int bx2 = f2i(floorf(p.x / P.block_length));
-          const int by2 = f2i(floorf(p.y / P.block_length));
-          const int bz2 = f2i(floorf(p.z / P.block_length));
-          const int data2 = find_block(P, cache, bx2, by2, bz2);
+          // int(w) can reach 8 on a block face: clamped, see DESIGN.md
+          const int vx = vmini(f2i(wx), 7);
+          const int vy = vmini(f2i(wy), 7);
+          const int vz = vmini(f2i(wz), 7);
 
-          if (data2 >= 0)
-          {
-            interpolate(P, cache, bx2, by2, bz2, data2, p, sdf, color);
-            p = add3(p, scale3(dir, P.trunc_length * sdf));
-          }
+          sdf = reinterpret_cast<const float*>(P.voxels)[(size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5];
+          sample = (sdf <= 0.1f && sdf >= -0.5f);
+        }
 
-          final_depth = xform_point(P.Tcw, p).z;
-          break;
+        if (sample) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
+
+        if (refine)
+        {
+          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :417
+          done = true;
+        }
+        else if (sdf <= 0.0f)
+        {
+          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :397
+          refine = true;
+          continue;                                             // :399-418 happen next trip
         }
         else
         {
           p = add3(p, scale3(dir, vmax(P.voxel_length, P.trunc_length * sdf)));
         }
       }
+      else if (refine)
+      {
+        done = true;                                            // :410 false: no second sample
+      }
       else
       {
         p = add3(p, scale3(dir, P.block_length));
       }
 
-      depth = xform_point(P.Tcw, p).z;
+      const float depth = xform_point(P.Tcw, p).z;
+
+      if (done)
+      {
+        final_depth = depth;                                    // :420-422
+        break;
+      }
 
       if (++iters >= 500)
       {
         color = make3(1, 0, 0);
         break;
       }
+
+      if (!(depth < bound.y)) break;
     }
-    while (depth < bound.y);
   }
 
   const int pixel = y * P.image_width + x;

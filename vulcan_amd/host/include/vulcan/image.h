@@ -1,0 +1,106 @@
+// image.h — single-channel float image and packed float3 image in device memory
+// (ref: include/vulcan/image.h). The reference's OpenCV Load/Save are replaced
+// by CopyFromHost / CopyToHost; Resize discards contents when the pixel count
+// changes (image.h:85-97).
+#pragma once
+
+#include <vulcan/device.h>
+#include <vulcan/matrix.h>
+
+namespace vulcan
+{
+
+namespace detail
+{
+
+// shared storage logic of Image (1 float / pixel) and ColorImage (3 floats / pixel)
+template <typename Pixel>
+class ImageStorage
+{
+  public:
+
+    ImageStorage() : size_(0, 0), data_(nullptr) {}
+
+    ImageStorage(int w, int h) : size_(0, 0), data_(nullptr) { Resize(w, h); }
+
+    ~ImageStorage() { vk_free(data_); }
+
+    int GetWidth() const { return size_[0]; }
+
+    int GetHeight() const { return size_[1]; }
+
+    const Vector2i& GetSize() const { return size_; }
+
+    int GetTotal() const { return size_[0] * size_[1]; }
+
+    int GetBytes() const { return sizeof(Pixel) * GetTotal(); }
+
+    const Pixel* GetData() const { return data_; }
+
+    Pixel* GetData() { return data_; }
+
+    void Resize(int w, int h) { Resize(Vector2i(w, h)); }
+
+    void Resize(const Vector2i& size)
+    {
+      VULCAN_DEBUG(size[0] >= 0 && size[1] >= 0);
+      const int old_total = GetTotal();
+      size_ = size;
+      if (GetTotal() == old_total) return;
+      VK_ASSERT(vk_free(data_));
+      data_ = nullptr;
+      void* ptr = nullptr;
+      VK_ASSERT(vk_malloc(&ptr, GetBytes()));
+      data_ = static_cast<Pixel*>(ptr);
+    }
+
+    void CopyFromHost(const Pixel* pixels)
+    {
+      VK_ASSERT(vk_memcpy_h2d(data_, pixels, GetBytes(), Device::GetStream()));
+    }
+
+    void CopyToHost(Pixel* pixels) const
+    {
+      VK_ASSERT(vk_memcpy_d2h(pixels, data_, GetBytes(), Device::GetStream()));
+    }
+
+  private:
+
+    ImageStorage(const ImageStorage&);
+
+    ImageStorage& operator=(const ImageStorage&);
+
+  protected:
+
+    Vector2i size_;
+
+    Pixel* data_;
+};
+
+} // namespace detail
+
+class Image : public detail::ImageStorage<float>
+{
+  public:
+
+    Image() {}
+
+    Image(int w, int h) : detail::ImageStorage<float>(w, h) {}
+
+    // ref: image.cu:183-211 — 2x nearest or 2x2 box
+    void Downsample(Image& image, bool nearest) const;
+};
+
+class ColorImage : public detail::ImageStorage<Vector3f>
+{
+  public:
+
+    ColorImage() {}
+
+    ColorImage(int w, int h) : detail::ImageStorage<Vector3f>(w, h) {}
+
+    // ref: image.cu:234-262
+    void Downsample(ColorImage& image, bool nearest) const;
+};
+
+} // namespace vulcan

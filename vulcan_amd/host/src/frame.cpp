@@ -1,0 +1,98 @@
+// frame.cpp — Frame / Image host methods over the C ABI
+// (ref: src/frame.cpp, src/image.cu:183-262).
+#include <vulcan/frame.h>
+#include <vulcan/frame.cuh>
+#include <vulcan/exception.h>
+
+namespace vulcan
+{
+
+void Image::Downsample(Image& image, bool nearest) const
+{
+  VULCAN_DEBUG_MSG(size_[0] % 2 == 0 && size_[1] % 2 == 0, "even image dimensions required");
+  image.Resize(size_ / 2);
+  VK_ASSERT(vk_image_downsample(size_[0], size_[1], data_, image.GetData(), nearest ? 1 : 0,
+      Device::GetStream()));
+}
+
+void ColorImage::Downsample(ColorImage& image, bool nearest) const
+{
+  VULCAN_DEBUG_MSG(size_[0] % 2 == 0 && size_[1] % 2 == 0, "even image dimensions required");
+  image.Resize(size_ / 2);
+  VK_ASSERT(vk_color_image_downsample(size_[0], size_[1], reinterpret_cast<const float*>(data_),
+      reinterpret_cast<float*>(image.GetData()), nearest ? 1 : 0, Device::GetStream()));
+}
+
+void ComputeNormals(const float* depths, const Projection& projection,
+    Vector3f* normals, int image_width, int image_height)
+{
+  const vk_projection k = projection.ToVk();
+  VK_ASSERT(vk_frame_compute_normals(depths, &k, reinterpret_cast<float*>(normals), image_width,
+      image_height, Device::GetStream()));
+}
+
+void FilterDepths(int image_width, int image_height, const float* src, float* dst)
+{
+  VK_ASSERT(vk_frame_filter_depths(image_width, image_height, src, dst, Device::GetStream()));
+}
+
+void Frame::FilterDepths()
+{
+  VULCAN_ASSERT_MSG(depth_image, "missing depth image");
+  const int w = depth_image->GetWidth();
+  const int h = depth_image->GetHeight();
+  Image filtered(w, h);
+  vulcan::FilterDepths(w, h, depth_image->GetData(), filtered.GetData());
+  VK_ASSERT(vk_memcpy_d2d(depth_image->GetData(), filtered.GetData(), filtered.GetBytes(),
+      Device::GetStream()));
+  Device::Synchronize();  // `filtered` is freed on return
+}
+
+void Frame::ComputeNormals()
+{
+  VULCAN_ASSERT_MSG(depth_image, "missing depth image");
+  if (!normal_image) normal_image = std::make_shared<ColorImage>();
+  const int w = depth_image->GetWidth();
+  const int h = depth_image->GetHeight();
+  normal_image->Resize(w, h);
+  vulcan::ComputeNormals(depth_image->GetData(), depth_projection, normal_image->GetData(), w, h);
+}
+
+void Frame::Downsample(Frame& frame) const
+{
+  VULCAN_DEBUG(depth_image);
+  VULCAN_DEBUG(color_image);
+  VULCAN_DEBUG(normal_image);
+
+  if (!frame.depth_image) frame.depth_image = std::make_shared<Image>();
+  if (!frame.color_image) frame.color_image = std::make_shared<ColorImage>();
+  if (!frame.normal_image) frame.normal_image = std::make_shared<ColorImage>();
+
+  depth_image->Downsample(*frame.depth_image, true);     // nearest
+  color_image->Downsample(*frame.color_image, false);    // 2x2 box
+  normal_image->Downsample(*frame.normal_image, true);   // nearest
+
+  frame.depth_projection.SetFocalLength(depth_projection.GetFocalLength() / 2);
+  frame.depth_projection.SetCenterPoint(depth_projection.GetCenterPoint() / 2);
+  frame.color_projection.SetFocalLength(color_projection.GetFocalLength() / 2);
+  frame.color_projection.SetCenterPoint(color_projection.GetCenterPoint() / 2);
+  frame.depth_to_world_transform = depth_to_world_transform;
+  frame.depth_to_color_transform = depth_to_color_transform;
+}
+
+vk_frame Frame::ToVk() const
+{
+  vk_frame f;
+  f.depth = depth_image ? depth_image->GetData() : nullptr;
+  f.color = color_image ? reinterpret_cast<const float*>(color_image->GetData()) : nullptr;
+  f.normals = normal_image ? reinterpret_cast<const float*>(normal_image->GetData()) : nullptr;
+  f.width = depth_image ? depth_image->GetWidth() : (color_image ? color_image->GetWidth() : 0);
+  f.height = depth_image ? depth_image->GetHeight() : (color_image ? color_image->GetHeight() : 0);
+  f.depth_projection = depth_projection.ToVk();
+  f.color_projection = color_projection.ToVk();
+  f.depth_to_world = depth_to_world_transform.ToVk();
+  f.depth_to_color = depth_to_color_transform.ToVk();
+  return f;
+}
+
+} // namespace vulcan

@@ -1,0 +1,147 @@
+// integrators.cpp — Integrator and its three subclasses over vk_integrate_*
+// (ref: src/integrator.cu, src/depth_integrator.cu:83-115,
+//  src/color_integrator.cu:139-204, src/light_integrator.cu:254-354).
+#include <vulcan/color_integrator.h>
+#include <vulcan/depth_integrator.h>
+#include <vulcan/light_integrator.h>
+#include <vulcan/exception.h>
+#include <vulcan/frame.h>
+#include <vulcan/volume.h>
+
+namespace vulcan
+{
+
+Integrator::Integrator(std::shared_ptr<Volume> volume) :
+  volume_(volume),
+  depth_range_(0.1f, 5.0f),
+  max_distance_weight_(16),
+  max_color_weight_(16)
+{
+}
+
+std::shared_ptr<Volume> Integrator::GetVolume() const { return volume_; }
+
+const Vector2f& Integrator::GetDepthRange() const { return depth_range_; }
+
+void Integrator::SetDepthRange(const Vector2f& range)
+{
+  VULCAN_DEBUG(range[0] > 0 && range[0] < range[1]);
+  depth_range_ = range;
+}
+
+void Integrator::SetDepthRange(float min, float max) { SetDepthRange(Vector2f(min, max)); }
+
+float Integrator::GetMaxDistanceWeight() const { return max_distance_weight_; }
+
+void Integrator::SetMaxDistanceWeight(float weight)
+{
+  VULCAN_DEBUG(weight > 0);
+  max_distance_weight_ = weight;
+}
+
+float Integrator::GetMaxColorWeight() const { return max_color_weight_; }
+
+void Integrator::SetMaxColorWeight(float weight)
+{
+  VULCAN_DEBUG(weight > 0);
+  max_color_weight_ = weight;
+}
+
+vk_integrator Integrator::ToVk() const
+{
+  vk_integrator p;
+  p.min_depth = depth_range_[0];
+  p.max_depth = depth_range_[1];
+  p.max_distance_weight = max_distance_weight_;
+  p.max_color_weight = max_color_weight_;
+  return p;
+}
+
+// ---- depth -------------------------------------------------------------------
+
+DepthIntegrator::DepthIntegrator(std::shared_ptr<Volume> volume) : Integrator(volume) {}
+
+void DepthIntegrator::Integrate(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+}
+
+// ---- colour ------------------------------------------------------------------
+
+ColorIntegrator::ColorIntegrator(std::shared_ptr<Volume> volume) : Integrator(volume) {}
+
+void ColorIntegrator::Integrate(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_depth_color(&v, &p, &f, Device::GetStream()));
+}
+
+void ColorIntegrator::IntegrateDepth(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+}
+
+void ColorIntegrator::IntegrateColor(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_color(&v, &p, &f, Device::GetStream()));
+}
+
+// ---- light -------------------------------------------------------------------
+
+LightIntegrator::LightIntegrator(std::shared_ptr<Volume> volume) :
+  Integrator(volume),
+  depth_threshold_(0.2f)
+{
+}
+
+const Light& LightIntegrator::GetLight() const { return light_; }
+
+void LightIntegrator::SetLight(const Light& light) { light_ = light; }
+
+void LightIntegrator::Integrate(const Frame& frame)
+{
+  ComputeFrameMask(frame);
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_light l = light_.ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_depth_light(&v, &p, &l, frame_mask_.GetData(), &f, Device::GetStream()));
+}
+
+void LightIntegrator::ComputeFrameMask(const Frame& frame)
+{
+  VULCAN_ASSERT_MSG(frame.depth_image && frame.color_image, "missing depth or color image");
+  frame_mask_.Resize(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_light_compute_frame_mask(&f, depth_threshold_, frame_mask_.GetData(), Device::GetStream()));
+}
+
+void LightIntegrator::IntegrateDepth(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+}
+
+void LightIntegrator::IntegrateColor(const Frame& frame)
+{
+  const vk_volume v = volume_->ToVk();
+  const vk_integrator p = ToVk();
+  const vk_light l = light_.ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_integrate_light_color(&v, &p, &l, frame_mask_.GetData(), &f, Device::GetStream()));
+}
+
+} // namespace vulcan

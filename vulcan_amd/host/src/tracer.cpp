@@ -1,0 +1,169 @@
+// tracer.cpp — Tracer host class and the tracer.cuh stage functions
+// (ref: src/tracer.cpp, src/tracer.cu:453-500).
+#include <vulcan/tracer.h>
+#include <vulcan/tracer.cuh>
+#include <vulcan/block.h>
+#include <vulcan/device.h>
+#include <vulcan/exception.h>
+#include <vulcan/frame.h>
+#include <vulcan/hash.h>
+#include <vulcan/volume.h>
+#include <vulcan/voxel.h>
+
+namespace vulcan
+{
+
+static_assert(sizeof(Patch) == sizeof(vk_patch), "Patch must match vk_patch");
+
+// ---- stage functions (raw device pointers) -----------------------------------
+
+void ComputePatches(const int* indices, const HashEntry* entries,
+    const Transform& Tcw, const Projection& projection, float block_length,
+    float min_depth, float max_depth, int block_count, int image_width,
+    int image_height, int bounds_width, int bounds_height, Patch* patches,
+    int* patch_count)
+{
+  const vk_transform T = Tcw.ToVk();
+  const vk_projection k = projection.ToVk();
+  // the reference takes no capacity; Tracer reserves 262144 patches (tracer.cpp:134)
+  VK_ASSERT(vk_trace_compute_patches(indices, reinterpret_cast<const vk_hash_entry*>(entries), &T, &k,
+      block_length, min_depth, max_depth, block_count, nullptr, image_width, image_height,
+      bounds_width, bounds_height, reinterpret_cast<vk_patch*>(patches), 262144, patch_count,
+      Device::GetStream()));
+}
+
+void ComputeBounds(const Patch* patches, Vector2f* bounds, int bounds_width, int patch_count)
+{
+  VK_ASSERT(vk_trace_compute_bounds(reinterpret_cast<const vk_patch*>(patches),
+      reinterpret_cast<float*>(bounds), bounds_width, patch_count, nullptr, Device::GetStream()));
+}
+
+void ComputePoints(const HashEntry* entries, const Voxel* voxels,
+    const Vector2f* bounds, int block_count, float block_length,
+    float voxel_length, float trunc_length, const Transform& Twc,
+    const Projection& projection, float* depths, Vector3f* colors,
+    int image_width, int image_height, int bounds_width, int bounds_height)
+{
+  const vk_transform T = Twc.ToVk();
+  const vk_projection k = projection.ToVk();
+  VK_ASSERT(vk_trace_compute_points(reinterpret_cast<const vk_hash_entry*>(entries),
+      reinterpret_cast<const vk_voxel*>(voxels), reinterpret_cast<const float*>(bounds), block_count,
+      block_length, voxel_length, trunc_length, &T, &k, depths, reinterpret_cast<float*>(colors),
+      image_width, image_height, bounds_width, bounds_height, Device::GetStream()));
+}
+
+void ResetBoundsBuffer(Vector2f* bounds, int count)
+{
+  VK_ASSERT(vk_trace_reset_bounds(reinterpret_cast<float*>(bounds), count, Device::GetStream()));
+}
+
+// ---- Tracer --------------------------------------------------------------------
+
+Tracer::Tracer(std::shared_ptr<const Volume> volume) :
+  volume_(volume),
+  depth_range_(0.1f, 5.0f),
+  bounds_width_(80),    // tracer.cpp:56-57 "TODO: expose variable"
+  bounds_height_(60)
+{
+  Initialize();
+}
+
+std::shared_ptr<const Volume> Tracer::GetVolume() const { return volume_; }
+
+const Vector2f& Tracer::GetDepthRange() const { return depth_range_; }
+
+void Tracer::SetDepthRange(const Vector2f& range)
+{
+  VULCAN_DEBUG(range[0] > 0 && range[0] < range[1]);
+  depth_range_ = range;
+}
+
+void Tracer::SetDepthRange(float min, float max) { SetDepthRange(Vector2f(min, max)); }
+
+void Tracer::Trace(Frame& frame)
+{
+  VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+  const int w = frame.depth_image->GetWidth();
+  const int h = frame.depth_image->GetHeight();
+  if (!frame.color_image) frame.color_image = std::make_shared<ColorImage>();
+  if (!frame.normal_image) frame.normal_image = std::make_shared<ColorImage>();
+  frame.color_image->Resize(w, h);
+  frame.normal_image->Resize(w, h);
+
+  const vk_volume v = volume_->ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_trace(&v, &f, depth_range_[0], depth_range_[1], reinterpret_cast<float*>(bounds_.GetData()),
+      bounds_width_, bounds_height_, frame.depth_image->GetData(),
+      reinterpret_cast<float*>(frame.color_image->GetData()),
+      reinterpret_cast<float*>(frame.normal_image->GetData()), Device::GetStream()));
+}
+
+void Tracer::ComputePatches(const Frame& frame)
+{
+  const Buffer<int>& visible = volume_->GetVisibleBlocks();
+  const Buffer<HashEntry>& entries = volume_->GetHashEntries();
+  const float block_length = Block::resolution * volume_->GetVoxelLength();
+
+  ResetBufferSize();
+
+  vulcan::ComputePatches(visible.GetData(), entries.GetData(),
+      frame.depth_to_world_transform.Inverse(), frame.depth_projection, block_length,
+      depth_range_[0], depth_range_[1], visible.GetSize(), frame.depth_image->GetWidth(),
+      frame.depth_image->GetHeight(), bounds_width_, bounds_height_, patches_.GetData(),
+      buffer_size_.GetData());
+
+  patches_.Resize(min<size_t>(GetBufferSize(), patches_.GetCapacity()));
+}
+
+void Tracer::ComputeBounds(const Frame&)
+{
+  ResetBoundsBuffer();
+  vulcan::ComputeBounds(patches_.GetData(), bounds_.GetData(), bounds_width_, patches_.GetSize());
+}
+
+void Tracer::ComputePoints(Frame& frame)
+{
+  const int w = frame.depth_image->GetWidth();
+  const int h = frame.depth_image->GetHeight();
+  const float voxel_length = volume_->GetVoxelLength();
+  if (!frame.color_image) frame.color_image = std::make_shared<ColorImage>();
+  frame.color_image->Resize(w, h);
+
+  vulcan::ComputePoints(volume_->GetHashEntries().GetData(), volume_->GetVoxels().GetData(),
+      bounds_.GetData(), volume_->GetMainBlockCount(), Block::resolution * voxel_length, voxel_length,
+      volume_->GetTruncationLength(), frame.depth_to_world_transform, frame.depth_projection,
+      frame.depth_image->GetData(), frame.color_image->GetData(), w, h, bounds_width_, bounds_height_);
+}
+
+void Tracer::ComputeNormals(Frame& frame)
+{
+  frame.ComputeNormals();
+}
+
+void Tracer::ResetBoundsBuffer()
+{
+  vulcan::ResetBoundsBuffer(bounds_.GetData(), bounds_width_ * bounds_height_);
+}
+
+void Tracer::ResetBufferSize()
+{
+  VK_ASSERT(vk_memset(buffer_size_.GetData(), 0, sizeof(int), Device::GetStream()));
+}
+
+int Tracer::GetBufferSize()
+{
+  int value = 0;
+  VK_ASSERT(vk_memcpy_d2h(&value, buffer_size_.GetData(), sizeof(int), Device::GetStream()));
+  return value;
+}
+
+void Tracer::Initialize()
+{
+  patches_.Reserve(262144);  // tracer.cpp:134
+  // tracer.cpp:140 sizes this 80*60; the fused bounds pass keeps its per-workgroup
+  // copies behind the grid (vk_trace_bounds_floats)
+  bounds_.Resize(vk_trace_bounds_floats(bounds_width_, bounds_height_) / 2);
+  buffer_size_.Resize(1);
+}
+
+} // namespace vulcan

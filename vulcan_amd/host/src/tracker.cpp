@@ -1,0 +1,262 @@
+// tracker.cpp — Tracker, DepthTracker and PyramidTracker<DepthTracker>
+// (ref: src/tracker.cpp, src/depth_tracker.cpp, src/depth_tracker.cu:272-378,
+//  src/pyramid_tracker.cpp).
+#include <vulcan/depth_tracker.h>
+#include <vulcan/pyramid_tracker.h>
+#include <vulcan/tracker.h>
+#include <vulcan/exception.h>
+#include <vulcan/frame.h>
+
+namespace vulcan
+{
+
+namespace
+{
+
+vk_icp_view ViewOf(const Frame& frame)
+{
+  vk_icp_view v;
+  v.depths = frame.depth_image->GetData();
+  v.normals = reinterpret_cast<const float*>(frame.normal_image->GetData());
+  v.width = frame.depth_image->GetWidth();
+  v.height = frame.depth_image->GetHeight();
+  v.projection = frame.depth_projection.ToVk();
+  return v;
+}
+
+} // namespace
+
+// ---- Tracker -------------------------------------------------------------------
+
+Tracker::Tracker() :
+  translation_enabled_(true),
+  iteration_(0),
+  max_iterations_(20),
+  reduce_hook_(nullptr),
+  reduce_user_(nullptr)
+{
+  system_.Resize(48);
+  pose_.Resize(1);
+  state_.Resize(2);
+  update_.Resize(6);
+}
+
+Tracker::~Tracker() {}
+
+std::shared_ptr<const Frame> Tracker::GetKeyframe() const { return keyframe_; }
+
+void Tracker::SetKeyframe(std::shared_ptr<const Frame> keyframe) { keyframe_ = keyframe; }
+
+bool Tracker::GetTranslationEnabled() const { return translation_enabled_; }
+
+void Tracker::SetTranslationEnabled(bool enabled) { translation_enabled_ = enabled; }
+
+int Tracker::GetMaxIterations() const { return max_iterations_; }
+
+void Tracker::SetMaxIterations(int iterations)
+{
+  VULCAN_DEBUG(iterations > 0);
+  max_iterations_ = iterations;
+}
+
+void Tracker::SetReduceHook(ReduceHook hook, void* user)
+{
+  reduce_hook_ = hook;
+  reduce_user_ = user;
+}
+
+// ref: tracker.cpp:53-63. Every iteration is enqueued without a host round
+// trip: system -> (optional all-reduce) -> device solve + pose update. Once the
+// update norm drops below 1e-6 (tracker.cpp:162) the device-side state marks
+// the solve converged and the remaining updates are no-ops.
+void Tracker::Track(Frame& frame)
+{
+  BeginSolve(frame);
+
+  while (IsSolving())
+  {
+    ComputeSystem(frame);
+    if (reduce_hook_) reduce_hook_(system_.GetData(), 48, reduce_user_);
+    VK_ASSERT(vk_icp_solve_update(system_.GetData(), system_.GetData() + 36, translation_enabled_ ? 1 : 0,
+        pose_.GetData(), state_.GetData(), update_.GetData(), Device::GetStream()));
+    ++iteration_;
+  }
+
+  EndSolve(frame);
+}
+
+bool Tracker::IsSolving() const { return iteration_ < max_iterations_; }
+
+void Tracker::BeginSolve(const Frame& frame)
+{
+  ValidateKeyframe();
+  ValidateFrame(frame);
+  ResizeBuffers(frame);
+  iteration_ = 0;
+  const vk_transform pose = frame.depth_to_world_transform.ToVk();
+  pose_.CopyFromHost(&pose);
+  VK_ASSERT(vk_memset(state_.GetData(), 0, 2 * sizeof(int), Device::GetStream()));
+}
+
+void Tracker::EndSolve(Frame& frame)
+{
+  vk_transform pose;
+  pose_.CopyToHost(&pose);  // the only readback of the solve
+  frame.depth_to_world_transform = Transform::FromVk(pose);
+}
+
+void Tracker::ValidateKeyframe() const
+{
+  VULCAN_DEBUG_MSG(keyframe_, "keyframe has not been assigned");
+  VULCAN_DEBUG_MSG(keyframe_->depth_image, "keyframe missing depth image");
+  VULCAN_DEBUG_MSG(keyframe_->normal_image, "keyframe missing normal image");
+  VULCAN_DEBUG_MSG(keyframe_->depth_image->GetTotal() > 0, "invalid keyframe depth image size");
+  VULCAN_DEBUG_MSG(keyframe_->depth_image->GetSize() == keyframe_->normal_image->GetSize(),
+      "keyframe image size mismatch");
+}
+
+void Tracker::ValidateFrame(const Frame& frame) const
+{
+  VULCAN_DEBUG_MSG(frame.depth_image, "frame missing depth image");
+  VULCAN_DEBUG_MSG(frame.normal_image, "frame missing normal image");
+  VULCAN_DEBUG_MSG(frame.depth_image->GetTotal() > 0, "invalid frame depth image size");
+  VULCAN_DEBUG_MSG(frame.depth_image->GetSize() == frame.normal_image->GetSize(),
+      "frame image size mismatch");
+}
+
+void Tracker::ResizeBuffers(const Frame& frame)
+{
+  const size_t floats = vk_icp_workspace_floats(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+  if (floats > workspace_.GetSize()) workspace_.Resize(floats);
+}
+
+int Tracker::GetParameterCount() const { return translation_enabled_ ? 6 : 3; }
+
+// ---- DepthTracker ----------------------------------------------------------------
+
+DepthTracker::DepthTracker() {}
+
+DepthTracker::~DepthTracker() {}
+
+int DepthTracker::GetResidualCount(const Frame& frame) const
+{
+  return frame.depth_image->GetWidth() * frame.depth_image->GetHeight();
+}
+
+void DepthTracker::ComputeResiduals(const Frame& frame, Buffer<float>& residuals) const
+{
+  residuals.Resize(GetResidualCount(frame));
+  const vk_icp_view key = ViewOf(*keyframe_), frm = ViewOf(frame);
+  const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
+  const vk_transform Twc = frame.depth_to_world_transform.ToVk();
+  VK_ASSERT(vk_icp_compute_residuals(&key, &Twm, &frm, &Twc, residuals.GetData(), Device::GetStream()));
+}
+
+void DepthTracker::ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian) const
+{
+  jacobian.Resize(GetResidualCount(frame));
+  const vk_icp_view key = ViewOf(*keyframe_), frm = ViewOf(frame);
+  const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
+  const vk_transform Twc = frame.depth_to_world_transform.ToVk();
+  VK_ASSERT(vk_icp_compute_jacobian(&key, &Twm, &frm, &Twc, translation_enabled_ ? 1 : 0,
+      reinterpret_cast<float*>(jacobian.GetData()), Device::GetStream()));
+}
+
+void DepthTracker::ComputeSystem(const Frame& frame)
+{
+  const vk_icp_view key = ViewOf(*keyframe_), frm = ViewOf(frame);
+  const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
+  const vk_transform Twc = frame.depth_to_world_transform.ToVk();
+  // the pose being refined lives on the device (pose_), Twc is only the fallback
+  VK_ASSERT(vk_icp_compute_system(&key, &Twm, &frm, &Twc, pose_.GetData(), translation_enabled_ ? 1 : 0,
+      workspace_.GetData(), system_.GetData(), system_.GetData() + 36, Device::GetStream()));
+}
+
+// ref: depth_tracker.cpp:22-86 (host form; Track() uses the device form)
+void DepthTracker::ApplyUpdate(Frame& frame, const Vector6f& update) const
+{
+  Matrix4f Tinc = Matrix4f::Identity();
+  Tinc(0, 1) = -update[2]; Tinc(0, 2) = +update[1]; Tinc(0, 3) = +update[3];
+  Tinc(1, 0) = +update[2]; Tinc(1, 2) = +update[0]; Tinc(1, 3) = +update[4];   // (1,2) sign as upstream
+  Tinc(2, 0) = -update[1]; Tinc(2, 1) = +update[0]; Tinc(2, 3) = +update[5];
+
+  const Matrix4f M = Tinc * frame.depth_to_world_transform.GetMatrix();
+
+  Vector3f x_axis(M(0, 0), M(1, 0), M(2, 0));
+  Vector3f y_axis(M(0, 1), M(1, 1), M(2, 1));
+  x_axis.Normalize();
+  y_axis.Normalize();
+  const Vector3f z_axis = x_axis.Cross(y_axis);
+  y_axis = z_axis.Cross(x_axis);
+
+  Matrix3f R;
+  for (int r = 0; r < 3; ++r)
+  {
+    R(r, 0) = x_axis[r];
+    R(r, 1) = y_axis[r];
+    R(r, 2) = z_axis[r];
+  }
+
+  const Vector3f t(M(0, 3), M(1, 3), M(2, 3));
+  frame.depth_to_world_transform = Transform::Translate(t) * Transform::Rotate(R);
+}
+
+// ---- PyramidTracker ---------------------------------------------------------------
+
+template <typename Tracker>
+PyramidTracker<Tracker>::PyramidTracker() :
+  tracker_(std::shared_ptr<Tracker>(new Tracker())),
+  half_keyframe_(std::make_shared<Frame>()),
+  quarter_keyframe_(std::make_shared<Frame>()),
+  iter_(0)
+{
+}
+
+template <typename Tracker>
+PyramidTracker<Tracker>::PyramidTracker(std::shared_ptr<Tracker> tracker) :
+  tracker_(tracker),
+  half_keyframe_(std::make_shared<Frame>()),
+  quarter_keyframe_(std::make_shared<Frame>()),
+  iter_(0)
+{
+}
+
+template <typename Tracker>
+PyramidTracker<Tracker>::~PyramidTracker() {}
+
+template <typename Tracker>
+std::shared_ptr<const Tracker> PyramidTracker<Tracker>::GetTracker() const { return tracker_; }
+
+template <typename Tracker>
+std::shared_ptr<const Frame> PyramidTracker<Tracker>::GetKeyframe() const { return keyframe_; }
+
+template <typename Tracker>
+void PyramidTracker<Tracker>::SetKeyframe(std::shared_ptr<const Frame> keyframe) { keyframe_ = keyframe; }
+
+// ref: pyramid_tracker.cpp:52-90. The quarter level is built but not tracked
+// upstream (:69-77 commented out); it is not built here.
+template <typename Tracker>
+void PyramidTracker<Tracker>::Track(Frame& frame)
+{
+  VULCAN_DEBUG(keyframe_);
+
+  Frame half_frame;
+  frame.Downsample(half_frame);
+  keyframe_->Downsample(*half_keyframe_);
+
+  tracker_->SetMaxIterations(15);
+  tracker_->SetTranslationEnabled(true);
+  tracker_->SetKeyframe(half_keyframe_);
+  tracker_->Track(half_frame);
+
+  tracker_->SetMaxIterations(20);
+  tracker_->SetTranslationEnabled(true);
+  frame.depth_to_world_transform = half_frame.depth_to_world_transform;
+  tracker_->SetKeyframe(keyframe_);
+  tracker_->Track(frame);
+  ++iter_;
+}
+
+template class PyramidTracker<DepthTracker>;
+
+} // namespace vulcan

@@ -1,0 +1,176 @@
+// volume.cpp — Volume host class over vk_volume_* (ref: src/volume.cu:370-627).
+#include <vulcan/volume.h>
+#include <vulcan/block.h>
+#include <vulcan/exception.h>
+#include <vulcan/frame.h>
+#include <vulcan/hash.h>
+#include <vulcan/voxel.h>
+
+namespace vulcan
+{
+
+Volume::Volume(int main_block_count, int excess_block_count) :
+  depth_range_(0.1f, 5.0f),
+  max_block_count_(main_block_count + excess_block_count),
+  main_block_count_(main_block_count),
+  excess_block_count_(excess_block_count),
+  truncation_length_(0.04f),
+  voxel_length_(0.008f),
+  empty_(true),
+  visible_count_stale_(false)
+{
+  Initialize();
+}
+
+Volume::~Volume()
+{
+}
+
+int Volume::GetMainBlockCount() const { return main_block_count_; }
+
+int Volume::GetExcessBlockCount() const { return excess_block_count_; }
+
+const Vector2f& Volume::GetDepthRange() const { return depth_range_; }
+
+void Volume::SetDepthRange(const Vector2f& range)
+{
+  VULCAN_DEBUG(range[0] > 0 && range[0] < range[1]);
+  depth_range_ = range;
+}
+
+void Volume::SetDepthRange(float min, float max) { SetDepthRange(Vector2f(min, max)); }
+
+float Volume::GetVoxelLength() const { return voxel_length_; }
+
+void Volume::SetVoxelLength(float length)
+{
+  VULCAN_DEBUG(length > 0);
+  voxel_length_ = length;
+}
+
+float Volume::GetTruncationLength() const { return truncation_length_; }
+
+void Volume::SetTruncationLength(float length)
+{
+  VULCAN_DEBUG(length > 0);
+  truncation_length_ = length;
+}
+
+vk_volume Volume::ToVk() const
+{
+  vk_volume v;
+  v.voxels = reinterpret_cast<vk_voxel*>(const_cast<Voxel*>(voxels_.GetData()));
+  v.hash_entries = reinterpret_cast<vk_hash_entry*>(const_cast<HashEntry*>(hash_entries_.GetData()));
+  v.free_voxel_blocks = const_cast<int*>(free_voxel_blocks_.GetData());
+  v.allocation_types = reinterpret_cast<uint8_t*>(const_cast<AllocationType*>(allocation_types_.GetData()));
+  v.allocation_blocks = reinterpret_cast<vk_block*>(const_cast<Block*>(allocation_blocks_.GetData()));
+  v.block_visibility = reinterpret_cast<uint8_t*>(const_cast<Visibility*>(block_visibility_.GetData()));
+  v.visible_blocks = const_cast<int*>(visible_blocks_.GetData());
+  v.counters = const_cast<int*>(counters_.GetData());
+  v.main_block_count = main_block_count_;
+  v.excess_block_count = excess_block_count_;
+  v.voxel_length = voxel_length_;
+  v.truncation_length = truncation_length_;
+  v.min_depth = depth_range_[0];
+  v.max_depth = depth_range_[1];
+  return v;
+}
+
+void Volume::SetView(const Frame& frame)
+{
+  VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+  const vk_volume v = ToVk();
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_volume_set_view(&v, &f, Device::GetStream()));
+  visible_count_stale_ = true;
+  empty_ = false;
+}
+
+const Buffer<HashEntry>& Volume::GetHashEntries() const { return hash_entries_; }
+
+const Buffer<int>& Volume::GetAllocatedBlocks() const
+{
+  VULCAN_THROW("not implemented");  // as in the reference (volume.cu:444-448)
+}
+
+const Buffer<int>& Volume::GetVisibleBlocks() const
+{
+  if (visible_count_stale_)
+  {
+    visible_blocks_.Resize(GetBufferSize());  // volume.cu:494, deferred to first use
+    visible_count_stale_ = false;
+  }
+  return visible_blocks_;
+}
+
+const Buffer<Voxel>& Volume::GetVoxels() const { return voxels_; }
+
+Buffer<Voxel>& Volume::GetVoxels() { return voxels_; }
+
+void Volume::GetCounters(int32_t* counters) const
+{
+  const vk_volume v = ToVk();
+  VK_ASSERT(vk_volume_read_counters_sync(&v, counters, Device::GetStream()));
+}
+
+void Volume::ResetBlockVisibility()
+{
+  const vk_volume v = ToVk();
+  VK_ASSERT(vk_volume_reset_block_visibility(&v, Device::GetStream()));
+}
+
+void Volume::UpdateBlockVisibility(const Frame& frame)
+{
+  const vk_volume v = ToVk();
+  const vk_projection k = frame.depth_projection.ToVk();
+  const vk_transform Tdw = frame.depth_to_world_transform.Inverse().ToVk();
+  VK_ASSERT(vk_volume_update_block_visibility(&v, frame.depth_image->GetWidth(),
+      frame.depth_image->GetHeight(), &k, &Tdw, Device::GetStream()));
+  visible_blocks_.Resize(GetBufferSize());
+  visible_count_stale_ = false;
+}
+
+void Volume::CreateAllocationRequests(const Frame& frame)
+{
+  const vk_volume v = ToVk();
+  const vk_projection k = frame.depth_projection.ToVk();
+  const vk_transform Twd = frame.depth_to_world_transform.ToVk();
+  VK_ASSERT(vk_volume_create_allocation_requests(&v, frame.depth_image->GetData(),
+      frame.depth_image->GetWidth(), frame.depth_image->GetHeight(), &k, &Twd, Device::GetStream()));
+}
+
+void Volume::HandleAllocationRequests()
+{
+  const vk_volume v = ToVk();
+  VK_ASSERT(vk_volume_handle_allocation_requests(&v, Device::GetStream()));
+}
+
+int Volume::GetBufferSize() const
+{
+  int32_t counters[VK_CTR_COUNT];
+  GetCounters(counters);
+  return counters[VK_CTR_VISIBLE];
+}
+
+void Volume::ResetBufferSize() const
+{
+  VK_ASSERT(vk_memset(const_cast<int*>(counters_.GetData()) + VK_CTR_VISIBLE, 0, sizeof(int),
+      Device::GetStream()));
+}
+
+void Volume::Initialize()
+{
+  // sizes as in volume.cu:565-627
+  voxels_.Resize(size_t(max_block_count_) * Block::voxel_count);
+  hash_entries_.Resize(max_block_count_);
+  free_voxel_blocks_.Resize(max_block_count_);
+  allocation_types_.Resize(main_block_count_);
+  allocation_blocks_.Resize(main_block_count_);
+  block_visibility_.Resize(max_block_count_);
+  visible_blocks_.Reserve(max_block_count_);
+  counters_.Resize(VK_CTR_COUNT);
+  const vk_volume v = ToVk();
+  VK_ASSERT(vk_volume_initialize(&v, Device::GetStream()));
+}
+
+} // namespace vulcan
