@@ -83,16 +83,28 @@ def main():
     vol, frame, out, integ, tracer = fresh()
     stream = api.stream()
 
+    # The timed loop calls the C ABI directly with descriptors built once, the way a
+    # C++ caller would (the api.* wrappers rebuild their ctypes structs per call).
+    vdesc, fdesc, odesc = vol.desc(), frame.desc(), out.desc()
+    pdesc = integ.params
+    vref, fref, oref, pref = C.byref(vdesc), C.byref(fdesc), C.byref(odesc), C.byref(pdesc)
+    bounds_ptr = C.c_void_p(tracer.bounds_scratch.data_ptr())
+    d_ptr, c_ptr, n_ptr = (C.c_void_p(t.data_ptr()) for t in (out.depth, out.color, out.normals))
+    dmin, dmax = tracer.depth_range
+
     def step(i, ev=None):
-        frame.depth_to_world = poses[i]
-        out.depth_to_world = poses[i]
-        vol.set_view(frame)                      # volume.cu:430-437
+        fdesc.depth_to_world = poses[i]
+        odesc.depth_to_world = poses[i]
+        rc = lib.vk_volume_set_view(vref, fref, stream)                    # volume.cu:430-437
         if ev:
             lib.vk_event_record(ev[0], stream)
-        integ.integrate(frame)                   # depth_integrator.cu:89-115
+        rc |= lib.vk_integrate_depth(vref, pref, fref, stream)             # depth_integrator.cu:89-115
         if ev:
             lib.vk_event_record(ev[1], stream)
-        tracer.trace(out)                        # tracer.cpp:41-47
+        rc |= lib.vk_trace(vref, oref, dmin, dmax, bounds_ptr, tracer.BOUNDS_W, tracer.BOUNDS_H,
+                           d_ptr, c_ptr, n_ptr, stream)                    # tracer.cpp:41-47
+        if rc:
+            raise api.VkError(f"frame {i}: C ABI returned {rc}")
 
     def make_event():
         e = C.c_void_p()
