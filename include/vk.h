@@ -393,6 +393,9 @@ VK_API int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, void* 
 VK_API int vk_probe_block_rmw(const vk_volume* v, void* stream);
 /* Timing-only ablations of the depth integrate kernel (variant 1..3 produce WRONG
  * voxels on purpose: 1 = no depth gather, 2 = no update, 3 = no LDS staging). */
+/* Selects a timing-only ablation of the raycast kernel for subsequent launches
+ * (0 = product; 1 = no trilinear sampling, 2 = in-block sampling only). */
+VK_API int vk_probe_points_variant(int variant);
 VK_API int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame,
     int variant, void* stream);
 

@@ -67,6 +67,8 @@ def main():
         "points": lambda: tracer.compute_points(frame, out2, col2),
         "normals": lambda: out.compute_normals(),
         "trace": lambda: tracer.trace(out),
+        "points_v1": lambda: (api.lib().vk_probe_points_variant(1), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
+        "points_v2": lambda: (api.lib().vk_probe_points_variant(2), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
         "integ_v0": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 0, api.stream()), "p"),
         "integ_v1": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 1, api.stream()), "p"),
         "integ_v2": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 2, api.stream()), "p"),

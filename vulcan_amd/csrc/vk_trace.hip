@@ -313,6 +313,7 @@ struct PointParams
   float* depths;
   float* colors;
   int image_width, image_height, bounds_width, bounds_height;
+  int variant;                // 0 = product; >0 = timing-only ablations (vk_probe_points)
 };
 
 // A voxel is 5 dwords {distance, r, g, b, (cw << 16 | dw)} at a 4-byte aligned
@@ -346,42 +347,6 @@ __device__ __forceinline__ int color_weight_of(float packed)
 // A voxel whose colour weight is 0 has never had its colour written (every
 // colour update increments the weight), so its colour is the initial (0,0,0):
 // the 12 colour bytes are only fetched when the weight is positive.
-__device__ __forceinline__ Corner load_corner(const float* __restrict__ vox)
-{
-  Corner c;
-  c.distance = vox[0];
-  c.color_weight = color_weight_of(vox[4]);
-  c.r = c.g = c.b = 0.0f;
-  if (c.color_weight > 0)
-  {
-    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 1);
-    c.r = rgb.x; c.g = rgb.y; c.b = rgb.z;
-  }
-  return c;
-}
-
-// two x-adjacent voxels: d0 | (w0, d1) | w1 as dword, dwordx2, dword
-__device__ __forceinline__ void load_corner_pair(const float* __restrict__ vox, Corner& c0, Corner& c1)
-{
-  c0.distance = vox[0];
-  const vf2 mid = *reinterpret_cast<const vf2*>(vox + 4);
-  const float w1 = vox[9];
-  c0.color_weight = color_weight_of(mid.x);
-  c1.distance = mid.y;
-  c1.color_weight = color_weight_of(w1);
-  c0.r = c0.g = c0.b = 0.0f;
-  c1.r = c1.g = c1.b = 0.0f;
-  if (c0.color_weight > 0)
-  {
-    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 1);
-    c0.r = rgb.x; c0.g = rgb.y; c0.b = rgb.z;
-  }
-  if (c1.color_weight > 0)
-  {
-    const vf3 rgb = *reinterpret_cast<const vf3*>(vox + 6);
-    c1.r = rgb.x; c1.g = rgb.y; c1.b = rgb.z;
-  }
-}
 
 // One-entry cache of the last hash lookup: consecutive march steps and the
 // eight trilinear corners mostly stay in one block, and the table is read-only
@@ -423,7 +388,6 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   const float wy = (p.y - by * P.block_length) / P.voxel_length;
   const float wz = (p.z - bz * P.block_length) / P.voxel_length;
 
-  const int block_offset = VK_BLOCK_VOXELS * data;
   const int i0x = f2i(floorf(wx - 0.5f));
   const int i0y = f2i(floorf(wy - 0.5f));
   const int i0z = f2i(floorf(wz - 0.5f));
@@ -431,48 +395,80 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   Corner vv[8];  // index dz*4 + dy*2 + dx
   const float* voxf = reinterpret_cast<const float*>(P.voxels);
 
-  if (i0x >= 0 && i0y >= 0 && i0z >= 0 && i0x < 7 && i0y < 7 && i0z < 7)
+  // The eight corners touch at most 2x2x2 blocks. The reference has two code
+  // paths (all corners in this block: eight direct reads, tracer.cu:219-243;
+  // otherwise GetVoxel x8, each walking the hash table, :244-256). Here there is
+  // ONE path for every lane of the wave: per axis, sx/sy/sz say which way each of
+  // the two corners leaves the block (0 = stays; always 0 for interior samples)
+  // and lx/ly/lz are the wrapped voxel indices; a block is looked up only if it
+  // differs from this one AND from the block of a corner already resolved, so an
+  // interior sample costs no lookup and a face-crossing sample costs one.
+  int lx[2], ly[2], lz[2], sx[2], sy[2], sz[2];
+  wrap_axis(i0x, lx[0], sx[0]); wrap_axis(i0x + 1, lx[1], sx[1]);
+  wrap_axis(i0y, ly[0], sy[0]); wrap_axis(i0y + 1, ly[1], sy[1]);
+  wrap_axis(i0z, lz[0], sz[0]); wrap_axis(i0z + 1, lz[1], sz[1]);
+  if (P.variant == 2) { sx[0] = sx[1] = sy[0] = sy[1] = sz[0] = sz[1] = 0; }
+
+  int slot[8];  // pool slot of the block holding corner c, -1 = absent
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
   {
-    // all eight corners in this block: four x-adjacent pairs
-    const float* base = voxf + (size_t)(block_offset + i0z * 64 + i0y * 8 + i0x) * 5;
-    load_corner_pair(base, vv[0], vv[1]);
-    load_corner_pair(base + 8 * 5, vv[2], vv[3]);
-    load_corner_pair(base + 64 * 5, vv[4], vv[5]);
-    load_corner_pair(base + 72 * 5, vv[6], vv[7]);
+    const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
+    if (dx && sx[1] == sx[0]) { slot[c] = slot[c ^ 1]; continue; }
+    if (dy && sy[1] == sy[0]) { slot[c] = slot[c ^ 2]; continue; }
+    if (dz && sz[1] == sz[0]) { slot[c] = slot[c ^ 4]; continue; }
+    if ((sx[dx] | sy[dy] | sz[dz]) == 0) { slot[c] = data; continue; }
+    BlockCache scratch;
+    scratch.valid = false;
+    slot[c] = find_block(P, scratch, bx + sx[dx], by + sy[dy], bz + sz[dz]);
   }
-  else
+
+  // Four rows of two x-neighbours. When both voxels of a row sit in the same
+  // block they are 10 contiguous dwords {d0 rgb0 w0 | d1 rgb1 w1}: d0, (w0,d1), w1
+  // = 3 loads for the row. Only lanes whose sample straddles a block face in x
+  // (1 in 8) fetch d1 separately (4th, exec-masked load).
+#pragma unroll
+  for (int row = 0; row < 4; ++row)
   {
-    // The eight corners touch at most 2x2x2 blocks. The reference walks the hash
-    // table once per corner (GetVoxel x8); here every DISTINCT neighbour block is
-    // looked up once: sx/sy/sz say which way each of the two corners per axis
-    // leaves the block (0 = stays), and corner (dx,dy,dz) lives in block
-    // b + (sx[dx], sy[dy], sz[dz]).
-    int lx[2], ly[2], lz[2], sx[2], sy[2], sz[2];
-    wrap_axis(i0x, lx[0], sx[0]); wrap_axis(i0x + 1, lx[1], sx[1]);
-    wrap_axis(i0y, ly[0], sy[0]); wrap_axis(i0y + 1, ly[1], sy[1]);
-    wrap_axis(i0z, lz[0], sz[0]); wrap_axis(i0z + 1, lz[1], sz[1]);
+    const int dy = row & 1, dz = row >> 1;
+    const int c0 = dz * 4 + dy * 2, c1 = c0 + 1;
+    const int row_voxel = lz[dz] * 64 + ly[dy] * 8;
+    const bool has0 = slot[c0] >= 0, has1 = slot[c1] >= 0;
+    const bool split = sx[0] != sx[1];   // x-neighbours in different blocks
+    // absent blocks read voxel 0 of the pool and are overridden with Voxel::Empty() below
+    const float* a0 = voxf + (size_t)(has0 ? VK_BLOCK_VOXELS * slot[c0] + row_voxel + lx[0] : 0) * 5;
+    const float* a1 = split ? voxf + (size_t)(has1 ? VK_BLOCK_VOXELS * slot[c1] + row_voxel + lx[1] : 0) * 5 : a0 + 5;
 
-    int slot[8];  // pool slot of the block holding corner c, -1 = absent
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
+    const float d0 = a0[0];
+    // (w0, d1) when contiguous; a split lane reads (b0, w0) instead so the 8-byte
+    // load never leaves its own voxel (the pool may end right after it)
+    const vf2 mid = *reinterpret_cast<const vf2*>(a0 + (split ? 3 : 4));
+    const float w0 = split ? mid.y : mid.x;
+    const float w1 = a1[4];
+    float d1 = mid.y;
+    if (split) d1 = a1[0];
+
+    vv[c0] = empty_corner();
+    vv[c1] = empty_corner();
+    if (has0)
     {
-      const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
-      // reuse the answer of the corner that differs only in an axis along which both corners share a block
-      if (dx && sx[1] == sx[0]) { slot[c] = slot[c ^ 1]; continue; }
-      if (dy && sy[1] == sy[0]) { slot[c] = slot[c ^ 2]; continue; }
-      if (dz && sz[1] == sz[0]) { slot[c] = slot[c ^ 4]; continue; }
-      if ((sx[dx] | sy[dy] | sz[dz]) == 0) { slot[c] = data; continue; }
-      BlockCache scratch;
-      scratch.valid = false;
-      slot[c] = find_block(P, scratch, bx + sx[dx], by + sy[dy], bz + sz[dz]);
+      vv[c0].distance = d0;
+      vv[c0].color_weight = color_weight_of(w0);
+      if (vv[c0].color_weight > 0)
+      {
+        const vf3 rgb = *reinterpret_cast<const vf3*>(a0 + 1);
+        vv[c0].r = rgb.x; vv[c0].g = rgb.y; vv[c0].b = rgb.z;
+      }
     }
-
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
+    if (has1)
     {
-      const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
-      vv[c] = (slot[c] < 0) ? empty_corner()
-                            : load_corner(voxf + (size_t)(VK_BLOCK_VOXELS * slot[c] + lz[dz] * 64 + ly[dy] * 8 + lx[dx]) * 5);
+      vv[c1].distance = d1;
+      vv[c1].color_weight = color_weight_of(w1);
+      if (vv[c1].color_weight > 0)
+      {
+        const vf3 rgb = *reinterpret_cast<const vf3*>(a1 + 1);
+        vv[c1].r = rgb.x; vv[c1].g = rgb.y; vv[c1].b = rgb.z;
+      }
     }
   }
 
@@ -486,24 +482,34 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   const float n0 = n00 * w0y + n01 * w1y;
   const float n1 = n10 * w0y + n11 * w1y;
 
-  // tracer.cu:282-289: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`
+  // tracer.cu:282-289: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`, i.e. the
+  // colour is the plain mean of the corners that carry colour. When no corner of
+  // any lane in the wave has a colour weight (depth-only volumes) every weight is
+  // 0 and the result is (0,0,0): the whole block is skipped wave-uniformly.
   float total = 0.0f;
   f3 acc = make3(0.0f, 0.0f, 0.0f);
-  float cwt[8];
+  int any_weight = 0;
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
+  for (int c = 0; c < 8; ++c) any_weight |= (vv[c].color_weight > 0) ? 1 : 0;
+
+  if (__any(any_weight))
   {
-    const float fz = ((c >> 2) & 1) ? w1z : w0z;
-    const float fy = ((c >> 1) & 1) ? w1y : w0y;
-    const float fx = (c & 1) ? w1x : w0x;
-    const float prod = fz * fy * fx * (float)(vv[c].color_weight > 0 ? 1 : 0);
-    cwt[c] = (prod != 0.0f) ? 1.0f : 0.0f;   // NaN counts as true, as in C
+    float cwt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+      const float fz = ((c >> 2) & 1) ? w1z : w0z;
+      const float fy = ((c >> 1) & 1) ? w1y : w0y;
+      const float fx = (c & 1) ? w1x : w0x;
+      const float prod = fz * fy * fx * (float)(vv[c].color_weight > 0 ? 1 : 0);
+      cwt[c] = (prod != 0.0f) ? 1.0f : 0.0f;   // NaN counts as true, as in C
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) total += cwt[c];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc = add3(acc, scale3(make3(vv[c].r, vv[c].g, vv[c].b), cwt[c]));
+    if (total > 0) acc = div3(acc, total);
   }
-#pragma unroll
-  for (int c = 0; c < 8; ++c) total += cwt[c];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) acc = add3(acc, scale3(make3(vv[c].r, vv[c].g, vv[c].b), cwt[c]));
-  if (total > 0) acc = div3(acc, total);
 
   sdf = n0 * w0z + n1 * w1z;
   color = acc;
@@ -590,7 +596,8 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
           sample = (sdf <= 0.1f && sdf >= -0.5f);
         }
 
-        if (sample) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
+        if (sample && P.variant != 1) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
+        if (P.variant == 1 && refine) sdf = 0.0f;
 
         if (refine)
         {
@@ -781,6 +788,8 @@ int launch_block_bounds(PatchParams& P, float* bounds, float2* partials, bool me
   return VK_OK;
 }
 
+int g_points_variant = 0;   // set by vk_probe_points_variant (diagnostics only)
+
 int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
@@ -805,6 +814,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.image_height = image_height;
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
+  P.variant = g_points_variant;
   const dim3 grid((image_width + 15) / 16, (image_height + 15) / 16);
   hipLaunchKernelGGL(compute_points_kernel, grid, dim3(256), 0, s, P);
   VK_LAUNCH_CHECK();
@@ -904,6 +914,12 @@ int vk_frame_filter_depths(int image_width, int image_height, const float* src, 
   const dim3 grid((image_width + 63) / 64, (image_height + 3) / 4);
   hipLaunchKernelGGL(filter_depths_kernel, grid, dim3(256), 0, vk_s(stream), image_width, image_height, src, dst);
   VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_probe_points_variant(int variant)
+{
+  g_points_variant = variant;
   return VK_OK;
 }
 

@@ -105,6 +105,42 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
   if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
 }
 
+// volume.cu:183-239: what one ray does with one crossed block once the bucket's
+// main entry is known
+__device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
+    int bx, int by, int bz)
+{
+  if (entry_is(entry, bx, by, bz))
+  {
+    mark_visible(v.block_visibility, hash_code);
+  }
+  else if (entry.data == -1)
+  {
+    mark_visible(v.block_visibility, hash_code);
+    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz);
+  }
+  else
+  {
+    bool found = false;
+    uint32_t index = hash_code;
+
+    while (entry.next != -1)
+    {
+      index = (uint32_t)entry.next;
+      entry = load_entry(v.hash_entries, index);
+
+      if (entry_is(entry, bx, by, bz))
+      {
+        mark_visible(v.block_visibility, index);
+        found = true;
+        break;
+      }
+    }
+
+    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz);
+  }
+}
+
 struct RequestParams
 {
   vk_volume v;
@@ -166,42 +202,56 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   const float tdelta_y = (step_y * block_length) / direction.y;
   const float tdelta_z = (step_z * block_length) / direction.z;
 
+  // The walk itself never depends on what the hash table holds, so it is run
+  // first and its probes are issued together: the reference's loop (one dependent
+  // table read per crossed block, :174-299) becomes kProbe independent reads in
+  // flight. A 2*trunc segment crosses 3-4 blocks; walks longer than kProbe fall
+  // back to the step-by-step loop below.
+  constexpr int kProbe = 8;
+  int sbx[kProbe], sby[kProbe], sbz[kProbe];
+  uint32_t shash[kProbe];
+  bool walking = true;
+
+#pragma unroll
+  for (int sidx = 0; sidx < kProbe; ++sidx)
+  {
+    sbx[sidx] = bx; sby[sidx] = by; sbz[sidx] = bz;
+    shash[sidx] = walking ? block_hash(bx, by, bz, K) : 0xffffffffu;
+
+    if (walking)
+    {
+      // :242-295 advance to the next block; `walking` drops when the end block is passed
+      if (tmax_x < tmax_y)
+      {
+        if (tmax_x < tmax_z) { bx += step_x; if (bx == ex + step_x) walking = false; else tmax_x += tdelta_x; }
+        else                 { bz += step_z; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
+      }
+      else
+      {
+        if (tmax_y < tmax_z) { by += step_y; if (by == ey + step_y) walking = false; else tmax_y += tdelta_y; }
+        else                 { bz += step_z; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
+      }
+    }
+  }
+
+  Entry sent[kProbe];
+#pragma unroll
+  for (int sidx = 0; sidx < kProbe; ++sidx)
+    sent[sidx] = load_entry(v.hash_entries, shash[sidx] == 0xffffffffu ? 0u : shash[sidx]);
+
+#pragma unroll
+  for (int sidx = 0; sidx < kProbe; ++sidx)
+  {
+    if (shash[sidx] == 0xffffffffu) continue;
+    probe_block(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx]);
+  }
+
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
   // guarantees that every wave exits on NaN / degenerate input.
-  for (int guard = 0; guard < 4096; ++guard)
+  for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    Entry entry = load_entry(v.hash_entries, hash_code);
-
-    if (entry_is(entry, bx, by, bz))
-    {
-      mark_visible(v.block_visibility, hash_code);
-    }
-    else if (entry.data == -1)
-    {
-      mark_visible(v.block_visibility, hash_code);
-      post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz);
-    }
-    else
-    {
-      bool found = false;
-      uint32_t index = hash_code;
-
-      while (entry.next != -1)
-      {
-        index = (uint32_t)entry.next;
-        entry = load_entry(v.hash_entries, index);
-
-        if (entry_is(entry, bx, by, bz))
-        {
-          mark_visible(v.block_visibility, index);
-          found = true;
-          break;
-        }
-      }
-
-      if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz);
-    }
+    probe_block(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz);
 
     if (tmax_x < tmax_y)
     {
