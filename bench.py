@@ -173,7 +173,7 @@ def main():
         "roofline": {
             "kernel": "integrate_kernel<depth> (vk_integrate_depth)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
             "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
             "avg_launch_us": float(np.mean(kernel_ms) * 1e3),
         },
@@ -185,6 +185,19 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     vd.shutdown()
+
+
+def pmc_traffic():
+    """HBM-side bytes per integrate launch from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes): counters cannot
+    be collected from inside an unprofiled run, so the newest measurement on file is
+    reported; None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_integrate_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        return json.load(f)["bytes_per_launch"]
 
 
 def cpu_baseline(depth_np, k, poses, frames):

@@ -391,6 +391,7 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
  * reports the integrate kernel's GB/s against both. */
 VK_API int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
 VK_API int vk_probe_block_rmw(const vk_volume* v, void* stream);
+VK_API int vk_probe_block_rmw_mode(int mode);   /* 0 plain, 1 nt stores, 2 nt loads+stores, 3 delayed stores */
 /* Timing-only ablations of the depth integrate kernel (variant 1..3 produce WRONG
  * voxels on purpose: 1 = no depth gather, 2 = no update, 3 = no LDS staging). */
 /* Selects a timing-only ablation of the raycast kernel for subsequent launches

@@ -533,3 +533,39 @@ def test_full_size_properties(api, orc):
     assert np.abs(d[3:-2, 3:-2] - 1.5).max() < 0.01               # tracer_test.cu:355-370 bar at 5 mm
     n = out.normals.cpu().numpy()[8:-8, 8:-8]
     assert np.abs(n[..., 2] + 1).max() < 2e-2
+
+
+def test_bench_sequence_matches_oracle(api, orc):
+    """The exact bench.py workload (BASELINE configs[1]: 640x480, 5 mm voxels,
+    Volume(65024, 8192), camera yawing inside a 2 m sphere): every frame's
+    SetView + Integrate + Trace on the device equals the oracle's, bit for bit."""
+    import sys, os, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    orc.set_threads(16)
+    hv = orc.HostVolume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    dv = api.Volume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    hf = orc.HostFrame(depth, k, T.Transform.identity())
+    df = api.Frame(depth, k, T.Transform.identity())
+    out = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, T.Transform.identity())
+    integ, tracer = api.DepthIntegrator(dv), api.Tracer(dv)
+    for i in range(5):
+        pose = scenes.orbit_pose(i, bench.YAW_STEP)
+        hf.depth_to_world = df.depth_to_world = out.depth_to_world = pose
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+        dv.set_view(df)
+        integ.integrate(df)
+        tracer.trace(out)
+        sync()
+        assert dv.visible_count == hv.visible_count > 5000
+        assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
+        assert np.array_equal(out.depth.cpu().numpy(), odepth)
+        assert np.array_equal(out.color.cpu().numpy(), ocolor)
+        assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
+    assert_volume_equal(dv, hv)
+    # and the result is the scene: a sphere of radius 2 m seen from its centre
+    assert np.abs(out.depth.cpu().numpy()[4:-4, 4:-4] - depth[4:-4, 4:-4]).max() < 0.01

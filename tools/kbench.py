@@ -69,12 +69,22 @@ def main():
         "trace": lambda: tracer.trace(out),
         "points_v1": lambda: (api.lib().vk_probe_points_variant(1), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
         "points_v2": lambda: (api.lib().vk_probe_points_variant(2), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
+        "integ_block": lambda: (api.lib().vk_probe_integrate(None, None, None, 10, None), integ.integrate(frame), api.lib().vk_probe_integrate(None, None, None, 15, None)),
+        "integ_pipe4": lambda: (api.lib().vk_probe_integrate(None, None, None, 14, None), integ.integrate(frame)),
+        "integ_pipe5": lambda: (api.lib().vk_probe_integrate(None, None, None, 15, None), integ.integrate(frame)),
+        "integ_pipe6": lambda: (api.lib().vk_probe_integrate(None, None, None, 16, None), integ.integrate(frame)),
+        "integ_pipe8": lambda: (api.lib().vk_probe_integrate(None, None, None, 18, None), integ.integrate(frame), api.lib().vk_probe_integrate(None, None, None, 15, None)),
+        "integ_pipe2": lambda: (api.lib().vk_probe_integrate(None, None, None, 12, None), integ.integrate(frame), api.lib().vk_probe_integrate(None, None, None, 15, None)),
+        "integ_pipe3": lambda: (api.lib().vk_probe_integrate(None, None, None, 13, None), integ.integrate(frame), api.lib().vk_probe_integrate(None, None, None, 15, None)),
         "integ_v0": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 0, api.stream()), "p"),
         "integ_v1": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 1, api.stream()), "p"),
         "integ_v2": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 2, api.stream()), "p"),
         "integ_v3": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 3, api.stream()), "p"),
         "integ_v4": lambda: api.check(api.lib().vk_probe_integrate(api._ref(vol.desc()), api._ref(integ.params), api._ref(frame.desc()), 4, api.stream()), "p"),
         "probe_rmw": lambda: api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"),
+        "probe_rmw1": lambda: (api.lib().vk_probe_block_rmw_mode(1), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
+        "probe_rmw2": lambda: (api.lib().vk_probe_block_rmw_mode(2), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
+        "probe_rmw3": lambda: (api.lib().vk_probe_block_rmw_mode(3), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
         "probe_copy": lambda: api.check(api.lib().vk_probe_stream_copy(api._ptr(copy_dst), api._ptr(copy_src), copy_src.numel(), api.stream()), "probe"),
     }
     only = [s for s in args.only.split(",") if s]

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
     "vk_probe_stream_copy": ([_P, _P, _SZ, _P], _I),
     "vk_probe_block_rmw": ([_P, _P], _I),
+    "vk_probe_block_rmw_mode": ([_I], _I),
     "vk_probe_integrate": ([_P, _P, _P, _I, _P], _I),
     "vk_probe_points_variant": ([_I], _I),
 }

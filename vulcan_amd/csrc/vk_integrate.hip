@@ -15,6 +15,10 @@
 // (SURVEY.md §8d).
 #include "vk_common.hpp"
 
+#ifndef VK_INTEGRATE_NT_STORES
+#define VK_INTEGRATE_NT_STORES 0
+#endif
+
 using namespace vk;
 
 namespace
@@ -298,13 +302,278 @@ __global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(Integrat
   }    // 64-block groups
 }
 
+// ---------------------------------------------------------------------------
+// Pipelined form. The kernel above moves a whole block per step: every wave of a
+// CU loads, then computes, then stores at about the same time, so the ~10 us of
+// per-voxel arithmetic does not overlap with the ~15 us of data movement (r01
+// ablations). Here the unit of work is HALF a block (four z
+// slices = 5 KiB = 320 float4, five float4 per lane) and a wave keeps two units
+// in flight: while unit s is updated out of LDS, the tile loads and the depth
+// gathers of unit s+1 are already on their way into the other register set.
+// ---------------------------------------------------------------------------
+
+constexpr int kHalfF4 = 320;          // float4 per half block
+constexpr bool g_nt_stores = VK_INTEGRATE_NT_STORES;
+typedef float nf4 __attribute__((ext_vector_type(4)));
+constexpr int kPipeWavesPerGroup = 4;
+
+// Per-unit state. It is deliberately a bundle of separate locals passed by
+// reference (not a struct with array members): hipcc's SROA left the struct form
+// in scratch memory, which serialised every tile load behind a scratch store.
+#define UNIT_DECL(U)                                                                      \
+  float4 U##_r0, U##_r1, U##_r2, U##_r3, U##_r4;   /* the half tile, five float4 per lane */ \
+  float U##_depth[4], U##_z[4], U##_du[4], U##_dv[4];                                      \
+  uint32_t U##_valid = 0;                                                                  \
+  float4* U##_base = nullptr;                                                              \
+  bool U##_skip = true;                                                                    \
+  f3 U##_off = make3(0, 0, 0);                                                             \
+  int U##_half = 0
+#define UNIT_ARGS(U) U##_r0, U##_r1, U##_r2, U##_r3, U##_r4, U##_depth, U##_z, U##_du, U##_dv, U##_valid, \
+  U##_base, U##_skip, U##_off, U##_half
+#define UNIT_PARAMS float4& r0, float4& r1, float4& r2, float4& r3, float4& r4, float (&u_depth)[4],       \
+  float (&u_z)[4], float (&u_du)[4], float (&u_dv)[4], uint32_t& u_valid, float4*& u_base, bool& u_skip,  \
+  f3& u_off, int& u_half
+
+// unit s of the wave = half (s & 1) of its (s >> 1)-th block, whose hash entry sits
+// in lane (s >> 1) of my_entry
+template <bool DEPTH, int COLOR>
+__device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_entry, int s, int lane, UNIT_PARAMS)
+{
+  const int j = s >> 1, half = s & 1;
+  const int e0 = __builtin_amdgcn_readlane(my_entry.x, j);
+  const int e1 = __builtin_amdgcn_readlane(my_entry.y, j);
+  const int data = __builtin_amdgcn_readlane(my_entry.z, j);
+  const int ox = (int16_t)(e0 & 0xffff), oy = (int16_t)((uint32_t)e0 >> 16), oz = (int16_t)(e1 & 0xffff);
+  const int vx = lane & 7, vy = lane >> 3;
+  u_half = half;
+  u_off = scale3(make3((float)ox, (float)oy, (float)oz), P.block_length);
+  // the never-allocated origin block (data == -1) reads slot 0 and is
+  // flagged so that unit_update writes nothing
+  u_skip = data < 0;
+  u_base = P.voxels4 + (size_t)(data < 0 ? 0 : data) * kTileF4 + half * kHalfF4;
+  u_valid = 0;
+
+  if (DEPTH || COLOR == COLOR_LIGHT)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const int vz = half * 4 + k;
+      const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+      const f3 Xdp = xform_point(P.Tdw, add3(u_off, voxel_offset));
+      project(P.kd, Xdp, u_du[k], u_dv[k]);
+      u_z[k] = Xdp.z;
+      const bool valid = (u_du[k] >= 0) & (u_du[k] < P.width) & (u_dv[k] >= 0) & (u_dv[k] < P.height);
+      u_valid |= (valid ? 1u : 0u) << k;
+      u_depth[k] = 0.0f;
+      if (DEPTH)
+      {
+        // 32-bit unsigned index: a signed 64-bit mad here made hipcc read a register
+        // pair whose upper half was a pending gather result (forced s_waitcnt vmcnt(0))
+        // (v_mad_u32_u24: row and width are < 2^24, checked on the host)
+        const uint32_t pixel = valid ? __umul24((uint32_t)f2i(u_dv[k]), (uint32_t)P.width) + (uint32_t)f2i(u_du[k]) : 0u;
+        u_depth[k] = P.depth[pixel];
+      }
+    }
+  }
+
+  r0 = u_base[0 * 64 + lane];
+  r1 = u_base[1 * 64 + lane];
+  r2 = u_base[2 * 64 + lane];
+  r3 = u_base[3 * 64 + lane];
+  r4 = u_base[4 * 64 + lane];
+}
+
+template <bool DEPTH, int COLOR>
+__device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, float4* tile4, UNIT_PARAMS)
+{
+  float* tile = reinterpret_cast<float*>(tile4);
+  const int vx = lane & 7, vy = lane >> 3;
+  if (u_skip) return;
+
+  tile4[0 * 64 + lane] = r0;
+  tile4[1 * 64 + lane] = r1;
+  tile4[2 * 64 + lane] = r2;
+  tile4[3 * 64 + lane] = r3;
+  tile4[4 * 64 + lane] = r4;
+
+  float old_d[4];
+  uint32_t old_w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const float* vox = tile + (k * 64 + lane) * 5;
+    old_d[k] = vox[0];
+    old_w[k] = __float_as_uint(vox[4]);
+  }
+
+  bool dirty = false;
+
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    float* vox = tile + (k * 64 + lane) * 5;
+    float distance_value = 0.0f;
+    bool have_distance = false;
+    const bool valid = (u_valid >> k) & 1u;
+
+    if (DEPTH)
+    {
+      // depth_integrator.cu:54-78, evaluated branch-free: the new value is computed
+      // for every voxel and selected, so the four division chains of a lane's
+      // voxels interleave instead of running one after another behind branches.
+      const float depth = u_depth[k];
+      const float distance = depth - u_z[k];
+      const bool update = valid & !((depth < P.min_depth) | (depth > P.max_depth)) & (distance > -P.truncation_length);
+      const uint32_t weights = old_w[k];
+      const int16_t dw = (int16_t)(weights & 0xffff);
+      const float prev_dist = dw * old_d[k];
+      const float curr_dist = vmin(1.0f, distance / P.truncation_length);
+      const float dist_weight = dw + 1;
+      const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
+      const float new_distance = (prev_dist + curr_dist) / dist_weight;
+      distance_value = update ? new_distance : old_d[k];
+      have_distance = true;   // distance_value is the voxel's current distance either way
+      old_w[k] = update ? ((weights & 0xffff0000u) | (uint16_t)new_dw) : weights;
+      if (update)
+      {
+        vox[0] = distance_value;
+        vox[4] = __uint_as_float(old_w[k]);
+      }
+      dirty |= update;
+    }
+
+    if (COLOR != COLOR_NONE)
+    {
+      const int vz = u_half * 4 + k;
+      const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+      const f3 Xcp = xform_point(P.Tcw, add3(u_off, voxel_offset));
+      float cu, cv;
+      project(P.kc, Xcp, cu, cv);
+      const bool color_valid = cu >= 0 && cu < P.width && cv >= 0 && cv < P.height;
+      const float dist = have_distance ? distance_value : old_d[k];
+
+      if (COLOR == COLOR_PLAIN && color_valid && fabsf(dist) < 1.0f)
+      {
+        // color_integrator.cu:100-134
+        const int image_index = (int)cv * P.width + (int)cu;
+        const uint32_t weights = old_w[k];
+        const int16_t cw = (int16_t)(weights >> 16);
+        const float cwf = cw;
+        const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+        const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
+            P.color[3 * image_index + 2]);
+        const float color_weight = cw + 1;
+        const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+        const f3 c = div3(add3(prev_color, curr_color), color_weight);
+        vox[1] = c.x;
+        vox[2] = c.y;
+        vox[3] = c.z;
+        vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+        dirty = true;
+      }
+
+      if (COLOR == COLOR_LIGHT && valid && color_valid)
+      {
+        // light_integrator.cu:197-248
+        const int depth_index = (int)u_dv[k] * P.width + (int)u_du[k];
+        const int color_index = (int)cv * P.width + (int)cu;
+
+        if (P.mask[depth_index] > 0.5f && fabsf(dist) < 1.0f)
+        {
+          f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
+              P.color[3 * color_index + 2]);
+          const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
+              P.normals[3 * depth_index + 2]);
+          const f3 Xcn = xform_dir(P.Tcd, Xdn);
+          const float shading = light_shading(P.light, Xcp, Xcn);
+
+          if (shading > 0.05f)
+          {
+            curr_color = div3(curr_color, shading);
+            const uint32_t weights = old_w[k];
+            const int16_t cw = (int16_t)(weights >> 16);
+            const float color_weight = cw + 1;
+            const float cwf = cw;
+            const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+            const f3 c = div3(add3(prev_color, curr_color), color_weight);
+            const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+            vox[1] = c.x;
+            vox[2] = c.y;
+            vox[3] = c.z;
+            vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+            dirty = true;
+          }
+        }
+      }
+    }
+  }
+
+  if (__any(dirty))
+  {
+    float4 out[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = tile4[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+    {
+      if (g_nt_stores)
+      {
+        nf4 t; t.x = out[k].x; t.y = out[k].y; t.z = out[k].z; t.w = out[k].w;
+        __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(&u_base[k * 64 + lane]));
+      }
+      else u_base[k * 64 + lane] = out[k];
+    }
+  }
+}
+
+template <bool DEPTH, int COLOR>
+__global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_kernel(IntegrateParams P)
+{
+  __shared__ float4 tiles[kPipeWavesPerGroup][kHalfF4];
+
+  const int lane = lane_id();
+  const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = blockIdx.x * kPipeWavesPerGroup + wave_in_group;
+  const int total_waves = gridDim.x * kPipeWavesPerGroup;
+  const int count = P.counters[VK_CTR_VISIBLE];
+  float4* tile4 = tiles[wave_in_group];
+
+  for (int first = wave; first < count; first += 64 * total_waves)
+  {
+    // lane j holds the hash entry of this wave's j-th block of the group
+    const int mine = first + lane * total_waves;
+    int4 my_entry = make_int4(0, 0, -1, -1);
+    if (mine < count) my_entry = reinterpret_cast<const int4*>(P.entries)[P.visible[mine]];
+    int blocks = (count - first + total_waves - 1) / total_waves;
+    if (blocks > 64) blocks = 64;
+    const int units = 2 * blocks;   // unit s = (block s >> 1, half s & 1)
+
+    UNIT_DECL(A);
+    UNIT_DECL(B);
+    unit_issue<DEPTH, COLOR>(P, my_entry, 0, lane, UNIT_ARGS(A));
+    int s = 0;
+    for (; s + 2 < units; s += 2)   // steady state: two units per trip, next one always in flight
+    {
+      unit_issue<DEPTH, COLOR>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
+      unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(A));
+      unit_issue<DEPTH, COLOR>(P, my_entry, s + 2, lane, UNIT_ARGS(A));
+      unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(B));
+    }
+    // units is even and >= 2: exactly two remain (s, s + 1)
+    unit_issue<DEPTH, COLOR>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
+    unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(A));
+    unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(B));
+  }
+}
+
 int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, const vk_frame* f,
     const vk_light* light, const float* mask, bool need_depth, bool need_color, bool need_light)
 {
   if (!v || !p || !f) return VK_ERR_ARGUMENT;
   if (!v->voxels || !v->hash_entries || !v->visible_blocks || !v->counters) return VK_ERR_ARGUMENT;
   if (reinterpret_cast<uintptr_t>(v->voxels) & 15) return VK_ERR_ARGUMENT;
-  if (f->width <= 0 || f->height <= 0) return VK_ERR_ARGUMENT;
+  if (f->width <= 0 || f->height <= 0 || f->width >= (1 << 24) || f->height >= (1 << 24)) return VK_ERR_ARGUMENT;
   if (need_depth && !f->depth) return VK_ERR_ARGUMENT;
   if (need_color && !f->color) return VK_ERR_ARGUMENT;
   if (need_light && (!f->normals || !mask || !light)) return VK_ERR_ARGUMENT;
@@ -357,10 +626,27 @@ int grid_for(const vk_volume* v)
   return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
+bool g_integrate_pipelined = true;   // vk_probe_integrate(variant 10/11) flips it for A/B timing
+
+// 20 KiB of LDS per workgroup: up to 8 workgroups (32 waves) per CU by LDS, the
+// register budget decides; the grid is sized for 5 workgroups per CU.
+int g_pipe_groups_per_cu = 5;
+int pipe_grid_for(const vk_volume* v)
+{
+  const int max_count = v->main_block_count + v->excess_block_count;
+  const int want = (max_count + kPipeWavesPerGroup - 1) / kPipeWavesPerGroup;
+  const int cap = kCUs * g_pipe_groups_per_cu;
+  return want < cap ? (want > 0 ? want : 1) : cap;
+}
+
 template <bool DEPTH, int COLOR>
 int launch(const IntegrateParams& P, const vk_volume* v, hipStream_t s)
 {
-  hipLaunchKernelGGL((integrate_kernel<DEPTH, COLOR>), dim3(grid_for(v)), dim3(kWavesPerGroup * 64), 0, s, P);
+  if (g_integrate_pipelined)
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR>), dim3(pipe_grid_for(v)),
+        dim3(kPipeWavesPerGroup * 64), 0, s, P);
+  else
+    hipLaunchKernelGGL((integrate_kernel<DEPTH, COLOR>), dim3(grid_for(v)), dim3(kWavesPerGroup * 64), 0, s, P);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -478,6 +764,12 @@ int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const v
 
 int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int variant, void* stream)
 {
+  if (variant >= 10)   // 10 = block-at-a-time kernel, 11.. = pipelined with (variant - 10) workgroups per CU
+  {
+    g_integrate_pipelined = variant > 10;
+    if (variant > 10) g_pipe_groups_per_cu = variant - 10;
+    return VK_OK;
+  }
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
   if (rc != VK_OK) return rc;

@@ -9,6 +9,8 @@ using namespace vk;
 namespace
 {
 
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(float4* __restrict__ dst,
     const float4* __restrict__ src, size_t n4)
 {
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(float4* __restrict__ d
 
 // Reads every visible block (10 240 B) and writes it back unchanged: one wave per
 // block, ten float4 per lane, same persistent grid as integrate_kernel.
+template <int MODE>   // 0 plain, 1 nontemporal stores, 2 nontemporal loads + stores, 3 delayed plain stores
 __global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ voxels4,
     const vk_hash_entry* __restrict__ entries, const int32_t* __restrict__ visible,
     const int32_t* __restrict__ counters)
@@ -40,12 +43,32 @@ __global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ vox
     float4* block4 = voxels4 + (size_t)entry.data * 640;
     float4 r[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) r[k] = block4[k * 64 + lane];
+    for (int k = 0; k < 10; ++k)
+    {
+      if (MODE == 2)
+      {
+        const nf4 t = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(&block4[k * 64 + lane]));
+        r[k] = make_float4(t.x, t.y, t.z, t.w);
+      }
+      else r[k] = block4[k * 64 + lane];
+    }
+    if (MODE == 3)
+    {
+      // ~2000 cycles of dependent ALU work between the loads and the stores
+      float acc = r[0].x;
+      for (int t = 0; t < 500; ++t) acc = acc * 1.0000001f + 1e-9f;
+      r[9].w += acc * 0.0f;
+    }
 #pragma unroll
     for (int k = 0; k < 10; ++k)
     {
       r[k].x += 0.0f;   // keeps the store: x + 0.0f is not an identity for -0.0f
-      block4[k * 64 + lane] = r[k];
+      if (MODE == 1 || MODE == 2)
+      {
+        nf4 t; t.x = r[k].x; t.y = r[k].y; t.z = r[k].z; t.w = r[k].w;
+        __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(&block4[k * 64 + lane]));
+      }
+      else block4[k * 64 + lane] = r[k];
     }
   }
 }
@@ -63,14 +86,23 @@ int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, void* stream)
   return VK_OK;
 }
 
+int g_rmw_mode = 0;
+int vk_probe_block_rmw_mode(int mode) { g_rmw_mode = mode; return VK_OK; }
+
 int vk_probe_block_rmw(const vk_volume* v, void* stream)
 {
   VK_REQUIRE(v && v->voxels && v->hash_entries && v->visible_blocks && v->counters);
   const int max_count = v->main_block_count + v->excess_block_count;
   int grid = (max_count + 3) / 4;
   if (grid > kCUs * 4) grid = kCUs * 4;
-  hipLaunchKernelGGL(block_rmw_kernel, dim3(grid), dim3(256), 0, vk_s(stream),
-      reinterpret_cast<float4*>(v->voxels), v->hash_entries, v->visible_blocks, v->counters);
+  float4* vox = reinterpret_cast<float4*>(v->voxels);
+  switch (g_rmw_mode)
+  {
+    case 1: hipLaunchKernelGGL(block_rmw_kernel<1>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+    case 2: hipLaunchKernelGGL(block_rmw_kernel<2>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+    case 3: hipLaunchKernelGGL(block_rmw_kernel<3>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+    default: hipLaunchKernelGGL(block_rmw_kernel<0>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+  }
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
