@@ -54,7 +54,13 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--workload", default="depth", choices=["depth", "rgbd", "rgbd-icp"],
+                    help="depth = BASELINE configs[1] (the headline line); rgbd = configs[2] without tracking "
+                         "(light integrator + tracer); rgbd-icp = configs[2] with the pyramid ICP tracker. "
+                         "The extra workloads print the same JSON shape without roofline/cpu_baseline.")
     args = ap.parse_args()
+    if args.workload != "depth":
+        return extra_workload(args)
 
     import torch
     from vulcan_amd import api, dist as vd, vk_types as T
@@ -184,6 +190,70 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    vd.shutdown()
+
+
+def extra_workload(args):
+    """BASELINE configs[2]: 640x480 RGB-D, depth + light-colour integration (mask, shading)
+    and raycast, optionally preceded by PyramidTracker<DepthTracker> against the previous
+    raycast (tracker -> SetView -> Integrate -> Trace, apps/vulcan/vulcan.cu:300-325)."""
+    import torch
+    from vulcan_amd import api, dist as vd, vk_types as T
+    import scenes
+
+    rank, local_rank, world = vd.init()
+    torch.cuda.set_device(local_rank)
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth_np = sphere_room_depth(k)
+    color_np = scenes.checker_color(W, H, 0.1, 0.9)
+    total = args.warmup + args.steps
+    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
+    vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+    frame = api.Frame(depth_np, k, poses[0], color=color_np)
+    frame.compute_normals()
+    key = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
+                    color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
+                    normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
+    integ = api.LightIntegrator(vol)
+    integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))     # apps/vulcan/vulcan.cu:87-88
+    tracer = api.Tracer(vol)
+    tracker = api.PyramidTracker()
+    track = args.workload == "rgbd-icp"
+    if track and world > 1:
+        tracker.tracker.reduce_hook = vd.allreduce_system   # rigid rig: one system for all cameras
+
+    def step(i):
+        if track and i > 0:
+            frame.depth_to_world = poses[i - 1]             # previous pose as the initial guess
+            tracker.keyframe = key
+            tracker.track(frame)                            # one 128-byte pose readback per level
+        frame.depth_to_world = poses[i]                     # ground truth keeps the map consistent
+        key.depth_to_world = poses[i]
+        vol.set_view(frame)
+        integ.integrate(frame)
+        tracer.trace(key)
+
+    for i in range(args.warmup):
+        step(i)
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    vd.barrier()
+    elapsed = vd.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    frames_all = vd.sum_over_ranks(args.steps, device="cuda")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels", "value": frames_all / elapsed,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 640x480 RGB-D, LightIntegrator (mask + depth + shaded colour) + "
+                                   "Tracer" + (" + PyramidTracker<DepthTracker> (15 + 20 Gauss-Newton iterations)" if track else ""),
+                       "visible_blocks": vol.visible_count, "parallelism": f"replica volume per GPU x{world}"},
+        }), flush=True)
     vd.shutdown()
 
 

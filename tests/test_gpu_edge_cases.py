@@ -1,0 +1,130 @@
+"""Edge cases on the device vs the oracle: empty and ragged inputs, odd table
+sizes, pool exhaustion, invalid depth, two volumes in one process."""
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import api, assert_volume_equal, frames, make_pair, sync  # noqa: F401  (fixtures/helpers)
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_frame_is_a_no_op(api, orc):
+    """No valid depth: nothing allocated, nothing visible, integrate and trace run on an empty list."""
+    import torch
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    depth = np.zeros((h, w), np.float32)
+    depth[::7, ::5] = 9.0            # beyond max depth: ignored too
+    hf, df = frames(api, orc, depth, k, T.Transform.identity(), color=scenes.constant_color(w, h))
+    hv, dv = make_pair(api, orc, 1000, 37, 0.008, 0.04)        # table sizes that are multiples of nothing
+    hv.set_view(hf, orc.POLICY_MAXKEY)
+    dv.set_view(df)
+    assert_volume_equal(dv, hv)
+    assert dv.visible_count == 0
+    api.ColorIntegrator(dv).integrate(df)
+    orc.integrate_depth(hv, hf)
+    out = api.Frame(torch.full((h, w), 7.0, dtype=torch.float32, device="cuda"), k, T.Transform.identity())
+    api.Tracer(dv).trace(out)
+    sync()
+    assert_volume_equal(dv, hv)
+    assert np.all(out.depth.cpu().numpy() == 0) and np.all(out.color.cpu().numpy() == 0)
+    assert np.all(out.normals.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("size", [(101, 77), (66, 50), (17, 9)])
+def test_ragged_image_sizes(api, orc, size):
+    """Widths/heights that are not multiples of the 8/16/64-wide tiles the kernels use."""
+    import torch
+    w, h = size
+    k = T.Projection.make(0.85 * w, 0.85 * w, 0.49 * w, 0.52 * h)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.2 + 0.3 * np.sin(x / 9.0) * np.cos(y / 7.0)).astype(np.float32)
+    depth[h // 3, w // 4:w // 2] = 0.0
+    color = np.stack([0.2 + 0.6 * (x % 7) / 7.0, 0.5 + 0 * x, 0.3 + 0.5 * (y % 5) / 5.0], -1).astype(np.float32)
+    pose = scenes.tracer_test_pose()
+    hf, df = frames(api, orc, depth, k, pose, color=color)
+    hf.compute_normals()
+    df.compute_normals()
+    sync()
+    assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+    hv, dv = make_pair(api, orc, 4099, 1021, 0.01, 0.04)
+    for _ in range(6):
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        dv.set_view(df)
+    orc.integrate_depth(hv, hf)
+    orc.integrate_color(hv, hf)
+    api.ColorIntegrator(dv).integrate(df)
+    assert_volume_equal(dv, hv)
+    odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose)
+    tracer = api.Tracer(dv)
+    tracer.trace(out)
+    sync()
+    assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
+    assert np.array_equal(out.depth.cpu().numpy(), odepth)
+    assert np.array_equal(out.color.cpu().numpy(), ocolor)
+    assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
+    # ICP hooks on the same ragged frame
+    tracker = api.DepthTracker()
+    tracker.keyframe = df
+    hk = orc.HostFrame(depth, k, pose, normals=hf.normals)
+    moved = T.Transform.translate(0.002, -0.001, 0.001) * pose
+    hf2, df2 = frames(api, orc, depth, k, moved, normals=hf.normals)
+    assert np.array_equal(tracker.compute_residuals(df2).cpu().numpy(), orc.icp_residuals(hk, hf2))
+    assert np.array_equal(tracker.compute_jacobian(df2).cpu().numpy(), orc.icp_jacobian(hk, hf2, True))
+
+
+def test_pool_and_excess_exhaustion(api, orc):
+    """More blocks than the pool holds: the same requests are dropped on both sides
+    (volume.cu:356) and the volume stays consistent."""
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    hf, df = frames(api, orc, scenes.plane(w, h, 1.5), k, scenes.tracer_test_pose())
+    hv, dv = make_pair(api, orc, 257, 40, 0.008, 0.04)
+    for _ in range(5):
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        dv.set_view(df)
+        assert_volume_equal(dv, hv, voxels=False)
+    assert hv.counters[T.VK_CTR_DROPPED] > 100
+    entries = dv.host_entries()
+    used = entries["data"][entries["data"] >= 0]
+    assert len(np.unique(used)) == len(used) <= hv.max
+    api.DepthIntegrator(dv).integrate(df)
+    orc.integrate_depth(hv, hf)
+    assert_volume_equal(dv, hv)
+
+
+def test_two_volumes_in_one_process(api, orc):
+    """The reference keeps its counters in process-wide __device__ symbols
+    (volume.cu:17-21), so two Volumes corrupt each other; here they are independent."""
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    hfa, dfa = frames(api, orc, scenes.plane(w, h, 1.5), k, T.Transform.identity())
+    hfb, dfb = frames(api, orc, scenes.ramp(w, h), k, scenes.tracer_test_pose())
+    hva, dva = make_pair(api, orc, 4096, 1024, 0.008, 0.04)
+    hvb, dvb = make_pair(api, orc, 2048, 512, 0.02, 0.08)
+    for _ in range(4):                 # interleaved on the same stream
+        dva.set_view(dfa)
+        dvb.set_view(dfb)
+        api.DepthIntegrator(dva).integrate(dfa)
+        api.DepthIntegrator(dvb).integrate(dfb)
+        hva.set_view(hfa, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hva, hfa)
+        hvb.set_view(hfb, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hvb, hfb)
+    assert_volume_equal(dva, hva)
+    assert_volume_equal(dvb, hvb)
+
+
+def test_argument_errors_are_reported_not_thrown(api):
+    lib = api.lib()
+    import ctypes as C
+    v = T.Volume()          # all-null descriptor
+    assert lib.vk_volume_set_view(C.byref(v), None, None) == -1
+    assert lib.vk_volume_initialize(C.byref(v), None) == -1
+    assert lib.vk_trace_reset_bounds(None, 10, None) == -1
+    assert lib.vk_image_downsample(641, 480, None, None, 1, None) == -1
+    with pytest.raises(api.VkError):
+        api.check(-1, "vk_volume_set_view")

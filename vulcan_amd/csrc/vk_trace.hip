@@ -525,6 +525,17 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   const int wave = threadIdx.x >> 6;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+
+  // fused path: publish the merged grid (Tracer::bounds_) — every cell, whether or
+  // not a pixel maps to it
+  if (P.partials)
+  {
+    const int cells = P.bounds_width * P.bounds_height;
+    const int threads = gridDim.x * gridDim.y * 256;
+    for (int c = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; c < cells; c += threads)
+      P.bounds_out[c] = merged_bound(P.partials, cells, c);
+  }
+
   if (x >= P.image_width || y >= P.image_height) return;
 
   const int px = P.bounds_width * x / P.image_width;
@@ -535,10 +546,6 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   if (P.partials)
   {
     bound = merged_bound(P.partials, P.bounds_width * P.bounds_height, cell);
-    // the first pixel that maps to a cell publishes the merged value (Tracer::bounds_)
-    const bool first_x = (x == 0) || (P.bounds_width * (x - 1) / P.image_width != px);
-    const bool first_y = (y == 0) || (P.bounds_height * (y - 1) / P.image_height != py);
-    if (first_x && first_y) P.bounds_out[cell] = bound;
   }
   else
   {
