@@ -383,6 +383,22 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
     int translation_enabled, vk_transform* Twc_dev, int32_t* state_dev,
     float* update_dev, void* stream);
 
+/* Called between the system and the solve of every iteration with the packed
+ * device system (48 floats: hessian[36], gradient[6], pad): a multi-GPU rig sums
+ * it over ranks here (ncclAllReduce on `stream`). Returns 0 on success. */
+typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* stream);
+
+/* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker — `iterations`
+ * Gauss-Newton steps enqueued back to back with no host round trip: per step one
+ * partial-sum launch and one launch that finishes the sums, solves the 6x6
+ * system and updates *Twc_dev (three launches when `reduce` is given). `system`:
+ * device float[48]; `state_dev`: device int[2] {iterations run, converged}, the
+ * caller zeroes it; `workspace`: vk_icp_workspace_floats(w, h) floats. */
+VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, vk_transform* Twc_dev, int iterations,
+    int translation_enabled, float* workspace, float* system, int32_t* state_dev,
+    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream);
+
 /* ------------------------------------------------------------------ probes -- */
 
 /* Measurement aids, no reference counterpart (the reference has no benchmarks,

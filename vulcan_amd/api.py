@@ -68,6 +68,7 @@ _SIGNATURES = {
     "vk_icp_workspace_floats": ([_I, _I], _SZ),
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_probe_stream_copy": ([_P, _P, _SZ, _P], _I),
     "vk_probe_block_rmw": ([_P, _P], _I),
     "vk_probe_block_rmw_mode": ([_I], _I),
@@ -497,13 +498,19 @@ class DepthTracker:
         host = np.frombuffer(bytes(frame.depth_to_world), dtype=np.uint8).copy()
         self.pose.copy_(torch.from_numpy(host).to(self.device))
         self.state.zero_()
-        for _ in range(self.max_iterations):
-            self.compute_system(frame, pose_on_device=True)
-            if self.reduce_hook is not None:
+        if self.reduce_hook is None:
+            # one C call enqueues every iteration (2 launches each)
+            check(lib().vk_icp_track(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
+                                     _ref(self._view(frame)), _ptr(self.pose), self.max_iterations,
+                                     int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),
+                                     _ptr(self.state), _ptr(self.update), None, None, stream()), "vk_icp_track")
+        else:
+            for _ in range(self.max_iterations):
+                self.compute_system(frame, pose_on_device=True)
                 self.reduce_hook(self.system)
-            check(lib().vk_icp_solve_update(_ptr(self.hessian), _ptr(self.gradient), int(self.translation_enabled),
-                                            _ptr(self.pose), _ptr(self.state), _ptr(self.update), stream()),
-                  "vk_icp_solve_update")
+                check(lib().vk_icp_solve_update(_ptr(self.hessian), _ptr(self.gradient), int(self.translation_enabled),
+                                                _ptr(self.pose), _ptr(self.state), _ptr(self.update), stream()),
+                      "vk_icp_solve_update")
         out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out
         return out

@@ -28,6 +28,7 @@ struct IcpParams
   View key, frm;
   Rt Twm, Tmw, Twc;
   const vk_transform* Twc_dev;  // optional device override of Twc
+  const int32_t* state;         // optional {iterations, converged}: a converged solve skips the pass
 };
 
 __device__ __forceinline__ Rt rt_from_colmajor(const float* m)
@@ -121,6 +122,9 @@ __global__ __launch_bounds__(256) void jacobian_kernel(IcpParams P, float* __res
   for (int i = 0; i < 6; ++i) out[i] = J[i];
 }
 
+__device__ void solve_update(const float* hessian, const float* gradient, int translation_enabled,
+    vk_transform* Twc, int32_t* state, float* update_out);
+
 constexpr int kSysThreads = 256;
 constexpr int kSysPixelsPerThread = 4;
 constexpr int kSysStride = 32;  // floats per workgroup partial: 6 gradient + 21 hessian + pad
@@ -131,6 +135,10 @@ template <bool TRANSLATION>
 __global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P, float* __restrict__ workspace)
 {
   __shared__ float lds[kSysThreads / 64][kSysStride];
+
+  // tracker.cpp:162: once the update norm fell below 1e-6 the reference leaves its
+  // loop; here the remaining (already enqueued) iterations turn into empty launches
+  if (P.state && P.state[1]) return;
 
   const Rt Twc = P.Twc_dev ? rt_from_colmajor(P.Twc_dev->m) : P.Twc;
   const int total = P.frm.width * P.frm.height;
@@ -187,12 +195,18 @@ __global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P
 
 // Fixed-order sum of the partials: 8 slices x 32 components, then the slices in
 // order. Writes hessian[36] (packed lower triangle first, rest 0) and gradient[6].
+// With `Twc` non-null the same workgroup goes on to solve the system and update the
+// pose (one launch per Gauss-Newton iteration instead of two).
 __global__ __launch_bounds__(256) void system_final_kernel(const float* __restrict__ workspace,
-    int partials, int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient)
+    int partials, int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient,
+    vk_transform* Twc, int32_t* state, float* update_out)
 {
   __shared__ float slices[8][kSysStride];
+  __shared__ float sums[48];   // hessian[36] | gradient[6]: the solve reads them from LDS
   const int c = threadIdx.x & 31;
   const int s = threadIdx.x >> 5;
+
+  if (state && state[1]) return;   // converged: the system was not recomputed, keep the last one
 
   float v = 0.0f;
   for (int j = s; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
       if ((int)threadIdx.x < n)
         for (int k = 0; k < 8; ++k) g += slices[k][threadIdx.x];
       gradient[threadIdx.x] = g;
+      sums[36 + threadIdx.x] = g;
     }
     else
     {
@@ -219,7 +234,14 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
       if (out < n)
         for (int k = 0; k < 8; ++k) h += slices[k][6 + out];
       hessian[out] = h;
+      sums[out] = h;
     }
+  }
+
+  if (Twc)
+  {
+    __syncthreads();
+    if (threadIdx.x == 0) solve_update(sums, sums + 36, translation_enabled, Twc, state, update_out);
   }
 }
 
@@ -277,10 +299,9 @@ __device__ void matmul4(const float* A, const float* B, float* C)  // matrix.h:2
 
 // ref: tracker.cpp:124-163 + depth_tracker.cpp:22-86. One lane; 6x6 is too
 // small to spread.
-__global__ void solve_update_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
+__device__ void solve_update(const float* hessian, const float* gradient,
     int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out)
 {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (state && state[1]) return;  // converged earlier: tracker.cpp:162
 
   const int n = translation_enabled ? 6 : 3;
@@ -341,6 +362,12 @@ __global__ void solve_update_kernel(const float* __restrict__ hessian, const flo
     state[0] += 1;
     if (sqrtf(sq) < 1E-6f) state[1] = 1;
   }
+}
+
+__global__ void solve_update_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) solve_update(hessian, gradient, translation_enabled, Twc, state, update_out);
 }
 
 // ------------------------------------------------------------------ pyramid ----
@@ -423,6 +450,7 @@ int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
   P.Tmw = make_rt(Twm->inv);
   P.Twc = make_rt(Twc->m);
   P.Twc_dev = nullptr;
+  P.state = nullptr;
   return VK_OK;
 }
 
@@ -494,8 +522,53 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
     hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, vk_s(stream), P, workspace);
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
-      translation_enabled, hessian, gradient);
+      translation_enabled, hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr);
   VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, int iterations, int translation_enabled, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+{
+  IcpParams P;
+  vk_transform identity;
+  for (int i = 0; i < 16; ++i) identity.m[i] = identity.inv[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  const int rc = fill_icp(P, keyframe, Twm, frame, &identity);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(Twc_dev && workspace && system && state_dev && iterations > 0);
+  P.Twc_dev = Twc_dev;
+  P.state = state_dev;
+  float* hessian = system;
+  float* gradient = system + 36;
+  const int partials = partial_count(frame->width, frame->height);
+  hipStream_t s = vk_s(stream);
+
+  for (int it = 0; it < iterations; ++it)
+  {
+    if (translation_enabled)
+      hipLaunchKernelGGL(system_partial_kernel<true>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+    else
+      hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+
+    if (reduce)
+    {
+      // multi-GPU rig: sum the packed system over ranks before every rank solves it
+      hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
+          hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+      VK_LAUNCH_CHECK();
+      const int rr = reduce(system, 48, reduce_user, stream);
+      if (rr != 0) return rr;
+      hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, s, hessian, gradient, translation_enabled,
+          Twc_dev, state_dev, update_dev);
+    }
+    else
+    {
+      hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
+          hessian, gradient, Twc_dev, state_dev, update_dev);
+    }
+    VK_LAUNCH_CHECK();
+  }
   return VK_OK;
 }
 

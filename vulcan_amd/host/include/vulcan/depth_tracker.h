@@ -27,6 +27,8 @@ class DepthTracker : public Tracker
     int GetResidualCount(const Frame& frame) const override;
 
     void ComputeSystem(const Frame& frame) override;
+
+    void TrackOnDevice(Frame& frame) override;
 };
 
 } // namespace vulcan

@@ -49,6 +49,8 @@ class Tracker
 
     bool IsSolving() const;
 
+    virtual void TrackOnDevice(Frame& frame);
+
     virtual void BeginSolve(const Frame& frame);
 
     void ValidateKeyframe() const;

@@ -72,7 +72,14 @@ void Tracker::SetReduceHook(ReduceHook hook, void* user)
 void Tracker::Track(Frame& frame)
 {
   BeginSolve(frame);
+  TrackOnDevice(frame);
+  iteration_ = max_iterations_;
+  EndSolve(frame);
+}
 
+// default: iterate ComputeSystem + solve; DepthTracker enqueues the whole loop with one C call
+void Tracker::TrackOnDevice(Frame& frame)
+{
   while (IsSolving())
   {
     ComputeSystem(frame);
@@ -81,8 +88,6 @@ void Tracker::Track(Frame& frame)
         pose_.GetData(), state_.GetData(), update_.GetData(), Device::GetStream()));
     ++iteration_;
   }
-
-  EndSolve(frame);
 }
 
 bool Tracker::IsSolving() const { return iteration_ < max_iterations_; }
@@ -160,6 +165,30 @@ void DepthTracker::ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobia
   const vk_transform Twc = frame.depth_to_world_transform.ToVk();
   VK_ASSERT(vk_icp_compute_jacobian(&key, &Twm, &frm, &Twc, translation_enabled_ ? 1 : 0,
       reinterpret_cast<float*>(jacobian.GetData()), Device::GetStream()));
+}
+
+namespace
+{
+
+struct HookAdapter { Tracker::ReduceHook hook; void* user; };
+
+int CallReduceHook(float* system_dev, int count, void* user, void*)
+{
+  const HookAdapter* a = static_cast<const HookAdapter*>(user);
+  a->hook(system_dev, count, a->user);
+  return 0;
+}
+
+} // namespace
+
+void DepthTracker::TrackOnDevice(Frame& frame)
+{
+  const vk_icp_view key = ViewOf(*keyframe_), frm = ViewOf(frame);
+  const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
+  HookAdapter adapter = { reduce_hook_, reduce_user_ };
+  VK_ASSERT(vk_icp_track(&key, &Twm, &frm, pose_.GetData(), max_iterations_, translation_enabled_ ? 1 : 0,
+      workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
 }
 
 void DepthTracker::ComputeSystem(const Frame& frame)
