@@ -358,16 +358,54 @@ struct BlockCache
   bool valid;
 };
 
+// Per-wave block directory in LDS: 64 direct-mapped entries {bx, by, bz, slot}.
+// The reference walks the global hash table once per ray per step (and once per
+// trilinear corner near block faces). The 64 rays of a wave cross the same
+// handful of blocks over and over, so here a block is resolved against the
+// global table about once per wave and every later use, by any lane, is one LDS read. The
+// table is read-only during the kernel, so a cached answer is the answer a fresh
+// walk would give.
+constexpr int kDirEntries = 64;
+
+__device__ __forceinline__ int dir_index(int bx, int by, int bz)
+{
+  return (bx * 3 + by * 5 + bz * 7) & (kDirEntries - 1);
+}
+
 // tracer.cu:364-371: walk the chain until the block matches or the chain ends;
 // a hit needs the match AND IsAllocated().
-__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int bx, int by, int bz)
+__device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by, int bz)
+{
+  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
+  while (!entry_is(entry, bx, by, bz) && entry.next != -1) entry = load_entry(P.entries, (uint32_t)entry.next);
+  return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
+}
+
+__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
 {
   if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
 
-  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
-  while (!entry_is(entry, bx, by, bz) && entry.next != -1) entry = load_entry(P.entries, (uint32_t)entry.next);
+  const int4 e = dir[dir_index(bx, by, bz)];
+  int data = e.w;
+  bool missed = !(e.x == bx && e.y == by && e.z == bz);
 
-  const int data = (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
+  // directory misses probe the global table, all lanes in parallel ...
+  if (missed) data = probe_table(P, bx, by, bz);
+
+  // ... and then file their answers, one distinct block per trip, written by a
+  // single lane so that an entry is never a mix of two lanes' stores
+  while (__any(missed))
+  {
+    const unsigned long long mask = __ballot(missed);
+    const int leader = __ffsll((long long)mask) - 1;
+    const int ubx = __builtin_amdgcn_readlane(bx, leader);
+    const int uby = __builtin_amdgcn_readlane(by, leader);
+    const int ubz = __builtin_amdgcn_readlane(bz, leader);
+    const int udata = __builtin_amdgcn_readlane(data, leader);
+    if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
+    if (bx == ubx && by == uby && bz == ubz) missed = false;
+  }
+
   cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
   return data;
 }
@@ -381,7 +419,7 @@ __device__ __forceinline__ void wrap_axis(int v, int& local, int& shift)
 }
 
 // tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
-__device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& cache, int bx, int by,
+__device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by,
     int bz, int data, f3 p, float& sdf, f3& color)
 {
   const float wx = (p.x - bx * P.block_length) / P.voxel_length;
@@ -420,7 +458,7 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
     if ((sx[dx] | sy[dy] | sz[dz]) == 0) { slot[c] = data; continue; }
     BlockCache scratch;
     scratch.valid = false;
-    slot[c] = find_block(P, scratch, bx + sx[dx], by + sy[dy], bz + sz[dz]);
+    slot[c] = find_block(P, scratch, dir, bx + sx[dx], by + sy[dy], bz + sz[dz]);
   }
 
   // Four rows of two x-neighbours. When both voxels of a row sit in the same
@@ -521,22 +559,36 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
 // such tiles.
 __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
 {
+  __shared__ int4 directories[4][kDirEntries];
+
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  int4* bdir = directories[wave];
+  bdir[lane] = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, -1);   // no block has these coordinates after f2i
+
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, each
+  // with its own L2, and neighbouring 16x16 tiles march through the same voxel
+  // blocks. Workgroup w therefore takes tile (w % 8) * chunk + w / 8, which gives
+  // every XCD one contiguous band of the image (placement only affects speed).
+  const int tiles_x = (P.image_width + 15) / 16, tiles_y = (P.image_height + 15) / 16;
+  const int tiles = tiles_x * tiles_y;
+  const int chunk = (tiles + 7) / 8;
+  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
 
   // fused path: publish the merged grid (Tracer::bounds_) — every cell, whether or
   // not a pixel maps to it
   if (P.partials)
   {
     const int cells = P.bounds_width * P.bounds_height;
-    const int threads = gridDim.x * gridDim.y * 256;
-    for (int c = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; c < cells; c += threads)
+    const int threads = gridDim.x * 256;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += threads)
       P.bounds_out[c] = merged_bound(P.partials, cells, c);
   }
 
-  if (x >= P.image_width || y >= P.image_height) return;
+  if (tile >= tiles || x >= P.image_width || y >= P.image_height) return;
 
   const int px = P.bounds_width * x / P.image_width;
   const int py = P.bounds_height * y / P.image_height;
@@ -580,7 +632,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
       const int bx = f2i(floorf(p.x / P.block_length));
       const int by = f2i(floorf(p.y / P.block_length));
       const int bz = f2i(floorf(p.z / P.block_length));
-      const int data = find_block(P, cache, bx, by, bz);
+      const int data = find_block(P, cache, bdir, bx, by, bz);
       bool done = false;
 
       if (data >= 0)
@@ -603,7 +655,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
           sample = (sdf <= 0.1f && sdf >= -0.5f);
         }
 
-        if (sample && P.variant != 1) interpolate(P, cache, bx, by, bz, data, p, sdf, color);
+        if (sample && P.variant != 1) interpolate(P, cache, bdir, bx, by, bz, data, p, sdf, color);
         if (P.variant == 1 && refine) sdf = 0.0f;
 
         if (refine)
@@ -822,7 +874,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
   P.variant = g_points_variant;
-  const dim3 grid((image_width + 15) / 16, (image_height + 15) / 16);
+  const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
+  const dim3 grid(8 * ((tiles + 7) / 8));   // padded so every XCD gets an equal band
   hipLaunchKernelGGL(compute_points_kernel, grid, dim3(256), 0, s, P);
   VK_LAUNCH_CHECK();
   return VK_OK;
