@@ -1,0 +1,123 @@
+// tracking.h — frame-to-keyframe pose tracking: the Gauss-Newton base, the
+// projective point-to-plane ICP and the coarse-to-fine wrapper.
+//
+// API parity: Tracker, DepthTracker and PyramidTracker<T> keep the names and
+// methods of the reference's tracker.h, depth_tracker.h and pyramid_tracker.h
+// (which remain as forwarders to this file). What differs underneath: the
+// reference reads 42 floats back and solves with Eigen::LDLT on the host every
+// iteration (src/tracker.cpp:124-163); here the 6x6 solve and the SE(3) update
+// run on the device (vk_icp_solve_update / vk_icp_track), Track() enqueues every
+// iteration and reads the pose back once, and ApplyUpdate therefore takes a
+// Vector6f rather than an Eigen::VectorXf.
+#pragma once
+
+#include <memory>
+#include <vk.h>
+#include <vulcan/buffer.h>
+#include <vulcan/matrix.h>
+
+namespace vulcan
+{
+
+struct Frame;
+
+class Tracker
+{
+  public:
+    Tracker();
+    virtual ~Tracker();
+
+    std::shared_ptr<const Frame> GetKeyframe() const;
+    void SetKeyframe(std::shared_ptr<const Frame> keyframe);
+
+    bool GetTranslationEnabled() const;
+    void SetTranslationEnabled(bool enabled);
+
+    int GetMaxIterations() const;
+    void SetMaxIterations(int iterations);
+
+    // refine frame.depth_to_world_transform against the keyframe
+    void Track(Frame& frame);
+
+    // Multi-GPU rigs: called between ComputeSystem and the solve with the packed
+    // device system (48 floats: hessian[36], gradient[6], pad[6]); the hook
+    // all-reduces it in place on the compute stream.
+    typedef void (*ReduceHook)(float* system_device, int count, void* user);
+    void SetReduceHook(ReduceHook hook, void* user);
+
+  protected:
+    // -- the reference's solve loop, stage by stage --
+    bool IsSolving() const;
+    virtual void BeginSolve(const Frame& frame);
+    virtual void ComputeSystem(const Frame& frame) = 0;
+    virtual void ApplyUpdate(Frame& frame, const Vector6f& x) const = 0;
+    void EndSolve(Frame& frame);
+
+    // whole loop on the device; subclasses with a fused ABI entry override it
+    virtual void TrackOnDevice(Frame& frame);
+
+    void ValidateKeyframe() const;
+    void ValidateFrame(const Frame& frame) const;
+    void ResizeBuffers(const Frame& frame);
+    virtual int GetResidualCount(const Frame& frame) const = 0;
+    int GetParameterCount() const;
+
+    bool translation_enabled_;
+    int iteration_;
+    int max_iterations_;
+    std::shared_ptr<const Frame> keyframe_;
+
+    Buffer<float> system_;        // hessian = [0,36), gradient = [36,42)
+    Buffer<float> workspace_;     // per-workgroup partial sums
+    Buffer<vk_transform> pose_;   // device copy of the pose being refined
+    Buffer<int> state_;           // {iterations run, converged}
+    Buffer<float> update_;        // last 6-vector
+
+    ReduceHook reduce_hook_;
+    void* reduce_user_;
+};
+
+// Projective point-to-plane ICP on depth + normals.
+class DepthTracker : public Tracker
+{
+  public:
+    DepthTracker();
+    virtual ~DepthTracker();
+
+    // per-pixel residuals / Jacobian rows, exposed for tests as upstream
+    void ComputeResiduals(const Frame& frame, Buffer<float>& residuals) const;
+    void ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian) const;
+
+    // host form of the pose update (ref: depth_tracker.cpp:22-86)
+    void ApplyUpdate(Frame& frame, const Vector6f& x) const override;
+
+  protected:
+    int GetResidualCount(const Frame& frame) const override;
+    void ComputeSystem(const Frame& frame) override;
+    void TrackOnDevice(Frame& frame) override;
+};
+
+// Coarse-to-fine: half resolution first (15 iterations), then full (20).
+template <typename Tracker>
+class PyramidTracker
+{
+  public:
+    PyramidTracker();
+    explicit PyramidTracker(std::shared_ptr<Tracker> tracker);
+    virtual ~PyramidTracker();
+
+    std::shared_ptr<const Tracker> GetTracker() const;
+    std::shared_ptr<const Frame> GetKeyframe() const;
+    void SetKeyframe(std::shared_ptr<const Frame> keyframe);
+
+    void Track(Frame& frame);
+
+  protected:
+    std::shared_ptr<Tracker> tracker_;
+    std::shared_ptr<const Frame> keyframe_;
+    std::shared_ptr<Frame> half_keyframe_;
+    std::shared_ptr<Frame> quarter_keyframe_;
+    int iter_;
+};
+
+} // namespace vulcan

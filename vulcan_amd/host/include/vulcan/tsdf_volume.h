@@ -1,0 +1,108 @@
+// tsdf_volume.h — the voxel-hashed TSDF volume and the per-entry flag enums.
+//
+// API parity: class Volume keeps the public AND protected surface of the
+// reference's volume.h:16-117 (its tests subclass Volume to reach the four
+// SetView stages, tests/volume_test.cpp:23-31); Visibility / AllocationType
+// keep the values of types.h. Both header names remain as forwarders.
+// What differs behind the names:
+//   * the device counters (visible count, free-slot pointer, excess pointer)
+//     live in a per-volume buffer instead of process-wide __device__ symbols
+//     (volume.cu:17-21), so one process can hold several volumes;
+//   * SetView never blocks; the visible count is read back lazily by the first
+//     GetVisibleBlocks() after it (volume.cu:494 synchronised every frame).
+#pragma once
+
+#include <cstdint>
+#include <vk.h>
+#include <vulcan/buffer.h>
+#include <vulcan/matrix.h>
+
+namespace vulcan
+{
+
+// per hash entry: was the block seen by the current view
+enum Visibility : uint8_t
+{
+  VISIBILITY_UNKNOWN = 0,
+  VISIBILITY_FALSE   = 1,
+  VISIBILITY_TRUE    = 2,
+};
+
+// per hash entry: what kind of allocation the current view requested there
+enum AllocationType : uint8_t
+{
+  ALLOC_TYPE_NONE   = 0,
+  ALLOC_TYPE_MAIN   = 1,
+  ALLOC_TYPE_EXCESS = 2,
+};
+
+class Block;
+struct Frame;
+class HashEntry;
+class Voxel;
+
+class Volume
+{
+  public:
+    Volume(int main_block_count, int excess_block_count);
+    virtual ~Volume();
+
+    // ---- geometry ----
+    int GetMainBlockCount() const;
+    int GetExcessBlockCount() const;
+    float GetVoxelLength() const;
+    void SetVoxelLength(float length);
+    float GetTruncationLength() const;
+    void SetTruncationLength(float length);
+    const Vector2f& GetDepthRange() const;
+    void SetDepthRange(const Vector2f& range);
+    void SetDepthRange(float min, float max);
+
+    // ---- per frame: allocate what the depth image touches, list what is visible ----
+    void SetView(const Frame& frame);
+
+    // ---- storage ----
+    const Buffer<HashEntry>& GetHashEntries() const;
+    const Buffer<int>& GetAllocatedBlocks() const;
+    const Buffer<int>& GetVisibleBlocks() const;   // first call after SetView syncs
+    const Buffer<Voxel>& GetVoxels() const;
+    Buffer<Voxel>& GetVoxels();
+
+    vk_volume ToVk() const;                        // device view for the C ABI
+    void GetCounters(int32_t* counters) const;     // blocking readback of VK_CTR_*
+
+  protected:
+    // the four stages of SetView, in call order
+    void ResetBlockVisibility();
+    void CreateAllocationRequests(const Frame& frame);
+    void HandleAllocationRequests();
+    void UpdateBlockVisibility(const Frame& frame);
+
+    int GetBufferSize() const;
+    void ResetBufferSize() const;
+
+    Buffer<Voxel> voxels_;
+    Buffer<HashEntry> hash_entries_;
+    Buffer<int> free_voxel_blocks_;
+    Buffer<AllocationType> allocation_types_;
+    Buffer<Block> allocation_blocks_;
+    Buffer<Visibility> block_visibility_;
+    mutable Buffer<int> visible_blocks_;
+    Buffer<int> counters_;
+
+    Vector2f depth_range_;
+    int max_block_count_;
+    int main_block_count_;
+    int excess_block_count_;
+    float truncation_length_;
+    float voxel_length_;
+    bool empty_;
+    mutable bool visible_count_stale_;
+
+  private:
+    void Initialize();
+    Volume(const Volume&);              // not copyable
+    Volume& operator=(const Volume&);
+};
+
+} // namespace vulcan

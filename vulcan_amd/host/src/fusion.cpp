@@ -1,12 +1,10 @@
-// integrators.cpp — Integrator and its three subclasses over vk_integrate_*
+// fusion.cpp — Integrator and its three subclasses over vk_integrate_*
 // (ref: src/integrator.cu, src/depth_integrator.cu:83-115,
 //  src/color_integrator.cu:139-204, src/light_integrator.cu:254-354).
-#include <vulcan/color_integrator.h>
-#include <vulcan/depth_integrator.h>
-#include <vulcan/light_integrator.h>
+#include <vulcan/fusion.h>
 #include <vulcan/exception.h>
-#include <vulcan/frame.h>
-#include <vulcan/volume.h>
+#include <vulcan/observation.h>
+#include <vulcan/tsdf_volume.h>
 
 namespace vulcan
 {

@@ -1,7 +1,6 @@
-// frame.cpp — Frame / Image host methods over the C ABI
+// observation.cpp — Frame / Image host methods over the C ABI
 // (ref: src/frame.cpp, src/image.cu:183-262).
-#include <vulcan/frame.h>
-#include <vulcan/frame.cuh>
+#include <vulcan/observation.h>
 #include <vulcan/exception.h>
 
 namespace vulcan

@@ -1,13 +1,12 @@
-// tracer.cpp — Tracer host class and the tracer.cuh stage functions
+// raycast.cpp — Tracer host class and the raycast stage functions
 // (ref: src/tracer.cpp, src/tracer.cu:453-500).
-#include <vulcan/tracer.h>
-#include <vulcan/tracer.cuh>
+#include <vulcan/raycast.h>
 #include <vulcan/block.h>
 #include <vulcan/device.h>
 #include <vulcan/exception.h>
-#include <vulcan/frame.h>
+#include <vulcan/observation.h>
 #include <vulcan/hash.h>
-#include <vulcan/volume.h>
+#include <vulcan/tsdf_volume.h>
 #include <vulcan/voxel.h>
 
 namespace vulcan

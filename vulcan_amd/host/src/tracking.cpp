@@ -1,11 +1,9 @@
-// tracker.cpp — Tracker, DepthTracker and PyramidTracker<DepthTracker>
+// tracking.cpp — Tracker, DepthTracker and PyramidTracker<DepthTracker>
 // (ref: src/tracker.cpp, src/depth_tracker.cpp, src/depth_tracker.cu:272-378,
 //  src/pyramid_tracker.cpp).
-#include <vulcan/depth_tracker.h>
-#include <vulcan/pyramid_tracker.h>
-#include <vulcan/tracker.h>
+#include <vulcan/tracking.h>
 #include <vulcan/exception.h>
-#include <vulcan/frame.h>
+#include <vulcan/observation.h>
 
 namespace vulcan
 {

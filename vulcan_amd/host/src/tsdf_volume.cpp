@@ -1,8 +1,8 @@
-// volume.cpp — Volume host class over vk_volume_* (ref: src/volume.cu:370-627).
-#include <vulcan/volume.h>
+// tsdf_volume.cpp — Volume host class over vk_volume_* (ref: src/volume.cu:370-627).
+#include <vulcan/tsdf_volume.h>
 #include <vulcan/block.h>
 #include <vulcan/exception.h>
-#include <vulcan/frame.h>
+#include <vulcan/observation.h>
 #include <vulcan/hash.h>
 #include <vulcan/voxel.h>
 
