@@ -177,7 +177,7 @@ def main():
             "dropped_requests": int(ctr[T.VK_CTR_DROPPED]), "parallelism": f"replica volume per GPU x{world}",
         },
         "roofline": {
-            "kernel": "integrate_kernel<depth> (vk_integrate_depth)",
+            "kernel": "integrate_pipelined_kernel<depth> (vk_integrate_depth)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
             "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
