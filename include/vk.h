@@ -399,6 +399,55 @@ VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev,
     float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream);
 
+/* ---------------------------------------------------------------- detector -- */
+
+/* ref: include/vulcan/detector.h:10-72, src/detector.cu — box detector over a
+ * point cloud (nothing upstream instantiates it).
+ * `bounds[a]` = {lo, hi}; an axis with lo > hi is unbounded (detector.cu:214-221
+ * starts all three at {1,-1}). */
+typedef struct vk_detector {
+  float   radius;             /* <= 0: no radius test                          */
+  float   origin[3];
+  float   bounds[3][2];
+  int32_t min_inlier_count;   /* fewer survivors => position is NaN            */
+  int32_t bounds_use_own_axis;/* 0 = as upstream: the y and z intervals are
+                                 tested against point[0] (detector.cu:27-28);
+                                 1 = test point[1] / point[2]                  */
+} vk_detector;
+
+/* What the detector leaves on the device after a call (one blocking copy reads
+ * it all). Sums are fixed-order (4096-point chunks, 256-way strided partials,
+ * binary tree, chunks added in order), so every field is reproducible. */
+typedef struct vk_detect_state {
+  int32_t filtered_count;     /* after the radius / interval test              */
+  int32_t inlier_count;       /* after the 1.5-sigma removal                   */
+  int32_t detected;           /* inlier_count >= min_inlier_count              */
+  int32_t reserved;
+  float   center[3];          /* sum|x| / n of the filtered points (Sasum, :137-139) */
+  float   limit;              /* 1.5 * sqrt(sum d^2 / n)  (:177-179)           */
+  float   position[3];        /* sum|x| / n of the inliers, or NaN             */
+  float   squared_error;
+} vk_detect_state;
+
+/* bytes of device scratch for a cloud of `count` points (ref: detector.h:66-68
+ * points_ / distances_, which this replaces) */
+VK_API size_t vk_detect_workspace_bytes(int32_t count);
+
+/* ref: src/detector.cu:152-188 Detector::Filter — interval/radius filter, then
+ * removal of points further than 1.5 sigma from the centroid. `inliers`: device
+ * float[3*count], receives the survivors in input order (the reference compacts
+ * per thread block through an atomic, so its order varies run to run; the set is
+ * the same). Fills every field of *state_dev except position / detected. */
+VK_API int vk_detect_filter(const vk_detector* detector, const float* points,
+    int32_t count, float* inliers, vk_detect_state* state_dev, void* workspace,
+    void* stream);
+
+/* ref: src/detector.cu:120-147 Detector::Detect = Filter + BoxDetected +
+ * GetValidPosition / GetInvalidPosition; the answer is state_dev->position. */
+VK_API int vk_detect(const vk_detector* detector, const float* points,
+    int32_t count, float* inliers, vk_detect_state* state_dev, void* workspace,
+    void* stream);
+
 /* ------------------------------------------------------------------ probes -- */
 
 /* Measurement aids, no reference counterpart (the reference has no benchmarks,

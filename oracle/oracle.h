@@ -95,6 +95,11 @@ float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
     int translation_enabled, vk_transform* Twc, float* update);
 
 /* known-answer hooks (tests/test_oracle_kats.py) */
+/* detector (oracle_detect.c). PARITY UNPINNED: the reference holds no test or
+ * vector for Detector (tests/detector_test.cu is empty). */
+void orc_detect(const vk_detector* detector, const float* points, int count,
+    float* inliers, vk_detect_state* state);
+
 uint32_t orc_kat_hash(int bx, int by, int bz, uint32_t K);
 void orc_kat_project(const vk_projection* k, float x, float y, float z, float* uv);
 void orc_kat_unproject(const vk_projection* k, float u, float v, float d, float* xyz);

@@ -287,3 +287,12 @@ def icp_solve_update(hessian_packed, gradient, Twc, translation_enabled=True):
     update = np.zeros(6, dtype=np.float32)
     norm = lib().orc_icp_solve_update(_p(h), _p(g), int(translation_enabled), C.byref(out), _p(update))
     return out, update, float(norm)
+
+
+def detect(points, params):
+    """orc_detect: returns (DetectState, inlier points [m,3])."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    inliers = np.zeros((max(len(pts), 1), 3), dtype=np.float32)
+    state = T.DetectState()
+    lib().orc_detect(C.byref(params), _p(pts), len(pts), _p(inliers), C.byref(state))
+    return state, inliers[: state.inlier_count].copy()

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
+    "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
+    "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_probe_stream_copy": ([_P, _P, _SZ, _P], _I),
     "vk_probe_block_rmw": ([_P, _P], _I),
     "vk_probe_block_rmw_mode": ([_I], _I),
@@ -535,3 +538,83 @@ class PyramidTracker:
         frame.depth_to_world = half_frame.depth_to_world
         t.keyframe = self.keyframe
         return t.track(frame)
+
+
+class Detector:
+    """vulcan::Detector (detector.h:10-72): radius / interval filter, 1.5-sigma
+    outlier removal, centroid. Everything stays on the device until `detect`
+    reads the 48-byte state back."""
+
+    def __init__(self, device="cuda"):
+        import torch
+        self.device = device
+        self.params = T.Detector.default()
+        self.state = torch.zeros(C.sizeof(T.DetectState) // 4, dtype=torch.int32, device=device)
+        self.inliers = None
+        self._workspace = None
+
+    # -- reference accessors -------------------------------------------------------------
+    @property
+    def radius(self):
+        return self.params.radius
+
+    @radius.setter
+    def radius(self, value):
+        self.params.radius = float(value)
+
+    @property
+    def origin(self):
+        return tuple(self.params.origin)
+
+    @origin.setter
+    def origin(self, value):
+        self.params.origin[:] = [float(v) for v in value]
+
+    def get_bounds(self, axis):
+        return tuple(self.params.bounds[axis])
+
+    def set_bounds(self, axis, bounds):
+        self.params.bounds[axis][0], self.params.bounds[axis][1] = float(bounds[0]), float(bounds[1])
+
+    @property
+    def min_inlier_count(self):
+        return self.params.min_inlier_count
+
+    @min_inlier_count.setter
+    def min_inlier_count(self, value):
+        self.params.min_inlier_count = int(value)
+
+    # -- device work ---------------------------------------------------------------------
+    def _prepare(self, points):
+        import torch
+        assert points.dtype == torch.float32 and points.is_contiguous() and points.shape[-1] == 3
+        count = points.numel() // 3
+        need = lib().vk_detect_workspace_bytes(count)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.inliers is None or self.inliers.shape[0] < max(count, 1):
+            self.inliers = torch.empty((max(count, 1), 3), dtype=torch.float32, device=self.device)
+        return count
+
+    def filter(self, points):
+        """Detector::Filter; returns nothing, see read_state()/inlier_points()."""
+        count = self._prepare(points)
+        check(lib().vk_detect_filter(_ref(self.params), _ptr(points), count, _ptr(self.inliers), _ptr(self.state),
+                                     _ptr(self._workspace), stream()), "vk_detect_filter")
+
+    def enqueue(self, points):
+        """Detector::Detect without the readback."""
+        count = self._prepare(points)
+        check(lib().vk_detect(_ref(self.params), _ptr(points), count, _ptr(self.inliers), _ptr(self.state),
+                              _ptr(self._workspace), stream()), "vk_detect")
+
+    def read_state(self):
+        return T.DetectState.from_buffer_copy(self.state.cpu().numpy().tobytes())
+
+    def inlier_points(self):
+        return self.inliers[: self.read_state().inlier_count]
+
+    def detect(self, points):
+        """Detector::Detect: the box position as 3 floats (NaN when not detected)."""
+        self.enqueue(points)
+        return np.array(self.read_state().position, dtype=np.float32)

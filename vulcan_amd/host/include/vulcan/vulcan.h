@@ -6,6 +6,7 @@
 #include <vulcan/color_integrator.h>
 #include <vulcan/depth_integrator.h>
 #include <vulcan/depth_tracker.h>
+#include <vulcan/detector.h>
 #include <vulcan/device.h>
 #include <vulcan/exception.h>
 #include <vulcan/frame.h>

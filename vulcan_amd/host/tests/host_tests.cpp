@@ -843,6 +843,64 @@ TEST(Frame, DownsampleAndFilter)   // frame.cpp:8-58, image.cu:101-165
   ASSERT_NEAR(1.0f + 0.01f * 30 + 0.02f * 20, filtered[20 * w + 30], 5e-3);
 }
 
+// ---- Detector (no upstream case: tests/detector_test.cu is empty) -------------------------
+
+TEST(Detector, Constructor)   // detector.cu:66-72, 214-221
+{
+  Detector detector;
+  ASSERT_FLOAT_EQ(2.0f, detector.GetRadius());
+  ASSERT_EQ(100, detector.GetMinInlierCount());
+  ASSERT_EQ(0.0f, detector.GetOrigin()[0]);
+  for (int axis = 0; axis < 3; ++axis) { ASSERT_EQ(1.0f, detector.GetBounds(axis)[0]); ASSERT_EQ(-1.0f, detector.GetBounds(axis)[1]); }
+}
+
+TEST(Detector, Detect)   // Filter + 1.5-sigma removal + mean of |x| (detector.cu:120-188)
+{
+  // a 20x20x20 lattice of 1 cm pitch centred at (0.3, -0.2, 1.0) plus far points
+  std::vector<Vector3f> host;
+  for (int i = 0; i < 20; ++i)
+    for (int j = 0; j < 20; ++j)
+      for (int k = 0; k < 20; ++k)
+        host.push_back(Vector3f(0.3f + 0.01f * (i - 9.5f), -0.2f + 0.01f * (j - 9.5f), 1.0f + 0.01f * (k - 9.5f)));
+  for (int i = 0; i < 50; ++i) host.push_back(Vector3f(4.0f + i, 0, 0));   // outside the 2 m radius
+  Buffer<Vector3f> points(host.size());
+  points.CopyFromHost(host.data());
+
+  Detector detector;
+  const Vector3f position = detector.Detect(points);
+  ASSERT_EQ(8000, detector.GetState().filtered_count);
+
+  // host replay in double
+  double centre[3] = {0, 0, 0};
+  for (int i = 0; i < 8000; ++i) for (int a = 0; a < 3; ++a) centre[a] += std::fabs((double)host[i][a]) / 8000;
+  double sq = 0;
+  std::vector<double> dist(8000);
+  for (int i = 0; i < 8000; ++i)
+  {
+    double d2 = 0;
+    for (int a = 0; a < 3; ++a) d2 += ((double)host[i][a] - centre[a]) * ((double)host[i][a] - centre[a]);
+    dist[i] = std::sqrt(d2);
+    sq += d2;
+  }
+  const double limit = 1.5 * std::sqrt(sq / 8000);
+  ASSERT_NEAR(limit, detector.GetState().limit, 1e-5);
+  int survivors = 0;
+  double mean[3] = {0, 0, 0};
+  for (int i = 0; i < 8000; ++i)
+  {
+    ASSERT_TRUE(std::fabs(dist[i] - limit) > 1e-5);       // the lattice keeps clear of the threshold
+    if (dist[i] <= limit) { ++survivors; for (int a = 0; a < 3; ++a) mean[a] += std::fabs((double)host[i][a]); }
+  }
+  ASSERT_EQ(survivors, detector.GetState().inlier_count);
+  ASSERT_EQ(size_t(survivors), detector.GetInliers().GetSize());
+  for (int a = 0; a < 3; ++a) ASSERT_NEAR(mean[a] / survivors, position[a], 1e-5);
+  ASSERT_TRUE(position[1] > 0);                           // Sasum: the cloud sits at y = -0.2
+
+  detector.SetMinInlierCount(survivors + 1);
+  const Vector3f missing = detector.Detect(points);
+  ASSERT_TRUE(std::isnan(missing[0]) && std::isnan(missing[1]) && std::isnan(missing[2]));
+}
+
 int main(int argc, char** argv)
 {
   int count = 0;

@@ -141,6 +141,27 @@ class Integrator(C.Structure):
         return Integrator(0.1, 5.0, 16.0, 16.0)   # integrator.cu:7-13
 
 
+class Detector(C.Structure):
+    _fields_ = [("radius", C.c_float), ("origin", C.c_float * 3), ("bounds", (C.c_float * 2) * 3),
+                ("min_inlier_count", C.c_int32), ("bounds_use_own_axis", C.c_int32)]
+
+    @staticmethod
+    def default():
+        """detector.cu:66-72,214-221: radius 2, origin 0, all intervals open, 100 inliers."""
+        d = Detector()
+        d.radius = 2.0
+        d.min_inlier_count = 100
+        for a in range(3):
+            d.bounds[a][0], d.bounds[a][1] = 1.0, -1.0
+        return d
+
+
+class DetectState(C.Structure):
+    _fields_ = [("filtered_count", C.c_int32), ("inlier_count", C.c_int32), ("detected", C.c_int32),
+                ("reserved", C.c_int32), ("center", C.c_float * 3), ("limit", C.c_float),
+                ("position", C.c_float * 3), ("squared_error", C.c_float)]
+
+
 class IcpView(C.Structure):
     _fields_ = [("depths", C.c_void_p), ("normals", C.c_void_p),
                 ("width", C.c_int32), ("height", C.c_int32), ("projection", Projection)]
