@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256) void block_bounds_kernel(PatchParams P)
 // copy with plain coalesced writes. The consumer takes min/max over the
 // kBoundsGroups copies (compute_points_kernel, or merge_bounds_kernel for the
 // stand-alone API). No global atomics, no reset pass, no inter-workgroup order.
-constexpr int kBoundsGroups = 8;
-constexpr int kBoundsThreads = 1024;
+constexpr int kBoundsGroups = 32;
+constexpr int kBoundsThreads = 512;
 constexpr int kBoundsMaxCells = 8192;  // 64 KiB of LDS
 
 __global__ __launch_bounds__(kBoundsThreads) void block_bounds_partial_kernel(PatchParams P, float2* __restrict__ partials)
@@ -252,7 +252,9 @@ __global__ __launch_bounds__(kBoundsThreads) void block_bounds_partial_kernel(Pa
   }
   __syncthreads();
 
-  for (int index = blockIdx.x * kBoundsThreads + threadIdx.x; index < block_count; index += kBoundsGroups * kBoundsThreads)
+  // visible block i goes to group i % kBoundsGroups: every group gets the same share
+  // whatever the count
+  for (int index = blockIdx.x + kBoundsGroups * (int)threadIdx.x; index < block_count; index += kBoundsGroups * kBoundsThreads)
   {
     const Entry entry = load_entry(P.entries, (uint32_t)P.indices[index]);
     const BlockRect r = block_rect(entry, P.Tcw, P.k, P.block_length, P.min_depth, P.max_depth,
@@ -265,9 +267,12 @@ __global__ __launch_bounds__(kBoundsThreads) void block_bounds_partial_kernel(Pa
     for (int y = r.bmin_y; y <= y_end; ++y)
       for (int x = r.bmin_x; x <= x_end; ++x)
       {
+        // the values only ever move one way, so a plain read that already beats
+        // ours makes the atomic unnecessary; neighbouring blocks cover the same
+        // cells and same-address LDS atomics serialise
         const int c = y * P.bounds_width + x;
-        atomicMin(&grid[2 * c + 0], n);
-        atomicMax(&grid[2 * c + 1], f);
+        if (n < grid[2 * c + 0]) atomicMin(&grid[2 * c + 0], n);
+        if (f > grid[2 * c + 1]) atomicMax(&grid[2 * c + 1], f);
       }
   }
   __syncthreads();
@@ -286,6 +291,25 @@ __device__ __forceinline__ float2 merged_bound(const float2* __restrict__ partia
     const float2 o = partials[(size_t)g * cells + cell];
     b.x = vmin(o.x, b.x);
     b.y = vmax(o.y, b.y);
+  }
+  return b;
+}
+
+// The same merge for a wave-uniform cell, read through the scalar cache: the
+// partial grids were written by the previous kernel and are read-only here, so
+// they can be addressed as constant memory (s_load instead of 64-lane loads).
+typedef const float __attribute__((address_space(4)))* scalar_floats;
+
+__device__ __forceinline__ float2 merged_bound_uniform(const float2* partials, int cells, int cell)
+{
+  const scalar_floats base = (scalar_floats)reinterpret_cast<const float*>(partials);
+  float2 b = make_float2(base[2 * cell + 0], base[2 * cell + 1]);
+#pragma unroll
+  for (int g = 1; g < kBoundsGroups; ++g)
+  {
+    const size_t at = 2 * ((size_t)g * cells + cell);
+    b.x = vmin(base[at + 0], b.x);
+    b.y = vmax(base[at + 1], b.y);
   }
   return b;
 }
@@ -367,9 +391,13 @@ struct BlockCache
 // walk would give.
 constexpr int kDirEntries = 64;
 
+// Entry = the block's coordinates modulo 4 per axis: any 4x4x4 neighbourhood of
+// blocks (16 cm at 5 mm voxels, far more than one wave's 8x8 pixels see in a
+// step) maps to 64 different entries, so the blocks a wave works on never evict
+// one another.
 __device__ __forceinline__ int dir_index(int bx, int by, int bz)
 {
-  return (bx * 3 + by * 5 + bz * 7) & (kDirEntries - 1);
+  return (bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4);
 }
 
 // tracer.cu:364-371: walk the chain until the block matches or the chain ends;
@@ -381,30 +409,35 @@ __device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by,
   return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
 }
 
-__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
+// files a resolved block in the directory: one distinct block per trip, written
+// by a single lane so that an entry is never a mix of two lanes' stores
+__device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
 {
-  if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
-
-  const int4 e = dir[dir_index(bx, by, bz)];
-  int data = e.w;
-  bool missed = !(e.x == bx && e.y == by && e.z == bz);
-
-  // directory misses probe the global table, all lanes in parallel ...
-  if (missed) data = probe_table(P, bx, by, bz);
-
-  // ... and then file their answers, one distinct block per trip, written by a
-  // single lane so that an entry is never a mix of two lanes' stores
-  while (__any(missed))
+  while (__any(pending))
   {
-    const unsigned long long mask = __ballot(missed);
+    const unsigned long long mask = __ballot(pending);
     const int leader = __ffsll((long long)mask) - 1;
     const int ubx = __builtin_amdgcn_readlane(bx, leader);
     const int uby = __builtin_amdgcn_readlane(by, leader);
     const int ubz = __builtin_amdgcn_readlane(bz, leader);
     const int udata = __builtin_amdgcn_readlane(data, leader);
     if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
-    if (bx == ubx && by == uby && bz == ubz) missed = false;
+    if (bx == ubx && by == uby && bz == ubz) pending = false;
   }
+}
+
+__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
+{
+  if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
+
+  const int4 e = dir[dir_index(bx, by, bz)];
+  int data = e.w;
+  const bool missed = !(e.x == bx && e.y == by && e.z == bz);
+
+  // directory misses probe the global table, all lanes in parallel, then file
+  // their answers
+  if (missed) data = probe_table(P, bx, by, bz);
+  file_blocks(dir, missed, bx, by, bz, data);
 
   cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
   return data;
@@ -419,13 +452,11 @@ __device__ __forceinline__ void wrap_axis(int v, int& local, int& shift)
 }
 
 // tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
+// (wx, wy, wz): the sample position in voxel units relative to block (bx, by, bz),
+// i.e. (p - b * block_length) / voxel_length as computed by the caller
 __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by,
-    int bz, int data, f3 p, float& sdf, f3& color)
+    int bz, int data, float wx, float wy, float wz, float& sdf, f3& color)
 {
-  const float wx = (p.x - bx * P.block_length) / P.voxel_length;
-  const float wy = (p.y - by * P.block_length) / P.voxel_length;
-  const float wz = (p.z - bz * P.block_length) / P.voxel_length;
-
   const int i0x = f2i(floorf(wx - 0.5f));
   const int i0y = f2i(floorf(wy - 0.5f));
   const int i0z = f2i(floorf(wz - 0.5f));
@@ -578,31 +609,34 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
 
-  // fused path: publish the merged grid (Tracer::bounds_) — every cell, whether or
-  // not a pixel maps to it
-  if (P.partials)
-  {
-    const int cells = P.bounds_width * P.bounds_height;
-    const int threads = gridDim.x * 256;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += threads)
-      P.bounds_out[c] = merged_bound(P.partials, cells, c);
-  }
-
-  if (tile >= tiles || x >= P.image_width || y >= P.image_height) return;
-
-  const int px = P.bounds_width * x / P.image_width;
-  const int py = P.bounds_height * y / P.image_height;
-  const int cell = py * P.bounds_width + px;
+  // This wave's bound first, while no store has been issued yet: with a
+  // wave-uniform cell (always, when a bounds cell is 8x8 pixels) the kBoundsGroups
+  // partial grids are then read through the scalar cache instead of by 64 lanes.
+  const bool inside = tile < tiles && x < P.image_width && y < P.image_height;
+  const int px = P.bounds_width * vmini(x, P.image_width - 1) / P.image_width;
+  const int py = P.bounds_height * vmini(y, P.image_height - 1) / P.image_height;
+  const int cell = (tile < tiles) ? py * P.bounds_width + px : 0;
   float2 bound;
 
   if (P.partials)
   {
-    bound = merged_bound(P.partials, P.bounds_width * P.bounds_height, cell);
+    const int cells = P.bounds_width * P.bounds_height;
+    const int first = __builtin_amdgcn_readfirstlane(cell);
+    if (__all(cell == first)) bound = merged_bound_uniform(P.partials, cells, first);
+    else bound = merged_bound(P.partials, cells, cell);
+
+    // publish the merged grid (Tracer::bounds_) — every cell, whether or not a
+    // pixel maps to it
+    const int threads = gridDim.x * 256;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += threads)
+      P.bounds_out[c] = merged_bound(P.partials, cells, c);
   }
   else
   {
     bound = reinterpret_cast<const float2*>(P.bounds)[cell];
   }
+
+  if (!inside) return;
 
   float final_depth = 0;
   f3 color = make3(0, 0, 0);
@@ -640,12 +674,14 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
         float sdf;
         bool sample = refine;
 
+        // position in voxel units inside the block: tracer.cu:373-375 for the
+        // nearest-voxel read and, with the same expression, :193-195 for the sample
+        const float wx = (p.x - bx * P.block_length) / P.voxel_length;
+        const float wy = (p.y - by * P.block_length) / P.voxel_length;
+        const float wz = (p.z - bz * P.block_length) / P.voxel_length;
+
         if (!refine)
         {
-          const float wx = (p.x - bx * P.block_length) / P.voxel_length;
-          const float wy = (p.y - by * P.block_length) / P.voxel_length;
-          const float wz = (p.z - bz * P.block_length) / P.voxel_length;
-
           // int(w) can reach 8 on a block face: clamped, see DESIGN.md
           const int vx = vmini(f2i(wx), 7);
           const int vy = vmini(f2i(wy), 7);
@@ -655,7 +691,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
           sample = (sdf <= 0.1f && sdf >= -0.5f);
         }
 
-        if (sample && P.variant != 1) interpolate(P, cache, bdir, bx, by, bz, data, p, sdf, color);
+        if (sample && P.variant != 1) interpolate(P, cache, bdir, bx, by, bz, data, wx, wy, wz, sdf, color);
         if (P.variant == 1 && refine) sdf = 0.0f;
 
         if (refine)

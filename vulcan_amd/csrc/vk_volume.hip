@@ -141,6 +141,17 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   }
 }
 
+// value held by lane - 1 (lane 0 gets its own): one DPP move (wave_shr:1)
+// instead of the ds_bpermute that __shfl_up costs
+__device__ __forceinline__ int left_lane(int v)
+{
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+
+#ifndef VK_REQUEST_PROBES
+#define VK_REQUEST_PROBES 6
+#endif
+
 struct RequestParams
 {
   vk_volume v;
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= P.width || y >= P.height) return;
+  if (y >= P.height) return;                       // whole wave
 
   const vk_volume& v = P.v;
   const uint32_t K = (uint32_t)v.main_block_count;
@@ -167,8 +178,11 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   direction = xform_dir(P.Twd, direction);
   const f3 origin = make3(P.Twd.r[3], P.Twd.r[7], P.Twd.r[11]);
 
-  const float depth = P.depth[y * P.width + x];
-  if (depth < v.min_depth || depth > v.max_depth) return;
+  // lanes without a usable depth stay in the wave (their neighbours read their
+  // registers below) but walk nothing
+  float depth = 0.0f;
+  if (x < P.width) depth = P.depth[y * P.width + x];
+  const bool usable = x < P.width && !(depth < v.min_depth || depth > v.max_depth);
 
   const f3 Xwp = add3(origin, scale3(direction, depth));
   direction = normalized3(direction);
@@ -207,10 +221,10 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   // table read per crossed block, :174-299) becomes kProbe independent reads in
   // flight. A 2*trunc segment crosses 3-4 blocks; walks longer than kProbe fall
   // back to the step-by-step loop below.
-  constexpr int kProbe = 8;
+  constexpr int kProbe = VK_REQUEST_PROBES;
   int sbx[kProbe], sby[kProbe], sbz[kProbe];
   uint32_t shash[kProbe];
-  bool walking = true;
+  bool walking = usable;
 
 #pragma unroll
   for (int sidx = 0; sidx < kProbe; ++sidx)
@@ -232,6 +246,21 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
         else                 { bz += step_z; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
       }
     }
+  }
+
+  // Neighbouring pixels of a row cross the same blocks (a block is ~11 px wide at
+  // 2 m), and everything a probe does — marking the entry visible, posting the
+  // max-key request — is idempotent. A lane therefore skips a probe when the lane
+  // to its left makes the identical one in the same slot; what remains is about
+  // one probe per distinct block per wave instead of one per ray.
+  const int lane = lane_id();
+#pragma unroll
+  for (int sidx = 0; sidx < kProbe; ++sidx)
+  {
+    const uint32_t left_hash = (uint32_t)left_lane((int)shash[sidx]);
+    const int left_x = left_lane(sbx[sidx]), left_y = left_lane(sby[sidx]), left_z = left_lane(sbz[sidx]);
+    const bool same = lane > 0 && left_hash == shash[sidx] && left_x == sbx[sidx] && left_y == sby[sidx] && left_z == sbz[sidx];
+    if (same) shash[sidx] = 0xffffffffu;
   }
 
   Entry sent[kProbe];
