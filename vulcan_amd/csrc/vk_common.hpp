@@ -175,4 +175,15 @@ __device__ __forceinline__ bool entry_is(const Entry& e, int bx, int by, int bz)
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Lanes of ONE wave exchanging data through LDS need no hardware barrier (a
+// wave's LDS operations execute in order), but the compiler must be told that
+// other lanes wrote what this lane is about to read: without it the optimiser may
+// forward this lane's own earlier store to the load. Emits no instruction.
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 }  // namespace vk

@@ -424,6 +424,7 @@ __device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int
     if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
     if (bx == ubx && by == uby && bz == ubz) pending = false;
   }
+  wave_lds_fence();   // later reads of the directory, by any lane, see these entries
 }
 
 __device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   const int wave = threadIdx.x >> 6;
   int4* bdir = directories[wave];
   bdir[lane] = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, -1);   // no block has these coordinates after f2i
+  wave_lds_fence();
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, each
   // with its own L2, and neighbouring 16x16 tiles march through the same voxel
