@@ -88,11 +88,22 @@ __device__ __forceinline__ unsigned long long request_key(int type, int bx, int 
          ((unsigned long long)(uint16_t)(int16_t)by << 16) | (unsigned long long)(uint16_t)(int16_t)bx;
 }
 
+// SetView normally starts with a pass that turns every TRUE of the previous frame
+// into UNKNOWN (volume.cu:465-471). The fused vk_volume_set_view skips that pass:
+// whatever marks an entry visible during the frame sets bit 2 of the byte on top
+// of its old value instead, and update_visibility_kernel — which reads every byte
+// anyway — decodes (bit 2 ? TRUE : the reset of the old value) and stores the plain
+// 0/1/2 the reference would hold. Bit 2 never survives the call.
+constexpr uint8_t kTouched = 4;
+
+template <bool DEFER>
 __device__ __forceinline__ void mark_visible(uint8_t* vis, uint32_t index)
 {
   // the reference stores unconditionally (volume.cu:190); reading first keeps
   // hundreds of rays that cross the same block from all storing the same byte
-  if (vis[index] != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
+  const uint8_t old = vis[index];
+  if (DEFER) { if (!(old & kTouched)) vis[index] = old | kTouched; }
+  else if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
 }
 
 __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz)
@@ -107,16 +118,17 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 
 // volume.cu:183-239: what one ray does with one crossed block once the bucket's
 // main entry is known
+template <bool DEFER>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
     int bx, int by, int bz)
 {
   if (entry_is(entry, bx, by, bz))
   {
-    mark_visible(v.block_visibility, hash_code);
+    mark_visible<DEFER>(v.block_visibility, hash_code);
   }
   else if (entry.data == -1)
   {
-    mark_visible(v.block_visibility, hash_code);
+    mark_visible<DEFER>(v.block_visibility, hash_code);
     post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz);
   }
   else
@@ -131,7 +143,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
 
       if (entry_is(entry, bx, by, bz))
       {
-        mark_visible(v.block_visibility, index);
+        mark_visible<DEFER>(v.block_visibility, index);
         found = true;
         break;
       }
@@ -163,6 +175,7 @@ struct RequestParams
 
 // ref: volume.cu:87-301. One lane per depth pixel; the lanes of a wave cover a
 // 64x1 run of a row so the depth read is one coalesced 256-byte load.
+template <bool DEFER>
 __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx]);
+    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx]);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    probe_block(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz);
+    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz);
 
     if (tmax_x < tmax_y)
     {
@@ -357,7 +370,7 @@ __device__ __forceinline__ void count_flags(uint32_t w, int& n_all, int& n_exces
 // workgroup publishes the totals in VK_CTR_PENDING_*, and finish_handle() —
 // run by the kernel that follows — folds them in and clears the flags
 // (volume.cu:365).
-__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible)
+__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible, int deferred_reset)
 {
   __shared__ int red[2 * (kHandleThreads / 64)];
   __shared__ int wave_a[kHandleThreads / 64], wave_b[kHandleThreads / 64];
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volu
         if (entry_index < max_count)
         {
           v.hash_entries[other_index].next = entry_index;
-          v.block_visibility[entry_index] = VK_VISIBILITY_TRUE;
+          v.block_visibility[entry_index] = deferred_reset ? (uint8_t)(VK_VISIBILITY_TRUE | kTouched) : (uint8_t)VK_VISIBILITY_TRUE;
         }
       }
 
@@ -516,6 +529,7 @@ struct VisibilityParams
 {
   vk_volume v;
   int finish_handle;   // SetView: this kernel also completes the handle pass before it
+  int deferred_reset;  // SetView: the reset pass was skipped, bytes may carry kTouched
   int width, height;
   vk_projection k;
   Rt Tdw;
@@ -542,8 +556,17 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
 
   if (index < count)
   {
-    const int visibility = v.block_visibility[index];
+    const int stored = v.block_visibility[index];
+    int visibility = stored;
+    if (P.deferred_reset)
+    {
+      // touched this frame -> TRUE; otherwise what the reset pass would have left
+      const int before = stored & 3;
+      visibility = (stored & kTouched) ? VK_VISIBILITY_TRUE
+                 : (before == VK_VISIBILITY_TRUE ? VK_VISIBILITY_UNKNOWN : before);
+    }
     visible = (visibility == VK_VISIBILITY_TRUE);
+    int result = visibility;
 
     if (visibility == VK_VISIBILITY_UNKNOWN)
     {
@@ -568,8 +591,10 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
         }
       }
 
-      if (!visible) v.block_visibility[index] = VK_VISIBILITY_FALSE;
+      if (!visible) result = VK_VISIBILITY_FALSE;
     }
+
+    if (result != stored) v.block_visibility[index] = (uint8_t)result;
   }
 
   const unsigned long long mask = __ballot(visible);
@@ -614,7 +639,7 @@ int check_volume(const vk_volume* v)
 }
 
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
-    const vk_projection* projection, const vk_transform* Twd, hipStream_t s)
+    const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s)
 {
   RequestParams P;
   P.v = *v;
@@ -624,17 +649,19 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
   P.k = *projection;
   P.Twd = make_rt(Twd->m);
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
-  hipLaunchKernelGGL(create_requests_kernel, grid, dim3(256), 0, s, P);
+  if (deferred_reset) hipLaunchKernelGGL(create_requests_kernel<true>, grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(create_requests_kernel<false>, grid, dim3(256), 0, s, P);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
 
 int launch_update_visibility(const vk_volume* v, int width, int height,
-    const vk_projection* projection, const float* Tdw_m, bool finish, hipStream_t s)
+    const vk_projection* projection, const float* Tdw_m, bool finish, bool deferred_reset, hipStream_t s)
 {
   VisibilityParams P;
   P.v = *v;
   P.finish_handle = finish ? 1 : 0;
+  P.deferred_reset = deferred_reset ? 1 : 0;
   P.width = width;
   P.height = height;
   P.k = *projection;
@@ -688,7 +715,7 @@ int vk_volume_create_allocation_requests(const vk_volume* v, const float* depth,
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   VK_REQUIRE(depth && projection && Twd && width > 0 && height > 0);
-  return launch_create_requests(v, depth, width, height, projection, Twd, vk_s(stream));
+  return launch_create_requests(v, depth, width, height, projection, Twd, false, vk_s(stream));
 }
 
 int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
@@ -696,7 +723,7 @@ int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, vk_s(stream), *v, 0);
+      dim3(kHandleThreads), 0, vk_s(stream), *v, 0, 0);
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(finish_handle_kernel, dim3((v->main_block_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
   VK_LAUNCH_CHECK();
@@ -711,7 +738,7 @@ int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
   VK_REQUIRE(projection && Tdw && width > 0 && height > 0);
   // volume.cu:488 ResetBufferSize
   VK_CHECK(hipMemsetAsync(v->counters + VK_CTR_VISIBLE, 0, sizeof(int32_t), vk_s(stream)));
-  return launch_update_visibility(v, width, height, projection, Tdw->m, false, vk_s(stream));
+  return launch_update_visibility(v, width, height, projection, Tdw->m, false, false, vk_s(stream));
 }
 
 int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
@@ -720,15 +747,15 @@ int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
   if (rc != VK_OK) return rc;
   VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0);
   hipStream_t s = vk_s(stream);
+  // three launches: the reset pass is folded into the other three (see kTouched)
   int r;
-  if ((r = launch_reset_visibility(v, s)) != VK_OK) return r;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
-           &frame->depth_projection, &frame->depth_to_world, s)) != VK_OK) return r;
+           &frame->depth_projection, &frame->depth_to_world, true, s)) != VK_OK) return r;
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, s, *v, 1);
+      dim3(kHandleThreads), 0, s, *v, 1, 1);
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
   return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
-      frame->depth_to_world.inv, true, s);
+      frame->depth_to_world.inv, true, true, s);
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)
