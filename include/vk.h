@@ -399,6 +399,75 @@ VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev,
     float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream);
 
+/* ------------------------------------------------------------ colour tracker -- */
+
+/* ref: src/image.cu:10-19,235-247 ColorImage::ConvertTo — intensity = (r+g+b)/3.
+ * src: [total*3] floats, dst: [total]. */
+VK_API int vk_color_image_convert(int total, const float* src, float* dst, void* stream);
+
+/* ref: src/image.cu:21-99,166-179 Image::GetGradients — 3x3 stencil
+ * (1/8, 1/4, 1/8 rows), zero padding outside the image. */
+VK_API int vk_image_gradients(int width, int height, const float* src,
+    float* gradient_x, float* gradient_y, void* stream);
+
+/* One side of the photometric problem. The keyframe needs depths, normals and
+ * intensities; the frame also needs the two gradient images. */
+typedef struct vk_color_view {
+  const float*  depths;        /* [h*w]   */
+  const float*  normals;       /* [h*w*3] */
+  const float*  intensities;   /* [h*w]   */
+  const float*  gradient_x;    /* [h*w], frame only */
+  const float*  gradient_y;    /* [h*w], frame only */
+  int32_t       width;
+  int32_t       height;
+  vk_projection projection;    /* the COLOUR camera's, color_tracker.cu:309-310 */
+} vk_color_view;
+
+/* ref: src/color_tracker.cu:43-163,296-344 ColorTracker::ComputeResiduals. One
+ * residual per KEYFRAME pixel. Tcm = frame_Tcw * keyframe_Tcw^-1 with
+ * X_Tcw = X.depth_to_color * X.depth_to_world^-1 (color_tracker.cu:312-320). */
+VK_API int vk_color_tracker_compute_residuals(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_transform* Tcm, float* residuals, void* stream);
+
+/* ref: src/color_tracker.cu:165-204,346-410 ColorTracker::ComputeJacobian;
+ * jacobian: [h*w*6] floats, columns 3..5 are 0 when !translation_enabled. */
+VK_API int vk_color_tracker_compute_jacobian(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_transform* Tcm, int translation_enabled,
+    float* jacobian, void* stream);
+
+/* ref: src/color_tracker.cu:206-343,412-470 ColorTracker::ComputeSystem; same
+ * outputs, workspace and fixed-order reduction as vk_icp_compute_system
+ * (workspace: vk_icp_workspace_floats(keyframe w, h) floats). `Tcm_dev`:
+ * optional DEVICE transform that overrides Tcm. */
+VK_API int vk_color_tracker_compute_system(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_transform* Tcm, const vk_transform* Tcm_dev,
+    int translation_enabled, float* workspace, float* hessian, float* gradient, void* stream);
+
+/* The frame pose as the device-side loop keeps it. */
+typedef struct vk_color_pose {
+  vk_transform depth_to_world;  /* frame.depth_to_world_transform, updated in place */
+  vk_transform Tcm;             /* derived: what the kernels above consume         */
+} vk_color_pose;
+
+/* ref: src/tracker.cpp:124-163 Tracker::ComputeUpdate + src/color_tracker.cpp:
+ * 34-96 ColorTracker::ApplyUpdate on the device: solve, M = Tinc *
+ * depth_to_world^-1, re-orthonormalise, depth_to_world = (T(t) R)^-1, then
+ * Tcm = (frame_Tcd * depth_to_world^-1) * keyframe_Twc for the next iteration.
+ * `keyframe_Twc` = (keyframe.depth_to_color * keyframe.depth_to_world^-1)^-1.
+ * state_dev / update_dev as in vk_icp_solve_update. */
+VK_API int vk_color_tracker_solve_update(const float* hessian, const float* gradient,
+    int translation_enabled, const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc,
+    vk_color_pose* pose_dev, int32_t* state_dev, float* update_dev, void* stream);
+
+/* ref: src/tracker.cpp:53-63 Tracker::Track for ColorTracker: derive Tcm from
+ * pose_dev->depth_to_world, then `iterations` Gauss-Newton steps of two launches
+ * each (three with `reduce`), no host round trip. Buffers as in vk_icp_track. */
+VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
+    int iterations, int translation_enabled, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
+    void* stream);
+
 /* ---------------------------------------------------------------- detector -- */
 
 /* ref: include/vulcan/detector.h:10-72, src/detector.cu — box detector over a

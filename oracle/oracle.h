@@ -95,6 +95,21 @@ float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
     int translation_enabled, vk_transform* Twc, float* update);
 
 /* known-answer hooks (tests/test_oracle_kats.py) */
+/* colour tracker (oracle_color_tracker.c) */
+void orc_color_image_convert(int total, const float* src, float* dst);
+void orc_image_gradients(int width, int height, const float* src, float* gx, float* gy);
+void orc_color_tracker_compute_residuals(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, float* residuals);
+void orc_color_tracker_compute_jacobian(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, int translation_enabled, float* jacobian);
+void orc_color_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, int translation_enabled, double* hessian, double* gradient);
+float orc_color_tracker_solve_update(const float* hessian_packed, const float* gradient,
+    int translation_enabled, const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc,
+    vk_color_pose* pose, float* update_out);
+void orc_color_tracker_tcm(const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc,
+    vk_color_pose* pose);
+
 /* detector (oracle_detect.c). PARITY UNPINNED: the reference holds no test or
  * vector for Detector (tests/detector_test.cu is empty). */
 void orc_detect(const vk_detector* detector, const float* points, int count,

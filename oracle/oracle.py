@@ -296,3 +296,80 @@ def detect(points, params):
     state = T.DetectState()
     lib().orc_detect(C.byref(params), _p(pts), len(pts), _p(inliers), C.byref(state))
     return state, inliers[: state.inlier_count].copy()
+
+
+# ---- colour tracker ------------------------------------------------------
+
+def color_convert(colors):
+    c = np.ascontiguousarray(colors, dtype=np.float32)
+    out = np.zeros(c.shape[:-1], dtype=np.float32)
+    lib().orc_color_image_convert(out.size, _p(c), _p(out))
+    return out
+
+
+def image_gradients(img):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape
+    gx, gy = np.zeros_like(img), np.zeros_like(img)
+    lib().orc_image_gradients(w, h, _p(img), _p(gx), _p(gy))
+    return gx, gy
+
+
+class ColorSide:
+    """What ColorTracker keeps per frame (color_tracker.h:38-44): depth, normals,
+    intensities and (frame side) their gradients, with the colour intrinsics."""
+
+    def __init__(self, frame, with_gradients):
+        self.frame = frame
+        self.depth = np.ascontiguousarray(frame.depth, dtype=np.float32)
+        self.normals = np.ascontiguousarray(frame.normals, dtype=np.float32)
+        self.intensities = color_convert(frame.color)
+        self.gx, self.gy = image_gradients(self.intensities) if with_gradients else (None, None)
+
+    def view(self):
+        v = T.ColorView()
+        v.depths, v.normals, v.intensities = _p(self.depth).value, _p(self.normals).value, _p(self.intensities).value
+        v.gradient_x = _p(self.gx).value if self.gx is not None else None
+        v.gradient_y = _p(self.gy).value if self.gy is not None else None
+        v.height, v.width = self.depth.shape
+        v.projection = self.frame.color_projection
+        return v
+
+
+def color_tcm(key_frame, frame):
+    """color_tracker.cu:312-320"""
+    key_Tcw = key_frame.depth_to_color * key_frame.depth_to_world.inverse()
+    frame_Tcw = frame.depth_to_color * frame.depth_to_world.inverse()
+    return frame_Tcw * key_Tcw.inverse()
+
+
+def color_residuals(key, frm, Tcm):
+    out = np.zeros(key.depth.shape, dtype=np.float32)
+    kv, fv = key.view(), frm.view()
+    lib().orc_color_tracker_compute_residuals(C.byref(kv), C.byref(fv), C.byref(Tcm), _p(out))
+    return out
+
+
+def color_jacobian(key, frm, Tcm, translation_enabled=True):
+    out = np.zeros(key.depth.shape + (6,), dtype=np.float32)
+    kv, fv = key.view(), frm.view()
+    lib().orc_color_tracker_compute_jacobian(C.byref(kv), C.byref(fv), C.byref(Tcm), int(translation_enabled), _p(out))
+    return out
+
+
+def color_system(key, frm, Tcm, translation_enabled=True):
+    h = np.zeros(21, dtype=np.float64)
+    g = np.zeros(6, dtype=np.float64)
+    kv, fv = key.view(), frm.view()
+    lib().orc_color_tracker_compute_system(C.byref(kv), C.byref(fv), C.byref(Tcm), int(translation_enabled), _p(h), _p(g))
+    return h, g
+
+
+def color_solve_update(hessian_packed, gradient, frame_Tcd, key_Twc, pose, translation_enabled=True):
+    h = np.ascontiguousarray(hessian_packed, dtype=np.float32)
+    g = np.ascontiguousarray(gradient, dtype=np.float32)
+    update = np.zeros(6, dtype=np.float32)
+    lib().orc_color_tracker_solve_update.restype = C.c_float
+    norm = lib().orc_color_tracker_solve_update(_p(h), _p(g), int(translation_enabled), C.byref(frame_Tcd),
+                                                C.byref(key_Twc), C.byref(pose), _p(update))
+    return update, float(norm)

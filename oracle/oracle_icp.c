@@ -129,7 +129,7 @@ void orc_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm
 /* LDL^T without pivoting, float32. The reference calls Eigen::LDLT (pivoted,
  * tracker.cpp:127,153-159; Eigen is not vendored and its version is unpinned,
  * so the solve is "parity unpinned": agreement is to rounding, not bit-exact). */
-static void ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
+void orc_ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
     const float* b, float* x)
 {
   float L[36], D[6], y[6];
@@ -167,14 +167,15 @@ static void ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
   }
 }
 
-/* ref: tracker.cpp:124-163 ComputeUpdate + depth_tracker.cpp:22-86 ApplyUpdate */
-float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
-    int translation_enabled, vk_transform* Twc, float* update_out)
+/* ref: tracker.cpp:142-159: unpack the packed lower triangle (mirrored), solve,
+ * update = -x; entries beyond the parameter count stay 0 */
+void orc_solve_step(const float* hessian_packed, const float* gradient, int translation_enabled,
+    float* update)
 {
   const int n = translation_enabled ? 6 : 3;
-  float H[36], x[6], update[6];
+  float H[36], x[6];
 
-  int index = 0;  /* tracker.cpp:142-152 unpack lower triangle, mirror */
+  int index = 0;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j <= i; ++j)
     {
@@ -183,20 +184,15 @@ float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
       ++index;
     }
 
-  ldlt_solve(n, H, gradient, x);
+  orc_ldlt_solve(n, H, gradient, x);
   for (int i = 0; i < 6; ++i) update[i] = 0;
   for (int i = 0; i < n; ++i) update[i] = -x[i];   /* tracker.cpp:159 */
+}
 
-  /* depth_tracker.cpp:33-53; note Tinc(1,2) = +update[0] (SURVEY §2.5-11) */
-  float Tinc[16];
-  Tinc[0 + 4 * 0] = 1.0f;       Tinc[0 + 4 * 1] = -update[2]; Tinc[0 + 4 * 2] = +update[1]; Tinc[0 + 4 * 3] = +update[3];
-  Tinc[1 + 4 * 0] = +update[2]; Tinc[1 + 4 * 1] = 1.0f;       Tinc[1 + 4 * 2] = +update[0]; Tinc[1 + 4 * 3] = +update[4];
-  Tinc[2 + 4 * 0] = -update[1]; Tinc[2 + 4 * 1] = +update[0]; Tinc[2 + 4 * 2] = 1.0f;       Tinc[2 + 4 * 3] = +update[5];
-  Tinc[3 + 4 * 0] = 0.0f;       Tinc[3 + 4 * 1] = 0.0f;       Tinc[3 + 4 * 2] = 0.0f;       Tinc[3 + 4 * 3] = 1.0f;
-
-  float M[16];
-  o_matmul4(Tinc, Twc->m, M);  /* :55 */
-
+/* depth_tracker.cpp:57-84 / color_tracker.cpp:67-95: re-orthonormalised
+ * Translate(t) * Rotate(R) of the 4x4 M (transform.h:62-66,74-99,146-159) */
+vk_transform orc_rigid_from(const float* M)
+{
   of3 x_axis = o3(M[0], M[1], M[2]);
   of3 y_axis = o3(M[4], M[5], M[6]);
   of3 z_axis;
@@ -205,7 +201,6 @@ float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
   z_axis = o_cross3(x_axis, y_axis);
   y_axis = o_cross3(z_axis, x_axis);
 
-  /* :84 Translate(t) * Rotate(R): transform.h:62-66,74-99,146-159 */
   vk_transform T, R;
   memset(&T, 0, sizeof(T));
   memset(&R, 0, sizeof(R));
@@ -222,7 +217,27 @@ float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
     for (int c = 0; c < 4; ++c)
       R.inv[c * 4 + r] = R.m[r * 4 + c];  /* matrix.Transpose() */
 
-  *Twc = o_transform_mul(&T, &R);
+  return o_transform_mul(&T, &R);
+}
+
+/* ref: tracker.cpp:124-163 ComputeUpdate + depth_tracker.cpp:22-86 ApplyUpdate */
+float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
+    int translation_enabled, vk_transform* Twc, float* update_out)
+{
+  const int n = translation_enabled ? 6 : 3;
+  float update[6];
+  orc_solve_step(hessian_packed, gradient, translation_enabled, update);
+
+  /* depth_tracker.cpp:33-53; note Tinc(1,2) = +update[0] (SURVEY §2.5-11) */
+  float Tinc[16];
+  Tinc[0 + 4 * 0] = 1.0f;       Tinc[0 + 4 * 1] = -update[2]; Tinc[0 + 4 * 2] = +update[1]; Tinc[0 + 4 * 3] = +update[3];
+  Tinc[1 + 4 * 0] = +update[2]; Tinc[1 + 4 * 1] = 1.0f;       Tinc[1 + 4 * 2] = +update[0]; Tinc[1 + 4 * 3] = +update[4];
+  Tinc[2 + 4 * 0] = -update[1]; Tinc[2 + 4 * 1] = +update[0]; Tinc[2 + 4 * 2] = 1.0f;       Tinc[2 + 4 * 3] = +update[5];
+  Tinc[3 + 4 * 0] = 0.0f;       Tinc[3 + 4 * 1] = 0.0f;       Tinc[3 + 4 * 2] = 0.0f;       Tinc[3 + 4 * 3] = 1.0f;
+
+  float M[16];
+  o_matmul4(Tinc, Twc->m, M);  /* :55 */
+  *Twc = orc_rigid_from(M);    /* :57-84 */
 
   float sq = 0;
   for (int i = 0; i < n; ++i) sq += update[i] * update[i];

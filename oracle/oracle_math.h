@@ -160,4 +160,9 @@ static inline int o_block_eq(const vk_block* b, int bx, int by, int bz)
          b->origin[2] == (int16_t)bz;
 }
 
+/* shared by the trackers (defined in oracle_icp.c) */
+void orc_ldlt_solve(int n, const float* A, const float* b, float* x);
+void orc_solve_step(const float* hessian_packed, const float* gradient, int translation_enabled, float* update);
+vk_transform orc_rigid_from(const float* M);
+
 #endif

@@ -1,0 +1,155 @@
+"""vulcan::ColorTracker on the device (vk_color_*) vs the oracle: image operators,
+residuals and Jacobians bit for bit, the 27 sums to float-tree tolerance, the pose
+update bit for bit given the same system, Track() against the oracle's loop."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import color_scenes as cs
+from test_gpu_parity import api, sync  # noqa: F401  (fixture)
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def pair(api, orc):
+    k = cs.projection()
+    kd, kc = cs.keyframe_images()
+    fd, fc = cs.frame_images()
+    hk = orc.HostFrame(kd, k, cs.keyframe_pose(), color=kc)
+    hf = orc.HostFrame(fd, k, cs.frame_pose(), color=fc)
+    hk.compute_normals()
+    hf.compute_normals()
+    dk = api.Frame(kd, k, cs.keyframe_pose(), color=kc, normals=hk.normals)
+    df = api.Frame(fd, k, cs.frame_pose(), color=fc, normals=hf.normals)
+    return hk, hf, orc.ColorSide(hk, False), orc.ColorSide(hf, True), dk, df
+
+
+def test_convert_and_gradients_match(api, orc):
+    import torch
+    rng = np.random.default_rng(3)
+    for (h, w) in ((480, 640), (77, 101), (1, 1), (5, 130)):
+        rgb = rng.random((h, w, 3), dtype=np.float32)
+        d_rgb = torch.from_numpy(rgb).cuda()
+        gray = torch.empty((h, w), dtype=torch.float32, device="cuda")
+        api.check(api.lib().vk_color_image_convert(h * w, api._ptr(d_rgb), api._ptr(gray), api.stream()), "convert")
+        gx, gy = torch.empty_like(gray), torch.empty_like(gray)
+        api.check(api.lib().vk_image_gradients(w, h, api._ptr(gray), api._ptr(gx), api._ptr(gy), api.stream()), "grad")
+        sync()
+        want = orc.color_convert(rgb)
+        assert np.array_equal(bits(gray.cpu().numpy()), bits(want))
+        wx, wy = orc.image_gradients(want)
+        assert np.array_equal(bits(gx.cpu().numpy()), bits(wx))
+        assert np.array_equal(bits(gy.cpu().numpy()), bits(wy))
+
+
+def test_residuals_and_jacobian_match(api, orc, pair):
+    hk, hf, ks, fs, dk, df = pair
+    tracker = api.ColorTracker()
+    tracker.keyframe = dk
+    Tcm = orc.color_tcm(hk, hf)
+    assert np.array_equal(np.array(tracker.tcm(df).m[:]), np.array(Tcm.m[:]))
+    r = tracker.compute_residuals(df)
+    sync()
+    assert np.array_equal(bits(r.cpu().numpy()), bits(orc.color_residuals(ks, fs, Tcm)))
+    for translation in (True, False):
+        tracker.translation_enabled = translation
+        J = tracker.compute_jacobian(df)
+        sync()
+        assert np.array_equal(bits(J.cpu().numpy()), bits(orc.color_jacobian(ks, fs, Tcm, translation)))
+
+
+def test_system_matches(api, orc, pair):
+    hk, hf, ks, fs, dk, df = pair
+    tracker = api.ColorTracker()
+    tracker.keyframe = dk
+    Tcm = orc.color_tcm(hk, hf)
+    J = orc.color_jacobian(ks, fs, Tcm, True).reshape(-1, 6).astype(np.float64)
+    r = orc.color_residuals(ks, fs, Tcm).reshape(-1).astype(np.float64)
+    for translation in (True, False):
+        tracker.translation_enabled = translation
+        tracker.compute_system(df)
+        sync()
+        h, g = orc.color_system(ks, fs, Tcm, translation)
+        n = 6 if translation else 3
+        got_h, got_g = tracker.hessian.cpu().numpy().astype(np.float64), tracker.gradient.cpu().numpy().astype(np.float64)
+        scale_g = np.abs(J[:, :n] * r[:, None]).sum(0)
+        assert np.all(np.abs(got_g[:n] - g[:n]) <= 2e-5 * scale_g + 1e-12)
+        idx = 0
+        for rr in range(n):
+            for c in range(rr + 1):
+                scale = np.abs(J[:, rr] * J[:, c]).sum()
+                assert abs(got_h[idx] - h[idx]) <= 2e-5 * scale + 1e-12
+                idx += 1
+        assert np.all(got_h[idx:] == 0) and np.all(got_g[n:] == 0)
+
+
+def test_solve_update_matches(api, orc, pair):
+    """Same packed system in, same pose and Tcm out (bit for bit)."""
+    import torch
+    hk, hf, ks, fs, dk, df = pair
+    Tcm = orc.color_tcm(hk, hf)
+    h, g = orc.color_system(ks, fs, Tcm, True)
+    h32, g32 = h.astype(np.float32), g.astype(np.float32)
+    key_Twc = (hk.depth_to_color * hk.depth_to_world.inverse()).inverse()
+    for translation in (True, False):
+        pose = T.ColorPose()
+        pose.depth_to_world = hf.depth_to_world
+        packed_h = h32 if translation else np.array([h32[0], h32[1], h32[2], h32[3], h32[4], h32[5]], np.float32)
+        want_update, _ = orc.color_solve_update(packed_h, g32, hf.depth_to_color, key_Twc, pose, translation)
+
+        dev_pose = torch.from_numpy(np.frombuffer(bytes(_pose_of(hf)), dtype=np.uint8).copy()).cuda()
+        dh = torch.zeros(36, dtype=torch.float32, device="cuda")
+        dh[: len(packed_h)] = torch.from_numpy(packed_h)
+        dg = torch.from_numpy(np.concatenate([g32, np.zeros(0, np.float32)])).cuda()
+        state = torch.zeros(2, dtype=torch.int32, device="cuda")
+        upd = torch.zeros(6, dtype=torch.float32, device="cuda")
+        api.check(api.lib().vk_color_tracker_solve_update(api._ptr(dh), api._ptr(dg), int(translation),
+                                                          api._ref(hf.depth_to_color), api._ref(key_Twc), api._ptr(dev_pose),
+                                                          api._ptr(state), api._ptr(upd), api.stream()), "solve")
+        sync()
+        got = T.ColorPose.from_buffer_copy(dev_pose.cpu().numpy().tobytes())
+        assert np.array_equal(bits(upd.cpu().numpy()), bits(want_update))
+        for name in ("depth_to_world", "Tcm"):
+            a, b = getattr(got, name), getattr(pose, name)
+            assert np.array_equal(bits(a.m[:]), bits(b.m[:])) and np.array_equal(bits(a.inv[:]), bits(b.inv[:]))
+        assert state.cpu().numpy().tolist() == [1, 0]
+
+
+def _pose_of(frame):
+    pose = T.ColorPose()
+    pose.depth_to_world = frame.depth_to_world
+    return pose
+
+
+def test_track_follows_the_oracle_loop(api, orc, pair):
+    """Track() = BeginSolve + 20 x (system, solve, update) on the device; the oracle
+    runs the same loop with double sums, so poses agree to rounding, and the
+    photometric cost must drop."""
+    hk, hf, ks, fs, dk, df = pair
+    tracker = api.ColorTracker()
+    tracker.keyframe = dk
+    tracker.max_iterations = 8
+    moved = api.Frame(df.depth, df.depth_projection, hf.depth_to_world, color=df.color, normals=df.normals)
+    before = float((tracker.compute_residuals(moved).double() ** 2).sum())
+    got = tracker.track(moved)
+    sync()
+    after = float((tracker.compute_residuals(moved).double() ** 2).sum())
+    assert after < 0.5 * before
+    assert tracker.state.cpu().numpy()[0] >= 1
+
+    pose = _pose_of(hf)
+    key_Twc = (hk.depth_to_color * hk.depth_to_world.inverse()).inverse()
+    orc.lib().orc_color_tracker_tcm(C.byref(hf.depth_to_color), C.byref(key_Twc), C.byref(pose))
+    for _ in range(8):
+        h, g = orc.color_system(ks, fs, pose.Tcm, True)
+        _, norm = orc.color_solve_update(h, g, hf.depth_to_color, key_Twc, pose, True)
+        if norm < 1e-6:
+            break
+    np.testing.assert_allclose(got.matrix(), pose.depth_to_world.matrix(), atol=2e-5)

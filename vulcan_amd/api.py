@@ -69,6 +69,13 @@ _SIGNATURES = {
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_color_image_convert": ([_I, _P, _P, _P], _I),
+    "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
+    "vk_color_tracker_compute_residuals": ([_P, _P, _P, _P, _P], _I),
+    "vk_color_tracker_compute_jacobian": ([_P, _P, _P, _I, _P, _P], _I),
+    "vk_color_tracker_compute_system": ([_P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_color_tracker_solve_update": ([_P, _P, _I, _P, _P, _P, _P, _P, _P], _I),
+    "vk_color_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
     "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
@@ -79,6 +86,7 @@ _SIGNATURES = {
     "vk_probe_points_variant": ([_I], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
+_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn
 
 
 class VkError(RuntimeError):
@@ -517,6 +525,129 @@ class DepthTracker:
         out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out
         return out
+
+
+class ColorTracker:
+    """vulcan::ColorTracker (color_tracker.h): photometric Gauss-Newton tracking of a
+    frame against a keyframe — intensity residuals sampled bilinearly in the frame,
+    one per keyframe pixel. Pose, system and solve stay on the device."""
+
+    def __init__(self, device="cuda"):
+        import torch
+        self.device = device
+        self.translation_enabled = True      # tracker.cpp:11
+        self.max_iterations = 20             # tracker.cpp:12
+        self._keyframe = None
+        self._key_side = None
+        self.system = torch.zeros(48, dtype=torch.float32, device=device)
+        self.hessian = self.system[:36]
+        self.gradient = self.system[36:42]
+        self.pose = _dev_bytes(C.sizeof(T.ColorPose), device)
+        self.state = torch.zeros(2, dtype=torch.int32, device=device)
+        self.update = torch.zeros(6, dtype=torch.float32, device=device)
+        self.workspace = None
+        self.reduce_hook = None
+
+    @property
+    def keyframe(self):
+        return self._keyframe
+
+    @keyframe.setter
+    def keyframe(self, frame):
+        self._keyframe = frame
+        self._key_side = None
+
+    # -- ColorTracker::ComputeKeyframeIntensities / FrameIntensities / FrameGradients ------
+    def _side(self, frame, with_gradients):
+        import torch
+        h, w = frame.height, frame.width
+        inten = torch.empty((h, w), dtype=torch.float32, device=self.device)
+        check(lib().vk_color_image_convert(h * w, _ptr(frame.color), _ptr(inten), stream()), "vk_color_image_convert")
+        gx = gy = None
+        if with_gradients:
+            gx, gy = torch.empty_like(inten), torch.empty_like(inten)
+            check(lib().vk_image_gradients(w, h, _ptr(inten), _ptr(gx), _ptr(gy), stream()), "vk_image_gradients")
+        v = T.ColorView()
+        v.depths, v.normals, v.intensities = frame.depth.data_ptr(), frame.normals.data_ptr(), inten.data_ptr()
+        v.gradient_x = gx.data_ptr() if gx is not None else None
+        v.gradient_y = gy.data_ptr() if gy is not None else None
+        v.width, v.height = w, h
+        v.projection = frame.color_projection
+        return v, (inten, gx, gy)          # the tensors must outlive the view
+
+    def _key(self):
+        if self._key_side is None:
+            self._key_side = self._side(self._keyframe, False)
+        return self._key_side
+
+    def tcm(self, frame):
+        """color_tracker.cu:312-320"""
+        key_Tcw = self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()
+        frame_Tcw = frame.depth_to_color * frame.depth_to_world.inverse()
+        return frame_Tcw * key_Tcw.inverse()
+
+    def _workspace(self):
+        import torch
+        n = int(lib().vk_icp_workspace_floats(self._keyframe.width, self._keyframe.height))
+        if self.workspace is None or self.workspace.numel() < n:
+            self.workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self.workspace
+
+    def compute_residuals(self, frame):      # color_tracker.cu:296-344
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, False)
+        out = torch.empty((self._keyframe.height, self._keyframe.width), dtype=torch.float32, device=self.device)
+        check(lib().vk_color_tracker_compute_residuals(_ref(kv), _ref(fv), _ref(self.tcm(frame)), _ptr(out), stream()),
+              "vk_color_tracker_compute_residuals")
+        return out
+
+    def compute_jacobian(self, frame):       # color_tracker.cu:346-410
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        out = torch.empty((self._keyframe.height, self._keyframe.width, 6), dtype=torch.float32, device=self.device)
+        check(lib().vk_color_tracker_compute_jacobian(_ref(kv), _ref(fv), _ref(self.tcm(frame)),
+                                                      int(self.translation_enabled), _ptr(out), stream()),
+              "vk_color_tracker_compute_jacobian")
+        return out
+
+    def compute_system(self, frame):         # color_tracker.cu:412-470
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        check(lib().vk_color_tracker_compute_system(_ref(kv), _ref(fv), _ref(self.tcm(frame)), None,
+                                                    int(self.translation_enabled), _ptr(self._workspace()),
+                                                    _ptr(self.hessian), _ptr(self.gradient), stream()),
+              "vk_color_tracker_compute_system")
+
+    def track(self, frame):
+        """Tracker::Track (tracker.cpp:53-63) with ColorTracker::BeginSolve
+        (color_tracker.cpp:19-25): intensities and gradients once, then
+        max_iterations steps enqueued without a host sync."""
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        pose = T.ColorPose()
+        pose.depth_to_world = frame.depth_to_world
+        host = np.frombuffer(bytes(pose), dtype=np.uint8).copy()
+        self.pose.copy_(torch.from_numpy(host).to(self.device))
+        self.state.zero_()
+        key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
+        hook = None
+        if self.reduce_hook is not None:
+            system, py_hook = self.system, self.reduce_hook
+
+            def _call(ptr, count, user, strm):
+                py_hook(system)
+                return 0
+            hook = _REDUCE_FN(_call)
+        check(lib().vk_color_tracker_track(_ref(kv), _ref(fv), _ref(frame.depth_to_color), _ref(key_Twc),
+                                           _ptr(self.pose), self.max_iterations, int(self.translation_enabled),
+                                           _ptr(self._workspace()), _ptr(self.system), _ptr(self.state),
+                                           _ptr(self.update), hook, None, stream()), "vk_color_tracker_track")
+        out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
+        frame.depth_to_world = out.depth_to_world
+        return out.depth_to_world
 
 
 class PyramidTracker:

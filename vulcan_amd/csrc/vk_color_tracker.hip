@@ -1,0 +1,488 @@
+// vk_color_tracker.hip — photometric frame-to-keyframe tracking for gfx950
+// (ref: src/color_tracker.cu, src/color_tracker.cpp:34-96, src/image.cu:10-99).
+//
+// Same shape as the depth tracker (vk_icp.hip): one keyframe pixel per lane, the
+// 27 sums reduced by DPP row operations and a fixed-order second stage, the 6x6
+// solve and the pose update done by one lane out of registers, so that a
+// Gauss-Newton iteration is two launches and Track() never reads anything back.
+// The reference zero-fills, accumulates with 27 float atomics per thread block and
+// copies 42 floats to the host for Eigen every iteration.
+#include "vk_gauss_newton.hpp"
+
+using namespace vk;
+
+namespace
+{
+
+// ---------------------------------------------------------------- images ----
+
+// ref: image.cu:10-19
+__global__ __launch_bounds__(256) void convert_kernel(int total, const float* __restrict__ src,
+    float* __restrict__ dst)
+{
+  const int index = blockIdx.x * 256 + threadIdx.x;
+  if (index < total) dst[index] = (src[3 * index + 0] + src[3 * index + 1] + src[3 * index + 2]) / 3.0f;
+}
+
+__device__ __forceinline__ float padded(const float* v, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? v[y * w + x] : 0.0f;
+}
+
+// ref: image.cu:21-99. The eight taps come through L1/L2 (each pixel is read by
+// its eight neighbours within the same few waves) instead of an 18x18 LDS patch.
+__global__ __launch_bounds__(256) void gradients_kernel(int width, int height, const float* __restrict__ values,
+    float* __restrict__ gx_out, float* __restrict__ gy_out)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= width || y >= height) return;
+
+  const float i00 = 0.125f * padded(values, width, height, x - 1, y - 1);
+  const float i01 = 0.250f * padded(values, width, height, x + 0, y - 1);
+  const float i02 = 0.125f * padded(values, width, height, x + 1, y - 1);
+  const float i10 = 0.250f * padded(values, width, height, x - 1, y + 0);
+  const float i12 = 0.250f * padded(values, width, height, x + 1, y + 0);
+  const float i20 = 0.125f * padded(values, width, height, x - 1, y + 1);
+  const float i21 = 0.250f * padded(values, width, height, x + 0, y + 1);
+  const float i22 = 0.125f * padded(values, width, height, x + 1, y + 1);
+
+  gx_out[y * width + x] = (i02 + i12 + i22) - (i00 + i10 + i20);
+  gy_out[y * width + x] = (i20 + i21 + i22) - (i00 + i01 + i02);
+}
+
+// -------------------------------------------------------------- evaluate ----
+
+struct ColorParams
+{
+  vk_color_view key, frm;
+  Rt Tcm;
+  const vk_transform* Tcm_dev;  // optional device override of Tcm
+  const int32_t* state;         // optional {iterations, converged}: a converged solve skips the pass
+};
+
+// ref: color_tracker.cu:17-41
+__device__ __forceinline__ float sample(int w, const float* values, float u, float v)
+{
+  const int x = f2i(floorf(u - 0.5f));
+  const int y = f2i(floorf(v - 0.5f));
+
+  const float v00 = values[(y + 0) * w + (x + 0)];
+  const float v01 = values[(y + 0) * w + (x + 1)];
+  const float v10 = values[(y + 1) * w + (x + 0)];
+  const float v11 = values[(y + 1) * w + (x + 1)];
+
+  const float u1 = u - (x + 0.5f);
+  const float v1 = v - (y + 0.5f);
+  const float u0 = 1.0f - u1;
+  const float v0 = 1.0f - v1;
+
+  const float w00 = v0 * u0;
+  const float w01 = v0 * u1;
+  const float w10 = v1 * u0;
+  const float w11 = v1 * u1;
+
+  return (w00 * v00) + (w01 * v01) + (w10 * v10) + (w11 * v11);
+}
+
+// ref: color_tracker.cu:43-138 Evaluate<translation_enabled>; returns false when
+// the pixel contributes nothing (residual 0, Jacobian 0).
+template <bool TRANSLATION, bool JACOBIAN>
+__device__ __forceinline__ bool evaluate(const ColorParams& P, const Rt& Tcm, int keyframe_x, int keyframe_y,
+    float& residual, float (&J)[6])
+{
+  residual = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) J[i] = 0.0f;
+
+  const vk_color_view& key = P.key;
+  const vk_color_view& frm = P.frm;
+
+  const int keyframe_index = keyframe_y * key.width + keyframe_x;
+  const float keyframe_depth = key.depths[keyframe_index];
+  if (!(keyframe_depth > 0)) return false;
+
+  const f3 Xmp = unproject_d(key.projection, keyframe_x + 0.5f, keyframe_y + 0.5f, keyframe_depth);
+  const f3 Xcp = xform_point(Tcm, Xmp);
+  float fu, fv;
+  project(frm.projection, Xcp, fu, fv);
+
+  if (!(fu >= 0.5f && fu < frm.width - 0.5f && fv >= 0.5f && fv < frm.height - 0.5f)) return false;
+
+  const int frame_index = f2i(fv) * frm.width + f2i(fu);
+  const float frame_depth = frm.depths[frame_index];
+  if (!(fabsf(frame_depth - Xcp.z) < 0.1f)) return false;
+
+  const f3 frame_normal = make3(frm.normals[3 * frame_index + 0], frm.normals[3 * frame_index + 1],
+      frm.normals[3 * frame_index + 2]);
+  f3 keyframe_normal = make3(key.normals[3 * keyframe_index + 0], key.normals[3 * keyframe_index + 1],
+      key.normals[3 * keyframe_index + 2]);
+  keyframe_normal = xform_dir(Tcm, keyframe_normal);
+
+  if (!(sqnorm3(keyframe_normal) > 0.5f && dot3(frame_normal, keyframe_normal) > 0.5f)) return false;
+
+  const float Im = key.intensities[keyframe_index];
+  const float Ic = sample(frm.width, frm.intensities, fu, fv);
+  residual = Ic - Im;
+
+  if (JACOBIAN)
+  {
+    const float px = Xcp.x, py = Xcp.y, pz = Xcp.z;
+    const float inv_pz = 1.0f / pz;
+    const float cu = fu, cv = fv;
+    const float fx = frm.projection.fx, fy = frm.projection.fy;
+    const float cx = frm.projection.cx, cy = frm.projection.cy;
+    const float gx = sample(frm.width, frm.gradient_x, fu, fv);
+    const float gy = sample(frm.width, frm.gradient_y, fu, fv);
+
+    J[0] = gy * ((py * cy - pz * fy) * inv_pz - py * cv * inv_pz) - gx * (py * cu * inv_pz - cx * py * inv_pz);
+    J[1] = gy * (px * cv * inv_pz - cy * px * inv_pz) - gx * ((px * cx - pz * fx) * inv_pz - px * cu * inv_pz);
+    J[2] = (gy * fy * px - gx * fx * py) * inv_pz;
+
+    if (TRANSLATION)
+    {
+      J[3] = gx * fx * inv_pz;
+      J[4] = gy * fy * inv_pz;
+      J[5] = (gx * (cx - cu) + gy * (cy - cv)) * inv_pz;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ Rt rt_of(const float* m)   // column-major 4x4 -> rows 0..2
+{
+  Rt t;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t.r[r * 4 + c] = m[c * 4 + r];
+  return t;
+}
+
+// ref: color_tracker.cu:140-163
+__global__ __launch_bounds__(256) void color_residuals_kernel(ColorParams P, float* __restrict__ residuals)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.key.width || y >= P.key.height) return;
+  float r, J[6];
+  evaluate<false, false>(P, P.Tcm, x, y, r, J);
+  residuals[y * P.key.width + x] = r;
+}
+
+// ref: color_tracker.cu:165-204
+template <bool TRANSLATION>
+__global__ __launch_bounds__(256) void color_jacobian_kernel(ColorParams P, float* __restrict__ jacobian)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.key.width || y >= P.key.height) return;
+  float r, J[6];
+  evaluate<TRANSLATION, true>(P, P.Tcm, x, y, r, J);
+  float* out = jacobian + 6 * (size_t)(y * P.key.width + x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = J[i];
+}
+
+// ref: color_tracker.cu:206-343, first stage (see vk_gauss_newton.hpp)
+template <bool TRANSLATION>
+__global__ __launch_bounds__(kSysThreads) void color_partial_kernel(ColorParams P, float* __restrict__ workspace)
+{
+  __shared__ float lds[kSysWaves][kSysStride];
+
+  if (P.state && P.state[1]) return;   // tracker.cpp:162, see system_partial_kernel
+
+  const Rt Tcm = P.Tcm_dev ? rt_of(P.Tcm_dev->m) : P.Tcm;
+  const int total = P.key.width * P.key.height;
+  const int pixel = blockIdx.x * kSysThreads + (int)threadIdx.x;
+
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+
+  float r, J[6];
+  if (pixel < total && evaluate<TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
+    outer_products(J, r, acc);
+
+  store_partial(acc, lds, workspace);
+}
+
+// ------------------------------------------------------------ pose update ----
+
+// color_tracker.cu:312-320: Tcm = (frame_Tcd * frame_Twd^-1) * keyframe_Tcw^-1 with
+// (A * B).m = A.m * B.m, (A * B).inv = B.inv * A.inv (transform.h:146-159)
+__device__ __forceinline__ void derive_tcm(const vk_transform& frame_Tcd, const vk_transform& key_Twc,
+    vk_color_pose* pose)
+{
+  float tcd_m[16], tcd_i[16], twd_m[16], twd_i[16], twc_m[16], twc_i[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+  {
+    tcd_m[i] = frame_Tcd.m[i];  tcd_i[i] = frame_Tcd.inv[i];
+    twd_m[i] = pose->depth_to_world.m[i];  twd_i[i] = pose->depth_to_world.inv[i];
+    twc_m[i] = key_Twc.m[i];  twc_i[i] = key_Twc.inv[i];
+  }
+  float tcw_m[16], tcw_i[16], out_m[16], out_i[16];
+  matmul4(tcd_m, twd_i, tcw_m);    // frame_Tcw.m   = Tcd.m * (Twd^-1).m
+  matmul4(twd_m, tcd_i, tcw_i);    // frame_Tcw.inv = (Twd^-1).inv * Tcd.inv
+  matmul4(tcw_m, twc_m, out_m);
+  matmul4(twc_i, tcw_i, out_i);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { pose->Tcm.m[i] = out_m[i]; pose->Tcm.inv[i] = out_i[i]; }
+}
+
+// ref: tracker.cpp:124-163 + color_tracker.cpp:34-96, one lane
+template <int N>
+__device__ __forceinline__ void color_solve_update_n(const float* hessian, const float* gradient,
+    const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
+    float* update_out)
+{
+  float update[6];
+  solve_step<N>(hessian, gradient, update);
+
+  // color_tracker.cpp:45-65: a proper skew matrix (DepthTracker's has Tinc(1,2) = +u0)
+  float Tinc[16];
+  Tinc[0] = 1.0f;        Tinc[4] = -update[2]; Tinc[8] = +update[1];  Tinc[12] = +update[3];
+  Tinc[1] = +update[2];  Tinc[5] = 1.0f;       Tinc[9] = -update[0];  Tinc[13] = +update[4];
+  Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
+  Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
+
+  float old_i[16], M[16], out_m[16], out_i[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) old_i[i] = pose->depth_to_world.inv[i];
+  matmul4(Tinc, old_i, M);             // :67  M = Tinc * Twd^-1
+  rigid_from(M, out_m, out_i);         // :69-95 world -> depth, re-orthonormalised
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { pose->depth_to_world.m[i] = out_i[i]; pose->depth_to_world.inv[i] = out_m[i]; }   // .Inverse()
+
+  derive_tcm(frame_Tcd, key_Twc, pose);
+  finish_step<N>(update, state, update_out);
+}
+
+__device__ void color_solve_update(const float* hessian, const float* gradient, int translation_enabled,
+    const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
+    float* update_out)
+{
+  if (state && state[1]) return;  // converged earlier: tracker.cpp:162
+  if (translation_enabled) color_solve_update_n<6>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out);
+  else color_solve_update_n<3>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out);
+}
+
+struct PoseArgs
+{
+  vk_transform frame_Tcd, key_Twc;
+  vk_color_pose* pose;      // null: sums only
+  int32_t* state;
+  float* update_out;
+};
+
+// second stage; with a pose it also solves and updates (one workgroup)
+__global__ __launch_bounds__(256) void color_final_kernel(const float* __restrict__ workspace, int partials,
+    int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient, PoseArgs A)
+{
+  __shared__ float slices[8][kSysStride];
+  __shared__ float sums[48];
+  if (A.state && A.state[1]) return;
+  sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
+  if (A.pose && threadIdx.x == 0)
+    color_solve_update(sums, sums + 36, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out);
+}
+
+__global__ void color_solve_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
+    int translation_enabled, PoseArgs A)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    color_solve_update(hessian, gradient, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out);
+}
+
+__global__ void color_prepare_kernel(PoseArgs A)
+{
+  if (threadIdx.x == 0 && blockIdx.x == 0) derive_tcm(A.frame_Tcd, A.key_Twc, A.pose);
+}
+
+// -------------------------------------------------------------- host side ----
+
+int fill_color(ColorParams& P, const vk_color_view* keyframe, const vk_color_view* frame, const vk_transform* Tcm,
+    bool need_gradients)
+{
+  if (!keyframe || !frame || !Tcm) return VK_ERR_ARGUMENT;
+  if (!keyframe->depths || !keyframe->normals || !keyframe->intensities) return VK_ERR_ARGUMENT;
+  if (!frame->depths || !frame->normals || !frame->intensities) return VK_ERR_ARGUMENT;
+  if (need_gradients && (!frame->gradient_x || !frame->gradient_y)) return VK_ERR_ARGUMENT;
+  // the bilinear taps need a 2x2 neighbourhood inside the frame (color_tracker.cu:22)
+  if (keyframe->width <= 0 || keyframe->height <= 0 || frame->width < 2 || frame->height < 2)
+    return VK_ERR_ARGUMENT;
+  P.key = *keyframe;
+  P.frm = *frame;
+  P.Tcm = make_rt(Tcm->m);
+  P.Tcm_dev = nullptr;
+  P.state = nullptr;
+  return VK_OK;
+}
+
+void launch_color_partials(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
+{
+  if (translation_enabled)
+    hipLaunchKernelGGL(color_partial_kernel<true>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+  else
+    hipLaunchKernelGGL(color_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+}
+
+vk_transform identity_transform()
+{
+  vk_transform t;
+  for (int i = 0; i < 16; ++i) t.m[i] = t.inv[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+VK_API int vk_color_image_convert(int total, const float* src, float* dst, void* stream)
+{
+  VK_REQUIRE(total >= 0 && (total == 0 || (src && dst)));
+  if (total == 0) return VK_OK;
+  hipLaunchKernelGGL(convert_kernel, dim3((total + 255) / 256), dim3(256), 0, vk_s(stream), total, src, dst);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_image_gradients(int width, int height, const float* src, float* gradient_x, float* gradient_y,
+    void* stream)
+{
+  VK_REQUIRE(src && gradient_x && gradient_y && width > 0 && height > 0);
+  const dim3 grid((width + 63) / 64, (height + 3) / 4);
+  hipLaunchKernelGGL(gradients_kernel, grid, dim3(256), 0, vk_s(stream), width, height, src, gradient_x, gradient_y);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_compute_residuals(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, float* residuals, void* stream)
+{
+  ColorParams P;
+  const int rc = fill_color(P, keyframe, frame, Tcm, false);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(residuals);
+  const dim3 grid((keyframe->width + 63) / 64, (keyframe->height + 3) / 4);
+  hipLaunchKernelGGL(color_residuals_kernel, grid, dim3(256), 0, vk_s(stream), P, residuals);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_compute_jacobian(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, int translation_enabled, float* jacobian, void* stream)
+{
+  ColorParams P;
+  const int rc = fill_color(P, keyframe, frame, Tcm, true);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(jacobian);
+  const dim3 grid((keyframe->width + 63) / 64, (keyframe->height + 3) / 4);
+  if (translation_enabled)
+    hipLaunchKernelGGL(color_jacobian_kernel<true>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
+  else
+    hipLaunchKernelGGL(color_jacobian_kernel<false>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, const vk_transform* Tcm_dev, int translation_enabled, float* workspace,
+    float* hessian, float* gradient, void* stream)
+{
+  ColorParams P;
+  const vk_transform identity = identity_transform();
+  if (!Tcm && Tcm_dev) Tcm = &identity;
+  const int rc = fill_color(P, keyframe, frame, Tcm, true);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(workspace && hessian && gradient);
+  P.Tcm_dev = Tcm_dev;
+  const int partials = partial_count(keyframe->width, keyframe->height);
+  launch_color_partials(P, translation_enabled, partials, workspace, vk_s(stream));
+  VK_LAUNCH_CHECK();
+  PoseArgs A;
+  A.frame_Tcd = identity;
+  A.key_Twc = identity;
+  A.pose = nullptr;
+  A.state = nullptr;
+  A.update_out = nullptr;
+  hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
+      translation_enabled, hessian, gradient, A);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_solve_update(const float* hessian, const float* gradient, int translation_enabled,
+    const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
+    int32_t* state_dev, float* update_dev, void* stream)
+{
+  VK_REQUIRE(hessian && gradient && frame_Tcd && keyframe_Twc && pose_dev);
+  PoseArgs A;
+  A.frame_Tcd = *frame_Tcd;
+  A.key_Twc = *keyframe_Twc;
+  A.pose = pose_dev;
+  A.state = state_dev;
+  A.update_out = update_dev;
+  hipLaunchKernelGGL(color_solve_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
+      translation_enabled, A);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
+    int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
+    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+{
+  ColorParams P;
+  const vk_transform identity = identity_transform();
+  const int rc = fill_color(P, keyframe, frame, &identity, true);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(frame_Tcd && keyframe_Twc && pose_dev && workspace && system && state_dev && iterations > 0);
+  P.Tcm_dev = &pose_dev->Tcm;
+  P.state = state_dev;
+  float* hessian = system;
+  float* gradient = system + 36;
+  const int partials = partial_count(keyframe->width, keyframe->height);
+  hipStream_t s = vk_s(stream);
+
+  PoseArgs A;
+  A.frame_Tcd = *frame_Tcd;
+  A.key_Twc = *keyframe_Twc;
+  A.pose = pose_dev;
+  A.state = state_dev;
+  A.update_out = update_dev;
+  PoseArgs sums_only = A;
+  sums_only.pose = nullptr;
+  sums_only.state = nullptr;
+  sums_only.update_out = nullptr;
+
+  hipLaunchKernelGGL(color_prepare_kernel, dim3(1), dim3(64), 0, s, A);
+  VK_LAUNCH_CHECK();
+
+  for (int it = 0; it < iterations; ++it)
+  {
+    launch_color_partials(P, translation_enabled, partials, workspace, s);
+
+    if (reduce)
+    {
+      // multi-GPU rig: sum the packed system over ranks before every rank solves it
+      hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
+          hessian, gradient, sums_only);
+      VK_LAUNCH_CHECK();
+      const int rr = reduce(system, 48, reduce_user, stream);
+      if (rr != 0) return rr;
+      hipLaunchKernelGGL(color_solve_kernel, dim3(1), dim3(64), 0, s, hessian, gradient, translation_enabled, A);
+    }
+    else
+    {
+      hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
+          hessian, gradient, A);
+    }
+    VK_LAUNCH_CHECK();
+  }
+  return VK_OK;
+}
+
+}  // extern "C"

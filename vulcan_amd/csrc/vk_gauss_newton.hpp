@@ -1,0 +1,268 @@
+// vk_gauss_newton.hpp — what the trackers share: the two-stage reduction of the
+// 27 sums of a 6-parameter normal system and the small dense algebra of a
+// Gauss-Newton step, all of it sized at compile time so that it stays in
+// registers (ref: src/tracker.cpp:124-163 and the ComputeSystemKernel of
+// src/depth_tracker.cu:144-268 / src/color_tracker.cu:206-343).
+#pragma once
+
+#include "vk_common.hpp"
+
+namespace vk
+{
+
+constexpr int kSysThreads = 1024;  // 16 waves, one pixel per lane
+constexpr int kSysWaves = kSysThreads / 64;
+constexpr int kSysStride = 32;     // floats per workgroup partial: 6 gradient + 21 hessian + pad
+
+// Wave64 sum without LDS: four DPP steps fold each row of 16 lanes (two quad
+// permutes, half-mirror, mirror), row_bcast:15 / row_bcast:31 carry the row
+// totals upwards; the wave's sum ends in lane 63. Six v_add_f32 with a DPP
+// operand per value, against six ds_bpermute round trips for __shfl_xor.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+  v += dpp_term<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_term<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_term<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_term<0x140, 0xf>(v);   // row_mirror
+  v += dpp_term<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_term<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+// One pixel's contribution: slots [0,6) J^T r, [6,27) the packed lower triangle of
+// J^T J in (r, c<=r) row-major order (depth_tracker.cu:163-165,208-214).
+__device__ __forceinline__ void outer_products(const float (&J)[6], float r, float (&acc)[27])
+{
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[i] = J[i] * r;
+  int counter = 6;
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+    for (int c = 0; c <= rr; ++c, ++counter) acc[counter] = J[rr] * J[c];
+}
+
+// First stage: the workgroup's 27 sums -> workspace[blockIdx.x]. Called by every
+// thread of a kSysThreads-wide workgroup.
+__device__ __forceinline__ void store_partial(const float (&acc)[27], float (*lds)[kSysStride], float* workspace)
+{
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 27; ++i)
+  {
+    const float v = wave_sum_lane63(acc[i]);
+    if (lane == 63) lds[wave][i] = v;
+  }
+  __syncthreads();
+
+  if (threadIdx.x < kSysStride)
+  {
+    float v = 0.0f;
+    if (threadIdx.x < 27)
+    {
+#pragma unroll
+      for (int w = 0; w < kSysWaves; ++w) v += lds[w][threadIdx.x];
+    }
+    workspace[(size_t)blockIdx.x * kSysStride + threadIdx.x] = v;
+  }
+}
+
+// Second stage: fixed-order sum of the per-workgroup partials (8 slices x 32
+// components, then the slices in order) into hessian[36] (packed lower triangle
+// first, rest 0) and gradient[6], and into sums[48] in LDS for a solve that
+// follows. Every thread of the (>= 256-wide) workgroup must call it; ends with a
+// barrier.
+__device__ __forceinline__ void sum_partials(const float* workspace, int partials, int translation_enabled,
+    float* hessian, float* gradient, float (*slices)[kSysStride], float* sums)
+{
+  const int c = threadIdx.x & 31;
+  const int s = threadIdx.x >> 5;
+
+  if (threadIdx.x < 256)
+  {
+    float v = 0.0f;
+    for (int j = s; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
+    slices[s][c] = v;
+  }
+  __syncthreads();
+
+  if (threadIdx.x < 36 + 6)
+  {
+    if (threadIdx.x < 6)
+    {
+      float g = 0.0f;
+      const int n = translation_enabled ? 6 : 3;
+      if ((int)threadIdx.x < n)
+        for (int k = 0; k < 8; ++k) g += slices[k][threadIdx.x];
+      gradient[threadIdx.x] = g;
+      sums[36 + threadIdx.x] = g;
+    }
+    else
+    {
+      // depth_tracker.cu:199-214: with translation disabled the packed triangle
+      // is that of the 3x3 rotation block (6 values)
+      const int out = threadIdx.x - 6;
+      const int n = translation_enabled ? 21 : 6;
+      float h = 0.0f;
+      if (out < n)
+        for (int k = 0; k < 8; ++k) h += slices[k][6 + out];
+      hessian[out] = h;
+      sums[out] = h;
+    }
+  }
+  __syncthreads();
+}
+
+// LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
+// not vendored; agreement is to rounding). N is a template parameter and every
+// loop is unrolled so that L, D, y live in registers: with a run-time size the
+// arrays are indexed dynamically, land in scratch memory, and the one lane that
+// solves spends ~10 us waiting on it.
+template <int N>
+__device__ __forceinline__ void ldlt_solve(const float (&A)[N * N], const float (&b)[N], float (&x)[N])
+{
+  float L[N * N], D[N], y[N];
+#pragma unroll
+  for (int i = 0; i < N * N; ++i) L[i] = 0.0f;
+
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    float d = A[j * N + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
+    D[j] = d;
+    L[j * N + j] = 1.0f;
+
+#pragma unroll
+    for (int i = j + 1; i < N; ++i)
+    {
+      float s = A[i * N + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
+      L[i * N + j] = s / d;
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+  {
+    float s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+    y[i] = s;
+  }
+
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = y[i] / D[i];
+
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i)
+  {
+    float s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+    x[i] = s;
+  }
+}
+
+__device__ __forceinline__ void matmul4(const float (&A)[16], const float (&B)[16], float (&C)[16])  // matrix.h:297-318
+{
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+    {
+      float r = 0.0f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) r += A[n * 4 + m] * B[p * 4 + n];
+      C[p * 4 + m] = r;
+    }
+}
+
+// tracker.cpp:142-159: unpack the packed lower triangle, solve H x = g, update = -x
+// (entries beyond N stay 0)
+template <int N>
+__device__ __forceinline__ void solve_step(const float* hessian, const float* gradient, float (&update)[6])
+{
+  float H[N * N], g[N], x[N];
+  int index = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j)
+    {
+      H[i * N + j] = hessian[index];
+      H[j * N + i] = hessian[index];
+      ++index;
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i) g[i] = gradient[i];
+  ldlt_solve<N>(H, g, x);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) update[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) update[i] = -x[i];
+}
+
+// depth_tracker.cpp:57-84 / color_tracker.cpp:67-95: re-orthonormalise the
+// rotation columns of M and rebuild the rigid transform Translate(t) * Rotate(R)
+// together with its inverse (transform.h:62-66,74-99,146-159).
+__device__ __forceinline__ void rigid_from(const float (&M)[16], float (&out_m)[16], float (&out_i)[16])
+{
+  f3 x_axis = normalized3(make3(M[0], M[1], M[2]));
+  f3 y_axis = normalized3(make3(M[4], M[5], M[6]));
+  const f3 z_axis = cross3(x_axis, y_axis);
+  y_axis = cross3(z_axis, x_axis);
+
+  float Tm[16], Ti[16], Rm[16], Ri[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { Tm[i] = Ti[i] = Rm[i] = 0.0f; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { Tm[5 * i] = Ti[5 * i] = Rm[5 * i] = 1.0f; }
+  Tm[12] = M[12];  Tm[13] = M[13];  Tm[14] = M[14];
+  Ti[12] = -M[12]; Ti[13] = -M[13]; Ti[14] = -M[14];
+  Rm[0] = x_axis.x; Rm[1] = x_axis.y; Rm[2] = x_axis.z;
+  Rm[4] = y_axis.x; Rm[5] = y_axis.y; Rm[6] = y_axis.z;
+  Rm[8] = z_axis.x; Rm[9] = z_axis.y; Rm[10] = z_axis.z;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Ri[c * 4 + r] = Rm[r * 4 + c];
+
+  matmul4(Tm, Rm, out_m);
+  matmul4(Ri, Ti, out_i);
+}
+
+// tracker.cpp:160-162: record the step and stop once it is shorter than 1e-6
+template <int N>
+__device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* state, float* update_out)
+{
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) sq += update[i] * update[i];
+  if (update_out)
+  {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) update_out[i] = update[i];
+  }
+  if (state)
+  {
+    state[0] += 1;
+    if (sqrtf(sq) < 1E-6f) state[1] = 1;
+  }
+}
+
+inline int partial_count(int width, int height)
+{
+  return (width * height + kSysThreads - 1) / kSysThreads;
+}
+
+}  // namespace vk

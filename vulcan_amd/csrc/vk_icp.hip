@@ -8,7 +8,7 @@
 // Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
 // summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
 // solve + SE(3) update can run on the device so an iteration needs no readback.
-#include "vk_common.hpp"
+#include "vk_gauss_newton.hpp"
 
 using namespace vk;
 
@@ -125,88 +125,11 @@ __global__ __launch_bounds__(256) void jacobian_kernel(IcpParams P, float* __res
 __device__ void solve_update(const float* hessian, const float* gradient, int translation_enabled,
     vk_transform* Twc, int32_t* state, float* update_out);
 
-constexpr int kSysThreads = 1024;  // 16 waves, one pixel per lane
-constexpr int kSysWaves = kSysThreads / 64;
-constexpr int kSysStride = 32;     // floats per workgroup partial: 6 gradient + 21 hessian + pad
-
-// Wave64 sum without LDS: four DPP steps fold each row of 16 lanes (two quad
-// permutes, half-mirror, mirror), row_bcast:15 / row_bcast:31 carry the row
-// totals upwards; the wave's sum ends in lane 63. Six v_add_f32 with a DPP
-// operand per value, against six ds_bpermute round trips for __shfl_xor.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_term(float v)
-{
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-
-__device__ __forceinline__ float wave_sum_lane63(float v)
-{
-  v += dpp_term<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v += dpp_term<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  v += dpp_term<0x141, 0xf>(v);   // row_half_mirror
-  v += dpp_term<0x140, 0xf>(v);   // row_mirror
-  v += dpp_term<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v += dpp_term<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-  return v;
-}
-
-// Fixed-order sum of the per-workgroup partials (8 slices x 32 components, then
-// the slices in order) into hessian[36] (packed lower triangle first, rest 0) and
-// gradient[6]; with `Twc` non-null the calling workgroup goes on to solve the
-// system and update the pose. Every thread of the workgroup must call it (it
-// synchronises); threads 0..255 do the work.
-__device__ __forceinline__ void finish_system(const float* workspace, int partials, int translation_enabled,
-    float* hessian, float* gradient, vk_transform* Twc, int32_t* state, float* update_out,
-    float (*slices)[kSysStride], float* sums)
-{
-  const int c = threadIdx.x & 31;
-  const int s = threadIdx.x >> 5;
-
-  if (threadIdx.x < 256)
-  {
-    float v = 0.0f;
-    for (int j = s; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
-    slices[s][c] = v;
-  }
-  __syncthreads();
-
-  if (threadIdx.x < 36 + 6)
-  {
-    if (threadIdx.x < 6)
-    {
-      float g = 0.0f;
-      const int n = translation_enabled ? 6 : 3;
-      if ((int)threadIdx.x < n)
-        for (int k = 0; k < 8; ++k) g += slices[k][threadIdx.x];
-      gradient[threadIdx.x] = g;
-      sums[36 + threadIdx.x] = g;
-    }
-    else
-    {
-      // depth_tracker.cu:199-214: with translation disabled the packed triangle
-      // is that of the 3x3 rotation block (6 values)
-      const int out = threadIdx.x - 6;
-      const int n = translation_enabled ? 21 : 6;
-      float h = 0.0f;
-      if (out < n)
-        for (int k = 0; k < 8; ++k) h += slices[k][6 + out];
-      hessian[out] = h;
-      sums[out] = h;
-    }
-  }
-
-  if (Twc)
-  {
-    __syncthreads();
-    if (threadIdx.x == 0) solve_update(sums, sums + 36, translation_enabled, Twc, state, update_out);
-  }
-}
-
 // ref: depth_tracker.cu:144-268. Slot layout of a partial: [0,6) J^T r,
 // [6,27) packed lower triangle of J^T J in (r, c<=r) row-major order.
 //
 // Measured and rejected: letting the workgroup that finishes last (atomic ticket)
-// also run finish_system, for one launch per iteration instead of two. On this
+// also run the second stage, for one launch per iteration instead of two. On this
 // multi-XCD part the agent-scope release/acquire fences that publish the partials
 // write back and invalidate whole L2s, once per workgroup: the fused iteration
 // took 2.5x as long as the two launches.
@@ -229,36 +152,9 @@ __global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P
 
   float r, J[6];
   if (pixel < total && evaluate<TRANSLATION>(P, Twc, pixel % P.frm.width, pixel / P.frm.width, r, J))
-  {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] = J[i] * r;
-    int counter = 6;
-#pragma unroll
-    for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-      for (int c = 0; c <= rr; ++c, ++counter) acc[counter] = J[rr] * J[c];
-  }
+    outer_products(J, r, acc);
 
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 27; ++i)
-  {
-    const float v = wave_sum_lane63(acc[i]);
-    if (lane == 63) lds[wave][i] = v;
-  }
-  __syncthreads();
-
-  if (threadIdx.x < kSysStride)
-  {
-    float v = 0.0f;
-    if (threadIdx.x < 27)
-    {
-#pragma unroll
-      for (int w = 0; w < kSysWaves; ++w) v += lds[w][threadIdx.x];
-    }
-    workspace[(size_t)blockIdx.x * kSysStride + threadIdx.x] = v;
-  }
+  store_partial(acc, lds, workspace);
 }
 
 // Second stage: one workgroup. With `Twc` non-null it also solves and updates the
@@ -270,77 +166,11 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
   __shared__ float slices[8][kSysStride];
   __shared__ float sums[48];   // hessian[36] | gradient[6]: the solve reads them from LDS
   if (state && state[1]) return;   // converged: the system was not recomputed, keep the last one
-  finish_system(workspace, partials, translation_enabled, hessian, gradient, Twc, state, update_out, slices, sums);
+  sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
+  if (Twc && threadIdx.x == 0) solve_update(sums, sums + 36, translation_enabled, Twc, state, update_out);
 }
 
-// ---- 6x6 solve + pose update on the device -----------------------------------
-
-// LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
-// not vendored; agreement is to rounding). N is a template parameter and every
-// loop is unrolled so that L, D, y live in registers: with a run-time size the
-// arrays are indexed dynamically, land in scratch memory, and the one lane that
-// solves spends ~10 us waiting on it.
-template <int N>
-__device__ __forceinline__ void ldlt_solve(const float (&A)[N * N], const float (&b)[N], float (&x)[N])
-{
-  float L[N * N], D[N], y[N];
-#pragma unroll
-  for (int i = 0; i < N * N; ++i) L[i] = 0.0f;
-
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-  {
-    float d = A[j * N + j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k] * D[k];
-    D[j] = d;
-    L[j * N + j] = 1.0f;
-
-#pragma unroll
-    for (int i = j + 1; i < N; ++i)
-    {
-      float s = A[i * N + j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
-      L[i * N + j] = s / d;
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-  {
-    float s = b[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
-    y[i] = s;
-  }
-
-#pragma unroll
-  for (int i = 0; i < N; ++i) y[i] = y[i] / D[i];
-
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i)
-  {
-    float s = y[i];
-#pragma unroll
-    for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
-    x[i] = s;
-  }
-}
-
-__device__ __forceinline__ void matmul4(const float (&A)[16], const float (&B)[16], float (&C)[16])  // matrix.h:297-318
-{
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-    {
-      float r = 0.0f;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) r += A[n * 4 + m] * B[p * 4 + n];
-      C[p * 4 + m] = r;
-    }
-}
+// ---- pose update on the device ------------------------------------------------
 
 // ref: tracker.cpp:124-163 + depth_tracker.cpp:22-86. One lane; 6x6 is too
 // small to spread.
@@ -348,26 +178,8 @@ template <int N>
 __device__ __forceinline__ void solve_update_n(const float* hessian, const float* gradient,
     vk_transform* Twc, int32_t* state, float* update_out)
 {
-  float H[N * N], g[N], x[N], update[6];
-
-  int index = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-#pragma unroll
-    for (int j = 0; j <= i; ++j)
-    {
-      H[i * N + j] = hessian[index];
-      H[j * N + i] = hessian[index];
-      ++index;
-    }
-
-#pragma unroll
-  for (int i = 0; i < N; ++i) g[i] = gradient[i];
-  ldlt_solve<N>(H, g, x);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) update[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < N; ++i) update[i] = -x[i];
+  float update[6];
+  solve_step<N>(hessian, gradient, update);
 
   // depth_tracker.cpp:33-53, including Tinc(1,2) = +update[0]
   float Tinc[16];
@@ -376,51 +188,15 @@ __device__ __forceinline__ void solve_update_n(const float* hessian, const float
   Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
   Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
 
-  float old_m[16], M[16];
+  float old_m[16], M[16], out_m[16], out_i[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) old_m[i] = Twc->m[i];
   matmul4(Tinc, old_m, M);
-
-  f3 x_axis = normalized3(make3(M[0], M[1], M[2]));
-  f3 y_axis = normalized3(make3(M[4], M[5], M[6]));
-  const f3 z_axis = cross3(x_axis, y_axis);
-  y_axis = cross3(z_axis, x_axis);
-
-  // Translate(t) * Rotate(R): transform.h:62-66,74-99,146-159
-  float Tm[16], Ti[16], Rm[16], Ri[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { Tm[i] = Ti[i] = Rm[i] = 0.0f; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { Tm[5 * i] = Ti[5 * i] = Rm[5 * i] = 1.0f; }
-  Tm[12] = M[12];  Tm[13] = M[13];  Tm[14] = M[14];
-  Ti[12] = -M[12]; Ti[13] = -M[13]; Ti[14] = -M[14];
-  Rm[0] = x_axis.x; Rm[1] = x_axis.y; Rm[2] = x_axis.z;
-  Rm[4] = y_axis.x; Rm[5] = y_axis.y; Rm[6] = y_axis.z;
-  Rm[8] = z_axis.x; Rm[9] = z_axis.y; Rm[10] = z_axis.z;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) Ri[c * 4 + r] = Rm[r * 4 + c];
-
-  float out_m[16], out_i[16];
-  matmul4(Tm, Rm, out_m);
-  matmul4(Ri, Ti, out_i);
+  rigid_from(M, out_m, out_i);
 #pragma unroll
   for (int i = 0; i < 16; ++i) { Twc->m[i] = out_m[i]; Twc->inv[i] = out_i[i]; }
 
-  float sq = 0.0f;
-#pragma unroll
-  for (int i = 0; i < N; ++i) sq += update[i] * update[i];
-  if (update_out)
-  {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) update_out[i] = update[i];
-  }
-  if (state)
-  {
-    state[0] += 1;
-    if (sqrtf(sq) < 1E-6f) state[1] = 1;
-  }
+  finish_step<N>(update, state, update_out);
 }
 
 __device__ void solve_update(const float* hessian, const float* gradient,
@@ -519,11 +295,6 @@ int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
   P.Twc_dev = nullptr;
   P.state = nullptr;
   return VK_OK;
-}
-
-int partial_count(int width, int height)
-{
-  return (width * height + kSysThreads - 1) / kSysThreads;
 }
 
 void launch_partials(const IcpParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)

@@ -141,6 +141,16 @@ class Integrator(C.Structure):
         return Integrator(0.1, 5.0, 16.0, 16.0)   # integrator.cu:7-13
 
 
+class ColorView(C.Structure):
+    _fields_ = [("depths", C.c_void_p), ("normals", C.c_void_p), ("intensities", C.c_void_p),
+                ("gradient_x", C.c_void_p), ("gradient_y", C.c_void_p),
+                ("width", C.c_int32), ("height", C.c_int32), ("projection", Projection)]
+
+
+class ColorPose(C.Structure):
+    _fields_ = [("depth_to_world", Transform), ("Tcm", Transform)]
+
+
 class Detector(C.Structure):
     _fields_ = [("radius", C.c_float), ("origin", C.c_float * 3), ("bounds", (C.c_float * 2) * 3),
                 ("min_inlier_count", C.c_int32), ("bounds_use_own_axis", C.c_int32)]
