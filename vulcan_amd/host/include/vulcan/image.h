@@ -89,6 +89,9 @@ class Image : public detail::ImageStorage<float>
 
     // ref: image.cu:183-211 — 2x nearest or 2x2 box
     void Downsample(Image& image, bool nearest) const;
+
+    // 3x3 smoothed central differences, zero padding (ref: image.cu:21-99,166-179)
+    void GetGradients(Image& gx, Image& gy) const;
 };
 
 class ColorImage : public detail::ImageStorage<Vector3f>
@@ -101,6 +104,9 @@ class ColorImage : public detail::ImageStorage<Vector3f>
 
     // ref: image.cu:234-262
     void Downsample(ColorImage& image, bool nearest) const;
+
+    // intensity = (r + g + b) / 3 (ref: image.cu:10-19,235-247)
+    void ConvertTo(Image& image) const;
 };
 
 } // namespace vulcan

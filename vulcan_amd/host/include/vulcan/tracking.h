@@ -14,6 +14,7 @@
 #include <memory>
 #include <vk.h>
 #include <vulcan/buffer.h>
+#include <vulcan/image.h>
 #include <vulcan/matrix.h>
 
 namespace vulcan
@@ -95,6 +96,44 @@ class DepthTracker : public Tracker
     int GetResidualCount(const Frame& frame) const override;
     void ComputeSystem(const Frame& frame) override;
     void TrackOnDevice(Frame& frame) override;
+};
+
+// Photometric tracking: one intensity residual per keyframe pixel, sampled
+// bilinearly in the frame (ref: color_tracker.h, color_tracker.cu,
+// color_tracker.cpp). Uses the COLOUR intrinsics and depth_to_color_transform of
+// both frames, as upstream.
+class ColorTracker : public Tracker
+{
+  public:
+    ColorTracker();
+    virtual ~ColorTracker();
+
+    void ComputeResiduals(const Frame& frame, Buffer<float>& residuals);
+    void ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian);
+
+    // host form of the pose update (ref: color_tracker.cpp:34-96)
+    void ApplyUpdate(Frame& frame, const Vector6f& x) const override;
+
+  protected:
+    void BeginSolve(const Frame& frame) override;
+    int GetResidualCount(const Frame& frame) const override;
+    void ComputeSystem(const Frame& frame) override;
+    void TrackOnDevice(Frame& frame) override;
+
+    void ComputeKeyframeIntensities();
+    void ComputeFrameIntensities(const Frame& frame);
+    void ComputeFrameGradients(const Frame& frame);
+
+    vk_color_view KeyframeView() const;
+    vk_color_view FrameView(const Frame& frame) const;
+    vk_transform GetTcm(const Frame& frame) const;        // color_tracker.cu:312-320
+    vk_transform GetKeyframeTwc() const;
+
+    Image keyframe_intensities_;
+    Image frame_intensities_;
+    Image frame_gradient_x_;
+    Image frame_gradient_y_;
+    Buffer<vk_color_pose> color_pose_;   // depth_to_world + derived Tcm, on the device
 };
 
 // Coarse-to-fine: half resolution first (15 iterations), then full (20).

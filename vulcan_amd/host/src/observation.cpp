@@ -22,6 +22,20 @@ void ColorImage::Downsample(ColorImage& image, bool nearest) const
       reinterpret_cast<float*>(image.GetData()), nearest ? 1 : 0, Device::GetStream()));
 }
 
+void Image::GetGradients(Image& gx, Image& gy) const
+{
+  gx.Resize(size_);
+  gy.Resize(size_);
+  VK_ASSERT(vk_image_gradients(size_[0], size_[1], data_, gx.GetData(), gy.GetData(), Device::GetStream()));
+}
+
+void ColorImage::ConvertTo(Image& image) const
+{
+  image.Resize(size_);
+  VK_ASSERT(vk_color_image_convert(GetTotal(), reinterpret_cast<const float*>(data_), image.GetData(),
+      Device::GetStream()));
+}
+
 void ComputeNormals(const float* depths, const Projection& projection,
     Vector3f* normals, int image_width, int image_height)
 {

@@ -1,6 +1,6 @@
-// tracking.cpp — Tracker, DepthTracker and PyramidTracker<DepthTracker>
+// tracking.cpp — Tracker, DepthTracker, ColorTracker and PyramidTracker<T>
 // (ref: src/tracker.cpp, src/depth_tracker.cpp, src/depth_tracker.cu:272-378,
-//  src/pyramid_tracker.cpp).
+//  src/color_tracker.cpp, src/color_tracker.cu:296-470, src/pyramid_tracker.cpp).
 #include <vulcan/tracking.h>
 #include <vulcan/exception.h>
 #include <vulcan/observation.h>
@@ -228,6 +228,152 @@ void DepthTracker::ApplyUpdate(Frame& frame, const Vector6f& update) const
   frame.depth_to_world_transform = Transform::Translate(t) * Transform::Rotate(R);
 }
 
+// ---- ColorTracker ----------------------------------------------------------------
+
+ColorTracker::ColorTracker() { color_pose_.Resize(1); }
+
+ColorTracker::~ColorTracker() {}
+
+void ColorTracker::ComputeKeyframeIntensities() { keyframe_->color_image->ConvertTo(keyframe_intensities_); }
+
+void ColorTracker::ComputeFrameIntensities(const Frame& frame) { frame.color_image->ConvertTo(frame_intensities_); }
+
+void ColorTracker::ComputeFrameGradients(const Frame& frame)
+{
+  frame_intensities_.GetGradients(frame_gradient_x_, frame_gradient_y_);
+}
+
+// ref: color_tracker.cpp:19-25
+void ColorTracker::BeginSolve(const Frame& frame)
+{
+  Tracker::BeginSolve(frame);
+  ComputeKeyframeIntensities();
+  ComputeFrameIntensities(frame);
+  ComputeFrameGradients(frame);
+  // the residuals are per KEYFRAME pixel (color_tracker.cpp:27-32)
+  const size_t floats = vk_icp_workspace_floats(keyframe_->depth_image->GetWidth(), keyframe_->depth_image->GetHeight());
+  if (floats > workspace_.GetSize()) workspace_.Resize(floats);
+}
+
+int ColorTracker::GetResidualCount(const Frame&) const
+{
+  return keyframe_->depth_image->GetWidth() * keyframe_->depth_image->GetHeight();
+}
+
+vk_color_view ColorTracker::KeyframeView() const
+{
+  vk_color_view v;
+  v.depths = keyframe_->depth_image->GetData();
+  v.normals = reinterpret_cast<const float*>(keyframe_->normal_image->GetData());
+  v.intensities = keyframe_intensities_.GetData();
+  v.gradient_x = nullptr;
+  v.gradient_y = nullptr;
+  v.width = keyframe_->depth_image->GetWidth();
+  v.height = keyframe_->depth_image->GetHeight();
+  v.projection = keyframe_->color_projection.ToVk();
+  return v;
+}
+
+vk_color_view ColorTracker::FrameView(const Frame& frame) const
+{
+  vk_color_view v;
+  v.depths = frame.depth_image->GetData();
+  v.normals = reinterpret_cast<const float*>(frame.normal_image->GetData());
+  v.intensities = frame_intensities_.GetData();
+  v.gradient_x = frame_gradient_x_.GetData();
+  v.gradient_y = frame_gradient_y_.GetData();
+  v.width = frame.depth_image->GetWidth();
+  v.height = frame.depth_image->GetHeight();
+  v.projection = frame.color_projection.ToVk();
+  return v;
+}
+
+vk_transform ColorTracker::GetKeyframeTwc() const
+{
+  const Transform Tcw = keyframe_->depth_to_color_transform * keyframe_->depth_to_world_transform.Inverse();
+  return Tcw.Inverse().ToVk();
+}
+
+vk_transform ColorTracker::GetTcm(const Frame& frame) const
+{
+  const Transform keyframe_Tcw = keyframe_->depth_to_color_transform * keyframe_->depth_to_world_transform.Inverse();
+  const Transform frame_Tcw = frame.depth_to_color_transform * frame.depth_to_world_transform.Inverse();
+  return (frame_Tcw * keyframe_Tcw.Inverse()).ToVk();
+}
+
+void ColorTracker::ComputeResiduals(const Frame& frame, Buffer<float>& residuals)
+{
+  ComputeKeyframeIntensities();
+  ComputeFrameIntensities(frame);
+  residuals.Resize(GetResidualCount(frame));
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_color_tracker_compute_residuals(&key, &frm, &Tcm, residuals.GetData(), Device::GetStream()));
+}
+
+void ColorTracker::ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian)
+{
+  ComputeKeyframeIntensities();
+  ComputeFrameIntensities(frame);
+  ComputeFrameGradients(frame);
+  jacobian.Resize(GetResidualCount(frame));
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_color_tracker_compute_jacobian(&key, &frm, &Tcm, translation_enabled_ ? 1 : 0,
+      reinterpret_cast<float*>(jacobian.GetData()), Device::GetStream()));
+}
+
+void ColorTracker::ComputeSystem(const Frame& frame)
+{
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_color_tracker_compute_system(&key, &frm, &Tcm, nullptr, translation_enabled_ ? 1 : 0,
+      workspace_.GetData(), system_.GetData(), system_.GetData() + 36, Device::GetStream()));
+}
+
+void ColorTracker::TrackOnDevice(Frame& frame)
+{
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_transform frame_Tcd = frame.depth_to_color_transform.ToVk();
+  const vk_transform key_Twc = GetKeyframeTwc();
+  // pose_ was filled by BeginSolve: it is the first member of the colour pose
+  VK_ASSERT(vk_memcpy_d2d(color_pose_.GetData(), pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
+  HookAdapter adapter = { reduce_hook_, reduce_user_ };
+  VK_ASSERT(vk_color_tracker_track(&key, &frm, &frame_Tcd, &key_Twc, color_pose_.GetData(), max_iterations_,
+      translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
+  VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
+}
+
+// ref: color_tracker.cpp:34-96 (host form; Track() uses the device form)
+void ColorTracker::ApplyUpdate(Frame& frame, const Vector6f& update) const
+{
+  Matrix4f Tinc = Matrix4f::Identity();
+  Tinc(0, 1) = -update[2]; Tinc(0, 2) = +update[1]; Tinc(0, 3) = +update[3];
+  Tinc(1, 0) = +update[2]; Tinc(1, 2) = -update[0]; Tinc(1, 3) = +update[4];
+  Tinc(2, 0) = -update[1]; Tinc(2, 1) = +update[0]; Tinc(2, 3) = +update[5];
+
+  const Matrix4f M = Tinc * frame.depth_to_world_transform.GetInverseMatrix();
+
+  Vector3f x_axis(M(0, 0), M(1, 0), M(2, 0));
+  Vector3f y_axis(M(0, 1), M(1, 1), M(2, 1));
+  x_axis.Normalize();
+  y_axis.Normalize();
+  const Vector3f z_axis = x_axis.Cross(y_axis);
+  y_axis = z_axis.Cross(x_axis);
+
+  Matrix3f R;
+  for (int r = 0; r < 3; ++r)
+  {
+    R(r, 0) = x_axis[r];
+    R(r, 1) = y_axis[r];
+    R(r, 2) = z_axis[r];
+  }
+
+  const Vector3f t(M(0, 3), M(1, 3), M(2, 3));
+  frame.depth_to_world_transform = (Transform::Translate(t) * Transform::Rotate(R)).Inverse();
+}
+
 // ---- PyramidTracker ---------------------------------------------------------------
 
 template <typename Tracker>
@@ -285,5 +431,6 @@ void PyramidTracker<Tracker>::Track(Frame& frame)
 }
 
 template class PyramidTracker<DepthTracker>;
+template class PyramidTracker<ColorTracker>;
 
 } // namespace vulcan

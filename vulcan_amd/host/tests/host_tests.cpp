@@ -843,6 +843,121 @@ TEST(Frame, DownsampleAndFilter)   // frame.cpp:8-58, image.cu:101-165
   ASSERT_NEAR(1.0f + 0.01f * 30 + 0.02f * 20, filtered[20 * w + 30], 5e-3);
 }
 
+// ---- ColorTracker (color_tracker_test.cu) ---------------------------------------------------
+
+static std::shared_ptr<Frame> TexturedFrame(double frequency, bool rippled, const Transform& pose)
+{
+  const int w = 640, h = 480;   // color_tracker_test.cu:12-148 CreateKeyframeX / CreateFrameX
+  auto frame = std::make_shared<Frame>();
+  frame->depth_projection.SetFocalLength(547, 547);
+  frame->depth_projection.SetCenterPoint(320, 240);
+  frame->color_projection = frame->depth_projection;
+  frame->depth_to_world_transform = pose;
+  frame->depth_image = MakeDepth(w, h, [&](int x, int y)
+  {
+    float d = 1;
+    if (rippled) { d += 0.01 * cos(16 * M_PI * x / (w - 1)); d += 0.01 * cos(16 * M_PI * y / (h - 1)); }
+    return d;
+  });
+  frame->color_image = MakeColor(w, h, [&](int x, int y)
+  {
+    float c = 0.5f;
+    c += 0.245 * cosf(frequency * M_PI * (float(x) / (w - 1)));
+    c += 0.245 * cosf(frequency * M_PI * (float(y) / (h - 1)));
+    return Vector3f(c, c, c);
+  });
+  frame->ComputeNormals();
+  return frame;
+}
+
+static const Transform kColorKeyPose = Transform::Translate(0.0011f, -0.0019f, 0.0031f) * Transform::Rotate(0.9998715f, 0.0086385f, -0.0103759f, 0.0086385f);
+static const Transform kColorFramePose = Transform::Translate(0.001f, -0.002f, 0.003f) * Transform::Rotate(0.9998719f, 0.0085884f, -0.0104268f, 0.0085884f);
+
+TEST(ColorTracker, ResidualsOfIdenticalFramesAreZero)   // color_tracker_test.cu:512-521
+{
+  auto keyframe = TexturedFrame(3.0, false, kColorKeyPose);
+  ColorTracker tracker;
+  tracker.SetKeyframe(keyframe);
+  Buffer<float> buffer;
+  tracker.ComputeResiduals(*keyframe, buffer);
+  std::vector<float> found(buffer.GetSize());
+  buffer.CopyToHost(found.data());
+  ASSERT_EQ(size_t(640 * 480), found.size());
+  for (float r : found) ASSERT_NEAR(0, r, 1E-6);
+}
+
+TEST(ColorTracker, JacobianPredictsResidualChange)   // first-order check through ApplyUpdate
+{
+  auto keyframe = TexturedFrame(3.0, false, kColorKeyPose);
+  auto frame = TexturedFrame(4.0, true, kColorFramePose);
+  ColorTracker tracker;
+  tracker.SetKeyframe(keyframe);
+  Buffer<float> rbuf;
+  Buffer<Vector6f> jbuf;
+  tracker.ComputeJacobian(*frame, jbuf);
+  tracker.ComputeResiduals(*frame, rbuf);
+  std::vector<Vector6f> J(jbuf.GetSize());
+  std::vector<float> r0(rbuf.GetSize()), r1(rbuf.GetSize());
+  jbuf.CopyToHost(J.data());
+  rbuf.CopyToHost(r0.data());
+
+  Vector6f step = Vector6f::Zeros();
+  step[3] = 1e-3f;   // translate along x
+  Frame moved = *frame;
+  tracker.ApplyUpdate(moved, step);
+  tracker.ComputeResiduals(moved, rbuf);
+  rbuf.CopyToHost(r1.data());
+  // least-squares slope of the measured change against the predicted one
+  double pm = 0, pp = 0;
+  int used = 0;
+  for (int y = 40; y < 440; ++y)
+    for (int x = 40; x < 600; ++x)
+    {
+      const int i = y * 640 + x;
+      if (r0[i] == 0 || r1[i] == 0) continue;
+      const double predicted = J[i][3] * step[3];
+      pm += predicted * (r1[i] - r0[i]);
+      pp += predicted * predicted;
+      ++used;
+    }
+  ASSERT_TRUE(used > 100000);
+  ASSERT_NEAR(1.0, pm / pp, 0.1);
+}
+
+TEST(ColorTracker, Track)   // no upstream case
+{
+  // A fronto-parallel plane with a smooth texture leaves rotation and in-plane
+  // translation nearly interchangeable, so the pose itself is not pinned; the
+  // photometric cost must fall (the CPU restatement reaches 0.08x in 20 steps).
+  auto keyframe = TexturedFrame(3.0, false, kColorKeyPose);
+  Frame frame = *keyframe;   // same images, slightly wrong pose
+  frame.depth_to_world_transform = Transform::Translate(0.004f, -0.002f, 0.001f) * kColorKeyPose;
+  ColorTracker tracker;
+  tracker.SetKeyframe(keyframe);
+  Buffer<float> buffer;
+  auto cost = [&](const Frame& f)
+  {
+    tracker.ComputeResiduals(f, buffer);
+    std::vector<float> r(buffer.GetSize());
+    buffer.CopyToHost(r.data());
+    double sum = 0;
+    for (float v : r) sum += double(v) * v;
+    return sum;
+  };
+  const double before = cost(frame);
+  tracker.Track(frame);
+  ASSERT_TRUE(cost(frame) < 0.2 * before);
+  const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
+  const Matrix4f I = M * frame.depth_to_world_transform.GetInverseMatrix();
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_NEAR(r == c ? 1 : 0, I(r, c), 1e-5);   // still rigid
+
+  PyramidTracker<ColorTracker> pyramid;
+  frame.depth_to_world_transform = Transform::Translate(0.004f, -0.002f, 0.001f) * kColorKeyPose;
+  pyramid.SetKeyframe(keyframe);
+  pyramid.Track(frame);
+  ASSERT_TRUE(cost(frame) < 0.3 * before);
+}
+
 // ---- Detector (no upstream case: tests/detector_test.cu is empty) -------------------------
 
 TEST(Detector, Constructor)   // detector.cu:66-72, 214-221
