@@ -69,7 +69,7 @@ def main():
     rank, local_rank, world = vd.init()
     assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())   # == local_rank on a full node
     lib = api.lib()
 
     k = T.Projection.make(*scenes.APP_INTRINSICS)
@@ -202,7 +202,7 @@ def extra_workload(args):
     import scenes
 
     rank, local_rank, world = vd.init()
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     k = T.Projection.make(*scenes.APP_INTRINSICS)
     depth_np = sphere_room_depth(k)
     color_np = scenes.checker_color(W, H, 0.1, 0.9)

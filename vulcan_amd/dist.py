@@ -28,7 +28,9 @@ def init(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # VK_DIST_BACKEND=gloo rehearses a multi-rank run on a box with fewer GPUs
+            # than ranks (ranks then share devices; RCCL cannot do that)
+            backend = os.environ.get("VK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
