@@ -94,21 +94,23 @@ def main():
     vdesc, fdesc, odesc = vol.desc(), frame.desc(), out.desc()
     pdesc = integ.params
     vref, fref, oref, pref = C.byref(vdesc), C.byref(fdesc), C.byref(odesc), C.byref(pdesc)
-    bounds_ptr = C.c_void_p(tracer.bounds_scratch.data_ptr())
     d_ptr, c_ptr, n_ptr = (C.c_void_p(t.data_ptr()) for t in (out.depth, out.color, out.normals))
-    dmin, dmax = tracer.depth_range
+    # the record through which DepthIntegrator::Integrate hands the raycast bounds of
+    # its view to Tracer::Trace (include/vk.h vk_view_bounds), as the class layer does
+    vb = tracer.view_bounds
+    bref = C.byref(vb)
 
     def step(i, ev=None):
         fdesc.depth_to_world = poses[i]
         odesc.depth_to_world = poses[i]
+        vb.valid = 0                                                       # Volume::SetView: new visible list
         rc = lib.vk_volume_set_view(vref, fref, stream)                    # volume.cu:430-437
         if ev:
             lib.vk_event_record(ev[0], stream)
-        rc |= lib.vk_integrate_depth(vref, pref, fref, stream)             # depth_integrator.cu:89-115
+        rc |= lib.vk_integrate_ahead(vref, pref, fref, 0, None, None, bref, stream)   # depth_integrator.cu:89-115
         if ev:
             lib.vk_event_record(ev[1], stream)
-        rc |= lib.vk_trace(vref, oref, dmin, dmax, bounds_ptr, tracer.BOUNDS_W, tracer.BOUNDS_H,
-                           d_ptr, c_ptr, n_ptr, stream)                    # tracer.cpp:41-47
+        rc |= lib.vk_trace_ahead(vref, oref, bref, d_ptr, c_ptr, n_ptr, stream)       # tracer.cpp:41-47
         if rc:
             raise api.VkError(f"frame {i}: C ABI returned {rc}")
 

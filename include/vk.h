@@ -325,6 +325,48 @@ VK_API int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth,
     float max_depth, float* bounds, int bounds_width, int bounds_height,
     float* out_depth, float* out_color, float* out_normals, void* stream);
 
+/* ---------------------------------------------------- raycast bounds, ahead -- */
+
+/* The first stage of a raycast (per-cell depth bounds of the visible blocks,
+ * tracer.cpp:49-76) depends only on the visible list and the view, not on the
+ * voxels, and it is a short latency-bound pass that keeps a few CUs busy. An
+ * application that raycasts from the pose it has just integrated (the reference's
+ * frame loop, apps/vulcan/vulcan.cu:316-325) can have it computed by a handful of
+ * extra workgroups INSIDE the integrate launch, where it costs nothing, and let
+ * the raycast skip it. This record carries the result and the view it is for.
+ * No reference counterpart; results are identical with or without it. */
+typedef struct vk_view_bounds {
+  /* set by the caller */
+  float*        scratch;          /* device, vk_trace_bounds_floats(bounds_width, bounds_height) floats */
+  int32_t       bounds_width;     /* the tracer's grid (80 x 60, tracer.cpp:108-111) */
+  int32_t       bounds_height;
+  float         min_depth;        /* the tracer's depth range (tracer.cpp:103-106)   */
+  float         max_depth;
+  /* set by vk_integrate_ahead / vk_trace_ahead, compared by vk_trace_ahead. The
+   * caller zeroes `valid` whenever the visible list changes: after
+   * vk_volume_set_view and after the staged visibility calls. */
+  int32_t       valid;
+  int32_t       width, height;
+  float         block_length;
+  const void*   visible_blocks;   /* which volume */
+  vk_projection projection;
+  vk_transform  depth_to_world;
+} vk_view_bounds;
+
+/* vk_integrate_depth / _depth_color / _depth_light (color_mode 0 / 1 / 2; `light`
+ * and `mask` as in vk_integrate_depth_light for mode 2) which, when `ahead` is
+ * given, also computes the raycast bounds of `frame`'s own view into
+ * ahead->scratch and records the view in *ahead. ref: as those three. */
+VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
+    const vk_frame* frame, int color_mode, const vk_light* light, const float* mask,
+    vk_view_bounds* ahead, void* stream);
+
+/* ref: src/tracer.cpp:41-47 Tracer::Trace, as vk_trace with the grid, depth range
+ * and scratch taken from *ahead: when *ahead holds the bounds of this very view
+ * the bounds pass is skipped, otherwise it runs and *ahead is updated. */
+VK_API int vk_trace_ahead(const vk_volume* v, const vk_frame* frame,
+    vk_view_bounds* ahead, float* depths, float* colors, float* normals, void* stream);
+
 /* ------------------------------------------------------------------- image -- */
 
 /* ref: src/image.cu:101-165,183-211 Image::Downsample (nearest or 2x2 box) */

@@ -128,3 +128,54 @@ def test_argument_errors_are_reported_not_thrown(api):
     assert lib.vk_image_downsample(641, 480, None, None, 1, None) == -1
     with pytest.raises(api.VkError):
         api.check(-1, "vk_volume_set_view")
+
+
+def test_bounds_ahead_hits_and_falls_back(api, orc):
+    """The raycast bounds prepared inside the integrate launch (vk_view_bounds) are used
+    only for the very view they were computed for; every other case recomputes them,
+    and all of them give the oracle's images."""
+    import torch
+    w, h = 320, 240
+    k = T.Projection.make(270, 270, 160, 120)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.3 + 0.2 * np.sin(x / 23.0) * np.cos(y / 17.0)).astype(np.float32)
+    pose_a = scenes.tracer_test_pose()
+    pose_b = T.Transform.translate(0.03, -0.02, 0.01) * pose_a
+    hf, df = frames(api, orc, depth, k, pose_a, color=scenes.checker_color(w, h, 0.2, 0.8))
+    hv, dv = make_pair(api, orc, 16384, 2048, 0.008, 0.04)
+    integ, tracer = api.ColorIntegrator(dv), api.Tracer(dv)
+    vb = tracer.view_bounds
+    assert dv.view_bounds is vb and vb.valid == 0
+
+    def check(pose):
+        hf.depth_to_world = pose
+        want = orc.trace(hv, hf)
+        out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose)
+        tracer.trace(out)
+        sync()
+        assert np.array_equal(tracer.bounds.cpu().numpy(), want[3])
+        assert np.array_equal(out.depth.cpu().numpy(), want[0])
+        assert np.array_equal(out.color.cpu().numpy(), want[1])
+        assert np.array_equal(out.normals.cpu().numpy(), want[2], equal_nan=True)
+        hf.depth_to_world = pose_a
+
+    for _ in range(4):
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        dv.set_view(df)
+        assert vb.valid == 0                      # a new visible list invalidates the record
+    orc.integrate_depth(hv, hf)
+    orc.integrate_color(hv, hf)
+    integ.integrate(df)
+    assert vb.valid == 1                          # prepared by the integrate launch
+    check(pose_a)                                 # hit
+    assert vb.valid == 1
+    check(pose_b)                                 # other view: recomputed, record now holds pose_b
+    assert vb.valid == 1 and np.array_equal(np.array(vb.depth_to_world.m[:]), np.array(pose_b.m[:]))
+    check(pose_a)                                 # and back
+    tracer.depth_range = (0.5, 1.35)              # other tracer settings: recomputed
+    hf_bounds = orc.trace(hv, hf, depth_range=(0.5, 1.35))
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose_a)
+    tracer.trace(out)
+    sync()
+    assert np.array_equal(tracer.bounds.cpu().numpy(), hf_bounds[3])
+    assert np.array_equal(out.depth.cpu().numpy(), hf_bounds[0])

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "vk_frame_filter_depths": ([_I, _I, _P, _P, _P], _I),
     "vk_trace_bounds_floats": ([_I, _I], _SZ),
     "vk_trace": ([_P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P], _I),
+    "vk_integrate_ahead": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_trace_ahead": ([_P, _P, _P, _P, _P, _P, _P], _I),
     "vk_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
     "vk_color_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
     "vk_icp_compute_residuals": ([_P, _P, _P, _P, _P, _P], _I),
@@ -237,7 +239,14 @@ class Volume:
         self.voxel_length = voxel_length
         self.truncation_length = truncation_length
         self.depth_range = depth_range
+        # raycast bounds computed ahead, inside the integrate launch (vk_view_bounds);
+        # a Tracer attaches its scratch and settings here
+        self.view_bounds = None
         check(lib().vk_volume_initialize(_ref(self.desc()), stream()), "vk_volume_initialize")
+
+    def _view_changed(self):
+        if self.view_bounds is not None:
+            self.view_bounds.valid = 0
 
     def desc(self):
         d = T.Volume()
@@ -256,6 +265,7 @@ class Volume:
 
     # -- Volume::SetView and its four protected stages (volume.cu:430-535)
     def set_view(self, frame):
+        self._view_changed()
         check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
 
     def reset_block_visibility(self):
@@ -270,6 +280,7 @@ class Volume:
         check(lib().vk_volume_handle_allocation_requests(_ref(self.desc()), stream()), "handle_allocation_requests")
 
     def update_block_visibility(self, frame):
+        self._view_changed()
         tdw = frame.depth_to_world.inverse()
         check(lib().vk_volume_update_block_visibility(
             _ref(self.desc()), frame.width, frame.height, _ref(frame.depth_projection), _ref(tdw), stream()),
@@ -308,6 +319,7 @@ class Volume:
         test start the device path from an exactly known state."""
         import torch
         assert host.main == self.main and host.excess == self.excess
+        self._view_changed()
         for name in ("voxels", "hash_entries", "allocation_types", "allocation_blocks", "block_visibility"):
             src = torch.from_numpy(np.frombuffer(getattr(host, name).tobytes(), dtype=np.uint8).copy())
             getattr(self, name).copy_(src.to(self.device))
@@ -329,15 +341,23 @@ class Integrator:
         check(getattr(lib(), fn)(_ref(self.volume.desc()), _ref(self.params), *extra,
                                  _ref(frame.desc()), stream()), fn)
 
+    def _fused(self, frame, mode, light=None, mask=None):
+        """depth (+ colour) in one pass; when a Tracer is attached to the volume the
+        same launch also prepares the raycast bounds of this frame's view."""
+        vb = self.volume.view_bounds
+        check(lib().vk_integrate_ahead(_ref(self.volume.desc()), _ref(self.params), _ref(frame.desc()), mode,
+                                       _ref(light) if light is not None else None, _ptr(mask),
+                                       _ref(vb) if vb is not None else None, stream()), "vk_integrate_ahead")
+
 
 class DepthIntegrator(Integrator):
     def integrate(self, frame):                      # depth_integrator.cu:89-115
-        self._call("vk_integrate_depth", frame)
+        self._fused(frame, 0)
 
 
 class ColorIntegrator(Integrator):
     def integrate(self, frame):                      # color_integrator.cu:144-148, one pass
-        self._call("vk_integrate_depth_color", frame)
+        self._fused(frame, 1)
 
     def integrate_depth(self, frame):                # color_integrator.cu:150-176
         self._call("vk_integrate_depth", frame)
@@ -363,7 +383,7 @@ class LightIntegrator(Integrator):
 
     def integrate(self, frame):                      # light_integrator.cu:270-275
         self.compute_frame_mask(frame)
-        self._call("vk_integrate_depth_light", frame, _ref(self.light), _ptr(self.frame_mask))
+        self._fused(frame, 2, self.light, self.frame_mask)
 
     def integrate_depth(self, frame):
         self._call("vk_integrate_depth", frame)
@@ -387,6 +407,13 @@ class Tracer:
         self.bounds = self.bounds_scratch[:self.BOUNDS_W * self.BOUNDS_H * 2].view(self.BOUNDS_H, self.BOUNDS_W, 2)
         self.patches = _dev_bytes(self.PATCH_CAPACITY * 16, dev)
         self.patch_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        # let the volume's integrators prepare this tracer's bounds ahead of time
+        vb = T.ViewBounds()
+        vb.scratch = self.bounds_scratch.data_ptr()
+        vb.bounds_width, vb.bounds_height = self.BOUNDS_W, self.BOUNDS_H
+        vb.min_depth, vb.max_depth = self.depth_range
+        self.view_bounds = vb
+        volume.view_bounds = vb
 
     def trace(self, frame):
         """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals."""
@@ -395,9 +422,12 @@ class Tracer:
             frame.color = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
         if frame.normals is None:
             frame.normals = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
-        check(lib().vk_trace(_ref(self.volume.desc()), _ref(frame.desc()), self.depth_range[0], self.depth_range[1],
-                             _ptr(self.bounds), self.BOUNDS_W, self.BOUNDS_H, _ptr(frame.depth), _ptr(frame.color),
-                             _ptr(frame.normals), stream()), "vk_trace")
+        vb = self.view_bounds
+        if (vb.min_depth, vb.max_depth) != tuple(np.float32(d) for d in self.depth_range):
+            vb.min_depth, vb.max_depth = self.depth_range
+            vb.valid = 0
+        check(lib().vk_trace_ahead(_ref(self.volume.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth),
+                                   _ptr(frame.color), _ptr(frame.normals), stream()), "vk_trace_ahead")
 
     # the tracer.cuh free functions, for the stage-by-stage tests
     def compute_patches(self, frame, block_count=None):

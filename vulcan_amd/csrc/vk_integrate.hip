@@ -13,7 +13,7 @@
 // HBM-bound: algorithmic bytes per visible block = 4 (index) + 16 (entry) +
 // 2*10240 (voxel read + write) = 20 500 B, plus the images once per frame
 // (SURVEY.md §8d).
-#include "vk_common.hpp"
+#include "vk_bounds.hpp"
 
 #ifndef VK_INTEGRATE_NT_STORES
 #define VK_INTEGRATE_NT_STORES 0
@@ -542,17 +542,42 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
   }
 }
 
-template <bool DEPTH, int COLOR>
-__global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_kernel(IntegrateParams P)
+// What the first kBoundsGroups workgroups of an AHEAD launch do instead of
+// integrating: the raycast bounds of the same view (vk_bounds.hpp). They only read
+// the visible list and the hash entries, so they run alongside the integrate
+// workgroups of the same launch for free.
+struct AheadParams
 {
-  __shared__ float4 tiles[kPipeWavesPerGroup][kHalfF4];
+  PatchParams patch;
+  float2* partials;
+};
+
+template <bool DEPTH, int COLOR, bool AHEAD>
+__global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_kernel(IntegrateParams P, AheadParams A)
+{
+  // one LDS pool: four half-block tiles (20 KiB), or one bounds grid (37.5 KiB)
+  constexpr int kTileInts = kPipeWavesPerGroup * kHalfF4 * 4;
+  constexpr int kPoolInts = AHEAD ? (2 * kAheadMaxCells > kTileInts ? 2 * kAheadMaxCells : kTileInts) : kTileInts;
+  __shared__ __attribute__((aligned(16))) int pool[kPoolInts];
+
+  int group = (int)blockIdx.x, groups = (int)gridDim.x;
+  if (AHEAD)
+  {
+    if (group < kBoundsGroups)
+    {
+      bounds_group(A.patch, A.partials, pool, group, kPipeWavesPerGroup * 64);
+      return;
+    }
+    group -= kBoundsGroups;
+    groups -= kBoundsGroups;
+  }
 
   const int lane = lane_id();
   const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wave = blockIdx.x * kPipeWavesPerGroup + wave_in_group;
-  const int total_waves = gridDim.x * kPipeWavesPerGroup;
+  const int wave = group * kPipeWavesPerGroup + wave_in_group;
+  const int total_waves = groups * kPipeWavesPerGroup;
   const int count = P.counters[VK_CTR_VISIBLE];
-  float4* tile4 = tiles[wave_in_group];
+  float4* tile4 = reinterpret_cast<float4*>(pool) + wave_in_group * kHalfF4;
 
   for (int first = wave; first < count; first += 64 * total_waves)
   {
@@ -654,15 +679,39 @@ int pipe_grid_for(const vk_volume* v)
   return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
+// `ahead` (optional): also compute the raycast bounds of the frame's own view
 template <bool DEPTH, int COLOR>
-int launch(const IntegrateParams& P, const vk_volume* v, hipStream_t s)
+int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, hipStream_t s)
 {
-  if (g_integrate_pipelined)
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR>), dim3(pipe_grid_for(v)),
-        dim3(kPipeWavesPerGroup * 64), 0, s, P);
+  AheadParams A;
+  A.partials = nullptr;
+  bool with_bounds = false;
+  if (ahead && g_integrate_pipelined && ahead->scratch && ahead->bounds_width > 0 && ahead->bounds_height > 0 &&
+      ahead->bounds_width * ahead->bounds_height <= kAheadMaxCells)
+  {
+    ahead->valid = 0;
+    if (view_patch_params(A.patch, v, frame, ahead) != VK_OK) return VK_ERR_ARGUMENT;
+    A.partials = reinterpret_cast<float2*>(ahead->scratch) + ahead->bounds_width * ahead->bounds_height;
+    with_bounds = true;
+  }
+
+  if (with_bounds)
+  {
+    // 37.5 KiB of LDS per workgroup: four per CU
+    const int max_count = v->main_block_count + v->excess_block_count;
+    const int want = (max_count + kPipeWavesPerGroup - 1) / kPipeWavesPerGroup;
+    const int cap = kCUs * 4;
+    const int grid = (want < cap ? (want > 0 ? want : 1) : cap) + kBoundsGroups;
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, true>), dim3(grid),
+        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+  }
+  else if (g_integrate_pipelined)
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false>), dim3(pipe_grid_for(v)),
+        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   else
     hipLaunchKernelGGL((integrate_kernel<DEPTH, COLOR>), dim3(grid_for(v)), dim3(kWavesPerGroup * 64), 0, s, P);
   VK_LAUNCH_CHECK();
+  if (with_bounds) view_record(ahead, v, frame);
   return VK_OK;
 }
 
@@ -730,7 +779,7 @@ int vk_integrate_depth(const vk_volume* v, const vk_integrator* p, const vk_fram
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
   if (rc != VK_OK) return rc;
-  return launch<true, COLOR_NONE>(P, v, vk_s(stream));
+  return launch<true, COLOR_NONE>(P, v, frame, nullptr, vk_s(stream));
 }
 
 int vk_integrate_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
@@ -738,7 +787,7 @@ int vk_integrate_color(const vk_volume* v, const vk_integrator* p, const vk_fram
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, false, true, false);
   if (rc != VK_OK) return rc;
-  return launch<false, COLOR_PLAIN>(P, v, vk_s(stream));
+  return launch<false, COLOR_PLAIN>(P, v, frame, nullptr, vk_s(stream));
 }
 
 int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
@@ -746,7 +795,7 @@ int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const v
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, true, false);
   if (rc != VK_OK) return rc;
-  return launch<true, COLOR_PLAIN>(P, v, vk_s(stream));
+  return launch<true, COLOR_PLAIN>(P, v, frame, nullptr, vk_s(stream));
 }
 
 int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold, float* mask, void* stream)
@@ -765,7 +814,7 @@ int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p, const v
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, light, mask, false, true, true);
   if (rc != VK_OK) return rc;
-  return launch<false, COLOR_LIGHT>(P, v, vk_s(stream));
+  return launch<false, COLOR_LIGHT>(P, v, frame, nullptr, vk_s(stream));
 }
 
 int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const vk_light* light,
@@ -774,7 +823,20 @@ int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const v
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, light, mask, true, true, true);
   if (rc != VK_OK) return rc;
-  return launch<true, COLOR_LIGHT>(P, v, vk_s(stream));
+  return launch<true, COLOR_LIGHT>(P, v, frame, nullptr, vk_s(stream));
+}
+
+int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int color_mode,
+    const vk_light* light, const float* mask, vk_view_bounds* ahead, void* stream)
+{
+  IntegrateParams P;
+  VK_REQUIRE(color_mode >= 0 && color_mode <= 2);
+  const int rc = fill_params(P, v, p, frame, color_mode == 2 ? light : nullptr, color_mode == 2 ? mask : nullptr, true,
+      color_mode != 0, color_mode == 2);
+  if (rc != VK_OK) return rc;
+  if (color_mode == 0) return launch<true, COLOR_NONE>(P, v, frame, ahead, vk_s(stream));
+  if (color_mode == 1) return launch<true, COLOR_PLAIN>(P, v, frame, ahead, vk_s(stream));
+  return launch<true, COLOR_LIGHT>(P, v, frame, ahead, vk_s(stream));
 }
 
 int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int variant, void* stream)

@@ -36,7 +36,7 @@ class Tracer
 {
   public:
     explicit Tracer(std::shared_ptr<const Volume> volume);
-    virtual ~Tracer() {}
+    virtual ~Tracer();
 
     std::shared_ptr<const Volume> GetVolume() const;
 

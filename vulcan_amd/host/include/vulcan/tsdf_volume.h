@@ -71,6 +71,15 @@ class Volume
     vk_volume ToVk() const;                        // device view for the C ABI
     void GetCounters(int32_t* counters) const;     // blocking readback of VK_CTR_*
 
+    // Raycast bounds prepared ahead of time (vk_view_bounds, not upstream): a Tracer
+    // registers its scratch buffer and settings here, the integrators then compute
+    // the bounds of the view they integrate inside their own launch and
+    // Tracer::Trace skips that pass when it raycasts the same view. SetView (a new
+    // visible list) invalidates the record. nullptr while no Tracer is attached.
+    vk_view_bounds* GetViewBounds() const;
+    void AttachViewBounds(float* scratch, int bounds_width, int bounds_height, const Vector2f& depth_range) const;
+    void DetachViewBounds(const float* scratch) const;   // no-op unless `scratch` is the attached one
+
   protected:
     // the four stages of SetView, in call order
     void ResetBlockVisibility();
@@ -98,6 +107,7 @@ class Volume
     float voxel_length_;
     bool empty_;
     mutable bool visible_count_stale_;
+    mutable vk_view_bounds view_bounds_;
 
   private:
     void Initialize();

@@ -59,12 +59,14 @@ vk_integrator Integrator::ToVk() const
 
 DepthIntegrator::DepthIntegrator(std::shared_ptr<Volume> volume) : Integrator(volume) {}
 
+// The Integrate() of each subclass goes through vk_integrate_ahead: when a Tracer is
+// attached to the volume, the same launch prepares the raycast bounds of this view.
 void DepthIntegrator::Integrate(const Frame& frame)
 {
   const vk_volume v = volume_->ToVk();
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 0, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
 }
 
 // ---- colour ------------------------------------------------------------------
@@ -76,7 +78,7 @@ void ColorIntegrator::Integrate(const Frame& frame)
   const vk_volume v = volume_->ToVk();
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_depth_color(&v, &p, &f, Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 1, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
 }
 
 void ColorIntegrator::IntegrateDepth(const Frame& frame)
@@ -114,7 +116,7 @@ void LightIntegrator::Integrate(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_light l = light_.ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_depth_light(&v, &p, &l, frame_mask_.GetData(), &f, Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 2, &l, frame_mask_.GetData(), volume_->GetViewBounds(), Device::GetStream()));
 }
 
 void LightIntegrator::ComputeFrameMask(const Frame& frame)

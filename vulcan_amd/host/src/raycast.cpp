@@ -67,6 +67,12 @@ Tracer::Tracer(std::shared_ptr<const Volume> volume) :
   Initialize();
 }
 
+Tracer::~Tracer()
+{
+  // the volume must not keep a pointer into a buffer that is about to be freed
+  if (volume_) volume_->DetachViewBounds(reinterpret_cast<const float*>(bounds_.GetData()));
+}
+
 std::shared_ptr<const Volume> Tracer::GetVolume() const { return volume_; }
 
 const Vector2f& Tracer::GetDepthRange() const { return depth_range_; }
@@ -91,8 +97,16 @@ void Tracer::Trace(Frame& frame)
 
   const vk_volume v = volume_->ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_trace(&v, &f, depth_range_[0], depth_range_[1], reinterpret_cast<float*>(bounds_.GetData()),
-      bounds_width_, bounds_height_, frame.depth_image->GetData(),
+  // the volume's record, if it is (still) this tracer's; the bounds pass is skipped
+  // when an integrator has already prepared the bounds of this very view
+  vk_view_bounds* ahead = volume_->GetViewBounds();
+  float* scratch = reinterpret_cast<float*>(bounds_.GetData());
+  if (!ahead || ahead->scratch != scratch || ahead->min_depth != depth_range_[0] || ahead->max_depth != depth_range_[1])
+  {
+    volume_->AttachViewBounds(scratch, bounds_width_, bounds_height_, depth_range_);
+    ahead = volume_->GetViewBounds();
+  }
+  VK_ASSERT(vk_trace_ahead(&v, &f, ahead, frame.depth_image->GetData(),
       reinterpret_cast<float*>(frame.color_image->GetData()),
       reinterpret_cast<float*>(frame.normal_image->GetData()), Device::GetStream()));
 }
@@ -163,6 +177,8 @@ void Tracer::Initialize()
   // copies behind the grid (vk_trace_bounds_floats)
   bounds_.Resize(vk_trace_bounds_floats(bounds_width_, bounds_height_) / 2);
   buffer_size_.Resize(1);
+  // from now on the volume's integrators prepare this tracer's bounds
+  volume_->AttachViewBounds(reinterpret_cast<float*>(bounds_.GetData()), bounds_width_, bounds_height_, depth_range_);
 }
 
 } // namespace vulcan

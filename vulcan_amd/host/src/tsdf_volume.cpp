@@ -1,5 +1,6 @@
 // tsdf_volume.cpp — Volume host class over vk_volume_* (ref: src/volume.cu:370-627).
 #include <vulcan/tsdf_volume.h>
+#include <cstring>
 #include <vulcan/block.h>
 #include <vulcan/exception.h>
 #include <vulcan/observation.h>
@@ -19,6 +20,7 @@ Volume::Volume(int main_block_count, int excess_block_count) :
   empty_(true),
   visible_count_stale_(false)
 {
+  std::memset(&view_bounds_, 0, sizeof(view_bounds_));
   Initialize();
 }
 
@@ -76,8 +78,26 @@ vk_volume Volume::ToVk() const
   return v;
 }
 
+vk_view_bounds* Volume::GetViewBounds() const { return view_bounds_.scratch ? &view_bounds_ : nullptr; }
+
+void Volume::AttachViewBounds(float* scratch, int bounds_width, int bounds_height, const Vector2f& depth_range) const
+{
+  std::memset(&view_bounds_, 0, sizeof(view_bounds_));
+  view_bounds_.scratch = scratch;
+  view_bounds_.bounds_width = bounds_width;
+  view_bounds_.bounds_height = bounds_height;
+  view_bounds_.min_depth = depth_range[0];
+  view_bounds_.max_depth = depth_range[1];
+}
+
+void Volume::DetachViewBounds(const float* scratch) const
+{
+  if (view_bounds_.scratch == scratch) std::memset(&view_bounds_, 0, sizeof(view_bounds_));
+}
+
 void Volume::SetView(const Frame& frame)
 {
+  view_bounds_.valid = 0;   // the visible list is about to change
   VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
   const vk_volume v = ToVk();
   const vk_frame f = frame.ToVk();
@@ -121,6 +141,7 @@ void Volume::ResetBlockVisibility()
 
 void Volume::UpdateBlockVisibility(const Frame& frame)
 {
+  view_bounds_.valid = 0;
   const vk_volume v = ToVk();
   const vk_projection k = frame.depth_projection.ToVk();
   const vk_transform Tdw = frame.depth_to_world_transform.Inverse().ToVk();

@@ -141,6 +141,14 @@ class Integrator(C.Structure):
         return Integrator(0.1, 5.0, 16.0, 16.0)   # integrator.cu:7-13
 
 
+class ViewBounds(C.Structure):
+    _fields_ = [("scratch", C.c_void_p), ("bounds_width", C.c_int32), ("bounds_height", C.c_int32),
+                ("min_depth", C.c_float), ("max_depth", C.c_float),
+                ("valid", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("block_length", C.c_float), ("visible_blocks", C.c_void_p),
+                ("projection", Projection), ("depth_to_world", Transform)]
+
+
 class ColorView(C.Structure):
     _fields_ = [("depths", C.c_void_p), ("normals", C.c_void_p), ("intensities", C.c_void_p),
                 ("gradient_x", C.c_void_p), ("gradient_y", C.c_void_p),
