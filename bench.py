@@ -187,7 +187,7 @@ def main():
         },
     }
 
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:   # the CPU leg is reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(depth_np, k, poses, args.cpu_frames)
 
     if rank == 0:

@@ -384,7 +384,25 @@ __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volu
   // (1) requests in buckets [0, first): 16 bytes per load, first is a multiple of 1024
   int base_all = 0, base_excess = 0;
   const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
-  for (int j = threadIdx.x; j < first / 16; j += kHandleThreads)
+  // up to 16 independent 16-byte loads per lane: issued eight at a time so that
+  // their latencies overlap (the loop is otherwise one L2 round trip per trip)
+  const int chunks = first / 16;
+  int j = threadIdx.x;
+  for (; j + 7 * kHandleThreads < chunks; j += 8 * kHandleThreads)
+  {
+    uint4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = flags16[j + u * kHandleThreads];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+    {
+      count_flags(q[u].x, base_all, base_excess);
+      count_flags(q[u].y, base_all, base_excess);
+      count_flags(q[u].z, base_all, base_excess);
+      count_flags(q[u].w, base_all, base_excess);
+    }
+  }
+  for (; j < chunks; j += kHandleThreads)
   {
     const uint4 q = flags16[j];
     count_flags(q.x, base_all, base_excess);
