@@ -510,6 +510,53 @@ VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_
     int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
     void* stream);
 
+/* ------------------------------------------------------------- light tracker -- */
+
+/* What LightTracker adds to the colour tracker's inputs (light_tracker.h:52-66):
+ * the frame's validity mask, the point light, and the frame's depth->colour
+ * extrinsics (its normals are stored in the depth frame). The keyframe's
+ * `intensities` are read as albedos. */
+typedef struct vk_light_terms {
+  const float*  frame_mask;   /* [h*w], vk_light_compute_frame_mask of the frame (light_tracker.cu:19-103 is the same kernel) */
+  vk_light      light;
+  vk_transform  frame_Tcd;
+} vk_light_terms;
+
+/* ref: src/light_tracker.cu:133-330,566-608 LightTracker::ComputeResiduals. Where
+ * the mask is set the residual is photometric with a shading model,
+ * Ic - albedo * light.GetShading(Xcp, n); elsewhere it falls back to the
+ * point-to-plane distance (:283-322). The reference's ComputeResiduals reads
+ * frame_mask_ without computing it (:569-577); here the mask is an input. */
+VK_API int vk_light_tracker_compute_residuals(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_light_terms* terms, const vk_transform* Tcm,
+    float* residuals, void* stream);
+
+/* ref: src/light_tracker.cu:332-371,610-668 LightTracker::ComputeJacobian. The
+ * reference evaluates machine-generated expressions (powf / sqrt chains,
+ * :233-242); here the same derivative is written in factored form
+ * (J_v = grad_p r, J_w = p x grad_p r + n x grad_n r), so values agree with the
+ * reference to rounding, not bit for bit — its own finite-difference test
+ * (light_tracker_test.cu:454-528, |f - e| < 0.05) is the pin. */
+VK_API int vk_light_tracker_compute_jacobian(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_light_terms* terms, const vk_transform* Tcm,
+    int translation_enabled, float* jacobian, void* stream);
+
+/* ref: src/light_tracker.cu:373-531,670-732 LightTracker::ComputeSystem; outputs
+ * and workspace as vk_color_tracker_compute_system. */
+VK_API int vk_light_tracker_compute_system(const vk_color_view* keyframe,
+    const vk_color_view* frame, const vk_light_terms* terms, const vk_transform* Tcm,
+    const vk_transform* Tcm_dev, int translation_enabled, float* workspace,
+    float* hessian, float* gradient, void* stream);
+
+/* ref: src/tracker.cpp:53-63 Tracker::Track for LightTracker. The pose update is
+ * ColorTracker's (light_tracker.cpp:50-114 is the same code as
+ * color_tracker.cpp:34-96): vk_color_tracker_solve_update, vk_color_pose. */
+VK_API int vk_light_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
+    int iterations, int translation_enabled, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
+    void* stream);
+
 /* ---------------------------------------------------------------- detector -- */
 
 /* ref: include/vulcan/detector.h:10-72, src/detector.cu — box detector over a

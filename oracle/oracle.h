@@ -110,6 +110,15 @@ float orc_color_tracker_solve_update(const float* hessian_packed, const float* g
 void orc_color_tracker_tcm(const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc,
     vk_color_pose* pose);
 
+/* light tracker (oracle_color_tracker.c) */
+void orc_light_tracker_compute_residuals(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, float* residuals);
+void orc_light_tracker_compute_jacobian(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, int translation_enabled, float* jacobian);
+void orc_light_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, int translation_enabled, double* hessian,
+    double* gradient);
+
 /* detector (oracle_detect.c). PARITY UNPINNED: the reference holds no test or
  * vector for Detector (tests/detector_test.cu is empty). */
 void orc_detect(const vk_detector* detector, const float* points, int count,

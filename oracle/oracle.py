@@ -373,3 +373,38 @@ def color_solve_update(hessian_packed, gradient, frame_Tcd, key_Twc, pose, trans
     norm = lib().orc_color_tracker_solve_update(_p(h), _p(g), int(translation_enabled), C.byref(frame_Tcd),
                                                 C.byref(key_Twc), C.byref(pose), _p(update))
     return update, float(norm)
+
+
+# ---- light tracker -------------------------------------------------------
+
+def light_terms(frame, light, mask):
+    """vk_light_terms for `frame`; `mask` must stay alive while the struct is used."""
+    t = T.LightTerms()
+    t.frame_mask = _p(mask).value
+    t.light = light
+    t.frame_Tcd = frame.depth_to_color
+    return t
+
+
+def light_residuals(key, frm, terms, Tcm):
+    out = np.zeros(key.depth.shape, dtype=np.float32)
+    kv, fv = key.view(), frm.view()
+    lib().orc_light_tracker_compute_residuals(C.byref(kv), C.byref(fv), C.byref(terms), C.byref(Tcm), _p(out))
+    return out
+
+
+def light_jacobian(key, frm, terms, Tcm, translation_enabled=True):
+    out = np.zeros(key.depth.shape + (6,), dtype=np.float32)
+    kv, fv = key.view(), frm.view()
+    lib().orc_light_tracker_compute_jacobian(C.byref(kv), C.byref(fv), C.byref(terms), C.byref(Tcm),
+                                             int(translation_enabled), _p(out))
+    return out
+
+
+def light_system(key, frm, terms, Tcm, translation_enabled=True):
+    h = np.zeros(21, dtype=np.float64)
+    g = np.zeros(6, dtype=np.float64)
+    kv, fv = key.view(), frm.view()
+    lib().orc_light_tracker_compute_system(C.byref(kv), C.byref(fv), C.byref(terms), C.byref(Tcm),
+                                           int(translation_enabled), _p(h), _p(g))
+    return h, g

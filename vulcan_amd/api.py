@@ -78,6 +78,10 @@ _SIGNATURES = {
     "vk_color_tracker_compute_system": ([_P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_solve_update": ([_P, _P, _I, _P, _P, _P, _P, _P, _P], _I),
     "vk_color_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_light_tracker_compute_residuals": ([_P, _P, _P, _P, _P, _P], _I),
+    "vk_light_tracker_compute_jacobian": ([_P, _P, _P, _P, _I, _P, _P], _I),
+    "vk_light_tracker_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_light_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
     "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
@@ -675,6 +679,83 @@ class ColorTracker:
                                            _ptr(self.pose), self.max_iterations, int(self.translation_enabled),
                                            _ptr(self._workspace()), _ptr(self.system), _ptr(self.state),
                                            _ptr(self.update), hook, None, stream()), "vk_color_tracker_track")
+        out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
+        frame.depth_to_world = out.depth_to_world
+        return out.depth_to_world
+
+
+class LightTracker(ColorTracker):
+    """vulcan::LightTracker (light_tracker.h): the colour tracker with a shading model —
+    residual Ic - albedo * light.GetShading(Xcp, n) where the frame mask is set,
+    point-to-plane elsewhere. The keyframe's colour image is read as albedo."""
+
+    def __init__(self, device="cuda"):
+        super().__init__(device)
+        self.light = T.Light.make(1.0, (0, 0, 0))    # light.h:14-18
+        self.depth_threshold = 0.2                   # light_tracker.cpp:13-14
+        self.frame_mask = None
+
+    def compute_frame_mask(self, frame):             # light_tracker.cu:548-564
+        import torch
+        self.frame_mask = torch.empty((frame.height, frame.width), dtype=torch.float32, device=self.device)
+        check(lib().vk_light_compute_frame_mask(_ref(frame.desc()), self.depth_threshold, _ptr(self.frame_mask),
+                                                stream()), "vk_light_compute_frame_mask")
+        return self.frame_mask
+
+    def _terms(self, frame, mask=None):
+        t = T.LightTerms()
+        m = mask if mask is not None else self.compute_frame_mask(frame)
+        t.frame_mask = m.data_ptr()
+        t.light = self.light
+        t.frame_Tcd = frame.depth_to_color
+        return t, m
+
+    def compute_residuals(self, frame, mask=None):   # light_tracker.cu:566-608 (the mask is computed here)
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, False)
+        terms, keep_m = self._terms(frame, mask)
+        out = torch.empty((self._keyframe.height, self._keyframe.width), dtype=torch.float32, device=self.device)
+        check(lib().vk_light_tracker_compute_residuals(_ref(kv), _ref(fv), _ref(terms), _ref(self.tcm(frame)),
+                                                       _ptr(out), stream()), "vk_light_tracker_compute_residuals")
+        return out
+
+    def compute_jacobian(self, frame, mask=None):    # light_tracker.cu:610-668
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        terms, keep_m = self._terms(frame, mask)
+        out = torch.empty((self._keyframe.height, self._keyframe.width, 6), dtype=torch.float32, device=self.device)
+        check(lib().vk_light_tracker_compute_jacobian(_ref(kv), _ref(fv), _ref(terms), _ref(self.tcm(frame)),
+                                                      int(self.translation_enabled), _ptr(out), stream()),
+              "vk_light_tracker_compute_jacobian")
+        return out
+
+    def compute_system(self, frame, mask=None):      # light_tracker.cu:670-732
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        terms, keep_m = self._terms(frame, mask)
+        check(lib().vk_light_tracker_compute_system(_ref(kv), _ref(fv), _ref(terms), _ref(self.tcm(frame)), None,
+                                                    int(self.translation_enabled), _ptr(self._workspace()),
+                                                    _ptr(self.hessian), _ptr(self.gradient), stream()),
+              "vk_light_tracker_compute_system")
+
+    def track(self, frame):
+        """Tracker::Track with LightTracker::BeginSolve (light_tracker.cpp:34-41)."""
+        import torch
+        kv, keep_k = self._key()
+        fv, keep_f = self._side(frame, True)
+        terms, keep_m = self._terms(frame)
+        pose = T.ColorPose()
+        pose.depth_to_world = frame.depth_to_world
+        host = np.frombuffer(bytes(pose), dtype=np.uint8).copy()
+        self.pose.copy_(torch.from_numpy(host).to(self.device))
+        self.state.zero_()
+        key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
+        check(lib().vk_light_tracker_track(_ref(kv), _ref(fv), _ref(terms), _ref(key_Twc), _ptr(self.pose),
+                                           self.max_iterations, int(self.translation_enabled), _ptr(self._workspace()),
+                                           _ptr(self.system), _ptr(self.state), _ptr(self.update), None, None,
+                                           stream()), "vk_light_tracker_track")
         out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out.depth_to_world
         return out.depth_to_world

@@ -59,6 +59,10 @@ struct ColorParams
   Rt Tcm;
   const vk_transform* Tcm_dev;  // optional device override of Tcm
   const int32_t* state;         // optional {iterations, converged}: a converged solve skips the pass
+  // light tracker only
+  const float* mask;
+  vk_light light;
+  Rt Tcd;
 };
 
 // ref: color_tracker.cu:17-41
@@ -149,6 +153,141 @@ __device__ __forceinline__ bool evaluate(const ColorParams& P, const Rt& Tcm, in
   return true;
 }
 
+// ref: light_tracker.cu:133-330 Evaluate<translation_enabled>. Residual and the
+// point-to-plane fallback (:283-322) line by line. The photometric Jacobian is the
+// reference's derivative in factored form instead of its six machine-generated
+// powf / sqrt expressions (:233-242): with r = Ic - aa * S, S = ii * (n . d) / |d|^3,
+// d = light - p,
+//   grad_p r = grad_p Ic - aa * ii * (-n / |d|^3 + 3 (n . d) d / |d|^5)
+//   grad_n r =           - aa * ii * d / |d|^3
+//   J[3..5] = grad_p r,   J[0..2] = p x grad_p r + n x grad_n r
+// (grad_p Ic and p x grad_p Ic are ColorTracker's expressions).
+template <bool TRANSLATION, bool JACOBIAN>
+__device__ __forceinline__ bool evaluate_light(const ColorParams& P, const Rt& Tcm, int keyframe_x, int keyframe_y,
+    float& residual, float (&J)[6])
+{
+  residual = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) J[i] = 0.0f;
+
+  const vk_color_view& key = P.key;
+  const vk_color_view& frm = P.frm;
+
+  const int keyframe_index = keyframe_y * key.width + keyframe_x;
+  const float keyframe_depth = key.depths[keyframe_index];
+  if (!(keyframe_depth > 0)) return false;
+
+  const f3 Xmp = unproject_d(key.projection, keyframe_x + 0.5f, keyframe_y + 0.5f, keyframe_depth);
+  const f3 Xcp = xform_point(Tcm, Xmp);
+  float fu, fv;
+  project(frm.projection, Xcp, fu, fv);
+
+  if (!(fu >= 0.5f && fu < frm.width - 0.5f && fv >= 0.5f && fv < frm.height - 0.5f)) return false;
+
+  const int frame_x = f2i(fu), frame_y = f2i(fv);
+  const int frame_index = frame_y * frm.width + frame_x;
+  const float frame_depth = frm.depths[frame_index];
+  if (!(fabsf(frame_depth - Xcp.z) < 0.2f)) return false;
+
+  const f3 frame_Xdn = make3(frm.normals[3 * frame_index + 0], frm.normals[3 * frame_index + 1],
+      frm.normals[3 * frame_index + 2]);
+  const f3 frame_normal = xform_dir(P.Tcd, frame_Xdn);
+  f3 n = make3(key.normals[3 * keyframe_index + 0], key.normals[3 * keyframe_index + 1],
+      key.normals[3 * keyframe_index + 2]);
+  n = xform_dir(Tcm, n);
+
+  if (!(sqnorm3(n) > 0.5f && dot3(frame_normal, n) > 0.8f)) return false;
+
+  const float px = Xcp.x, py = Xcp.y, pz = Xcp.z;
+
+  if (P.mask[frame_index] > 0.5f)
+  {
+    const float aa = key.intensities[keyframe_index];
+    if (!(aa > 0)) return false;
+
+    // light.h:53-60 GetShading
+    const f3 d = sub3(make3(P.light.position[0], P.light.position[1], P.light.position[2]), Xcp);
+    const float d2 = sqnorm3(d);
+    const float dn = sqrtf(d2);
+    const float inv_dn = 1.0f / dn;
+    const f3 direction = scale3(d, inv_dn);
+    const float cos_theta = dot3(n, direction);
+    const float ii = P.light.intensity;
+    const float shading = ii * cos_theta / d2;
+    const float Im = shading * aa;
+    const float Ic = sample(frm.width, frm.intensities, fu, fv);
+    residual = Ic - Im;
+
+    if (JACOBIAN)
+    {
+      const float inv_pz = 1.0f / pz;
+      const float cu = fu, cv = fv;
+      const float fx = frm.projection.fx, fy = frm.projection.fy;
+      const float cx = frm.projection.cx, cy = frm.projection.cy;
+      const float gx = sample(frm.width, frm.gradient_x, fu, fv);
+      const float gy = sample(frm.width, frm.gradient_y, fu, fv);
+
+      float I[6];
+      I[0] = gy * ((py * cy - pz * fy) * inv_pz - py * cv * inv_pz) - gx * (py * cu * inv_pz - cx * py * inv_pz);
+      I[1] = gy * (px * cv * inv_pz - cy * px * inv_pz) - gx * ((px * cx - pz * fx) * inv_pz - px * cu * inv_pz);
+      I[2] = (gy * fy * px - gx * fx * py) * inv_pz;
+      I[3] = gx * fx * inv_pz;
+      I[4] = gy * fy * inv_pz;
+      I[5] = (gx * (cx - cu) + gy * (cy - cv)) * inv_pz;
+
+      const float nd = dot3(n, d);
+      const float inv_d3 = 1.0f / (d2 * dn);
+      const float inv_d5 = inv_d3 / d2;
+      const float k3 = 3.0f * nd * inv_d5;
+      const float s = aa * ii;
+      const f3 a = make3(s * (k3 * d.x - n.x * inv_d3), s * (k3 * d.y - n.y * inv_d3), s * (k3 * d.z - n.z * inv_d3));
+      const f3 b = make3(s * d.x * inv_d3, s * d.y * inv_d3, s * d.z * inv_d3);
+      const f3 pa = cross3(Xcp, a);
+      const f3 nb = cross3(n, b);
+
+      J[0] = I[0] - (pa.x + nb.x);
+      J[1] = I[1] - (pa.y + nb.y);
+      J[2] = I[2] - (pa.z + nb.z);
+      if (TRANSLATION)
+      {
+        J[3] = I[3] - a.x;
+        J[4] = I[4] - a.y;
+        J[5] = I[5] - a.z;
+      }
+    }
+  }
+  else
+  {
+    // :283-322 default to standard depth tracking
+    const f3 Xcq = unproject_d(frm.projection, frame_x + 0.5f, frame_y + 0.5f, frame_depth);
+    const f3 delta = sub3(Xcp, Xcq);
+    residual = dot3(delta, n);
+
+    if (JACOBIAN)
+    {
+      J[0] = delta.z * n.y - delta.y * n.z - n.y * pz + n.z * py;
+      J[1] = delta.x * n.z - delta.z * n.x + n.x * pz - n.z * px;
+      J[2] = delta.y * n.x - delta.x * n.y - n.x * py + n.y * px;
+      if (TRANSLATION)
+      {
+        J[3] = n.x;
+        J[4] = n.y;
+        J[5] = n.z;
+      }
+    }
+  }
+  return true;
+}
+
+// one entry for both trackers
+template <bool LIGHT, bool TRANSLATION, bool JACOBIAN>
+__device__ __forceinline__ bool evaluate_any(const ColorParams& P, const Rt& Tcm, int x, int y, float& residual,
+    float (&J)[6])
+{
+  if (LIGHT) return evaluate_light<TRANSLATION, JACOBIAN>(P, Tcm, x, y, residual, J);
+  return evaluate<TRANSLATION, JACOBIAN>(P, Tcm, x, y, residual, J);
+}
+
 __device__ __forceinline__ Rt rt_of(const float* m)   // column-major 4x4 -> rows 0..2
 {
   Rt t;
@@ -160,32 +299,33 @@ __device__ __forceinline__ Rt rt_of(const float* m)   // column-major 4x4 -> row
 }
 
 // ref: color_tracker.cu:140-163
+template <bool LIGHT>
 __global__ __launch_bounds__(256) void color_residuals_kernel(ColorParams P, float* __restrict__ residuals)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= P.key.width || y >= P.key.height) return;
   float r, J[6];
-  evaluate<false, false>(P, P.Tcm, x, y, r, J);
+  evaluate_any<LIGHT, false, false>(P, P.Tcm, x, y, r, J);
   residuals[y * P.key.width + x] = r;
 }
 
 // ref: color_tracker.cu:165-204
-template <bool TRANSLATION>
+template <bool LIGHT, bool TRANSLATION>
 __global__ __launch_bounds__(256) void color_jacobian_kernel(ColorParams P, float* __restrict__ jacobian)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= P.key.width || y >= P.key.height) return;
   float r, J[6];
-  evaluate<TRANSLATION, true>(P, P.Tcm, x, y, r, J);
+  evaluate_any<LIGHT, TRANSLATION, true>(P, P.Tcm, x, y, r, J);
   float* out = jacobian + 6 * (size_t)(y * P.key.width + x);
 #pragma unroll
   for (int i = 0; i < 6; ++i) out[i] = J[i];
 }
 
 // ref: color_tracker.cu:206-343, first stage (see vk_gauss_newton.hpp)
-template <bool TRANSLATION>
+template <bool LIGHT, bool TRANSLATION>
 __global__ __launch_bounds__(kSysThreads) void color_partial_kernel(ColorParams P, float* __restrict__ workspace)
 {
   __shared__ float lds[kSysWaves][kSysStride];
@@ -201,7 +341,7 @@ __global__ __launch_bounds__(kSysThreads) void color_partial_kernel(ColorParams 
   for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
 
   float r, J[6];
-  if (pixel < total && evaluate<TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
+  if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
     outer_products(J, r, acc);
 
   store_partial(acc, lds, workspace);
@@ -317,15 +457,35 @@ int fill_color(ColorParams& P, const vk_color_view* keyframe, const vk_color_vie
   P.Tcm = make_rt(Tcm->m);
   P.Tcm_dev = nullptr;
   P.state = nullptr;
+  P.mask = nullptr;
+  P.light.intensity = 1.0f;
+  P.light.position[0] = P.light.position[1] = P.light.position[2] = 0.0f;
+  P.Tcd = P.Tcm;
   return VK_OK;
+}
+
+int fill_light(ColorParams& P, const vk_light_terms* terms)
+{
+  if (!terms || !terms->frame_mask) return VK_ERR_ARGUMENT;
+  P.mask = terms->frame_mask;
+  P.light = terms->light;
+  P.Tcd = make_rt(terms->frame_Tcd.m);
+  return VK_OK;
+}
+
+template <bool LIGHT>
+void launch_partials_of(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
+{
+  if (translation_enabled)
+    hipLaunchKernelGGL((color_partial_kernel<LIGHT, true>), dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+  else
+    hipLaunchKernelGGL((color_partial_kernel<LIGHT, false>), dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
 }
 
 void launch_color_partials(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
 {
-  if (translation_enabled)
-    hipLaunchKernelGGL(color_partial_kernel<true>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
-  else
-    hipLaunchKernelGGL(color_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+  if (P.mask) launch_partials_of<true>(P, translation_enabled, partials, workspace, s);
+  else launch_partials_of<false>(P, translation_enabled, partials, workspace, s);
 }
 
 vk_transform identity_transform()
@@ -358,15 +518,53 @@ VK_API int vk_image_gradients(int width, int height, const float* src, float* gr
   return VK_OK;
 }
 
+static int residuals_impl(const vk_color_view* keyframe, const vk_color_view* frame, const vk_light_terms* terms,
+    bool light, const vk_transform* Tcm, float* residuals, void* stream)
+{
+  ColorParams P;
+  int rc = fill_color(P, keyframe, frame, Tcm, false);
+  if (rc != VK_OK) return rc;
+  if (light && (rc = fill_light(P, terms)) != VK_OK) return rc;
+  VK_REQUIRE(residuals);
+  const dim3 grid((keyframe->width + 63) / 64, (keyframe->height + 3) / 4);
+  if (light) hipLaunchKernelGGL(color_residuals_kernel<true>, grid, dim3(256), 0, vk_s(stream), P, residuals);
+  else hipLaunchKernelGGL(color_residuals_kernel<false>, grid, dim3(256), 0, vk_s(stream), P, residuals);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
 VK_API int vk_color_tracker_compute_residuals(const vk_color_view* keyframe, const vk_color_view* frame,
     const vk_transform* Tcm, float* residuals, void* stream)
 {
+  return residuals_impl(keyframe, frame, nullptr, false, Tcm, residuals, stream);
+}
+
+VK_API int vk_light_tracker_compute_residuals(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, float* residuals, void* stream)
+{
+  return residuals_impl(keyframe, frame, terms, true, Tcm, residuals, stream);
+}
+
+static int jacobian_impl(const vk_color_view* keyframe, const vk_color_view* frame, const vk_light_terms* terms,
+    bool light, const vk_transform* Tcm, int translation_enabled, float* jacobian, void* stream)
+{
   ColorParams P;
-  const int rc = fill_color(P, keyframe, frame, Tcm, false);
+  int rc = fill_color(P, keyframe, frame, Tcm, true);
   if (rc != VK_OK) return rc;
-  VK_REQUIRE(residuals);
+  if (light && (rc = fill_light(P, terms)) != VK_OK) return rc;
+  VK_REQUIRE(jacobian);
   const dim3 grid((keyframe->width + 63) / 64, (keyframe->height + 3) / 4);
-  hipLaunchKernelGGL(color_residuals_kernel, grid, dim3(256), 0, vk_s(stream), P, residuals);
+  hipStream_t s = vk_s(stream);
+  if (light)
+  {
+    if (translation_enabled) hipLaunchKernelGGL((color_jacobian_kernel<true, true>), grid, dim3(256), 0, s, P, jacobian);
+    else hipLaunchKernelGGL((color_jacobian_kernel<true, false>), grid, dim3(256), 0, s, P, jacobian);
+  }
+  else
+  {
+    if (translation_enabled) hipLaunchKernelGGL((color_jacobian_kernel<false, true>), grid, dim3(256), 0, s, P, jacobian);
+    else hipLaunchKernelGGL((color_jacobian_kernel<false, false>), grid, dim3(256), 0, s, P, jacobian);
+  }
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -374,28 +572,25 @@ VK_API int vk_color_tracker_compute_residuals(const vk_color_view* keyframe, con
 VK_API int vk_color_tracker_compute_jacobian(const vk_color_view* keyframe, const vk_color_view* frame,
     const vk_transform* Tcm, int translation_enabled, float* jacobian, void* stream)
 {
-  ColorParams P;
-  const int rc = fill_color(P, keyframe, frame, Tcm, true);
-  if (rc != VK_OK) return rc;
-  VK_REQUIRE(jacobian);
-  const dim3 grid((keyframe->width + 63) / 64, (keyframe->height + 3) / 4);
-  if (translation_enabled)
-    hipLaunchKernelGGL(color_jacobian_kernel<true>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
-  else
-    hipLaunchKernelGGL(color_jacobian_kernel<false>, grid, dim3(256), 0, vk_s(stream), P, jacobian);
-  VK_LAUNCH_CHECK();
-  return VK_OK;
+  return jacobian_impl(keyframe, frame, nullptr, false, Tcm, translation_enabled, jacobian, stream);
 }
 
-VK_API int vk_color_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
-    const vk_transform* Tcm, const vk_transform* Tcm_dev, int translation_enabled, float* workspace,
+VK_API int vk_light_tracker_compute_jacobian(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, int translation_enabled, float* jacobian, void* stream)
+{
+  return jacobian_impl(keyframe, frame, terms, true, Tcm, translation_enabled, jacobian, stream);
+}
+
+static int system_impl(const vk_color_view* keyframe, const vk_color_view* frame, const vk_light_terms* terms,
+    bool light, const vk_transform* Tcm, const vk_transform* Tcm_dev, int translation_enabled, float* workspace,
     float* hessian, float* gradient, void* stream)
 {
   ColorParams P;
   const vk_transform identity = identity_transform();
   if (!Tcm && Tcm_dev) Tcm = &identity;
-  const int rc = fill_color(P, keyframe, frame, Tcm, true);
+  int rc = fill_color(P, keyframe, frame, Tcm, true);
   if (rc != VK_OK) return rc;
+  if (light && (rc = fill_light(P, terms)) != VK_OK) return rc;
   VK_REQUIRE(workspace && hessian && gradient);
   P.Tcm_dev = Tcm_dev;
   const int partials = partial_count(keyframe->width, keyframe->height);
@@ -411,6 +606,22 @@ VK_API int vk_color_tracker_compute_system(const vk_color_view* keyframe, const 
       translation_enabled, hessian, gradient, A);
   VK_LAUNCH_CHECK();
   return VK_OK;
+}
+
+VK_API int vk_color_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* Tcm, const vk_transform* Tcm_dev, int translation_enabled, float* workspace,
+    float* hessian, float* gradient, void* stream)
+{
+  return system_impl(keyframe, frame, nullptr, false, Tcm, Tcm_dev, translation_enabled, workspace, hessian,
+      gradient, stream);
+}
+
+VK_API int vk_light_tracker_compute_system(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* Tcm, const vk_transform* Tcm_dev, int translation_enabled,
+    float* workspace, float* hessian, float* gradient, void* stream)
+{
+  return system_impl(keyframe, frame, terms, true, Tcm, Tcm_dev, translation_enabled, workspace, hessian,
+      gradient, stream);
 }
 
 VK_API int vk_color_tracker_solve_update(const float* hessian, const float* gradient, int translation_enabled,
@@ -430,15 +641,16 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
   return VK_OK;
 }
 
-VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
-    const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
+static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame, const vk_light_terms* terms,
+    bool light, const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
     vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
 {
   ColorParams P;
   const vk_transform identity = identity_transform();
-  const int rc = fill_color(P, keyframe, frame, &identity, true);
+  int rc = fill_color(P, keyframe, frame, &identity, true);
   if (rc != VK_OK) return rc;
+  if (light && (rc = fill_light(P, terms)) != VK_OK) return rc;
   VK_REQUIRE(frame_Tcd && keyframe_Twc && pose_dev && workspace && system && state_dev && iterations > 0);
   P.Tcm_dev = &pose_dev->Tcm;
   P.state = state_dev;
@@ -483,6 +695,25 @@ VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_
     VK_LAUNCH_CHECK();
   }
   return VK_OK;
+}
+
+VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
+    int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
+    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+{
+  return track_impl(keyframe, frame, nullptr, false, frame_Tcd, keyframe_Twc, pose_dev, iterations,
+      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, stream);
+}
+
+VK_API int vk_light_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
+    const vk_light_terms* terms, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
+    int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
+    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+{
+  VK_REQUIRE(terms);
+  return track_impl(keyframe, frame, terms, true, &terms->frame_Tcd, keyframe_Twc, pose_dev, iterations,
+      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, stream);
 }
 
 }  // extern "C"

@@ -155,6 +155,10 @@ class ColorView(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("projection", Projection)]
 
 
+class LightTerms(C.Structure):
+    _fields_ = [("frame_mask", C.c_void_p), ("light", Light), ("frame_Tcd", Transform)]
+
+
 class ColorPose(C.Structure):
     _fields_ = [("depth_to_world", Transform), ("Tcm", Transform)]
 
