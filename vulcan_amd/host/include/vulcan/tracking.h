@@ -15,6 +15,7 @@
 #include <vk.h>
 #include <vulcan/buffer.h>
 #include <vulcan/image.h>
+#include <vulcan/light.h>
 #include <vulcan/matrix.h>
 
 namespace vulcan
@@ -134,6 +135,35 @@ class ColorTracker : public Tracker
     Image frame_gradient_x_;
     Image frame_gradient_y_;
     Buffer<vk_color_pose> color_pose_;   // depth_to_world + derived Tcm, on the device
+};
+
+// ColorTracker with a shading model: where the frame mask is set the residual is
+// Ic - albedo * light.GetShading(Xcp, n), elsewhere the point-to-plane distance
+// (ref: light_tracker.h, light_tracker.cu, light_tracker.cpp). The keyframe's
+// colour image is read as albedo. Upstream's WriteDataFiles / WriteImage /
+// TraceImage debugging output (light_tracker.cpp:116-178) is not provided.
+class LightTracker : public ColorTracker
+{
+  public:
+    LightTracker();
+    virtual ~LightTracker();
+
+    const Light& GetLight() const;
+    void SetLight(const Light& light);
+
+    void ComputeResiduals(const Frame& frame, Buffer<float>& residuals);
+    void ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian);
+
+  protected:
+    void BeginSolve(const Frame& frame) override;
+    void ComputeSystem(const Frame& frame) override;
+    void TrackOnDevice(Frame& frame) override;
+    void ComputeFrameMask(const Frame& frame);
+    vk_light_terms GetTerms(const Frame& frame) const;
+
+    Light light_;
+    Image frame_mask_;
+    float depth_threshold_;
 };
 
 // Coarse-to-fine: half resolution first (15 iterations), then full (20).

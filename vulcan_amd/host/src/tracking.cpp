@@ -1,4 +1,4 @@
-// tracking.cpp — Tracker, DepthTracker, ColorTracker and PyramidTracker<T>
+// tracking.cpp — Tracker, DepthTracker, ColorTracker, LightTracker and PyramidTracker<T>
 // (ref: src/tracker.cpp, src/depth_tracker.cpp, src/depth_tracker.cu:272-378,
 //  src/color_tracker.cpp, src/color_tracker.cu:296-470, src/pyramid_tracker.cpp).
 #include <vulcan/tracking.h>
@@ -374,6 +374,90 @@ void ColorTracker::ApplyUpdate(Frame& frame, const Vector6f& update) const
   frame.depth_to_world_transform = (Transform::Translate(t) * Transform::Rotate(R)).Inverse();
 }
 
+// ---- LightTracker ----------------------------------------------------------------
+
+LightTracker::LightTracker() : depth_threshold_(0.2f) {}   // light_tracker.cpp:13-14
+
+LightTracker::~LightTracker() {}
+
+const Light& LightTracker::GetLight() const { return light_; }
+
+void LightTracker::SetLight(const Light& light) { light_ = light; }
+
+// ref: light_tracker.cu:548-564 (the kernel is the light integrator's)
+void LightTracker::ComputeFrameMask(const Frame& frame)
+{
+  frame_mask_.Resize(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+  const vk_frame f = frame.ToVk();
+  VK_ASSERT(vk_light_compute_frame_mask(&f, depth_threshold_, frame_mask_.GetData(), Device::GetStream()));
+}
+
+vk_light_terms LightTracker::GetTerms(const Frame& frame) const
+{
+  vk_light_terms t;
+  t.frame_mask = frame_mask_.GetData();
+  t.light = light_.ToVk();
+  t.frame_Tcd = frame.depth_to_color_transform.ToVk();
+  return t;
+}
+
+// ref: light_tracker.cpp:34-41
+void LightTracker::BeginSolve(const Frame& frame)
+{
+  ColorTracker::BeginSolve(frame);
+  ComputeFrameMask(frame);
+}
+
+// Upstream's ComputeResiduals / ComputeJacobian read frame_mask_ without computing
+// it (light_tracker.cu:569-577,613-623); here they compute it first.
+void LightTracker::ComputeResiduals(const Frame& frame, Buffer<float>& residuals)
+{
+  ComputeKeyframeIntensities();
+  ComputeFrameIntensities(frame);
+  ComputeFrameMask(frame);
+  residuals.Resize(GetResidualCount(frame));
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_light_terms terms = GetTerms(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_light_tracker_compute_residuals(&key, &frm, &terms, &Tcm, residuals.GetData(), Device::GetStream()));
+}
+
+void LightTracker::ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobian)
+{
+  ComputeKeyframeIntensities();
+  ComputeFrameIntensities(frame);
+  ComputeFrameGradients(frame);
+  ComputeFrameMask(frame);
+  jacobian.Resize(GetResidualCount(frame));
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_light_terms terms = GetTerms(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_light_tracker_compute_jacobian(&key, &frm, &terms, &Tcm, translation_enabled_ ? 1 : 0,
+      reinterpret_cast<float*>(jacobian.GetData()), Device::GetStream()));
+}
+
+void LightTracker::ComputeSystem(const Frame& frame)
+{
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_light_terms terms = GetTerms(frame);
+  const vk_transform Tcm = GetTcm(frame);
+  VK_ASSERT(vk_light_tracker_compute_system(&key, &frm, &terms, &Tcm, nullptr, translation_enabled_ ? 1 : 0,
+      workspace_.GetData(), system_.GetData(), system_.GetData() + 36, Device::GetStream()));
+}
+
+void LightTracker::TrackOnDevice(Frame& frame)
+{
+  const vk_color_view key = KeyframeView(), frm = FrameView(frame);
+  const vk_light_terms terms = GetTerms(frame);
+  const vk_transform key_Twc = GetKeyframeTwc();
+  VK_ASSERT(vk_memcpy_d2d(color_pose_.GetData(), pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
+  HookAdapter adapter = { reduce_hook_, reduce_user_ };
+  VK_ASSERT(vk_light_tracker_track(&key, &frm, &terms, &key_Twc, color_pose_.GetData(), max_iterations_,
+      translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
+  VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
+}
+
 // ---- PyramidTracker ---------------------------------------------------------------
 
 template <typename Tracker>
@@ -432,5 +516,6 @@ void PyramidTracker<Tracker>::Track(Frame& frame)
 
 template class PyramidTracker<DepthTracker>;
 template class PyramidTracker<ColorTracker>;
+template class PyramidTracker<LightTracker>;
 
 } // namespace vulcan

@@ -958,6 +958,90 @@ TEST(ColorTracker, Track)   // no upstream case
   ASSERT_TRUE(cost(frame) < 0.3 * before);
 }
 
+// ---- LightTracker (light_tracker_test.cu) ---------------------------------------------------
+
+// light_tracker_test.cu:12-189 CreateKeyframeY / CreateFrameY: a camera in front of
+// the textured world plane z = 1; `shaded` multiplies the albedo by the light's shading
+static std::shared_ptr<Frame> PlaneFrame(const Transform& Twc, const Light& light, bool shaded)
+{
+  const int w = 640, h = 480;
+  auto frame = std::make_shared<Frame>();
+  frame->depth_projection.SetFocalLength(547, 547);
+  frame->depth_projection.SetCenterPoint(320, 240);
+  frame->color_projection = frame->depth_projection;
+  frame->depth_to_world_transform = Twc;
+  const Vector3f origin = Twc.GetTranslation();
+  const Transform Tcw = Twc.Inverse();
+  auto world_point = [&](int x, int y)
+  {
+    const Vector3f Xcp = frame->depth_projection.Unproject(x + 0.5f, y + 0.5f);
+    const Vector3f dir = Vector3f(Twc * Vector4f(Xcp, 0));
+    const float length = (1 - origin[2]) / dir[2];
+    return Vector3f(origin + length * dir);
+  };
+  frame->depth_image = MakeDepth(w, h, [&](int x, int y) { return Vector3f(Tcw * Vector4f(world_point(x, y), 1))[2]; });
+  frame->color_image = MakeColor(w, h, [&](int x, int y)
+  {
+    const Vector3f Xwp = world_point(x, y);
+    const Vector3f Xcp = Vector3f(Tcw * Vector4f(Xwp, 1));
+    const Vector3f normal = Vector3f(Tcw * Vector4f(0, 0, -1, 0));
+    float c = 0.5f;
+    c += 0.245 * cosf(3.0 * M_PI * Xwp[0]);
+    c += 0.245 * cosf(3.0 * M_PI * Xwp[1]);
+    if (shaded) c *= light.GetShading(Xcp, normal);
+    return Vector3f(c, c, c);
+  });
+  frame->ComputeNormals();
+  return frame;
+}
+
+static void AssertSamePose(const Transform& a, const Transform& b, double eps)
+{
+  const Matrix4f diff = a.GetInverseMatrix() * b.GetMatrix();
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_NEAR(r == c ? 1 : 0, diff(r, c), eps);
+}
+
+TEST(LightTracker, Residuals)   // light_tracker_test.cu:530-561: the shaded keyframe against itself
+{
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.1f, 0.0f, 0.0f);
+  const Transform key_pose = Transform::Translate(0.0011f, -0.0019f, -0.5531f) * Transform::Rotate(0.9998715f, 0.0086385f, -0.0103759f, 0.0086385f);
+  auto keyframe = PlaneFrame(key_pose, light, false);
+  auto same = PlaneFrame(key_pose, light, true);
+  LightTracker tracker;
+  tracker.SetKeyframe(keyframe);
+  tracker.SetLight(light);
+  Buffer<float> buffer;
+  tracker.ComputeResiduals(*same, buffer);
+  std::vector<float> found(buffer.GetSize());
+  buffer.CopyToHost(found.data());
+  for (float r : found) ASSERT_NEAR(0, r, 1E-4);
+}
+
+TEST(LightTracker, Track)   // light_tracker_test.cu:586-669
+{
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.1f, 0.0f, 0.0f);
+  const Transform key_pose = Transform::Translate(0.0011f, -0.0019f, -0.5531f) * Transform::Rotate(0.9998715f, 0.0086385f, -0.0103759f, 0.0086385f);
+  const Transform frame_pose = Transform::Translate(0.0010f, -0.002f, -0.4030f) * Transform::Rotate(0.9998719f, 0.0085884f, -0.0104268f, 0.0085884f);
+  auto keyframe = PlaneFrame(key_pose, light, false);
+  auto frame = PlaneFrame(frame_pose, light, true);
+  LightTracker tracker;
+  tracker.SetKeyframe(keyframe);
+  tracker.SetTranslationEnabled(true);
+  tracker.SetLight(light);
+
+  for (int i = 0; i < 20; ++i) tracker.Track(*frame);                 // from the true pose: stays
+  AssertSamePose(frame_pose, frame->depth_to_world_transform, 1E-5);
+
+  frame->depth_to_world_transform = Transform::Translate(0.1f, 0.1f, 0.1f) *
+      Transform::Rotate(0.999871f, 0.008638f, -0.010375f, 0.008638f) * frame_pose;
+  for (int i = 0; i < 20; ++i) tracker.Track(*frame);                 // perturbed: comes back
+  AssertSamePose(frame_pose, frame->depth_to_world_transform, 1E-5);
+}
+
 // ---- Detector (no upstream case: tests/detector_test.cu is empty) -------------------------
 
 TEST(Detector, Constructor)   // detector.cu:66-72, 214-221
