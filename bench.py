@@ -231,6 +231,17 @@ def extra_workload(args):
     if track and world > 1:
         tracker.tracker.reduce_hook = vd.allreduce_system   # rigid rig: one system for all cameras
 
+    # SetView / Integrate / Trace go straight to the C ABI with descriptors built once
+    # (the api.* wrappers rebuild their ctypes structs on every call: ~35 us per frame)
+    lib, stream = api.lib(), api.stream()
+    vdesc, fdesc, kdesc = vol.desc(), frame.desc(), key.desc()
+    vref, fref, kref, pref, lref = (C.byref(x) for x in (vdesc, fdesc, kdesc, integ.params, integ.light))
+    vb = tracer.view_bounds
+    bref = C.byref(vb)
+    mask = integ.compute_frame_mask(frame)
+    m_ptr = C.c_void_p(mask.data_ptr())
+    d_ptr, c_ptr, n_ptr = (C.c_void_p(t.data_ptr()) for t in (key.depth, key.color, key.normals))
+
     def step(i):
         if track and i > 0:
             frame.depth_to_world = poses[i - 1]             # previous pose as the initial guess
@@ -238,9 +249,15 @@ def extra_workload(args):
             tracker.track(frame)                            # one 128-byte pose readback per level
         frame.depth_to_world = poses[i]                     # ground truth keeps the map consistent
         key.depth_to_world = poses[i]
-        vol.set_view(frame)
-        integ.integrate(frame)
-        tracer.trace(key)
+        fdesc.depth_to_world = poses[i]
+        kdesc.depth_to_world = poses[i]
+        vb.valid = 0
+        rc = lib.vk_volume_set_view(vref, fref, stream)
+        rc |= lib.vk_light_compute_frame_mask(fref, integ.depth_threshold, m_ptr, stream)   # light_integrator.cu:270-275
+        rc |= lib.vk_integrate_ahead(vref, pref, fref, 2, lref, m_ptr, bref, stream)
+        rc |= lib.vk_trace_ahead(vref, kref, bref, d_ptr, c_ptr, n_ptr, stream)
+        if rc:
+            raise api.VkError(f"frame {i}: C ABI returned {rc}")
 
     for i in range(args.warmup):
         step(i)

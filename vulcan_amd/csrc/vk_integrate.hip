@@ -411,13 +411,13 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
   }
 
   bool dirty = false;
+  float dist[4];   // the voxel's current distance after the depth pass (or as stored)
 
 #pragma unroll
   for (int k = 0; k < 4; ++k)
   {
     float* vox = tile + (k * 64 + lane) * 5;
-    float distance_value = 0.0f;
-    bool have_distance = false;
+    dist[k] = old_d[k];
     const bool valid = (u_valid >> k) & 1u;
 
     if (DEPTH)
@@ -435,80 +435,96 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
       const float dist_weight = dw + 1;
       const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
       const float new_distance = (prev_dist + curr_dist) / dist_weight;
-      distance_value = update ? new_distance : old_d[k];
-      have_distance = true;   // distance_value is the voxel's current distance either way
+      dist[k] = update ? new_distance : old_d[k];
       old_w[k] = update ? ((weights & 0xffff0000u) | (uint16_t)new_dw) : weights;
       if (update)
       {
-        vox[0] = distance_value;
+        vox[0] = dist[k];
         vox[4] = __uint_as_float(old_w[k]);
       }
       dirty |= update;
     }
+  }
 
-    if (COLOR != COLOR_NONE)
+  if (COLOR != COLOR_NONE)
+  {
+    // Colour pass in three sweeps over the lane's four voxels, so that the image
+    // gathers of all four are in flight together instead of one dependent chain per
+    // voxel: (1) which voxels take colour and from which pixel, (2) the gathers,
+    // (3) the running averages. Conditions are pure, so testing |dist| < 1 before the
+    // mask (the reference tests the mask first) selects the same voxels.
+    f3 Xcp[4];
+    int color_index[4], depth_index[4];
+    bool want[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
     {
       const int vz = u_half * 4 + k;
       const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
-      const f3 Xcp = xform_point(P.Tcw, add3(u_off, voxel_offset));
+      Xcp[k] = xform_point(P.Tcw, add3(u_off, voxel_offset));
       float cu, cv;
-      project(P.kc, Xcp, cu, cv);
+      project(P.kc, Xcp[k], cu, cv);
       const bool color_valid = cu >= 0 && cu < P.width && cv >= 0 && cv < P.height;
-      const float dist = have_distance ? distance_value : old_d[k];
+      const bool valid = (u_valid >> k) & 1u;
+      want[k] = color_valid && fabsf(dist[k]) < 1.0f && (COLOR == COLOR_PLAIN || valid);
+      color_index[k] = want[k] ? (int)cv * P.width + (int)cu : 0;
+      depth_index[k] = (COLOR == COLOR_LIGHT && want[k]) ? (int)u_dv[k] * P.width + (int)u_du[k] : 0;
+    }
 
-      if (COLOR == COLOR_PLAIN && color_valid && fabsf(dist) < 1.0f)
+    if (COLOR == COLOR_LIGHT)
+    {
+      float m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = want[k] ? P.mask[depth_index[k]] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) want[k] = want[k] && m[k] > 0.5f;
+    }
+
+    f3 pixel_color[4], pixel_normal[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      pixel_color[k] = make3(0, 0, 0);
+      pixel_normal[k] = make3(0, 0, 0);
+      if (want[k])
       {
-        // color_integrator.cu:100-134
-        const int image_index = (int)cv * P.width + (int)cu;
-        const uint32_t weights = old_w[k];
-        const int16_t cw = (int16_t)(weights >> 16);
-        const float cwf = cw;
-        const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-        const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
-            P.color[3 * image_index + 2]);
-        const float color_weight = cw + 1;
-        const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-        const f3 c = div3(add3(prev_color, curr_color), color_weight);
-        vox[1] = c.x;
-        vox[2] = c.y;
-        vox[3] = c.z;
-        vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-        dirty = true;
+        pixel_color[k] = make3(P.color[3 * color_index[k] + 0], P.color[3 * color_index[k] + 1],
+            P.color[3 * color_index[k] + 2]);
+        if (COLOR == COLOR_LIGHT)
+          pixel_normal[k] = make3(P.normals[3 * depth_index[k] + 0], P.normals[3 * depth_index[k] + 1],
+              P.normals[3 * depth_index[k] + 2]);
       }
+    }
 
-      if (COLOR == COLOR_LIGHT && valid && color_valid)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      if (!want[k]) continue;
+      float* vox = tile + (k * 64 + lane) * 5;
+      f3 curr_color = pixel_color[k];
+
+      if (COLOR == COLOR_LIGHT)
       {
         // light_integrator.cu:197-248
-        const int depth_index = (int)u_dv[k] * P.width + (int)u_du[k];
-        const int color_index = (int)cv * P.width + (int)cu;
-
-        if (P.mask[depth_index] > 0.5f && fabsf(dist) < 1.0f)
-        {
-          f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
-              P.color[3 * color_index + 2]);
-          const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
-              P.normals[3 * depth_index + 2]);
-          const f3 Xcn = xform_dir(P.Tcd, Xdn);
-          const float shading = light_shading(P.light, Xcp, Xcn);
-
-          if (shading > 0.05f)
-          {
-            curr_color = div3(curr_color, shading);
-            const uint32_t weights = old_w[k];
-            const int16_t cw = (int16_t)(weights >> 16);
-            const float color_weight = cw + 1;
-            const float cwf = cw;
-            const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-            const f3 c = div3(add3(prev_color, curr_color), color_weight);
-            const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-            vox[1] = c.x;
-            vox[2] = c.y;
-            vox[3] = c.z;
-            vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-            dirty = true;
-          }
-        }
+        const f3 Xcn = xform_dir(P.Tcd, pixel_normal[k]);
+        const float shading = light_shading(P.light, Xcp[k], Xcn);
+        if (!(shading > 0.05f)) continue;
+        curr_color = div3(curr_color, shading);
       }
+
+      // color_integrator.cu:100-134 / light_integrator.cu:233-246
+      const uint32_t weights = old_w[k];
+      const int16_t cw = (int16_t)(weights >> 16);
+      const float cwf = cw;
+      const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
+      const float color_weight = cw + 1;
+      const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+      const f3 c = div3(add3(prev_color, curr_color), color_weight);
+      vox[1] = c.x;
+      vox[2] = c.y;
+      vox[3] = c.z;
+      vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
+      dirty = true;
     }
   }
 
