@@ -179,3 +179,45 @@ def test_bounds_ahead_hits_and_falls_back(api, orc):
     sync()
     assert np.array_equal(tracer.bounds.cpu().numpy(), hf_bounds[3])
     assert np.array_equal(out.depth.cpu().numpy(), hf_bounds[0])
+
+
+def test_pool_beyond_4_gib_gives_the_same_images(api):
+    """A 12.9 GB voxel pool (byte offsets past 2^32, slots past 2^20) against a small
+    one: slot numbers and table sizes differ, the fused surface and its raycast
+    cannot. Checks 64-bit addressing end to end without a CPU mirror of the pool."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 << 30:
+        pytest.skip("needs 20 GB of free HBM")
+    w, h = 320, 240
+    k = T.Projection.make(270, 270, 160, 120)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.3 + 0.2 * np.sin(x / 23.0) * np.cos(y / 17.0)).astype(np.float32)
+    color = scenes.checker_color(w, h, 0.2, 0.8)
+    outputs = []
+    for main, excess in ((16384, 2048), (1200007, 60001)):
+        vol = api.Volume(main, excess, voxel_length=0.008, truncation_length=0.04)
+        integ, tracer = api.ColorIntegrator(vol), api.Tracer(vol)
+        for i in range(3):
+            pose = scenes.orbit_pose(i, 2.0)
+            frame = api.Frame(depth, k, pose, color=color)
+            for _ in range(3):
+                vol.set_view(frame)
+            integ.integrate(frame)
+        out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, scenes.orbit_pose(1, 2.0))
+        tracer.trace(out)
+        sync()
+        ctr = vol.read_counters()
+        assert ctr[T.VK_CTR_DROPPED] == 0
+        if main > 1 << 20:
+            # the free list hands out the highest slots first: the blocks in use sit past 4 GiB
+            slots = vol.host_entries()["data"]
+            assert int(slots.max()) * 10240 > 1 << 32
+        outputs.append((vol.visible_count, out.depth.cpu().numpy(), out.color.cpu().numpy(), out.normals.cpu().numpy()))
+        del vol, integ, tracer, out
+        torch.cuda.empty_cache()
+    small, big = outputs
+    assert small[0] == big[0] > 500
+    for a, b in zip(small[1:], big[1:]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert (small[1] > 0).mean() > 0.8
