@@ -119,9 +119,9 @@ def main():
         api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
         return e
 
-    # HIP events around the integrate launch of every EVENT_STRIDE-th timed frame: an
-    # event record costs the stream a few microseconds, so bracketing every frame would
-    # slow the very loop being timed
+    # HIP events (created without the system-scope fence, vk_event_create) around the
+    # integrate launch of every EVENT_STRIDE-th timed frame: even so a pair of records
+    # costs the stream ~1.7 us, so bracketing every frame would slow the loop being timed
     EVENT_STRIDE = 4
     sampled = list(range(0, args.steps, EVENT_STRIDE))
     events = {i: (make_event(), make_event()) for i in sampled}

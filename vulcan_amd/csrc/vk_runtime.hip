@@ -126,7 +126,8 @@ int vk_event_create(void** event)
 {
   VK_REQUIRE(event);
   hipEvent_t e;
-  VK_CHECK(hipEventCreate(&e));
+  // timing events for kernels of one stream: no system-scope release (cache flush) at the record
+  VK_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
   *event = e;
   return VK_OK;
 }
