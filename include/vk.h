@@ -618,7 +618,8 @@ VK_API int vk_probe_block_rmw_mode(int mode);   /* 0 plain, 1 nt stores, 2 nt lo
 /* Timing-only ablations of the depth integrate kernel (variant 1..3 produce WRONG
  * voxels on purpose: 1 = no depth gather, 2 = no update, 3 = no LDS staging). */
 /* Selects a timing-only ablation of the raycast kernel for subsequent launches
- * (0 = product; 1 = no trilinear sampling, 2 = in-block sampling only). */
+ * (0 = product; 1 = no trilinear sampling, 2 = in-block sampling only,
+ * 3 = every trilinear sample reads the same few cache lines). */
 VK_API int vk_probe_points_variant(int variant);
 VK_API int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame,
     int variant, void* stream);

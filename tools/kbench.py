@@ -69,6 +69,7 @@ def main():
         "trace": lambda: tracer.trace(out),
         "points_v1": lambda: (api.lib().vk_probe_points_variant(1), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
         "points_v2": lambda: (api.lib().vk_probe_points_variant(2), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
+        "points_v3": lambda: (api.lib().vk_probe_points_variant(3), tracer.compute_points(frame, out2, col2), api.lib().vk_probe_points_variant(0)),
         "integ_block": lambda: (api.lib().vk_probe_integrate(None, None, None, 10, None), integ.integrate(frame), api.lib().vk_probe_integrate(None, None, None, 15, None)),
         "integ_pipe4": lambda: (api.lib().vk_probe_integrate(None, None, None, 14, None), integ.integrate(frame)),
         "integ_pipe5": lambda: (api.lib().vk_probe_integrate(None, None, None, 15, None), integ.integrate(frame)),

@@ -251,6 +251,14 @@ __device__ __forceinline__ int color_weight_of(float packed)
 // colour update increments the weight), so its colour is the initial (0,0,0):
 // the 12 colour bytes are only fetched when the weight is positive.
 
+// Address of voxel `voxel` (0..511) of pool slot `slot`; 64-bit throughout, a pool
+// may hold tens of millions of blocks (288 GB of HBM). Measured: 32-bit offsets for
+// pools under 4 GiB change nothing (the kernel is not bound by address arithmetic).
+__device__ __forceinline__ const float* voxel_address(const float* pool, int slot, int voxel)
+{
+  return pool + ((size_t)slot * VK_BLOCK_VOXELS + (size_t)voxel) * 5;
+}
+
 // One-entry cache of the last hash lookup: consecutive march steps and the
 // eight trilinear corners mostly stay in one block, and the table is read-only
 // during the kernel, so the cached answer is the answer a fresh walk would give.
@@ -385,8 +393,13 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
     const bool has0 = slot[c0] >= 0, has1 = slot[c1] >= 0;
     const bool split = sx[0] != sx[1];   // x-neighbours in different blocks
     // absent blocks read voxel 0 of the pool and are overridden with Voxel::Empty() below
-    const float* a0 = voxf + (size_t)(has0 ? VK_BLOCK_VOXELS * slot[c0] + row_voxel + lx[0] : 0) * 5;
-    const float* a1 = split ? voxf + (size_t)(has1 ? VK_BLOCK_VOXELS * slot[c1] + row_voxel + lx[1] : 0) * 5 : a0 + 5;
+    const float* a0 = voxel_address(voxf, has0 ? slot[c0] : 0, has0 ? row_voxel + lx[0] : 0);
+    const float* a1 = split ? voxel_address(voxf, has1 ? slot[c1] : 0, has1 ? row_voxel + lx[1] : 0) : a0 + 5;
+    if (P.variant == 3)   // timing only: every lane samples the same handful of cache lines
+    {
+      a0 = voxf + (size_t)(row_voxel + lx[0]) * 5;
+      a1 = a0 + 5;
+    }
 
     const float d0 = a0[0];
     // (w0, d1) when contiguous; a split lane reads (b0, w0) instead so the 8-byte
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
           const int vy = vmini(f2i(wy), 7);
           const int vz = vmini(f2i(wz), 7);
 
-          sdf = reinterpret_cast<const float*>(P.voxels)[(size_t)(VK_BLOCK_VOXELS * data + vz * 64 + vy * 8 + vx) * 5];
+          sdf = voxel_address(reinterpret_cast<const float*>(P.voxels), data, vz * 64 + vy * 8 + vx)[0];
           sample = (sdf <= 0.1f && sdf >= -0.5f);
         }
 
