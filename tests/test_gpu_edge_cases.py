@@ -221,3 +221,67 @@ def test_pool_beyond_4_gib_gives_the_same_images(api):
     for a, b in zip(small[1:], big[1:]):
         assert np.array_equal(a, b, equal_nan=True)
     assert (small[1] > 0).mean() > 0.8
+
+
+def test_separate_colour_camera(api, orc):
+    """Colour camera with its own intrinsics and a depth->colour offset (a real RGB-D
+    rig): the colour and light integrators project voxels into it, the colour and
+    light trackers work in it. Everything else in the suite uses registered cameras."""
+    import torch
+    w, h = 320, 240
+    kd = T.Projection.make(270, 271, 160.5, 119.25)
+    kc = T.Projection.make(281, 279, 157.0, 123.5)
+    Tcd = T.Transform.translate(0.025, -0.003, 0.004) * T.Transform.rotate(0.9999, 0.004, -0.01, 0.006)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.3 + 0.2 * np.sin(x / 23.0) * np.cos(y / 17.0)).astype(np.float32)
+    color = (0.25 + 0.5 * scenes.checker_color(w, h, 0.2, 0.8) * (0.6 + 0.4 * np.sin(x / 11.0))[..., None]).astype(np.float32)
+    pose = scenes.tracer_test_pose()
+
+    def make(p):
+        hf = orc.HostFrame(depth, kd, p, color=color, color_projection=kc, depth_to_color=Tcd)
+        hf.compute_normals()
+        df = api.Frame(depth, kd, p, color=color, normals=hf.normals, color_projection=kc, depth_to_color=Tcd)
+        return hf, df
+
+    hf, df = make(pose)
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+
+    # colour integrator (fused and two-pass), then light integrator on a second volume
+    for kind in ("color", "light"):
+        hv, dv = make_pair(api, orc, 16384, 2048, 0.008, 0.04)
+        for _ in range(4):
+            hv.set_view(hf, orc.POLICY_MAXKEY)
+            dv.set_view(df)
+        orc.integrate_depth(hv, hf)
+        if kind == "color":
+            orc.integrate_color(hv, hf)
+            api.ColorIntegrator(dv).integrate(df)
+        else:
+            mask = orc.light_frame_mask(hf, 0.2)
+            orc.integrate_light_color(hv, hf, light, mask)
+            integ = api.LightIntegrator(dv)
+            integ.light = light
+            integ.integrate(df)
+        sync()
+        assert_volume_equal(dv, hv)
+        assert (hv.voxels["color_weight"] > 0).sum() > 10000
+
+    # colour and light trackers: keyframe = this frame, frame = slightly moved copy
+    moved = T.Transform.translate(0.003, -0.002, 0.001) * pose
+    hf2, df2 = make(moved)
+    ks, fs = orc.ColorSide(hf, False), orc.ColorSide(hf2, True)
+    Tcm = orc.color_tcm(hf, hf2)
+    ct = api.ColorTracker()
+    ct.keyframe = df
+    assert np.array_equal(np.array(ct.tcm(df2).m[:]), np.array(Tcm.m[:]))
+    assert np.array_equal(ct.compute_residuals(df2).cpu().numpy().view(np.uint32), orc.color_residuals(ks, fs, Tcm).view(np.uint32))
+    assert np.array_equal(ct.compute_jacobian(df2).cpu().numpy().view(np.uint32), orc.color_jacobian(ks, fs, Tcm, True).view(np.uint32))
+    lt = api.LightTracker()
+    lt.keyframe = df
+    lt.light = light
+    mask = orc.light_frame_mask(hf2, 0.2)
+    terms = orc.light_terms(hf2, light, mask)
+    dmask = torch.from_numpy(mask).cuda()
+    assert np.array_equal(lt.compute_residuals(df2, dmask).cpu().numpy().view(np.uint32), orc.light_residuals(ks, fs, terms, Tcm).view(np.uint32))
+    assert np.array_equal(lt.compute_jacobian(df2, dmask).cpu().numpy().view(np.uint32), orc.light_jacobian(ks, fs, terms, Tcm, True).view(np.uint32))
+    assert np.count_nonzero(orc.light_residuals(ks, fs, terms, Tcm)) > 10000
