@@ -37,6 +37,11 @@ def main():
     frame = api.Frame(depth, k, poses[0], color=color)
     out = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, poses[0])
     integ = api.ColorIntegrator(vol) if args.color else api.DepthIntegrator(vol)
+    light_integ = None
+    if args.color:
+        frame.compute_normals()
+        light_integ = api.LightIntegrator(vol)
+        light_integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
     tracer = api.Tracer(vol)
     for i in range(args.frames):
         frame.depth_to_world = poses[i]
@@ -63,6 +68,7 @@ def main():
         "handle": lambda: vol.handle_allocation_requests(),
         "visibility": lambda: vol.update_block_visibility(frame),
         "integrate": lambda: integ.integrate(frame),
+        "integrate_light": lambda: light_integ.integrate(frame) if light_integ else None,
         "block_bounds": lambda: tracer.compute_block_bounds(frame),
         "points": lambda: tracer.compute_points(frame, out2, col2),
         "normals": lambda: out.compute_normals(),
