@@ -285,3 +285,58 @@ def test_separate_colour_camera(api, orc):
     assert np.array_equal(lt.compute_residuals(df2, dmask).cpu().numpy().view(np.uint32), orc.light_residuals(ks, fs, terms, Tcm).view(np.uint32))
     assert np.array_equal(lt.compute_jacobian(df2, dmask).cpu().numpy().view(np.uint32), orc.light_jacobian(ks, fs, terms, Tcm, True).view(np.uint32))
     assert np.count_nonzero(orc.light_residuals(ks, fs, terms, Tcm)) > 10000
+
+
+def test_plain_entry_points_equal_the_ahead_ones(api, orc):
+    """vk_integrate_depth / _depth_color / _depth_light and vk_trace (the entry points a
+    maintainer binds one to one) give the same voxels and images as vk_integrate_ahead /
+    vk_trace_ahead, which the Python and C++ class layers call."""
+    import ctypes as C
+    import torch
+    w, h = 320, 240
+    k = T.Projection.make(270, 270, 160, 120)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.3 + 0.2 * np.sin(x / 23.0) * np.cos(y / 17.0)).astype(np.float32)
+    pose = scenes.tracer_test_pose()
+    hf, df = frames(api, orc, depth, k, pose, color=scenes.checker_color(w, h, 0.2, 0.8))
+    df.compute_normals()
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    lib = api.lib()
+    for mode in (0, 1, 2):
+        vols = []
+        for ahead in (False, True):
+            vol = api.Volume(16384, 2048, voxel_length=0.008, truncation_length=0.04)
+            tracer = api.Tracer(vol)
+            for _ in range(4):
+                vol.set_view(df)
+            params = T.Integrator.default()
+            mask = torch.empty((h, w), dtype=torch.float32, device="cuda")
+            api.check(lib.vk_light_compute_frame_mask(api._ref(df.desc()), 0.2, api._ptr(mask), api.stream()), "mask")
+            out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose)
+            out.color = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            out.normals = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+            v, f, o = api._ref(vol.desc()), api._ref(df.desc()), api._ref(out.desc())
+            if ahead:
+                api.check(lib.vk_integrate_ahead(v, api._ref(params), f, mode, api._ref(light), api._ptr(mask),
+                                                 api._ref(tracer.view_bounds), api.stream()), "ahead")
+                assert tracer.view_bounds.valid == 1
+                api.check(lib.vk_trace_ahead(v, o, api._ref(tracer.view_bounds), api._ptr(out.depth), api._ptr(out.color),
+                                             api._ptr(out.normals), api.stream()), "trace_ahead")
+            else:
+                if mode == 0:
+                    api.check(lib.vk_integrate_depth(v, api._ref(params), f, api.stream()), "depth")
+                elif mode == 1:
+                    api.check(lib.vk_integrate_depth_color(v, api._ref(params), f, api.stream()), "depth_color")
+                else:
+                    api.check(lib.vk_integrate_depth_light(v, api._ref(params), api._ref(light), api._ptr(mask), f,
+                                                           api.stream()), "depth_light")
+                api.check(lib.vk_trace(v, o, 0.1, 5.0, api._ptr(tracer.bounds_scratch), tracer.BOUNDS_W, tracer.BOUNDS_H,
+                                       api._ptr(out.depth), api._ptr(out.color), api._ptr(out.normals), api.stream()), "trace")
+            sync()
+            vols.append((vol.host_voxels().tobytes(), out.depth.cpu().numpy(), out.color.cpu().numpy(),
+                         out.normals.cpu().numpy(), tracer.bounds.cpu().numpy()))
+        a, b = vols
+        assert a[0] == b[0]
+        for p, q in zip(a[1:], b[1:]):
+            assert np.array_equal(p, q, equal_nan=True)
+        assert (a[1] > 0).mean() > 0.5
