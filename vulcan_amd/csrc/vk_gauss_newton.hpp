@@ -87,8 +87,20 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
 
   if (threadIdx.x < 256)
   {
+    // slice s adds partials s, s + 8, s + 16, ... in that order; the loads of eight
+    // terms are issued together (a 640x480 image has 300 partials, 1280x960 has 1200:
+    // one L2 round trip per term made this the longest part of an iteration)
     float v = 0.0f;
-    for (int j = s; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
+    int j = s;
+    for (; j + 56 < partials; j += 64)
+    {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = workspace[(size_t)(j + 8 * u) * kSysStride + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
     slices[s][c] = v;
   }
   __syncthreads();
