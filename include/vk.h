@@ -168,7 +168,10 @@ VK_API int vk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
 VK_API int vk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 VK_API int vk_memset(void* dst, int value, size_t bytes, void* stream);
 
-/* Timing helpers (hipEvent) so hosts without HIP headers can time kernels. */
+/* Timing helpers (hipEvent) so hosts without HIP headers can time kernels. The
+ * events carry no system-scope fence (hipEventDisableSystemFence): they order and
+ * time work on a stream, they do not publish device writes to the host — use
+ * vk_stream_synchronize or a blocking copy for that. */
 VK_API int vk_event_create(void** event);
 VK_API int vk_event_destroy(void* event);
 VK_API int vk_event_record(void* event, void* stream);
