@@ -340,3 +340,38 @@ def test_plain_entry_points_equal_the_ahead_ones(api, orc):
         for p, q in zip(a[1:], b[1:]):
             assert np.array_equal(p, q, equal_nan=True)
         assert (a[1] > 0).mean() > 0.5
+
+
+def test_reduce_hook_between_system_and_solve(api, orc):
+    """The multi-GPU hook is called once per Gauss-Newton step with the packed
+    48-float system on the device. Two identical ranks: the all-reduce doubles the system,
+    which leaves every step — and so the final pose — bit-identical (a power-of-two scale
+    is exact through the LDL^T solve)."""
+    import torch
+    import color_scenes as cs
+    k = cs.projection()
+    kd, kc = cs.keyframe_images()
+    key_h = orc.HostFrame(kd, k, cs.keyframe_pose(), color=kc)
+    key_h.compute_normals()
+    key = api.Frame(kd, k, cs.keyframe_pose(), color=kc, normals=key_h.normals)
+    start = T.Transform.translate(0.004, -0.002, 0.001) * cs.keyframe_pose()
+    for cls in (api.DepthTracker, api.ColorTracker):
+        poses, calls = [], []
+        for hooked in (False, True):
+            tracker = cls()
+            tracker.keyframe = key
+            tracker.max_iterations = 6
+            if hooked:
+                def hook(system):
+                    assert system.is_cuda and system.numel() == 48
+                    system.mul_(2.0)
+                    calls.append(1)
+                    return system
+                tracker.reduce_hook = hook
+            frame = api.Frame(key.depth, k, start, color=key.color, normals=key.normals)
+            tracker.track(frame)
+            sync()
+            poses.append(np.array(frame.depth_to_world.m[:], dtype=np.float32))
+        assert len(calls) == 6
+        assert np.array_equal(poses[0].view(np.uint32), poses[1].view(np.uint32))
+        assert not np.array_equal(poses[0], np.array(start.m[:], dtype=np.float32))

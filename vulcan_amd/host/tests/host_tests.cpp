@@ -804,6 +804,38 @@ TEST(DepthTracker, Track)   // no upstream case; mirrors LightTracker.Track (lig
   for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_NEAR(r == c ? 1 : 0, M(r, c), 5e-4);
 }
 
+static int g_hook_calls = 0;
+
+static void DoublingHook(float* system_device, int count, void*)   // what a 2-rank all-reduce of equal systems does
+{
+  std::vector<float> host(count);
+  VK_ASSERT(vk_memcpy_d2h(host.data(), system_device, sizeof(float) * count, Device::GetStream()));
+  for (float& v : host) v *= 2.0f;
+  VK_ASSERT(vk_memcpy_h2d(system_device, host.data(), sizeof(float) * count, Device::GetStream()));
+  ++g_hook_calls;
+}
+
+TEST(DepthTracker, ReduceHook)   // the hook sits between the sums and the solve
+{
+  auto keyframe = CurvedKeyframe();
+  const Transform start = Transform::Translate(0.002f, -0.001f, 0.003f) * Transform::Rotate(0.999995f, 0.002f, -0.0015f, 0.001f);
+  Matrix4f poses[2];
+  for (int hooked = 0; hooked < 2; ++hooked)
+  {
+    Frame frame = *keyframe;
+    frame.depth_to_world_transform = start;
+    DepthTracker tracker;
+    tracker.SetKeyframe(keyframe);
+    tracker.SetMaxIterations(5);
+    g_hook_calls = 0;
+    if (hooked) tracker.SetReduceHook(DoublingHook, nullptr);
+    tracker.Track(frame);
+    poses[hooked] = frame.depth_to_world_transform.GetMatrix();
+    ASSERT_EQ(hooked ? 5 : 0, g_hook_calls);
+  }
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_EQ(poses[0](r, c), poses[1](r, c));   // x2 is exact
+}
+
 TEST(PyramidTracker, Track)   // pyramid_tracker.cpp:52-90
 {
   auto keyframe = CurvedKeyframe();
