@@ -162,6 +162,28 @@ def main():
     alg_bytes = nvis * BYTES_PER_BLOCK + W * H * 4
     achieved = float(alg_bytes[sampled].sum() / (np.sum(kernel_ms) * 1e-3) / 1e9)   # the sampled launches
 
+    # what this GPU sustains on (a) a plain float4 copy and (b) the integrate kernel's own
+    # access pattern with the arithmetic removed ("peak: measured"), outside
+    # the timed region; reported next to the 8 TB/s spec figure the fraction is taken of
+    def probe(fn, bytes_moved, reps=10):
+        e0, e1 = make_event(), make_event()
+        fn()
+        lib.vk_event_record(e0, stream)
+        for _ in range(reps):
+            fn()
+        lib.vk_event_record(e1, stream)
+        ms = C.c_float()
+        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
+        return bytes_moved * reps / (ms.value * 1e-3) / 1e9
+
+    buf_a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    buf_b = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    copy_gbs = probe(lambda: lib.vk_probe_stream_copy(C.c_void_p(buf_b.data_ptr()), C.c_void_p(buf_a.data_ptr()),
+                                                      buf_a.numel(), stream), 2 * buf_a.numel())
+    vdesc2 = vol.desc()
+    rmw_gbs = probe(lambda: lib.vk_probe_block_rmw(C.byref(vdesc2), stream), float(nvis[-1]) * 2 * 10240)
+    del buf_a, buf_b
+
     frames_all = vd.sum_over_ranks(args.steps, device="cuda")
     result = {
         "metric": "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels",
@@ -191,6 +213,7 @@ def main():
             "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
             "avg_launch_us": float(np.mean(kernel_ms) * 1e3),
             "launches_timed": len(sampled),
+            "measured_copy_GBps": copy_gbs, "measured_block_rmw_GBps": rmw_gbs,
         },
     }
 
