@@ -239,24 +239,32 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   uint32_t shash[kProbe];
   bool walking = usable;
 
+  // the three products of the hash (volume.cu:168-180) follow the walk by addition:
+  // a step changes one coordinate by +-1, i.e. its product by +-prime (mod 2^32), which
+  // replaces three quarter-rate 32-bit multiplies per crossed block by one add
+  uint32_t hx = (uint32_t)bx * 73856093u, hy = (uint32_t)by * 19349669u, hz = (uint32_t)bz * 83492791u;
+  const uint32_t dhx = step_x < 0 ? 0u - 73856093u : 73856093u;
+  const uint32_t dhy = step_y < 0 ? 0u - 19349669u : 19349669u;
+  const uint32_t dhz = step_z < 0 ? 0u - 83492791u : 83492791u;
+
 #pragma unroll
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     sbx[sidx] = bx; sby[sidx] = by; sbz[sidx] = bz;
-    shash[sidx] = walking ? block_hash(bx, by, bz, K) : 0xffffffffu;
+    shash[sidx] = walking ? (hx ^ hy ^ hz) % K : 0xffffffffu;
 
     if (walking)
     {
       // :242-295 advance to the next block; `walking` drops when the end block is passed
       if (tmax_x < tmax_y)
       {
-        if (tmax_x < tmax_z) { bx += step_x; if (bx == ex + step_x) walking = false; else tmax_x += tdelta_x; }
-        else                 { bz += step_z; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
+        if (tmax_x < tmax_z) { bx += step_x; hx += dhx; if (bx == ex + step_x) walking = false; else tmax_x += tdelta_x; }
+        else                 { bz += step_z; hz += dhz; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
       }
       else
       {
-        if (tmax_y < tmax_z) { by += step_y; if (by == ey + step_y) walking = false; else tmax_y += tdelta_y; }
-        else                 { bz += step_z; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
+        if (tmax_y < tmax_z) { by += step_y; hy += dhy; if (by == ey + step_y) walking = false; else tmax_y += tdelta_y; }
+        else                 { bz += step_z; hz += dhz; if (bz == ez + step_z) walking = false; else tmax_z += tdelta_z; }
       }
     }
   }
