@@ -277,6 +277,7 @@ struct BlockCache
 // table is read-only during the kernel, so a cached answer is the answer a fresh
 // walk would give.
 constexpr int kDirEntries = 64;
+constexpr int kMaxChain = 1 << 24;
 
 // Entry = the block's coordinates modulo 4 per axis: any 4x4x4 neighbourhood of
 // blocks (16 cm at 5 mm voxels, far more than one wave's 8x8 pixels see in a
@@ -292,7 +293,10 @@ __device__ __forceinline__ int dir_index(int bx, int by, int bz)
 __device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by, int bz)
 {
   Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
-  while (!entry_is(entry, bx, by, bz) && entry.next != -1) entry = load_entry(P.entries, (uint32_t)entry.next);
+  // a chain is at most the excess region long; the cap only guarantees that a wave
+  // leaves the loop if it is handed a corrupt table (a cycle would otherwise hang the GPU)
+  for (int guard = 0; !entry_is(entry, bx, by, bz) && entry.next != -1 && guard < kMaxChain; ++guard)
+    entry = load_entry(P.entries, (uint32_t)entry.next);
   return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
 }
 

@@ -136,7 +136,8 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
     bool found = false;
     uint32_t index = hash_code;
 
-    while (entry.next != -1)
+    // bounded by the excess region: a corrupt table (a cycle) must not hang the GPU
+    for (int guard = 0; entry.next != -1 && guard < v.excess_block_count; ++guard)
     {
       index = (uint32_t)entry.next;
       entry = load_entry(v.hash_entries, index);
