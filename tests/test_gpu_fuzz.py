@@ -19,7 +19,7 @@ def random_pose(rng, scale=1.0):
     return T.Transform.translate(*t) * T.Transform.rotate(*q)
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("VK_FUZZ_FIRST", "0")), int(__import__("os").environ.get("VK_FUZZ_LAST", "10"))))
 def test_random_configuration(api, orc, seed):
     import torch
     rng = np.random.default_rng(1000 + seed)
