@@ -118,3 +118,20 @@ def test_solve_update_moves_towards_the_keyframe(orc, sides):
         h, g = orc.color_system(key_side, frm_side, pose.Tcm, True)
         orc.color_solve_update(h, g, Tcd, key_Twc, pose, True)
     assert costs[-1] < 0.5 * costs[0]
+
+
+def test_gradients_equal_sobel_over_eight(orc):
+    """image_test.cu:36-99 Image.GetGradients: on the test's 640x480 image the result
+    equals a 3x3 Sobel filter / 8 to 1e-6 two pixels inside the border."""
+    w, h = 640, 480
+    y, x = np.mgrid[0:h, 0:w]
+    f32 = np.float32
+    value = (f32(0.25) + f32(0.25) * np.cos((64 * np.pi * x / (w - 1)).astype(np.float32), dtype=np.float32)).astype(np.float32)
+    value = value + (f32(0.25) + f32(0.25) * np.cos((64 * np.pi * y / (h - 1)).astype(np.float32), dtype=np.float32)).astype(np.float32)
+    image = (value * value).astype(np.float32)
+    gx, gy = orc.image_gradients(image)
+    p = image.astype(np.float64)
+    sx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    sy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    assert np.abs(gx[1:-1, 1:-1] - sx / 8)[1:-1, 1:-1].max() < 1e-6
+    assert np.abs(gy[1:-1, 1:-1] - sy / 8)[1:-1, 1:-1].max() < 1e-6
