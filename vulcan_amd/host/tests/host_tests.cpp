@@ -133,6 +133,93 @@ TEST(Math, KnownAnswers)
   ASSERT_EQ(3, GetKernelBlocks(1025, 512));
 }
 
+TEST(Transform, InverseSwapsTheTwoMatrices)   // transform_test.cpp:26-49
+{
+  const Transform a = Transform::Translate(0.1f, -0.3f, 0.9f) * Transform::Rotate(0.5925f, 0.7040f, -0.2221f, 0.3226f);
+  const Transform b = a.Inverse();
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+    {
+      ASSERT_FLOAT_EQ(a.GetInverseMatrix()(j, i), b.GetMatrix()(j, i));
+      ASSERT_FLOAT_EQ(a.GetMatrix()(j, i), b.GetInverseMatrix()(j, i));
+    }
+}
+
+TEST(Transform, RotateMatrix)   // transform_test.cpp:51-85
+{
+  Matrix3f expected;
+  expected(0, 0) =  0.6932f; expected(1, 0) = -0.6950f; expected(2, 0) =  0.1910f;
+  expected(0, 1) =  0.0696f; expected(1, 1) = -0.1992f; expected(2, 1) = -0.9775f;
+  expected(0, 2) =  0.7174f; expected(1, 2) =  0.6909f; expected(2, 2) = -0.0898f;
+  const Transform transform = Transform::Rotate(expected);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+    {
+      ASSERT_NEAR(expected(j, i), transform.GetMatrix()(j, i), 1E-4);
+      ASSERT_NEAR(expected(j, i), transform.GetInverseMatrix()(i, j), 1E-4);
+    }
+  const Vector3f t = transform.GetTranslation();
+  ASSERT_EQ(0, t[0]); ASSERT_EQ(0, t[1]); ASSERT_EQ(0, t[2]);
+}
+
+TEST(Transform, Translate)   // transform_test.cpp:132-180
+{
+  const Vector3f expected(1.1f, -2.7f, 3.9f);
+  Transform transform = Transform::Translate(expected);
+  Vector3f found = transform.GetTranslation();
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(expected[i], found[i]);
+  found = Vector3f(transform * Vector4f(0, 0, 0, 1));
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(expected[i], found[i]);
+  transform = transform.Inverse();
+  found = transform.GetTranslation();
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(-expected[i], found[i]);
+  found = Vector3f(transform * Vector4f(0, 0, 0, 1));
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(-expected[i], found[i]);
+  transform = Transform::Translate(expected[0], expected[1], expected[2]);
+  found = Vector3f(transform * Vector4f(0, 0, 0, 1));
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(expected[i], found[i]);
+}
+
+TEST(Projection, ProjectAndUnproject)   // projection_test.cpp:58-140
+{
+  Projection projection;
+  projection.SetFocalLength(325, 315);
+  projection.SetCenterPoint(325, 235);
+  Vector2f found = projection.Project(0, 0, 1);
+  ASSERT_FLOAT_EQ(325, found[0]); ASSERT_FLOAT_EQ(235, found[1]);
+  const Vector3f point(23.4f, -0.725f, 31.2f);
+  found = projection.Project(point);
+  ASSERT_FLOAT_EQ((325 * point[0] + 325 * point[2]) / point[2], found[0]);
+  ASSERT_FLOAT_EQ((315 * point[1] + 235 * point[2]) / point[2], found[1]);
+  Vector3f ray = projection.Unproject(projection.GetCenterPoint());
+  ASSERT_FLOAT_EQ(0, ray[0]); ASSERT_FLOAT_EQ(0, ray[1]); ASSERT_FLOAT_EQ(1, ray[2]);
+  ray = projection.Unproject(projection.GetCenterPoint(), 17.4f);
+  ASSERT_FLOAT_EQ(0, ray[0]); ASSERT_FLOAT_EQ(0, ray[1]); ASSERT_FLOAT_EQ(17.4f, ray[2]);
+  const Vector2f uv(112.4f, 401.3f);                       // K^-1 * (u, v, 1) * depth
+  ray = projection.Unproject(uv, 2.5f);
+  ASSERT_FLOAT_EQ(2.5f * (uv[0] - 325) / 325, ray[0]);
+  ASSERT_FLOAT_EQ(2.5f * (uv[1] - 235) / 315, ray[1]);
+  ASSERT_FLOAT_EQ(2.5f, ray[2]);
+  const Vector2f back = projection.Project(ray);            // round trip
+  ASSERT_NEAR(uv[0], back[0], 1e-3); ASSERT_NEAR(uv[1], back[1], 1e-3);
+}
+
+TEST(Vector, NormsAndDot)   // matrix_test.cpp:60-230
+{
+  const Vector3f a(1.5f, -2.0f, 0.5f), b(0.25f, 4.0f, -1.0f);
+  ASSERT_FLOAT_EQ(1.5f * 1.5f + 4.0f + 0.25f, a.SquaredNorm());
+  ASSERT_FLOAT_EQ(std::sqrt(6.5f), a.Norm());
+  ASSERT_FLOAT_EQ(1.5f * 0.25f - 8.0f - 0.5f, a.Dot(b));
+  const Vector3f n = a.Normalized();
+  ASSERT_NEAR(1.0, n.Norm(), 1e-6);
+  for (int i = 0; i < 3; ++i) ASSERT_FLOAT_EQ(a[i] / std::sqrt(6.5f), n[i]);
+  Vector3f c = a;
+  c.Normalize();
+  for (int i = 0; i < 3; ++i) ASSERT_EQ(n[i], c[i]);
+  const Vector3f x = Vector3f(1, 0, 0).Cross(Vector3f(0, 1, 0));
+  ASSERT_EQ(0, x[0]); ASSERT_EQ(0, x[1]); ASSERT_EQ(1, x[2]);
+}
+
 TEST(Exception, What)
 {
   try { VULCAN_THROW("boom"); }
