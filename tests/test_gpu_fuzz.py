@@ -71,3 +71,59 @@ def test_random_configuration(api, orc, seed):
         assert np.array_equal(out.color.cpu().numpy(), want[1])
         assert np.array_equal(out.normals.cpu().numpy(), want[2], equal_nan=True)
     assert dv.visible_count > 50
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_tracker_inputs(api, orc, seed):
+    """Residuals and Jacobians of the three trackers on random ragged images with holes,
+    separate colour intrinsics and a depth->colour offset: device vs oracle, bit for bit."""
+    import torch
+    rng = np.random.default_rng(5000 + seed)
+    w, h = int(rng.integers(65, 260)), int(rng.integers(50, 200))
+    kd = T.Projection.make(0.9 * w + rng.normal() * 4, 0.9 * w + rng.normal() * 4, 0.5 * w + rng.normal() * 2, 0.5 * h + rng.normal() * 2)
+    kc = T.Projection.make(kd.fx * 1.03, kd.fy * 0.98, kd.cx + 1.5, kd.cy - 2.0) if seed % 2 else kd
+    Tcd = T.Transform.translate(0.02, -0.004, 0.003) * T.Transform.rotate(0.9999, 0.003, -0.008, 0.005) if seed % 2 else T.Transform.identity()
+    y, x = np.mgrid[0:h, 0:w]
+    base = 0.9 + 0.5 * rng.random()
+    depth = (base + 0.1 * np.sin(x / (9.0 + 9 * rng.random())) * np.cos(y / (7.0 + 9 * rng.random()))).astype(np.float32)
+    depth[rng.random((h, w)) < 0.03] = 0.0
+    color = (0.2 + 0.6 * (0.5 + 0.5 * np.sin(x / 5.0 + rng.random()) * np.cos(y / 6.0))[..., None] * (0.7 + 0.3 * rng.random(3))).astype(np.float32)
+    color[rng.random((h, w)) < 0.01] = 0.995                     # saturated pixels: masked out by the light tracker
+    pose_k = random_pose(rng)
+    pose_f = random_pose(rng, 0.05) * pose_k
+
+    def make(p):
+        hf = orc.HostFrame(depth, kd, p, color=color, color_projection=kc, depth_to_color=Tcd)
+        hf.compute_normals()
+        return hf, api.Frame(depth, kd, p, color=color, normals=hf.normals, color_projection=kc, depth_to_color=Tcd)
+
+    hk, dk = make(pose_k)
+    hf, df = make(pose_f)
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+    dt = api.DepthTracker()
+    dt.keyframe = dk
+    assert np.array_equal(bits(dt.compute_residuals(df).cpu().numpy()), bits(orc.icp_residuals(hk, hf)))
+    assert np.array_equal(bits(dt.compute_jacobian(df).cpu().numpy()), bits(orc.icp_jacobian(hk, hf, True)))
+
+    ks, fs = orc.ColorSide(hk, False), orc.ColorSide(hf, True)
+    Tcm = orc.color_tcm(hk, hf)
+    ct = api.ColorTracker()
+    ct.keyframe = dk
+    assert np.array_equal(bits(ct.compute_residuals(df).cpu().numpy()), bits(orc.color_residuals(ks, fs, Tcm)))
+    assert np.array_equal(bits(ct.compute_jacobian(df).cpu().numpy()), bits(orc.color_jacobian(ks, fs, Tcm, True)))
+
+    light = T.Light.make(1.5 + rng.random(), tuple(rng.normal(size=3) * 0.05))
+    lt = api.LightTracker()
+    lt.keyframe = dk
+    lt.light = light
+    mask = orc.light_frame_mask(hf, 0.2)
+    dev_mask = lt.compute_frame_mask(df)
+    sync()
+    assert np.array_equal(dev_mask.cpu().numpy(), mask)
+    terms = orc.light_terms(hf, light, mask)
+    assert np.array_equal(bits(lt.compute_residuals(df, dev_mask).cpu().numpy()), bits(orc.light_residuals(ks, fs, terms, Tcm)))
+    for translation in (True, False):
+        lt.translation_enabled = translation
+        assert np.array_equal(bits(lt.compute_jacobian(df, dev_mask).cpu().numpy()), bits(orc.light_jacobian(ks, fs, terms, Tcm, translation)))
+    assert np.count_nonzero(orc.color_residuals(ks, fs, Tcm)) > 0.3 * w * h
