@@ -31,9 +31,14 @@ def test_cpp_frame_loop_runs_and_tracks():
     m = re.search(r"frames 60 .* fps ([\d.]+) +visible (\d+) +allocated (\d+) +dropped (\d+)", out)
     assert m, out
     assert int(m.group(2)) > 3000 and int(m.group(4)) == 0
-    # with tracking on, the ICP must follow the 0.5 deg/frame yaw: cos(15 deg) = 0.9659 after 60 frames
-    out = subprocess.run([exe, "60", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
-    assert re.search(r"dropped 0 +tracking on", out), out
+    # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: the shipped app's
+    # set-up (PyramidTracker<LightTracker> + LightIntegrator). The depth image is the same from
+    # every pose, so tracking must hold the pose it starts from.
+    for mode, label in (("1", "depth"), ("2", "light")):
+        out = subprocess.run([exe, "60", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+        assert re.search(r"dropped 0 +tracking " + label, out), out
+        row = re.search(r"final pose row0: ([-\d.]+) ([-\d.]+) ([-\d.]+) ([-\d.]+)", out)
+        assert row and abs(float(row.group(1)) - 1.0) < 1e-3 and abs(float(row.group(4))) < 0.01, out
 
 
 def test_host_layer_builds_and_links_only_the_c_abi():
