@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the fusion + raycast hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): a 640x480 depth-only sequence fused into a
-5 mm hashed volume, Volume(65024, 8192) (apps/vulcan/vulcan.cu:12-13). One
-"step" = one frame = Volume::SetView -> DepthIntegrator::Integrate ->
-Tracer::Trace through the C ABI (include/vk.h). The camera sits at the centre of
-a 2 m sphere and yaws 0.5 deg per frame, so the depth image (resident in HBM) is
-the same closed form every frame while new blocks are allocated every frame.
+Headline workload (`--workload rgbd`, the default): BASELINE.json's metric is "RGB-D
+frames/sec (integrate+raycast), 640x480 @ 5 mm voxels", so one step = one 640x480 RGB-D
+frame = Volume::SetView -> LightIntegrator::Integrate (frame mask, depth, shaded colour:
+configs[2]'s integrators) -> Tracer::Trace, through the C ABI (include/vk.h), into
+Volume(65024, 8192) (apps/vulcan/vulcan.cu:12-13). The camera sits at the centre of a 2 m
+sphere and yaws 0.5 deg per frame: the depth image (resident in HBM) is the same closed
+form every frame while new blocks are allocated every frame.
+
+  --workload depth      BASELINE configs[1]: depth-only sequence, DepthIntegrator + Tracer
+  --workload rgbd-icp   configs[2] in full: PyramidTracker<DepthTracker> against the previous
+                        raycast, then SetView + LightIntegrator + Tracer
+
+The default run prints ONE JSON line for `rgbd` that also carries the other two workloads
+under "other_workloads" (same loop, same sizes, fewer steps).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank owns a replica volume and its own frame
-sequence (weak scaling, no data-path collective: SURVEY.md §8e); value = frames
-of all ranks / max-over-ranks time.
+N > 1: `python bench.py --gpus N` starts its own N ranks (fresh child processes, one per
+GPU, before anything touches the GPU); under an external launcher (torchrun: RANK /
+WORLD_SIZE set) it joins that job instead. Every rank owns a replica volume and its own
+frames (weak scaling, no data-path collective: SURVEY.md §8e); value = frames of all ranks
+/ max-over-ranks time. After the timed loop the ranks run the one step of the path that
+does exchange data — the rigid multi-camera rig of configs[4]: per rank the ICP normal
+system of its own view, one 48-float all-reduce over RCCL per Gauss-Newton iteration, the
+same solve on every rank — and report it under "collective".
 
-Prints ONE JSON line on rank 0 with `roofline` (integrate kernel, HBM bound)
-and `cpu_baseline` (the CPU oracle timed on a bounded sample of the same frames).
+`roofline`: the dominant kernel of the workload (the fused integrate kernel), timed with HIP
+events on the launch stream inside the timed region; `cpu_baseline`: the CPU oracle on a
+bounded sample of the same frames plus BASELINE configs[0] (dense 128^3, 1 and all cores).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,7 +51,13 @@ VOXEL, TRUNC = 0.005, 0.04
 MAIN, EXCESS = 65024, 8192
 RADIUS, YAW_STEP = 2.0, 0.5
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0            # same guide: what a float4 copy sustains (79 % of spec)
+L3_BYTES = 256 << 20             # Infinity Cache
 BYTES_PER_BLOCK = 4 + 16 + 2 * 512 * 20   # index + entry + voxel read + write
+IMAGE_BYTES = {"depth": W * H * 4,                          # depth
+               "rgbd": W * H * (4 + 12 + 12 + 4)}           # + colour + normals + mask (light integrator)
+METRIC = "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels"
+LIGHT = (2.0, (0.025, 0.08, 0.0))                           # apps/vulcan/vulcan.cu:87-88
 
 
 def sphere_room_depth(k):
@@ -48,19 +69,362 @@ def sphere_room_depth(k):
     return (RADIUS / np.sqrt(rx * rx + ry * ry + 1.0)).astype(np.float32)
 
 
+# --------------------------------------------------------------------- launching ----
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh children, one per GPU, started
+    BEFORE this process imports torch or touches the GPU (a process that has initialised the
+    GPU must never be re-executed). The parent only waits and propagates failure."""
+    port = free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30          # one rank died: the others cannot finish
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()                              # exact children, by handle
+            break
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------- frame loops ----
+
+class FrameLoop:
+    """One rank's replica volume and frame loop, calling the C ABI with descriptors built
+    once, the way a C++ caller would (the api.* wrappers rebuild ctypes structs per call)."""
+
+    def __init__(self, workload, poses, volumes=1):
+        import torch
+        from vulcan_amd import api, vk_types as T
+        import scenes
+        self.api, self.T, self.torch = api, T, torch
+        self.workload, self.poses = workload, poses
+        self.lib, self.stream = api.lib(), api.stream()
+        k = T.Projection.make(*scenes.APP_INTRINSICS)
+        self.k = k
+        self.depth_np = sphere_room_depth(k)
+        self.color_np = scenes.checker_color(W, H, 0.1, 0.9) if workload != "depth" else None
+        self.frame = api.Frame(self.depth_np, k, poses[0], color=self.color_np)
+        if workload != "depth":
+            self.frame.compute_normals()
+        self.key = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
+                             color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
+                             normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
+        self.fdesc, self.kdesc = self.frame.desc(), self.key.desc()
+        self.fref, self.kref = C.byref(self.fdesc), C.byref(self.kdesc)
+        self.out_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self.key.depth, self.key.color, self.key.normals))
+        self.mode = 0 if workload == "depth" else 2
+        # `volumes` > 1: the same sequence applied to several replica volumes in lock step, so
+        # that consecutive integrate launches touch different voxels (the past-L3 measurement)
+        self.vols = []
+        for _ in range(volumes):
+            vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+            integ = api.DepthIntegrator(vol) if workload == "depth" else api.LightIntegrator(vol)
+            if workload != "depth":
+                integ.light = T.Light.make(*LIGHT)
+            tracer = api.Tracer(vol)
+            vdesc = vol.desc()
+            self.vols.append(dict(vol=vol, integ=integ, tracer=tracer, vdesc=vdesc, vref=C.byref(vdesc),
+                                  pref=C.byref(integ.params), bref=C.byref(tracer.view_bounds),
+                                  lref=C.byref(integ.light) if workload != "depth" else None))
+        self.mask = None
+        if workload != "depth":
+            self.mask = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        self.m_ptr = None if self.mask is None else C.c_void_p(self.mask.data_ptr())
+        self.depth_threshold = 0.2                                  # light_integrator.cu:256
+        self.tracker = None
+        if workload == "rgbd-icp":
+            self.tracker = api.PyramidTracker()
+        self.iterations = []
+
+    def step(self, i, ev=None, v=0):
+        lib, s, vv = self.lib, self.stream, self.vols[v]
+        if self.tracker is not None and i > 0:
+            # tracker -> SetView -> Integrate -> Trace (apps/vulcan/vulcan.cu:300-325): the frame
+            # starts from the previous pose and is tracked against the previous raycast
+            self.frame.depth_to_world = self.poses[i - 1]
+            self.tracker.keyframe = self.key
+            self.tracker.track(self.frame)
+        pose = self.poses[i]                       # ground truth keeps the map consistent
+        self.frame.depth_to_world = pose
+        self.key.depth_to_world = pose
+        self.fdesc.depth_to_world = pose
+        self.kdesc.depth_to_world = pose
+        vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
+        rc = lib.vk_volume_set_view(vv["vref"], self.fref, s)                       # volume.cu:430-437
+        if self.mode == 2:
+            rc |= lib.vk_light_compute_frame_mask(self.fref, self.depth_threshold, self.m_ptr, s)   # light_integrator.cu:277-293
+        if ev:
+            lib.vk_event_record(ev[0], s)
+        rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr,
+                                     vv["bref"], s)                                 # *_integrator.cu Integrate
+        if ev:
+            lib.vk_event_record(ev[1], s)
+        if ev and len(ev) > 2:
+            lib.vk_event_record(ev[2], s)
+        rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, s)   # tracer.cpp:41-47
+        if ev and len(ev) > 2:
+            lib.vk_event_record(ev[3], s)
+        if rc:
+            raise self.api.VkError(f"frame {i}: C ABI returned {rc}")
+
+    def make_event(self):
+        e = C.c_void_p()
+        self.api.check(self.lib.vk_event_create(C.byref(e)), "vk_event_create")
+        return e
+
+    def elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        self.api.check(self.lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
+        return ms.value
+
+
+def visible_counts(poses):
+    """Allocation depends only on the depth image and the pose and is deterministic, so an
+    untimed replay of SetView over the same poses gives the visible-block count every
+    integrate launch of the timed run saw."""
+    from vulcan_amd import api, vk_types as T
+    import scenes
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+    frame = api.Frame(sphere_room_depth(k), k, poses[0])
+    out = []
+    for p in poses:
+        frame.depth_to_world = p
+        vol.set_view(frame)
+        out.append(vol.visible_count)
+    return np.array(out, dtype=np.float64), vol
+
+
+def run_workload(workload, poses, warmup, steps, vd, with_roofline):
+    """W untimed + K timed frames; returns the JSON fields of that workload."""
+    import torch
+    loop = FrameLoop(workload, poses)
+    # HIP events (created without the system-scope fence, vk_event_create) around the integrate
+    # launch: a pair of records costs the stream ~1.7 us, so long runs sample every 4th frame
+    stride = 1 if steps <= 64 else 4
+    sampled = list(range(0, steps, stride)) if with_roofline else []
+    events = {i: tuple(loop.make_event() for _ in range(4)) for i in sampled}
+
+    for i in range(warmup):
+        loop.step(i)
+    vd.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loop.step(warmup + i, events.get(i))
+    torch.cuda.synchronize()
+    vd.barrier()
+    elapsed = vd.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    frames_all = vd.sum_over_ranks(steps, device="cuda")
+
+    out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+    if with_roofline:
+        integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled]
+        trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled]
+        out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, sampled
+    ctr = loop.vols[0]["vol"].read_counters()
+    out["_counters"] = ctr
+    if loop.tracker is not None:
+        out["gauss_newton_steps_last_frame"] = int(loop.tracker.tracker.state.cpu()[0])
+    return out, loop
+
+
+def past_l3(workload, poses, warmup, frames, nvis, replicas=8):
+    """The integrate kernel with its working set pushed past the 256 MiB Infinity Cache: the
+    same sequence is applied to `replicas` volumes in lock step, so between two integrate
+    launches on one volume the other replicas' voxels (replicas x ~75 MB) have gone through
+    the caches. Returns algorithmic GB/s over the event-bracketed launches."""
+    import torch
+    loop = FrameLoop(workload, poses, volumes=replicas)
+    for i in range(warmup):
+        for v in range(replicas):
+            loop.step(i, v=v)
+    pairs = []
+    for i in range(warmup, warmup + frames):
+        for v in range(replicas):
+            ev = (loop.make_event(), loop.make_event())
+            loop.step(i, ev, v=v)
+            pairs.append((i, ev))
+    torch.cuda.synchronize()
+    ms = np.array([loop.elapsed_ms(e[0], e[1]) for _, e in pairs])
+    alg = np.array([nvis[i] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if workload == "depth" else "rgbd"] for i, _ in pairs])
+    voxel_ws = float(np.mean([nvis[i] for i, _ in pairs])) * 10240 * replicas
+    return {"achieved": float(alg.sum() / (ms.sum() * 1e-3) / 1e9), "avg_launch_us": float(ms.mean() * 1e3),
+            "launches_timed": len(pairs), "replica_volumes": replicas,
+            "voxel_working_set_bytes": voxel_ws, "exceeds_l3": bool(voxel_ws > 2 * L3_BYTES)}
+
+
+def probes(loop, nvis_last):
+    """What this GPU sustains outside the timed region: float4 copies of 1 GiB (four launch
+    shapes, best reported) and the integrate kernel's block read-modify-write with the
+    arithmetic removed (tools/probe, libvk_probe.so — not part of the product)."""
+    import torch
+    path = os.path.join(ROOT, "vulcan_amd", "lib", "libvk_probe.so")
+    if not os.path.exists(path):
+        return {}
+    pl = C.CDLL(path)
+    pl.vk_probe_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    pl.vk_probe_stream_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    pl.vk_probe_block_rmw.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    s = loop.stream
+
+    def timed(fn, bytes_moved, reps=6):
+        e0, e1 = loop.make_event(), loop.make_event()
+        fn()
+        loop.lib.vk_event_record(e0, s)
+        for _ in range(reps):
+            fn()
+        loop.lib.vk_event_record(e1, s)
+        return bytes_moved * reps / (loop.elapsed_ms(e0, e1) * 1e-3) / 1e9
+
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    sink = torch.zeros(4, dtype=torch.float32, device="cuda")
+    ap, bp = C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr())
+    shapes = {}
+    for shape, name in enumerate(("one_float4_per_lane", "four_float4_per_lane", "persistent_grid", "four_float4_nontemporal")):
+        shapes[name] = timed(lambda: pl.vk_probe_stream_copy(bp, ap, n, shape, s), 2 * n)
+    read = timed(lambda: pl.vk_probe_stream_read(ap, n, C.c_void_p(sink.data_ptr()), s), n)
+    del a, b
+    vref = loop.vols[0]["vref"]
+    rmw = timed(lambda: pl.vk_probe_block_rmw(vref, 0, s), float(nvis_last) * 2 * 10240, reps=10)
+    return {"measured_copy_GBps": max(shapes.values()), "copy_shapes_GBps": shapes, "measured_read_GBps": read,
+            "measured_block_rmw_GBps": rmw, "copy_buffer_bytes": n}
+
+
+# ----------------------------------------------------------------- multi-GPU rig ----
+
+def rig_collective(rank, world, vd):
+    """BASELINE configs[4]: a rigid rig of `world` cameras, one per GPU. Every rank evaluates
+    the ICP normal system of its own view (a19); the packed 48-float system is all-reduced
+    over RCCL once per Gauss-Newton iteration; every rank then runs the same solve and applies
+    the same world-frame increment to its own camera."""
+    import torch
+    import torch.distributed as dist
+    from vulcan_amd import api, vk_types as T
+    import scenes
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    y, x = np.mgrid[0:H, 0:W]
+    depth = (1.5 + 0.08 * np.cos(3.0 * x / W + rank) * np.sin(2.0 * y / H + 0.5 * rank)).astype(np.float32)
+    rig_pose = scenes.yaw(360.0 * rank / max(world, 1))                 # camera `rank` of the ring
+    key = api.Frame(depth, k, rig_pose)
+    key.compute_normals()
+    # the whole rig has moved by `error` in the world frame: every camera's pose is off by it
+    error = T.Transform.translate(0.003, -0.002, 0.004) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    frame = api.Frame(depth, k, error * rig_pose, normals=key.normals)
+    tracker = api.DepthTracker()
+    tracker.keyframe = key
+    tracker.reduce_hook = vd.allreduce_system
+
+    def one():
+        frame.depth_to_world = error * rig_pose
+        return tracker.track(frame)
+
+    one()
+    torch.cuda.synchronize()
+    vd.barrier()
+    frames = 20
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        got = one()
+    torch.cuda.synchronize()
+    track_ms = vd.max_over_ranks((time.perf_counter() - t0) / frames * 1e3, device="cuda")
+    iterations = int(tracker.state.cpu()[0])
+
+    # the bare collective: 48 floats, device memory, compute stream
+    buf = torch.ones(48, dtype=torch.float32, device="cuda")
+    for _ in range(10):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    vd.barrier()
+    reps = 200
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    allreduce_us = vd.max_over_ranks((time.perf_counter() - t0) / reps * 1e6, device="cuda")
+
+    # every rank solved the same system: the last update vector must be identical everywhere
+    upd = tracker.update.clone()
+    gathered = [torch.empty_like(upd) for _ in range(world)]
+    dist.all_gather(gathered, upd)
+    identical = all(torch.equal(g, gathered[0]) for g in gathered)
+    residual = float(np.abs((got.matrix() @ rig_pose.inverse_matrix()) - np.eye(4)).max())
+    out = {"pattern": "all-reduce(sum) of the packed ICP system, 48 x f32, once per Gauss-Newton iteration",
+           "backend": dist.get_backend(), "ranks": dist.get_world_size(), "allreduce_us": allreduce_us,
+           "iterations_per_frame": iterations, "track_ms_per_frame": track_ms,
+           "update_identical_on_all_ranks": bool(identical), "pose_error_after_track": residual}
+    out["vk_comm"] = vk_comm_rig(rank, world, vd, tracker, key, frame, error * rig_pose)
+    return out
+
+
+def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
+    """The same rig step through the shipped C binding (libvk_comm.so: vk_comm_* over RCCL,
+    no Python between the Gauss-Newton iterations). Failure here is reported, not fatal: the
+    torch.distributed numbers above stand on their own."""
+    try:
+        import torch
+        import torch.distributed as dist
+        from vulcan_amd import comm
+        c = comm.Communicator.from_torch_group(rank, world)
+        tracker.reduce_hook = None
+        frame.depth_to_world = start
+        c.track(tracker, frame)
+        torch.cuda.synchronize()
+        vd.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            frame.depth_to_world = start
+            c.track(tracker, frame)
+        torch.cuda.synchronize()
+        ms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
+        us = c.time_allreduce(200)
+        us = vd.max_over_ranks(us, device="cuda")
+        it = int(tracker.state.cpu()[0])
+        c.close()
+        return {"ok": True, "allreduce_us": us, "track_ms_per_frame": ms, "iterations_per_frame": it}
+    except Exception as e:     # noqa: BLE001  (reported in the JSON line)
+        return {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+
+
+# --------------------------------------------------------------------------- main ----
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle sample (0 = skip)")
-    ap.add_argument("--workload", default="depth", choices=["depth", "rgbd", "rgbd-icp"],
-                    help="depth = BASELINE configs[1] (the headline line); rgbd = configs[2] without tracking "
-                         "(light integrator + tracer); rgbd-icp = configs[2] with the pyramid ICP tracker. "
-                         "The extra workloads print the same JSON shape without roofline/cpu_baseline.")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget (0 = skip)")
+    ap.add_argument("--workload", default="rgbd", choices=["rgbd", "depth", "rgbd-icp"])
+    ap.add_argument("--only", action="store_true", help="skip the other workloads, probes and the past-L3 pass")
     args = ap.parse_args()
-    if args.workload != "depth":
-        return extra_workload(args)
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     import torch
     from vulcan_amd import api, dist as vd, vk_types as T
@@ -70,280 +434,198 @@ def main():
     assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank % torch.cuda.device_count())   # == local_rank on a full node
-    lib = api.lib()
+    api.lib()
 
-    k = T.Projection.make(*scenes.APP_INTRINSICS)
-    depth_np = sphere_room_depth(k)
-    total_frames = args.warmup + args.steps
+    total = args.warmup + args.steps
     # every rank walks the same arc, offset so ranks do not share poses
-    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total_frames)]
+    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
+    wl = args.workload
+    res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True)
 
-    def fresh():
-        vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
-        frame = api.Frame(depth_np, k, poses[0])
-        out = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
-                        color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
-                        normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
-        return vol, frame, out, api.DepthIntegrator(vol), api.Tracer(vol)
+    nvis, _ = visible_counts(poses)
+    nvis_timed = nvis[args.warmup:]
+    image_bytes = IMAGE_BYTES["depth" if wl == "depth" else "rgbd"]
+    alg = nvis_timed * BYTES_PER_BLOCK + image_bytes
+    sampled = res.pop("_sampled")
+    integ_ms, trace_ms = np.array(res.pop("_integrate_ms")), np.array(res.pop("_trace_ms"))
+    achieved = float(alg[sampled].sum() / (integ_ms.sum() * 1e-3) / 1e9)
+    ctr = res.pop("_counters")
+    frame_bytes = float(alg.mean())
+    voxel_ws = float(nvis_timed.mean()) * 10240
 
-    vol, frame, out, integ, tracer = fresh()
-    stream = api.stream()
-
-    # The timed loop calls the C ABI directly with descriptors built once, the way a
-    # C++ caller would (the api.* wrappers rebuild their ctypes structs per call).
-    vdesc, fdesc, odesc = vol.desc(), frame.desc(), out.desc()
-    pdesc = integ.params
-    vref, fref, oref, pref = C.byref(vdesc), C.byref(fdesc), C.byref(odesc), C.byref(pdesc)
-    d_ptr, c_ptr, n_ptr = (C.c_void_p(t.data_ptr()) for t in (out.depth, out.color, out.normals))
-    # the record through which DepthIntegrator::Integrate hands the raycast bounds of
-    # its view to Tracer::Trace (include/vk.h vk_view_bounds), as the class layer does
-    vb = tracer.view_bounds
-    bref = C.byref(vb)
-
-    def step(i, ev=None):
-        fdesc.depth_to_world = poses[i]
-        odesc.depth_to_world = poses[i]
-        vb.valid = 0                                                       # Volume::SetView: new visible list
-        rc = lib.vk_volume_set_view(vref, fref, stream)                    # volume.cu:430-437
-        if ev:
-            lib.vk_event_record(ev[0], stream)
-        rc |= lib.vk_integrate_ahead(vref, pref, fref, 0, None, None, bref, stream)   # depth_integrator.cu:89-115
-        if ev:
-            lib.vk_event_record(ev[1], stream)
-        rc |= lib.vk_trace_ahead(vref, oref, bref, d_ptr, c_ptr, n_ptr, stream)       # tracer.cpp:41-47
-        if rc:
-            raise api.VkError(f"frame {i}: C ABI returned {rc}")
-
-    def make_event():
-        e = C.c_void_p()
-        api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
-        return e
-
-    # HIP events (created without the system-scope fence, vk_event_create) around the
-    # integrate launch of every EVENT_STRIDE-th timed frame: even so a pair of records
-    # costs the stream ~1.7 us, so bracketing every frame would slow the loop being timed
-    EVENT_STRIDE = 4
-    sampled = list(range(0, args.steps, EVENT_STRIDE))
-    events = {i: (make_event(), make_event()) for i in sampled}
-
-    for i in range(args.warmup):
-        step(i)
-    vd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i, events.get(i))
-    torch.cuda.synchronize()
-    vd.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = vd.max_over_ranks(elapsed, device="cuda")
-
-    # integrate kernel time from the HIP events recorded inside the timed region
-    kernel_ms = []
-    for i in sampled:
-        e0, e1 = events[i]
-        ms = C.c_float()
-        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
-        kernel_ms.append(ms.value)
-    ctr = vol.read_counters()
-
-    # Allocation is deterministic, so an untimed replay of the same poses gives the
-    # visible-block count the integrate launch of every timed frame saw.
-    del vol, frame, out, integ, tracer
-    vol, frame, out, integ, tracer = fresh()
-    nvis = []
-    for i in range(total_frames):
-        frame.depth_to_world = poses[i]
-        vol.set_view(frame)
-        integ.integrate(frame)
-        if i >= args.warmup:
-            nvis.append(vol.visible_count)
-    nvis = np.array(nvis, dtype=np.float64)
-    alg_bytes = nvis * BYTES_PER_BLOCK + W * H * 4
-    achieved = float(alg_bytes[sampled].sum() / (np.sum(kernel_ms) * 1e-3) / 1e9)   # the sampled launches
-
-    # what this GPU sustains on (a) a plain float4 copy and (b) the integrate kernel's own
-    # access pattern with the arithmetic removed ("peak: measured"), outside
-    # the timed region; reported next to the 8 TB/s spec figure the fraction is taken of
-    def probe(fn, bytes_moved, reps=10):
-        e0, e1 = make_event(), make_event()
-        fn()
-        lib.vk_event_record(e0, stream)
-        for _ in range(reps):
-            fn()
-        lib.vk_event_record(e1, stream)
-        ms = C.c_float()
-        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
-        return bytes_moved * reps / (ms.value * 1e-3) / 1e9
-
-    buf_a = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-    buf_b = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
-    copy_gbs = probe(lambda: lib.vk_probe_stream_copy(C.c_void_p(buf_b.data_ptr()), C.c_void_p(buf_a.data_ptr()),
-                                                      buf_a.numel(), stream), 2 * buf_a.numel())
-    vdesc2 = vol.desc()
-    rmw_gbs = probe(lambda: lib.vk_probe_block_rmw(C.byref(vdesc2), stream), float(nvis[-1]) * 2 * 10240)
-    del buf_a, buf_b
-
-    frames_all = vd.sum_over_ranks(args.steps, device="cuda")
+    names = {"rgbd": "BASELINE configs[2] fusion+raycast: 640x480 RGB-D, SetView + LightIntegrator (frame mask, depth, "
+                     "shaded colour in one pass) + Tracer",
+             "depth": "BASELINE configs[1]: 640x480 depth-only sequence, SetView + DepthIntegrator + Tracer",
+             "rgbd-icp": "BASELINE configs[2]: 640x480 RGB-D, PyramidTracker<DepthTracker> vs the previous raycast + SetView + "
+                         "LightIntegrator + Tracer"}
     result = {
-        "metric": "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels",
-        "value": frames_all / elapsed,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
+        "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: 640x480 depth-only sequence, SetView + DepthIntegrator + Tracer, "
-                        "5 mm voxels, Volume(65024,8192), camera at the centre of a 2 m sphere yawing 0.5 deg/frame",
-            "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL,
-            "truncation_length": TRUNC, "visible_blocks_mean": float(nvis.mean()),
+            "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192), camera at the centre of a 2 m sphere yawing "
+                                    "0.5 deg/frame, one SetView per frame (allocation is iterated on the device)",
+            "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
+            "visible_blocks_mean": float(nvis_timed.mean()),
             "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
             "dropped_requests": int(ctr[T.VK_CTR_DROPPED]), "parallelism": f"replica volume per GPU x{world}",
         },
         "roofline": {
-            "kernel": "integrate_pipelined_kernel<depth> (vk_integrate_depth)",
+            "kernel": "integrate_pipelined_kernel<depth%s> (vk_integrate_ahead)" % ("" if wl == "depth" else "+light colour"),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-            "algorithmic_bytes_per_launch": float(alg_bytes.mean()),
-            "avg_launch_us": float(np.mean(kernel_ms) * 1e3),
-            "launches_timed": len(sampled),
-            "measured_copy_GBps": copy_gbs, "measured_block_rmw_GBps": rmw_gbs,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wl),
+            "algorithmic_bytes_per_launch": float(alg[sampled].mean()),
+            "avg_launch_us": float(integ_ms.mean() * 1e3), "launches_timed": len(sampled),
+            # where the bytes come from at this size: a frame's voxel working set is ~75 MB and
+            # consecutive frames overlap almost entirely, so it lives in the 256 MiB Infinity Cache
+            "memory_level": "infinity-cache assisted" if voxel_ws < L3_BYTES else "hbm",
+            "voxel_working_set_bytes": voxel_ws,
+            "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+            "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9 * (1.0 / world) * world,
+            "raycast": {"kernel": "compute_points_kernel + compute_normals_kernel (vk_trace_ahead)",
+                        "avg_us": float(trace_ms.mean() * 1e3)},
         },
     }
+    for key_ in ("gauss_newton_steps_last_frame",):
+        if key_ in res:
+            result["config"][key_] = res[key_]
 
-    if rank == 0 and world == 1 and args.cpu_frames > 0:   # the CPU leg is reported at N=1 only
-        result["cpu_baseline"] = cpu_baseline(depth_np, k, poses, args.cpu_frames)
+    if not args.only:
+        pr = probes(loop, nvis[-1])
+        result["roofline"].update(pr)
+        if pr.get("measured_copy_GBps"):
+            result["roofline"]["frac_of_measured_copy_here"] = achieved / pr["measured_copy_GBps"]
+    del loop
+    torch.cuda.empty_cache()
+
+    if not args.only:
+        # the same kernel with the working set pushed out of the Infinity Cache
+        pl3 = past_l3(wl, poses, min(args.warmup, 10), 6, nvis)
+        pl3["frac"] = pl3["achieved"] / HBM_PEAK_GBS
+        pl3["frac_of_measured_copy_peak"] = pl3["achieved"] / HBM_COPY_GBS
+        result["roofline"]["past_l3"] = pl3
+        torch.cuda.empty_cache()
+
+        others = {}
+        for other in ("depth", "rgbd", "rgbd-icp"):
+            if other == wl:
+                continue
+            k_steps, k_warm = min(args.steps, 100), min(args.warmup, 10)
+            o, oloop = run_workload(other, poses[:k_warm + k_steps], k_warm, k_steps, vd, with_roofline=True)
+            ims, tms, smp = np.array(o.pop("_integrate_ms")), np.array(o.pop("_trace_ms")), o.pop("_sampled")
+            o.pop("_counters")
+            oalg = nvis[k_warm:k_warm + k_steps] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if other == "depth" else "rgbd"]
+            o["workload"] = names[other]
+            o["unit"] = "frames/s"
+            o["integrate_avg_us"] = float(ims.mean() * 1e3)
+            o["integrate_GBps"] = float(oalg[smp].sum() / (ims.sum() * 1e-3) / 1e9)
+            o["integrate_frac_of_8TBps"] = o["integrate_GBps"] / HBM_PEAK_GBS
+            o["raycast_avg_us"] = float(tms.mean() * 1e3)
+            others[other] = o
+            del oloop
+            torch.cuda.empty_cache()
+        result["other_workloads"] = others
+
+    if world > 1:
+        result["collective"] = rig_collective(rank, world, vd)
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:   # the CPU leg is reported at N=1 only
+        result["cpu_baseline"] = cpu_baseline(wl, poses, args.cpu_seconds)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
     vd.shutdown()
 
 
-def extra_workload(args):
-    """BASELINE configs[2]: 640x480 RGB-D, depth + light-colour integration (mask, shading)
-    and raycast, optionally preceded by PyramidTracker<DepthTracker> against the previous
-    raycast (tracker -> SetView -> Integrate -> Trace, apps/vulcan/vulcan.cu:300-325)."""
-    import torch
-    from vulcan_amd import api, dist as vd, vk_types as T
-    import scenes
-
-    rank, local_rank, world = vd.init()
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    k = T.Projection.make(*scenes.APP_INTRINSICS)
-    depth_np = sphere_room_depth(k)
-    color_np = scenes.checker_color(W, H, 0.1, 0.9)
-    total = args.warmup + args.steps
-    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
-    vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
-    frame = api.Frame(depth_np, k, poses[0], color=color_np)
-    frame.compute_normals()
-    key = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
-                    color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
-                    normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
-    integ = api.LightIntegrator(vol)
-    integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))     # apps/vulcan/vulcan.cu:87-88
-    tracer = api.Tracer(vol)
-    tracker = api.PyramidTracker()
-    track = args.workload == "rgbd-icp"
-    if track and world > 1:
-        tracker.tracker.reduce_hook = vd.allreduce_system   # rigid rig: one system for all cameras
-
-    # SetView / Integrate / Trace go straight to the C ABI with descriptors built once
-    # (the api.* wrappers rebuild their ctypes structs on every call: ~35 us per frame)
-    lib, stream = api.lib(), api.stream()
-    vdesc, fdesc, kdesc = vol.desc(), frame.desc(), key.desc()
-    vref, fref, kref, pref, lref = (C.byref(x) for x in (vdesc, fdesc, kdesc, integ.params, integ.light))
-    vb = tracer.view_bounds
-    bref = C.byref(vb)
-    mask = integ.compute_frame_mask(frame)
-    m_ptr = C.c_void_p(mask.data_ptr())
-    d_ptr, c_ptr, n_ptr = (C.c_void_p(t.data_ptr()) for t in (key.depth, key.color, key.normals))
-
-    def step(i):
-        if track and i > 0:
-            frame.depth_to_world = poses[i - 1]             # previous pose as the initial guess
-            tracker.keyframe = key
-            tracker.track(frame)                            # one 128-byte pose readback per level
-        frame.depth_to_world = poses[i]                     # ground truth keeps the map consistent
-        key.depth_to_world = poses[i]
-        fdesc.depth_to_world = poses[i]
-        kdesc.depth_to_world = poses[i]
-        vb.valid = 0
-        rc = lib.vk_volume_set_view(vref, fref, stream)
-        rc |= lib.vk_light_compute_frame_mask(fref, integ.depth_threshold, m_ptr, stream)   # light_integrator.cu:270-275
-        rc |= lib.vk_integrate_ahead(vref, pref, fref, 2, lref, m_ptr, bref, stream)
-        rc |= lib.vk_trace_ahead(vref, kref, bref, d_ptr, c_ptr, n_ptr, stream)
-        if rc:
-            raise api.VkError(f"frame {i}: C ABI returned {rc}")
-
-    for i in range(args.warmup):
-        step(i)
-    vd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    vd.barrier()
-    elapsed = vd.max_over_ranks(time.perf_counter() - t0, device="cuda")
-    frames_all = vd.sum_over_ranks(args.steps, device="cuda")
-    if rank == 0:
-        print(json.dumps({
-            "metric": "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels", "value": frames_all / elapsed,
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: 640x480 RGB-D, LightIntegrator (mask + depth + shaded colour) + "
-                                   "Tracer" + (" + PyramidTracker<DepthTracker> (15 + 20 Gauss-Newton iterations)" if track else ""),
-                       "visible_blocks": vol.visible_count, "parallelism": f"replica volume per GPU x{world}"},
-        }), flush=True)
-    vd.shutdown()
-
-
-def pmc_traffic():
+def pmc_traffic(workload):
     """HBM-side bytes per integrate launch from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes): counters cannot
-    be collected from inside an unprofiled run, so the newest measurement on file is
-    reported; None when there is none."""
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes, tools/traffic.sh): counters
+    cannot be collected from inside an unprofiled run, so the newest measurement on file for
+    this workload is reported; None when there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_integrate_traffic.json")))
+    tag = "integrate" if workload == "depth" else "integrate_rgbd"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_traffic.json")))
     if not files:
         return None
     with open(files[-1]) as f:
         return json.load(f)["bytes_per_launch"]
 
 
-def cpu_baseline(depth_np, k, poses, frames):
-    """The CPU oracle (oracle/, the restated reference kernels) on the first `frames`
-    poses of the same sequence; OpenMP over blocks / pixels where the reference's
-    threads are independent, allocation serial."""
+def cpu_baseline(workload, poses, seconds):
+    """The CPU oracle (oracle/, the restated reference kernels) on the first frames of the
+    same sequence until `seconds` of CPU time are spent; OpenMP over blocks / pixels where
+    the reference's threads are independent, allocation serial. Plus BASELINE configs[0]:
+    one 640x480 depth frame into a dense 128^3 region (4096 blocks), 1 thread and all cores."""
     from oracle import oracle as orc
+    from vulcan_amd import vk_types as T
+    import scenes
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth_np = sphere_room_depth(k)
     # a 1-GPU box owns a 16-core share of the host (not all 256 hardware threads)
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     orc.set_threads(cores)
     hv = orc.HostVolume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
-    hf = orc.HostFrame(depth_np, k, poses[0])
-    for i in range(2):                       # untimed: the cold first frames allocate ~7k blocks
+    color = scenes.checker_color(W, H, 0.1, 0.9) if workload != "depth" else None
+    hf = orc.HostFrame(depth_np, k, poses[0], color=color)
+    light = T.Light.make(*LIGHT)
+    if workload != "depth":
+        hf.compute_normals()
+
+    def frame(i):
         hf.depth_to_world = poses[i]
         hv.set_view(hf, orc.POLICY_SERIAL)
         orc.integrate_depth(hv, hf)
-    t0 = time.perf_counter()
-    for i in range(2, 2 + frames):
-        hf.depth_to_world = poses[i]
-        hv.set_view(hf, orc.POLICY_SERIAL)
-        orc.integrate_depth(hv, hf)
+        if workload != "depth":
+            mask = orc.light_frame_mask(hf, 0.2)
+            orc.integrate_light_color(hv, hf, light, mask)
         orc.trace(hv, hf)
+
+    for i in range(2):                       # untimed: the cold first frames allocate ~7k blocks
+        frame(i)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 0.7 * seconds and 2 + n < len(poses):
+        frame(2 + n)
+        n += 1
     dt = time.perf_counter() - t0
+
+    out = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"frames 2..{1 + n} of the same sequence ({dt:.1f} s: SetView + "
+                     + ("depth integrate" if workload == "depth" else "frame mask + depth + shaded-colour integrate")
+                     + f" + raycast + normals each), allocation serial, the rest OpenMP x{cores}"}
+    out["configs0_dense_128"] = dense_128(orc, T, depth_np, k, cores, 0.3 * seconds)
     orc.set_threads(1)
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"frames 2..{1 + frames} of the same sequence (SetView + integrate + raycast + normals each), "
-                      f"allocation serial, integrate/raycast/normals OpenMP x{cores}"}
+    return out
+
+
+def dense_128(orc, T, depth_np, k, cores, seconds):
+    """BASELINE configs[0] (SURVEY §8d Config 1): the integrate arithmetic of
+    tests/integrator_test.cu:141-199 over a dense 128^3 voxel region = 16^3 = 4096 blocks of
+    8^3 straddling the surface (away from block (0,0,0)), one 640x480 depth frame, identity
+    pose; ms and voxels/s on 1 thread and on all cores."""
+    hv = orc.HostVolume(8192, 1024, voxel_length=VOXEL, truncation_length=TRUNC)
+    hf = orc.HostFrame(depth_np, k, T.Transform.identity())
+    # 16^3 blocks centred on the optical axis at the sphere's surface (z = 2 m): x, y in [-8, 8), z in [42, 58)
+    origin = np.array([[x, y, z] for z in range(42, 58) for y in range(-8, 8) for x in range(-8, 8)], dtype=np.int16)
+    n = len(origin)
+    hv.hash_entries["block"]["origin"][:n] = origin
+    hv.hash_entries["data"][:n] = np.arange(n)
+    hv.hash_entries["next"][:n] = -1
+    hv.visible_blocks[:n] = np.arange(n)
+    hv.counters[T.VK_CTR_VISIBLE] = n
+    voxels = n * 512
+    out = {"voxels": voxels, "blocks": n}
+    for name, threads in (("1_core", 1), (f"{cores}_cores", cores)):
+        orc.set_threads(threads)
+        orc.integrate_depth(hv, hf)
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < 0.5 * seconds and reps < 200):
+            orc.integrate_depth(hv, hf)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"ms": dt * 1e3, "voxels_per_s": voxels / dt, "threads": threads}
+    touched = int((hv.voxels["distance_weight"][:voxels] > 0).sum())
+    out["voxels_updated"] = touched
+    return out
 
 
 if __name__ == "__main__":

@@ -138,10 +138,19 @@ typedef struct vk_volume {
  * row-major, no pitch; colour and normals are packed 12-byte float3. */
 typedef struct vk_frame {
   const float*  depth;        /* [height*width]   */
-  const float*  color;        /* [height*width*3] or NULL */
+  const float*  color;        /* [color_height*color_width*3] or NULL */
   const float*  normals;      /* [height*width*3] or NULL */
-  int32_t       width;
+  int32_t       width;        /* depth_image (and normal_image) size */
   int32_t       height;
+  /* color_image size (frame.h:21-25 holds three independent images). 0 = same
+   * as the depth image. ColorIntegrator::IntegrateColor bounds-tests and
+   * strides with THIS size (color_integrator.cu:183-184); LightIntegrator
+   * indexes colour with the depth image's size (light_integrator.cu:333-334,
+   * "TODO: handle different depth and color images sizes" :179), which is an
+   * out-of-bounds read when they differ: the light entry points return
+   * VK_ERR_ARGUMENT for such a frame instead. */
+  int32_t       color_width;
+  int32_t       color_height;
   vk_projection depth_projection;
   vk_projection color_projection;
   vk_transform  depth_to_world;   /* Twd */
@@ -167,6 +176,11 @@ VK_API int vk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 VK_API int vk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);  /* blocking */
 VK_API int vk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 VK_API int vk_memset(void* dst, int value, size_t bytes, void* stream);
+
+/* Pinned, device-visible, coherent host memory (hipHostMalloc): the same pointer
+ * is valid on the host and in kernels. Used for vk_track_poll.host_state. */
+VK_API int vk_malloc_host(void** ptr, size_t bytes);
+VK_API int vk_free_host(void* ptr);
 
 /* Timing helpers (hipEvent) so hosts without HIP headers can time kernels. The
  * events carry no system-scope fence (hipEventDisableSystemFence): they order and
@@ -433,6 +447,20 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
  * it over ranks here (ncclAllReduce on `stream`). Returns 0 on success. */
 typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* stream);
 
+/* Early exit for the device-side Gauss-Newton loops. The reference leaves its loop
+ * as soon as |update| < 1e-6 (tracker.cpp:162) because its host sees every update.
+ * The loops here are enqueued without a host round trip; steps after convergence
+ * are no-ops but still cost their launches. With a vk_track_poll the solve also
+ * publishes {iterations, converged} to `host_state` (ONE 64-bit store to pinned host
+ * memory, vk_malloc_host), and the enqueuing function looks at it after every
+ * `chunk` steps and stops once the loop has converged: the pose is the same, the
+ * call blocks for at most one chunk, and no launch follows convergence by more
+ * than chunk-1 steps. NULL (or chunk <= 0): enqueue every step, never block. */
+typedef struct vk_track_poll {
+  int32_t* host_state;   /* pinned int32[2], 8-byte aligned, written by the device */
+  int32_t  chunk;        /* steps enqueued between two looks at host_state         */
+} vk_track_poll;
+
 /* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker — `iterations`
  * Gauss-Newton steps enqueued back to back with no host round trip: per step one
  * partial-sum launch and one launch that finishes the sums, solves the 6x6
@@ -442,7 +470,8 @@ typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* 
 VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     const vk_icp_view* frame, vk_transform* Twc_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev,
-    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream);
+    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll,
+    void* stream);
 
 /* ------------------------------------------------------------ colour tracker -- */
 
@@ -511,7 +540,7 @@ VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_
     const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
     int iterations, int translation_enabled, float* workspace, float* system,
     int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
-    void* stream);
+    const vk_track_poll* poll, void* stream);
 
 /* ------------------------------------------------------------- light tracker -- */
 
@@ -558,7 +587,7 @@ VK_API int vk_light_tracker_track(const vk_color_view* keyframe, const vk_color_
     const vk_light_terms* terms, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
     int iterations, int translation_enabled, float* workspace, float* system,
     int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
-    void* stream);
+    const vk_track_poll* poll, void* stream);
 
 /* ---------------------------------------------------------------- detector -- */
 
@@ -608,24 +637,6 @@ VK_API int vk_detect_filter(const vk_detector* detector, const float* points,
 VK_API int vk_detect(const vk_detector* detector, const float* points,
     int32_t count, float* inliers, vk_detect_state* state_dev, void* workspace,
     void* stream);
-
-/* ------------------------------------------------------------------ probes -- */
-
-/* Measurement aids, no reference counterpart (the reference has no benchmarks,
- * SURVEY.md §6): a float4 device copy and the integrate kernel's access pattern
- * (read + write back every visible block) with the arithmetic removed. bench.py
- * reports the integrate kernel's GB/s against both. */
-VK_API int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, void* stream);
-VK_API int vk_probe_block_rmw(const vk_volume* v, void* stream);
-VK_API int vk_probe_block_rmw_mode(int mode);   /* 0 plain, 1 nt stores, 2 nt loads+stores, 3 delayed stores */
-/* Timing-only ablations of the depth integrate kernel (variant 1..3 produce WRONG
- * voxels on purpose: 1 = no depth gather, 2 = no update, 3 = no LDS staging). */
-/* Selects a timing-only ablation of the raycast kernel for subsequent launches
- * (0 = product; 1 = no trilinear sampling, 2 = in-block sampling only,
- * 3 = every trilinear sample reads the same few cache lines). */
-VK_API int vk_probe_points_variant(int variant);
-VK_API int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame,
-    int variant, void* stream);
 
 #ifdef __cplusplus
 }  /* extern "C" */

@@ -125,6 +125,8 @@ class HostFrame:
         d.color = None if self.color is None else self.color.ctypes.data
         d.normals = None if self.normals is None else self.normals.ctypes.data
         d.width, d.height = self.width, self.height
+        if self.color is not None:
+            d.color_height, d.color_width = self.color.shape[0], self.color.shape[1]
         d.depth_projection, d.color_projection = self.depth_projection, self.color_projection
         d.depth_to_world, d.depth_to_color = self.depth_to_world, self.depth_to_color
         return d
@@ -132,6 +134,19 @@ class HostFrame:
     def compute_normals(self):
         self.normals = compute_normals(self.depth, self.depth_projection)
         return self.normals
+
+    def downsample(self):
+        """Frame::Downsample (frame.cpp:38-58): nearest depth / normals, 2x2 box colour,
+        intrinsics / 2 (Vector2f / 2 multiplies by 1/2, matrix.h:279-295)."""
+        f32 = np.float32
+
+        def half(k):
+            return T.Projection.make(f32(k.fx) * f32(0.5), f32(k.fy) * f32(0.5),
+                                     f32(k.cx) * f32(0.5), f32(k.cy) * f32(0.5))
+        return HostFrame(downsample(self.depth, True), half(self.depth_projection), self.depth_to_world,
+                         None if self.color is None else downsample(self.color, False),
+                         None if self.normals is None else downsample(self.normals, True),
+                         half(self.color_projection), self.depth_to_color)
 
 
 def set_threads(n):
@@ -287,6 +302,30 @@ def icp_solve_update(hessian_packed, gradient, Twc, translation_enabled=True):
     update = np.zeros(6, dtype=np.float32)
     norm = lib().orc_icp_solve_update(_p(h), _p(g), int(translation_enabled), C.byref(out), _p(update))
     return out, update, float(norm)
+
+
+def icp_track(key, frame, max_iterations=20, translation_enabled=True):
+    """Tracker::Track for DepthTracker (tracker.cpp:53-63,124-163): Gauss-Newton until
+    max_iterations or |update| < 1e-6. Updates frame.depth_to_world; returns (pose, iterations run)."""
+    pose, it = frame.depth_to_world, 0
+    while it < max_iterations:
+        frame.depth_to_world = pose
+        Hs, g = icp_system(key, frame, translation_enabled)
+        pose, _, norm = icp_solve_update(Hs, g, pose, translation_enabled)
+        it += 1
+        if norm < 1e-6:
+            break
+    frame.depth_to_world = pose
+    return pose, it
+
+
+def pyramid_track(key, frame):
+    """PyramidTracker<DepthTracker>::Track (pyramid_tracker.cpp:52-90): half resolution
+    (15 iterations) then full resolution (20); the quarter level is built but unused."""
+    half_frame, half_key = frame.downsample(), key.downsample()
+    icp_track(half_key, half_frame, 15, True)
+    frame.depth_to_world = half_frame.depth_to_world
+    return icp_track(key, frame, 20, True)
 
 
 def detect(points, params):

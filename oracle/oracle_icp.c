@@ -4,6 +4,7 @@
  * src/depth_tracker.cpp:22-86 (ApplyUpdate) and src/image.cu:101-165
  * (Downsample). TEST INFRASTRUCTURE, see oracle.h.
  */
+#include <float.h>
 #include <string.h>
 #include "oracle.h"
 #include "oracle_math.h"
@@ -128,7 +129,10 @@ void orc_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm
 
 /* LDL^T without pivoting, float32. The reference calls Eigen::LDLT (pivoted,
  * tracker.cpp:127,153-159; Eigen is not vendored and its version is unpinned,
- * so the solve is "parity unpinned": agreement is to rounding, not bit-exact). */
+ * so the solve is "parity unpinned": agreement is to rounding, not bit-exact).
+ * Zero pivots follow Eigen's published behaviour (LDLT.h: a column under an
+ * invalid pivot is not divided; solve zeroes y[i] where |D[i]| <= FLT_MIN), so an
+ * empty system solves to x = 0 rather than NaN. */
 void orc_ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
     const float* b, float* x)
 {
@@ -146,7 +150,7 @@ void orc_ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
     {
       float s = A[i * n + j];
       for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k] * D[k];
-      L[i * n + j] = s / d;
+      L[i * n + j] = (fabsf(d) > 0.0f) ? s / d : 0.0f;
     }
   }
 
@@ -157,7 +161,7 @@ void orc_ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
     y[i] = s;
   }
 
-  for (int i = 0; i < n; ++i) y[i] = y[i] / D[i];
+  for (int i = 0; i < n; ++i) y[i] = (fabsf(D[i]) > FLT_MIN) ? y[i] / D[i] : 0.0f;
 
   for (int i = n - 1; i >= 0; --i)
   {

@@ -83,6 +83,10 @@ static void integrate_color_block(const vk_volume* v, const vk_integrator* p,
   const float voxel_length = v->voxel_length;
   const float block_length = VK_BLOCK_RESOLUTION * voxel_length;
 
+  /* color_integrator.cu:183-184: the COLOUR image's size */
+  const int image_width = f->color_width > 0 ? f->color_width : f->width;
+  const int image_height = f->color_height > 0 ? f->color_height : f->height;
+
   if (entry.data < 0) return;
 
   for (int z = 0; z < 8; ++z)
@@ -94,14 +98,14 @@ static void integrate_color_block(const vk_volume* v, const vk_integrator* p,
         float u, w;
         o_project(&f->color_projection, Xcp, &u, &w);
 
-        if (u >= 0 && u < f->width && w >= 0 && w < f->height)
+        if (u >= 0 && u < image_width && w >= 0 && w < image_height)
         {
           const int voxel_index = entry.data * VK_BLOCK_VOXELS + z * 64 + y * 8 + x;
           vk_voxel voxel = v->voxels[voxel_index];
 
           if (fabsf(voxel.distance) < 1.0)
           {
-            const int image_index = (int)w * f->width + (int)u;
+            const int image_index = (int)w * image_width + (int)u;
             const float cw = voxel.color_weight;
             const of3 prev_color = o_scale3(o3(voxel.color[0], voxel.color[1], voxel.color[2]), cw);
             const of3 curr_color = o3(f->color[3 * image_index + 0],

@@ -1,0 +1,238 @@
+"""BASELINE.json configs that round 1 left without a GPU parity test, plus the
+cases the round-1 review asked for:
+
+  configs[2]  640x480 RGB-D, LightIntegrator (mask + depth + shaded colour) + Tracer at
+              full size into Volume(65024, 8192) @ 5 mm — every voxel byte and every
+              raycast image against the oracle (light_integrator.cu:270-354)
+  configs[3]  PyramidTracker<DepthTracker>::Track at 320x240 / 640x480 / 1280x960 bases
+              against the oracle's pyramid loop (pyramid_tracker.cpp:52-90)
+  a colour image whose size differs from the depth image (color_integrator.cu:183-184)
+  an empty normal system (all-hole frame) must leave the pose finite (tracker.cpp:153-162)
+  two Tracers sharing one Volume
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import api, assert_volume_equal, frames, make_pair, sync  # noqa: F401
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ configs[2] --
+
+def test_rgbd_bench_sequence_matches_oracle(api, orc):
+    """The exact `bench.py --workload rgbd` frame loop (640x480, 5 mm, Volume(65024, 8192),
+    light (2, (.025,.08,0)) as in apps/vulcan/vulcan.cu:87-88): 5 frames, bit for bit."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    color = scenes.checker_color(bench.W, bench.H, 0.1, 0.9)
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    orc.set_threads(16)
+    hv, dv = make_pair(api, orc, bench.MAIN, bench.EXCESS, bench.VOXEL, bench.TRUNC)
+    hf, df = frames(api, orc, depth, k, T.Transform.identity(), color=color)
+    hf.compute_normals()
+    df.compute_normals()
+    sync()
+    assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+    out = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, T.Transform.identity())
+    integ, tracer = api.LightIntegrator(dv), api.Tracer(dv)
+    integ.light = light
+    for i in range(5):
+        pose = scenes.orbit_pose(i, bench.YAW_STEP)
+        hf.depth_to_world = df.depth_to_world = out.depth_to_world = pose
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        mask = orc.light_frame_mask(hf, 0.2)
+        orc.integrate_light_color(hv, hf, light, mask)
+        odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+        dv.set_view(df)
+        integ.integrate(df)                 # mask kernel + fused depth/shaded-colour pass + bounds ahead
+        tracer.trace(out)
+        sync()
+        assert tracer.view_bounds.valid == 1
+        assert np.array_equal(integ.frame_mask.cpu().numpy(), mask)
+        assert dv.visible_count == hv.visible_count > 5000
+        assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
+        assert np.array_equal(out.depth.cpu().numpy(), odepth)
+        assert np.array_equal(out.color.cpu().numpy(), ocolor)
+        assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
+    assert_volume_equal(dv, hv)
+    got = dv.host_voxels()
+    assert (got["color_weight"] > 0).sum() > 500000          # the colour pass really ran
+    orc.set_threads(1)
+
+
+# ------------------------------------------------------------------ configs[3] --
+
+def curved_depth(w, h):
+    y, x = np.mgrid[0:h, 0:w]
+    return (1.0 + 0.05 * np.cos(3.0 * x / w) * np.sin(2.0 * y / h)).astype(np.float32)
+
+
+@pytest.mark.parametrize("size", [(320, 240), (640, 480), (1280, 960)])
+def test_pyramid_tracker_matches_oracle(api, orc, size):
+    """PyramidTracker<DepthTracker>::Track: downsampled levels bit-exact, final pose within
+    2e-5 per matrix entry of the oracle's pyramid loop (float tree sums vs float64 sums are
+    the only difference between the two), and the pose is recovered."""
+    w, h = size
+    s = w / 640.0
+    k = T.Projection.make(547.0 * s, 547.0 * s, 320.0 * s, 240.0 * s)     # depth_tracker_test.cu:20-23 scaled
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity(), color=scenes.checker_color(w, h, 0.1, 0.9))
+    hk.compute_normals()
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start, color=scenes.checker_color(w, h, 0.1, 0.9))
+    hf.compute_normals()
+    df.compute_normals()
+    sync()
+    assert np.array_equal(dk.normals.cpu().numpy(), hk.normals, equal_nan=True)
+
+    # Frame::Downsample, both pyramid levels (frame.cpp:38-58)
+    hh, dh = hf.downsample(), df.downsample()
+    hq, dq = hh.downsample(), dh.downsample()
+    sync()
+    for host, dev in ((hh, dh), (hq, dq)):
+        assert (dev.width, dev.height) == (host.width, host.height)
+        assert np.array_equal(dev.depth.cpu().numpy(), host.depth)
+        assert np.array_equal(dev.normals.cpu().numpy(), host.normals, equal_nan=True)
+        assert np.array_equal(dev.color.cpu().numpy(), host.color)
+        assert bytes(dev.depth_projection) == bytes(host.depth_projection)
+
+    want, iters = orc.pyramid_track(hk, hf)
+    tracker = api.PyramidTracker()
+    tracker.keyframe = dk
+    got = tracker.track(df)
+    sync()
+    np.testing.assert_allclose(got.matrix(), want.matrix(), atol=2e-5)
+    np.testing.assert_allclose(got.inverse_matrix(), want.inverse_matrix(), atol=2e-5)
+    np.testing.assert_allclose(got.matrix(), np.eye(4), atol=5e-4)          # the keyframe's pose
+    np.testing.assert_allclose(got.matrix() @ got.inverse_matrix(), np.eye(4), atol=1e-5)
+    # run-to-run identical (fixed-order reduction)
+    df.depth_to_world = start
+    again = tracker.track(df)
+    assert bytes(again) == bytes(got)
+
+
+# ------------------------------------------------- colour image of another size --
+
+def test_color_image_of_a_different_size(api, orc):
+    """frame.h:21-25: three independent images. ColorIntegrator::IntegrateColor tests and
+    strides with the COLOUR image's size (color_integrator.cu:183-184)."""
+    w, h = 160, 120
+    kd = T.Projection.make(136, 136, 80, 60)
+    depth = scenes.plane(w, h, 1.5)
+    for cw, ch in ((320, 240), (96, 72)):
+        sx = cw / w
+        kc = T.Projection.make(136 * sx, 136 * sx, 80 * sx + 1.5, 60 * sx - 0.5)
+        y, x = np.mgrid[0:ch, 0:cw]
+        color = np.stack([0.1 + 0.8 * x / cw, 0.1 + 0.8 * y / ch, 0.5 + 0 * x], -1).astype(np.float32)
+        tcd = T.Transform.translate(0.01, -0.005, 0.0)
+        hf = orc.HostFrame(depth, kd, T.Transform.identity(), color=color, color_projection=kc, depth_to_color=tcd)
+        df = api.Frame(depth, kd, T.Transform.identity(), color=color, color_projection=kc, depth_to_color=tcd)
+        assert (df.desc().color_width, df.desc().color_height) == (cw, ch)
+        for fused in (True, False):
+            hv, dv = make_pair(api, orc, 4096, 1024, 0.008, 0.04)
+            for _ in range(4):
+                hv.set_view(hf, orc.POLICY_MAXKEY)
+                dv.set_view(df)
+            orc.integrate_depth(hv, hf)
+            orc.integrate_color(hv, hf)
+            integ = api.ColorIntegrator(dv)
+            if fused:
+                integ.integrate(df)
+            else:
+                integ.integrate_depth(df)
+                integ.integrate_color(df)
+            assert_volume_equal(dv, hv)
+            assert (hv.voxels["color_weight"] > 0).sum() > 10000
+        # the light path indexes colour with the depth size upstream (light_integrator.cu:333-334):
+        # a mismatching frame is refused instead of read out of bounds
+        df.compute_normals()
+        mask = api.LightIntegrator(dv)
+        with pytest.raises(api.VkError):
+            mask.compute_frame_mask(df)
+        lib = api.lib()
+        import torch
+        m = torch.zeros((h, w), dtype=torch.float32, device="cuda")
+        rc = lib.vk_integrate_depth_light(api._ref(dv.desc()), api._ref(mask.params), api._ref(mask.light),
+                                          api._ptr(m), api._ref(df.desc()), api.stream())
+        assert rc == -1                                        # VK_ERR_ARGUMENT
+
+
+# ----------------------------------------------------------- empty normal system --
+
+@pytest.mark.parametrize("translation", [True, False])
+def test_empty_system_leaves_pose_finite(api, orc, translation):
+    """No valid correspondence (an all-hole frame): H = 0, g = 0. Eigen's LDLT solves that to
+    x = 0, |x| < 1e-6 ends the loop and the pose stays what it was (tracker.cpp:153-162); an
+    unguarded LDL^T returns 0/0 = NaN and poisons the pose."""
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    hk, dk = frames(api, orc, curved_depth(w, h), k, T.Transform.identity())
+    hk.compute_normals()
+    dk.compute_normals()
+    start = T.Transform.translate(0.01, 0.02, -0.01) * T.Transform.rotate(0.9998, 0.01, -0.01, 0.012)
+    hf, df = frames(api, orc, np.zeros((h, w), np.float32), k, start)
+    hf.compute_normals()
+    df.compute_normals()
+    tracker = api.DepthTracker()
+    tracker.keyframe = dk
+    tracker.translation_enabled = translation
+    got = tracker.track(df)
+    sync()
+    state = tracker.state.cpu().numpy()
+    assert np.all(np.isfinite(got.matrix())) and np.all(np.isfinite(got.inverse_matrix()))
+    assert state[1] == 1 and state[0] == 1                      # stopped after the first (zero) step
+    assert np.all(tracker.update.cpu().numpy() == 0)
+    want, iters = orc.icp_track(hk, hf, 20, translation)
+    assert iters == 1
+    assert bytes(got) == bytes(want)                            # both re-orthonormalise the same pose
+    np.testing.assert_allclose(got.matrix(), start.matrix(), atol=1e-6)
+    # the pyramid on the same input
+    pyr = api.PyramidTracker()
+    pyr.keyframe = dk
+    df.depth_to_world = start
+    got = pyr.track(df)
+    assert np.all(np.isfinite(got.matrix()))
+    np.testing.assert_allclose(got.matrix(), start.matrix(), atol=1e-6)
+
+
+# ------------------------------------------------------- two tracers, one volume --
+
+def test_two_tracers_share_a_volume(api, orc):
+    """Every attached Tracer's cached bounds go stale when the visible list changes, not
+    only the most recently attached one's."""
+    import torch
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    pose = scenes.tracer_test_pose()
+    hf, df = frames(api, orc, scenes.plane(w, h, 1.5), k, pose)
+    hv, dv = make_pair(api, orc, 4096, 1024, 0.008, 0.04)
+    first, second = api.Tracer(dv), api.Tracer(dv)
+    integ = api.DepthIntegrator(dv)
+    out_a = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose)
+    out_b = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, pose)
+    for round_ in range(4):          # same pose every round; the visible list keeps growing
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        dv.set_view(df)
+        assert first.view_bounds.valid == 0 and second.view_bounds.valid == 0
+        integ.integrate(df)
+        first.trace(out_a)
+        second.trace(out_b)
+        sync()
+        odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+        for tracer, out in ((first, out_a), (second, out_b)):
+            assert np.array_equal(tracer.bounds.cpu().numpy(), obounds), round_
+            assert np.array_equal(out.depth.cpu().numpy(), odepth), round_

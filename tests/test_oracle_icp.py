@@ -153,3 +153,152 @@ def test_downsample(orc):
     assert np.array_equal(orc.downsample(rgb, True), rgb[::2, ::2])
     box = ((rgb[0::2, 1::2] + rgb[0::2, 0::2]) + rgb[1::2, 1::2] + rgb[1::2, 0::2]) * np.float32(0.25)
     assert np.array_equal(orc.downsample(rgb, False), box.astype(np.float32))
+
+
+# ---- pins asked for by the round-1 review ------------------------------------------
+
+def _get_transform_f32(update, Twc):
+    """tests/depth_tracker_test.cu:250-300 GetTransform (the reference test's own copy of
+    DepthTracker::ApplyUpdate, including Tinc(1,2) = +update[0]) in numpy float32, with the
+    reference's operation order: Matrix product accumulates from 0 in index order
+    (matrix.h:297-318), Normalize multiplies by 1/sqrt(dot) (matrix.h:131-154)."""
+    F = np.float32
+    u = np.asarray(update, dtype=F)
+    Tinc = np.array([[1, -u[2], +u[1], u[3]],
+                     [+u[2], 1, +u[0], u[4]],
+                     [-u[1], +u[0], 1, u[5]],
+                     [0, 0, 0, 1]], dtype=F)
+    A = Twc.matrix().astype(F)
+    M = np.zeros((4, 4), dtype=F)
+    for r in range(4):
+        for c in range(4):
+            acc = F(0)
+            for n in range(4):
+                acc = F(acc + F(Tinc[r, n] * A[n, c]))
+            M[r, c] = acc
+
+    def dot(a, b):
+        acc = F(0)
+        for i in range(3):
+            acc = F(acc + F(a[i] * b[i]))
+        return acc
+
+    def normalized(a):
+        return (a * F(F(1) / np.sqrt(dot(a, a), dtype=F))).astype(F)
+
+    def cross(a, b):
+        return np.array([F(a[1] * b[2]) - F(a[2] * b[1]), F(a[2] * b[0]) - F(a[0] * b[2]),
+                         F(a[0] * b[1]) - F(a[1] * b[0])], dtype=F)
+    x_axis, y_axis = normalized(M[:3, 0]), normalized(M[:3, 1])
+    z_axis = cross(x_axis, y_axis)
+    y_axis = cross(z_axis, x_axis)
+    out = np.eye(4, dtype=F)
+    out[:3, 0], out[:3, 1], out[:3, 2], out[:3, 3] = x_axis, y_axis, z_axis, M[:3, 3]
+    return out
+
+
+def test_apply_update_equals_the_reference_test_helper(orc):
+    """DepthTracker::ApplyUpdate (depth_tracker.cpp:22-86) vs the helper the reference's own
+    Jacobian test perturbs poses with (tests/depth_tracker_test.cu:250-300). The update is
+    injected through the solve with H = I, g = -x (an identity LDL^T is exact)."""
+    rng = np.random.default_rng(7)
+    eye_packed = np.zeros(21, dtype=np.float32)
+    eye_packed[[i * (i + 1) // 2 + i for i in range(6)]] = 1.0
+    for trial in range(50):
+        x = (rng.standard_normal(6) * np.array([1e-2, 1e-2, 1e-2, 1e-3, 1e-3, 1e-3]) * 10 ** rng.uniform(-2, 1)).astype(np.float32)
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        Twc = T.Transform.translate(*rng.uniform(-2, 2, 3)) * T.Transform.rotate(*q)
+        got, upd, norm = orc.icp_solve_update(eye_packed, -x, Twc, True)
+        assert np.array_equal(upd, x)
+        assert np.float32(norm) == np.sqrt(np.sum(x.astype(np.float32) ** 2, dtype=np.float32), dtype=np.float32) \
+            or abs(norm - np.linalg.norm(x)) <= 1e-6 * np.linalg.norm(x)
+        want = _get_transform_f32(x, Twc)
+        # Transform::Translate(t) * Transform::Rotate(R): the product with an identity-rotation
+        # translation adds exact zeros, so the 3x4 part is R | t bit for bit
+        assert np.array_equal(got.matrix()[:3, :3], want[:3, :3]), trial
+        assert np.array_equal(got.matrix()[:3, 3], want[:3, 3]), trial
+        # the cached inverse is Rotate(R).Inverse() * Translate(-t) with Rotate's inverse = R^T
+        # (transform.h:74-99,146-159). z = x X y is not re-normalised (depth_tracker.cpp:62-65), so
+        # R is orthonormal only to first order in the update: that is the reference's behaviour
+        assert np.array_equal(got.inverse_matrix()[:3, :3], want[:3, :3].T), trial
+
+
+def test_ldlt_against_float64_solve(orc):
+    """The 6x6 solve is the one piece with no reference-held vector (Eigen, unversioned). Bound
+    it instead: float32 LDL^T vs numpy's float64 solve on normal systems J^T J of widely
+    varying conditioning, error <= 8 * cond(H) * eps32 * |x| (backward-stable Cholesky-type
+    bound with a small constant)."""
+    rng = np.random.default_rng(11)
+    eps = np.finfo(np.float32).eps
+    worst = 0.0
+    for trial in range(300):
+        n = 6 if trial % 3 else 3
+        m = int(rng.integers(20, 2000))
+        scale = 10 ** rng.uniform(-3, 1, size=n)               # ill-scaled columns, like X x n vs n
+        J = rng.standard_normal((m, n)) * scale
+        r = rng.standard_normal(m) * 10 ** rng.uniform(-4, 0)
+        H = (J.T @ J).astype(np.float32)
+        g = (J.T @ r).astype(np.float32)
+        packed = np.zeros(21, dtype=np.float32)
+        idx = 0
+        for i in range(n):
+            for j in range(i + 1):
+                packed[idx] = H[i, j]
+                idx += 1
+        gg = np.zeros(6, dtype=np.float32)
+        gg[:n] = g
+        _, upd, _ = orc.icp_solve_update(packed, gg, T.Transform.identity(), n == 6)
+        H64 = np.tril(H.astype(np.float64)) + np.tril(H.astype(np.float64), -1).T
+        x64 = -np.linalg.solve(H64, g.astype(np.float64))
+        cond = np.linalg.cond(H64)
+        err = np.linalg.norm(upd[:n] - x64) / max(np.linalg.norm(x64), 1e-30)
+        worst = max(worst, err / (cond * eps))
+        assert err <= 8 * cond * eps, (trial, n, cond, err)
+        assert np.all(upd[n:] == 0)
+    assert worst > 0
+
+
+@pytest.mark.parametrize("translation", [True, False])
+def test_empty_system_solves_to_zero(orc, translation):
+    """H = 0, g = 0 (no valid correspondence): Eigen's LDLT returns x = 0 (zero pivots are
+    skipped), so |update| < 1e-6 stops the loop and the pose is only re-orthonormalised
+    (tracker.cpp:153-162). A rank-deficient system must stay finite too."""
+    zero_h, zero_g = np.zeros(21, np.float32), np.zeros(6, np.float32)
+    start = T.Transform.translate(0.01, 0.02, -0.01) * T.Transform.rotate(0.9998, 0.01, -0.01, 0.012)
+    pose, upd, norm = orc.icp_solve_update(zero_h, zero_g, start, translation)
+    assert np.all(upd == 0) and norm == 0
+    assert np.all(np.isfinite(pose.matrix()))
+    np.testing.assert_allclose(pose.matrix(), start.matrix(), atol=1e-6)
+    # rank 1: only rotation about x is observable
+    h = zero_h.copy()
+    g = zero_g.copy()
+    h[0], g[0] = 4.0, 2.0
+    pose, upd, norm = orc.icp_solve_update(h, g, start, translation)
+    assert np.array_equal(upd, np.array([-0.5, 0, 0, 0, 0, 0], np.float32))
+    assert np.all(np.isfinite(pose.matrix()))
+    # an all-hole frame through the whole loop
+    key = orc.HostFrame(scenes.ripple(160, 120), T.Projection.make(136, 136, 80, 60), T.Transform.identity())
+    key.compute_normals()
+    frm = orc.HostFrame(np.zeros((120, 160), np.float32), T.Projection.make(136, 136, 80, 60), start)
+    frm.compute_normals()
+    pose, iters = orc.icp_track(key, frm, 20, translation)
+    assert iters == 1 and np.all(np.isfinite(pose.matrix()))
+
+
+def test_pyramid_loop_recovers_the_pose(orc):
+    """pyramid_tracker.cpp:52-90 on the oracle: half level (15) then full level (20)."""
+    w, h = 320, 240
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.0 + 0.05 * np.cos(3.0 * x / w) * np.sin(2.0 * y / h)).astype(np.float32)
+    k = T.Projection.make(273.5, 273.5, 160, 120)
+    key = orc.HostFrame(depth, k, T.Transform.identity(), color=scenes.checker_color(w, h))
+    key.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    frm = orc.HostFrame(depth, k, start, color=scenes.checker_color(w, h))
+    frm.compute_normals()
+    half = frm.downsample()
+    assert (half.width, half.height) == (160, 120) and np.array_equal(half.depth, depth[::2, ::2])
+    assert half.depth_projection.fx == np.float32(273.5) * np.float32(0.5)
+    pose, iters = orc.pyramid_track(key, frm)
+    np.testing.assert_allclose(pose.matrix(), np.eye(4), atol=5e-4)

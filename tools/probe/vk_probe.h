@@ -1,0 +1,32 @@
+/*
+ * vk_probe.h — measurement aids (libvk_probe.so). NOT part of the product ABI
+ * (include/vk.h) and not linked into libvk_hip.so: bench.py and tools/ load it to
+ * put a kernel's GB/s next to what the same GPU sustains on a plain copy and on
+ * the integrate kernel's own access pattern with the arithmetic removed
+ * (SURVEY.md §8d "Peak to divide by: measured"). No reference counterpart.
+ */
+#ifndef VK_PROBE_H_
+#define VK_PROBE_H_
+
+#include "../../include/vk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* float4 device copy, `bytes` a multiple of 16. shape:
+ *   0  one float4 per lane, one-shot grid (bytes / 4096 workgroups of 256)
+ *   1  four float4 per lane (4 KiB per wave-instruction group), one-shot grid
+ *   2  persistent grid (8 workgroups per CU), 4 loads in flight per lane
+ *   3  as 1 with non-temporal loads and stores
+ */
+VK_API int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, int shape, void* stream);
+/* float4 read-only sweep (sum folded into one store per workgroup): the read half alone */
+VK_API int vk_probe_stream_read(const void* src, size_t bytes, float* sink, void* stream);
+/* every visible block read and written back unchanged (10 240 B each way) */
+VK_API int vk_probe_block_rmw(const vk_volume* v, int mode, void* stream);   /* 0 plain, 1 nt stores, 2 nt loads+stores */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

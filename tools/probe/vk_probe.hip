@@ -1,0 +1,163 @@
+// vk_probe.hip — bandwidth probes (libvk_probe.so, see vk_probe.h). Measurement
+// tooling only: nothing in libvk_hip.so or vulcan_amd/ depends on it.
+#include "../../vulcan_amd/csrc/vk_common.hpp"
+#include "vk_probe.h"
+
+using namespace vk;
+
+namespace
+{
+
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void copy_one_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) dst[i] = src[i];
+}
+
+// a workgroup moves 16 KiB: four 4-KiB rows, every wave-instruction a contiguous 1 KiB
+template <bool NT>
+__global__ __launch_bounds__(256) void copy_four_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4)
+{
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  float4 r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const size_t i = base + (size_t)k * 256;
+    if (i < n4)
+    {
+      if (NT) { const nf4 t = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(src + i)); r[k] = make_float4(t.x, t.y, t.z, t.w); }
+      else r[k] = src[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const size_t i = base + (size_t)k * 256;
+    if (i < n4)
+    {
+      if (NT) { nf4 t; t.x = r[k].x; t.y = r[k].y; t.z = r[k].z; t.w = r[k].w; __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(dst + i)); }
+      else dst[i] = r[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_persistent_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4)
+{
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride)
+  {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void read_kernel(const float4* __restrict__ src, size_t n4, float* __restrict__ sink)
+{
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const size_t i = base + (size_t)k * 256;
+    if (i < n4) { const float4 v = src[i]; acc += v.x + v.y + v.z + v.w; }
+  }
+  if (acc == 123.456f) sink[0] = acc;   // keeps the loads; practically never true
+}
+
+// Reads every visible block (10 240 B) and writes it back unchanged: one wave per
+// block, ten float4 per lane, the integrate kernel's persistent grid.
+template <int MODE>
+__global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ voxels4,
+    const vk_hash_entry* __restrict__ entries, const int32_t* __restrict__ visible,
+    const int32_t* __restrict__ counters)
+{
+  const int lane = lane_id();
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int total_waves = gridDim.x * 4;
+  const int count = counters[VK_CTR_VISIBLE];
+
+  for (int i = wave; i < count; i += total_waves)
+  {
+    const Entry entry = load_entry(entries, (uint32_t)__builtin_amdgcn_readfirstlane(visible[i]));
+    if (entry.data < 0) continue;
+    float4* block4 = voxels4 + (size_t)entry.data * 640;
+    float4 r[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+    {
+      if (MODE == 2)
+      {
+        const nf4 t = __builtin_nontemporal_load(reinterpret_cast<const nf4*>(&block4[k * 64 + lane]));
+        r[k] = make_float4(t.x, t.y, t.z, t.w);
+      }
+      else r[k] = block4[k * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+    {
+      r[k].x += 0.0f;   // keeps the store: x + 0.0f is not an identity for -0.0f
+      if (MODE == 1 || MODE == 2)
+      {
+        nf4 t; t.x = r[k].x; t.y = r[k].y; t.z = r[k].z; t.w = r[k].w;
+        __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(&block4[k * 64 + lane]));
+      }
+      else block4[k * 64 + lane] = r[k];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, int shape, void* stream)
+{
+  VK_REQUIRE(dst && src && bytes >= 16 && (bytes % 16) == 0 && shape >= 0 && shape <= 3);
+  const size_t n4 = bytes / 16;
+  float4* d = reinterpret_cast<float4*>(dst);
+  const float4* s = reinterpret_cast<const float4*>(src);
+  VK_REQUIRE((n4 + 255) / 256 < (size_t)1 << 31);
+  switch (shape)
+  {
+    case 0: hipLaunchKernelGGL(copy_one_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, vk_s(stream), d, s, n4); break;
+    case 1: hipLaunchKernelGGL(copy_four_kernel<false>, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, vk_s(stream), d, s, n4); break;
+    case 2: hipLaunchKernelGGL(copy_persistent_kernel, dim3(kCUs * 8), dim3(256), 0, vk_s(stream), d, s, n4); break;
+    default: hipLaunchKernelGGL(copy_four_kernel<true>, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, vk_s(stream), d, s, n4); break;
+  }
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_probe_stream_read(const void* src, size_t bytes, float* sink, void* stream)
+{
+  VK_REQUIRE(src && sink && bytes >= 16 && (bytes % 16) == 0);
+  const size_t n4 = bytes / 16;
+  hipLaunchKernelGGL(read_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, vk_s(stream),
+      reinterpret_cast<const float4*>(src), n4, sink);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_probe_block_rmw(const vk_volume* v, int mode, void* stream)
+{
+  VK_REQUIRE(v && v->voxels && v->hash_entries && v->visible_blocks && v->counters);
+  const int max_count = v->main_block_count + v->excess_block_count;
+  int grid = (max_count + 3) / 4;
+  if (grid > kCUs * 4) grid = kCUs * 4;
+  float4* vox = reinterpret_cast<float4*>(v->voxels);
+  switch (mode)
+  {
+    case 1: hipLaunchKernelGGL(block_rmw_kernel<1>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+    case 2: hipLaunchKernelGGL(block_rmw_kernel<2>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+    default: hipLaunchKernelGGL(block_rmw_kernel<0>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
+  }
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,8 @@ _SIGNATURES = {
     "vk_memcpy_d2h": ([_P, _P, _SZ, _P], _I),
     "vk_memcpy_d2d": ([_P, _P, _SZ, _P], _I),
     "vk_memset": ([_P, _I, _SZ, _P], _I),
+    "vk_malloc_host": ([_PP, _SZ], _I),
+    "vk_free_host": ([_P], _I),
     "vk_event_create": ([_PP], _I),
     "vk_event_destroy": ([_P], _I),
     "vk_event_record": ([_P, _P], _I),
@@ -70,26 +72,21 @@ _SIGNATURES = {
     "vk_icp_workspace_floats": ([_I, _I], _SZ),
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
-    "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_compute_residuals": ([_P, _P, _P, _P, _P], _I),
     "vk_color_tracker_compute_jacobian": ([_P, _P, _P, _I, _P, _P], _I),
     "vk_color_tracker_compute_system": ([_P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_solve_update": ([_P, _P, _I, _P, _P, _P, _P, _P, _P], _I),
-    "vk_color_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_color_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_light_tracker_compute_residuals": ([_P, _P, _P, _P, _P, _P], _I),
     "vk_light_tracker_compute_jacobian": ([_P, _P, _P, _P, _I, _P, _P], _I),
     "vk_light_tracker_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
-    "vk_light_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_light_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
     "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
-    "vk_probe_stream_copy": ([_P, _P, _SZ, _P], _I),
-    "vk_probe_block_rmw": ([_P, _P], _I),
-    "vk_probe_block_rmw_mode": ([_I], _I),
-    "vk_probe_integrate": ([_P, _P, _P, _I, _P], _I),
-    "vk_probe_points_variant": ([_I], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn
@@ -175,6 +172,8 @@ class Frame:
         d.color = None if self.color is None else self.color.data_ptr()
         d.normals = None if self.normals is None else self.normals.data_ptr()
         d.width, d.height = self.width, self.height
+        if self.color is not None:
+            d.color_height, d.color_width = self.color.shape[0], self.color.shape[1]
         d.depth_projection, d.color_projection = self.depth_projection, self.color_projection
         d.depth_to_world, d.depth_to_color = self.depth_to_world, self.depth_to_color
         return d
@@ -207,8 +206,9 @@ class Frame:
               "vk_image_downsample")
         color = normals = None
         if self.color is not None:
-            color = torch.empty((h2, w2, 3), dtype=torch.float32, device=self.device)
-            check(lib().vk_color_image_downsample(self.width, self.height, _ptr(self.color), _ptr(color), 0,
+            ch, cw = self.color.shape[0], self.color.shape[1]     # ColorImage::Downsample uses its own size
+            color = torch.empty((ch // 2, cw // 2, 3), dtype=torch.float32, device=self.device)
+            check(lib().vk_color_image_downsample(cw, ch, _ptr(self.color), _ptr(color), 0,
                                                   stream()), "vk_color_image_downsample")
         if self.normals is not None:
             normals = torch.empty((h2, w2, 3), dtype=torch.float32, device=self.device)
@@ -246,11 +246,18 @@ class Volume:
         # raycast bounds computed ahead, inside the integrate launch (vk_view_bounds);
         # a Tracer attaches its scratch and settings here
         self.view_bounds = None
+        self._view_records = []      # every Tracer's record: all go stale when the visible list changes
         check(lib().vk_volume_initialize(_ref(self.desc()), stream()), "vk_volume_initialize")
 
+    def attach_view_bounds(self, record):
+        """A Tracer registers its vk_view_bounds: the integrators prepare the bounds of
+        the most recently attached one; every attached record is invalidated together."""
+        self._view_records.append(record)
+        self.view_bounds = record
+
     def _view_changed(self):
-        if self.view_bounds is not None:
-            self.view_bounds.valid = 0
+        for record in self._view_records:
+            record.valid = 0
 
     def desc(self):
         d = T.Volume()
@@ -417,7 +424,7 @@ class Tracer:
         vb.bounds_width, vb.bounds_height = self.BOUNDS_W, self.BOUNDS_H
         vb.min_depth, vb.max_depth = self.depth_range
         self.view_bounds = vb
-        volume.view_bounds = vb
+        volume.attach_view_bounds(vb)
 
     def trace(self, frame):
         """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals."""
@@ -475,7 +482,43 @@ class Tracer:
         return to_numpy(self.patches[:n * 16], T.patch_dtype)
 
 
-class DepthTracker:
+class _PollMixin:
+    """Early exit of the device-side Gauss-Newton loop (vk_track_poll): a pinned
+    {iterations, converged} mirror the enqueuing call looks at every `poll_chunk` steps."""
+
+    poll_chunk = 4                           # 0: enqueue every step, never block
+
+    def _poll(self):
+        if not self.poll_chunk:
+            return None
+        if getattr(self, "_poll_desc", None) is None:
+            host = C.c_void_p()
+            check(lib().vk_malloc_host(C.byref(host), 8), "vk_malloc_host")
+            self._poll_host = host
+            self._poll_desc = T.TrackPoll(host.value, 0)
+        self._poll_desc.chunk = int(self.poll_chunk)
+        return _ref(self._poll_desc)
+
+    def _c_hook(self):
+        """The python reduce hook as a vk_icp_reduce_fn (or None)."""
+        if self.reduce_hook is None:
+            return None
+        system, py_hook = self.system, self.reduce_hook
+
+        def _call(ptr, count, user, strm):
+            py_hook(system)
+            return 0
+        self._hook_keepalive = _REDUCE_FN(_call)
+        return self._hook_keepalive
+
+    def __del__(self):
+        host = getattr(self, "_poll_host", None)
+        if host is not None and _LIB is not None:
+            _LIB.vk_free_host(host)
+            self._poll_host = None
+
+
+class DepthTracker(_PollMixin):
     """vulcan::DepthTracker (depth_tracker.h, tracker.h): Gauss-Newton ICP against a
     keyframe; the pose, the 27-float system and the solve stay on the device."""
 
@@ -543,25 +586,19 @@ class DepthTracker:
         host = np.frombuffer(bytes(frame.depth_to_world), dtype=np.uint8).copy()
         self.pose.copy_(torch.from_numpy(host).to(self.device))
         self.state.zero_()
-        if self.reduce_hook is None:
-            # one C call enqueues every iteration (2 launches each)
-            check(lib().vk_icp_track(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
-                                     _ref(self._view(frame)), _ptr(self.pose), self.max_iterations,
-                                     int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),
-                                     _ptr(self.state), _ptr(self.update), None, None, stream()), "vk_icp_track")
-        else:
-            for _ in range(self.max_iterations):
-                self.compute_system(frame, pose_on_device=True)
-                self.reduce_hook(self.system)
-                check(lib().vk_icp_solve_update(_ptr(self.hessian), _ptr(self.gradient), int(self.translation_enabled),
-                                                _ptr(self.pose), _ptr(self.state), _ptr(self.update), stream()),
-                      "vk_icp_solve_update")
+        # one C call enqueues the iterations (2 launches each, 3 with a reduce hook) and
+        # stops enqueuing once the loop has converged
+        check(lib().vk_icp_track(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
+                                 _ref(self._view(frame)), _ptr(self.pose), self.max_iterations,
+                                 int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),
+                                 _ptr(self.state), _ptr(self.update), self._c_hook(), None, self._poll(), stream()),
+              "vk_icp_track")
         out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out
         return out
 
 
-class ColorTracker:
+class ColorTracker(_PollMixin):
     """vulcan::ColorTracker (color_tracker.h): photometric Gauss-Newton tracking of a
     frame against a keyframe — intensity residuals sampled bilinearly in the frame,
     one per keyframe pixel. Pose, system and solve stay on the device."""
@@ -667,18 +704,12 @@ class ColorTracker:
         self.pose.copy_(torch.from_numpy(host).to(self.device))
         self.state.zero_()
         key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
-        hook = None
-        if self.reduce_hook is not None:
-            system, py_hook = self.system, self.reduce_hook
-
-            def _call(ptr, count, user, strm):
-                py_hook(system)
-                return 0
-            hook = _REDUCE_FN(_call)
+        hook = self._c_hook()
         check(lib().vk_color_tracker_track(_ref(kv), _ref(fv), _ref(frame.depth_to_color), _ref(key_Twc),
                                            _ptr(self.pose), self.max_iterations, int(self.translation_enabled),
                                            _ptr(self._workspace()), _ptr(self.system), _ptr(self.state),
-                                           _ptr(self.update), hook, None, stream()), "vk_color_tracker_track")
+                                           _ptr(self.update), hook, None, self._poll(), stream()),
+              "vk_color_tracker_track")
         out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out.depth_to_world
         return out.depth_to_world
@@ -754,8 +785,8 @@ class LightTracker(ColorTracker):
         key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
         check(lib().vk_light_tracker_track(_ref(kv), _ref(fv), _ref(terms), _ref(key_Twc), _ptr(self.pose),
                                            self.max_iterations, int(self.translation_enabled), _ptr(self._workspace()),
-                                           _ptr(self.system), _ptr(self.state), _ptr(self.update), None, None,
-                                           stream()), "vk_light_tracker_track")
+                                           _ptr(self.system), _ptr(self.state), _ptr(self.update), self._c_hook(), None,
+                                           self._poll(), stream()), "vk_light_tracker_track")
         out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out.depth_to_world
         return out.depth_to_world

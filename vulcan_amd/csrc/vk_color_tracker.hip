@@ -375,7 +375,7 @@ __device__ __forceinline__ void derive_tcm(const vk_transform& frame_Tcd, const 
 template <int N>
 __device__ __forceinline__ void color_solve_update_n(const float* hessian, const float* gradient,
     const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
-    float* update_out)
+    float* update_out, unsigned long long* mirror)
 {
   float update[6];
   solve_step<N>(hessian, gradient, update);
@@ -396,16 +396,16 @@ __device__ __forceinline__ void color_solve_update_n(const float* hessian, const
   for (int i = 0; i < 16; ++i) { pose->depth_to_world.m[i] = out_i[i]; pose->depth_to_world.inv[i] = out_m[i]; }   // .Inverse()
 
   derive_tcm(frame_Tcd, key_Twc, pose);
-  finish_step<N>(update, state, update_out);
+  finish_step<N>(update, state, update_out, mirror);
 }
 
 __device__ void color_solve_update(const float* hessian, const float* gradient, int translation_enabled,
     const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
-    float* update_out)
+    float* update_out, unsigned long long* mirror)
 {
   if (state && state[1]) return;  // converged earlier: tracker.cpp:162
-  if (translation_enabled) color_solve_update_n<6>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out);
-  else color_solve_update_n<3>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out);
+  if (translation_enabled) color_solve_update_n<6>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out, mirror);
+  else color_solve_update_n<3>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out, mirror);
 }
 
 struct PoseArgs
@@ -414,6 +414,7 @@ struct PoseArgs
   vk_color_pose* pose;      // null: sums only
   int32_t* state;
   float* update_out;
+  unsigned long long* mirror;   // pinned host {iterations, converged}, or null (vk_track_poll)
 };
 
 // second stage; with a pose it also solves and updates (one workgroup)
@@ -425,14 +426,14 @@ __global__ __launch_bounds__(256) void color_final_kernel(const float* __restric
   if (A.state && A.state[1]) return;
   sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
   if (A.pose && threadIdx.x == 0)
-    color_solve_update(sums, sums + 36, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out);
+    color_solve_update(sums, sums + 36, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out, A.mirror);
 }
 
 __global__ void color_solve_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
     int translation_enabled, PoseArgs A)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0)
-    color_solve_update(hessian, gradient, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out);
+    color_solve_update(hessian, gradient, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out, A.mirror);
 }
 
 __global__ void color_prepare_kernel(PoseArgs A)
@@ -602,6 +603,7 @@ static int system_impl(const vk_color_view* keyframe, const vk_color_view* frame
   A.pose = nullptr;
   A.state = nullptr;
   A.update_out = nullptr;
+  A.mirror = nullptr;
   hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
       translation_enabled, hessian, gradient, A);
   VK_LAUNCH_CHECK();
@@ -635,6 +637,7 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
   A.pose = pose_dev;
   A.state = state_dev;
   A.update_out = update_dev;
+  A.mirror = nullptr;
   hipLaunchKernelGGL(color_solve_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
       translation_enabled, A);
   VK_LAUNCH_CHECK();
@@ -644,7 +647,7 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
 static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame, const vk_light_terms* terms,
     bool light, const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
-    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+    vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
 {
   ColorParams P;
   const vk_transform identity = identity_transform();
@@ -665,7 +668,11 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
   A.pose = pose_dev;
   A.state = state_dev;
   A.update_out = update_dev;
+  const bool chunked = polling(poll);
+  A.mirror = chunked ? reinterpret_cast<unsigned long long*>(poll->host_state) : nullptr;
+  if (chunked) *reinterpret_cast<volatile unsigned long long*>(A.mirror) = 0;
   PoseArgs sums_only = A;
+  sums_only.mirror = nullptr;
   sums_only.pose = nullptr;
   sums_only.state = nullptr;
   sums_only.update_out = nullptr;
@@ -693,6 +700,8 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
           hessian, gradient, A);
     }
     VK_LAUNCH_CHECK();
+    // stop enqueuing once the loop has converged (tracker.cpp:162), see vk_icp_track
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(poll, it + 1, s)) break;
   }
   return VK_OK;
 }
@@ -700,20 +709,20 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
 VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
     const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
-    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+    vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
 {
   return track_impl(keyframe, frame, nullptr, false, frame_Tcd, keyframe_Twc, pose_dev, iterations,
-      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, stream);
+      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, poll, stream);
 }
 
 VK_API int vk_light_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
     const vk_light_terms* terms, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev, float* update_dev,
-    vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+    vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
 {
   VK_REQUIRE(terms);
   return track_impl(keyframe, frame, terms, true, &terms->frame_Tcd, keyframe_Twc, pose_dev, iterations,
-      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, stream);
+      translation_enabled, workspace, system, state_dev, update_dev, reduce, reduce_user, poll, stream);
 }
 
 }  // extern "C"

@@ -133,7 +133,12 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
 }
 
 // LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
-// not vendored; agreement is to rounding). N is a template parameter and every
+// not vendored; agreement is to rounding). A zero pivot is handled the way
+// Eigen's LDLT handles it (the column of L is left at 0, and the solve sets
+// y[j] = 0 where |D[j]| <= FLT_MIN): an empty or rank-deficient system — no valid
+// correspondence, e.g. an all-hole frame — then yields update = 0, the step norm
+// is below 1e-6 and the pose is left untouched, instead of 0/0 = NaN poisoning
+// the pose (tracker.cpp:153-162). N is a template parameter and every
 // loop is unrolled so that L, D, y live in registers: with a run-time size the
 // arrays are indexed dynamically, land in scratch memory, and the one lane that
 // solves spends ~10 us waiting on it.
@@ -159,7 +164,7 @@ __device__ __forceinline__ void ldlt_solve(const float (&A)[N * N], const float 
       float s = A[i * N + j];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k] * D[k];
-      L[i * N + j] = s / d;
+      L[i * N + j] = (fabsf(d) > 0.0f) ? s / d : 0.0f;
     }
   }
 
@@ -173,7 +178,7 @@ __device__ __forceinline__ void ldlt_solve(const float (&A)[N * N], const float 
   }
 
 #pragma unroll
-  for (int i = 0; i < N; ++i) y[i] = y[i] / D[i];
+  for (int i = 0; i < N; ++i) y[i] = (fabsf(D[i]) > FLT_MIN) ? y[i] / D[i] : 0.0f;
 
 #pragma unroll
   for (int i = N - 1; i >= 0; --i)
@@ -253,9 +258,13 @@ __device__ __forceinline__ void rigid_from(const float (&M)[16], float (&out_m)[
   matmul4(Ri, Ti, out_i);
 }
 
-// tracker.cpp:160-162: record the step and stop once it is shorter than 1e-6
+// tracker.cpp:160-162: record the step and stop once it is shorter than 1e-6.
+// `mirror` (optional): pinned host memory that receives {iterations, converged} as
+// ONE 64-bit system-scope store after every step, so a host that enqueues the loop
+// in chunks can stop enqueuing once it has converged (vk_track_poll, vk.h).
 template <int N>
-__device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* state, float* update_out)
+__device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* state, float* update_out,
+    unsigned long long* mirror = nullptr)
 {
   float sq = 0.0f;
 #pragma unroll
@@ -267,10 +276,40 @@ __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* s
   }
   if (state)
   {
-    state[0] += 1;
-    if (sqrtf(sq) < 1E-6f) state[1] = 1;
+    const int iterations = state[0] + 1;
+    const int converged = (sqrtf(sq) < 1E-6f) ? 1 : state[1];
+    state[0] = iterations;
+    state[1] = converged;
+    if (mirror)
+      __hip_atomic_store(mirror, ((unsigned long long)(uint32_t)converged << 32) | (uint32_t)iterations,
+          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// ---- host side of the chunked loop ------------------------------------------------
+
+// After the steps up to `target` have been enqueued on `s`: wait until the mirror shows
+// that many steps or a converged loop. Returns true when the loop has converged (stop
+// enqueuing). The spin is bounded by the stream itself: once the stream has drained
+// nothing more will be written.
+inline bool wait_for_steps(const vk_track_poll* poll, int target, hipStream_t s)
+{
+  const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(poll->host_state);
+  for (unsigned spin = 0;; ++spin)
+  {
+    const unsigned long long v = *word;
+    if ((v >> 32) != 0) return true;
+    if ((int)(uint32_t)v >= target) return false;
+    if ((spin & 1023u) == 1023u && hipStreamQuery(s) != hipErrorNotReady)
+    {
+      const unsigned long long last = *word;      // drained: the mirror is final
+      return (last >> 32) != 0;
+    }
+  }
+}
+
+inline bool polling(const vk_track_poll* poll) { return poll && poll->host_state && poll->chunk > 0; }
+
 
 inline int partial_count(int width, int height)
 {

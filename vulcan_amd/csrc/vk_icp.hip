@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void jacobian_kernel(IcpParams P, float* __res
 }
 
 __device__ void solve_update(const float* hessian, const float* gradient, int translation_enabled,
-    vk_transform* Twc, int32_t* state, float* update_out);
+    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror);
 
 // ref: depth_tracker.cu:144-268. Slot layout of a partial: [0,6) J^T r,
 // [6,27) packed lower triangle of J^T J in (r, c<=r) row-major order.
@@ -161,13 +161,13 @@ __global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P
 // pose, so a Gauss-Newton iteration is two launches.
 __global__ __launch_bounds__(256) void system_final_kernel(const float* __restrict__ workspace,
     int partials, int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient,
-    vk_transform* Twc, int32_t* state, float* update_out)
+    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
 {
   __shared__ float slices[8][kSysStride];
   __shared__ float sums[48];   // hessian[36] | gradient[6]: the solve reads them from LDS
   if (state && state[1]) return;   // converged: the system was not recomputed, keep the last one
   sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
-  if (Twc && threadIdx.x == 0) solve_update(sums, sums + 36, translation_enabled, Twc, state, update_out);
+  if (Twc && threadIdx.x == 0) solve_update(sums, sums + 36, translation_enabled, Twc, state, update_out, mirror);
 }
 
 // ---- pose update on the device ------------------------------------------------
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
 // small to spread.
 template <int N>
 __device__ __forceinline__ void solve_update_n(const float* hessian, const float* gradient,
-    vk_transform* Twc, int32_t* state, float* update_out)
+    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
 {
   float update[6];
   solve_step<N>(hessian, gradient, update);
@@ -196,21 +196,22 @@ __device__ __forceinline__ void solve_update_n(const float* hessian, const float
 #pragma unroll
   for (int i = 0; i < 16; ++i) { Twc->m[i] = out_m[i]; Twc->inv[i] = out_i[i]; }
 
-  finish_step<N>(update, state, update_out);
+  finish_step<N>(update, state, update_out, mirror);
 }
 
 __device__ void solve_update(const float* hessian, const float* gradient,
-    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out)
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
 {
   if (state && state[1]) return;  // converged earlier: tracker.cpp:162
-  if (translation_enabled) solve_update_n<6>(hessian, gradient, Twc, state, update_out);
-  else solve_update_n<3>(hessian, gradient, Twc, state, update_out);
+  if (translation_enabled) solve_update_n<6>(hessian, gradient, Twc, state, update_out, mirror);
+  else solve_update_n<3>(hessian, gradient, Twc, state, update_out, mirror);
 }
 
 __global__ void solve_update_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
-    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out)
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
 {
-  if (threadIdx.x == 0 && blockIdx.x == 0) solve_update(hessian, gradient, translation_enabled, Twc, state, update_out);
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    solve_update(hessian, gradient, translation_enabled, Twc, state, update_out, mirror);
 }
 
 // ------------------------------------------------------------------ pyramid ----
@@ -364,14 +365,16 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
   launch_partials(P, translation_enabled, partials, workspace, vk_s(stream));
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
-      translation_enabled, hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+      translation_enabled, hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr,
+      (unsigned long long*)nullptr);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
 
 int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
     vk_transform* Twc_dev, int iterations, int translation_enabled, float* workspace, float* system,
-    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, void* stream)
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
+    const vk_track_poll* poll, void* stream)
 {
   IcpParams P;
   vk_transform identity;
@@ -385,6 +388,9 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
   float* gradient = system + 36;
   const int partials = partial_count(frame->width, frame->height);
   hipStream_t s = vk_s(stream);
+  const bool chunked = polling(poll);
+  unsigned long long* mirror = chunked ? reinterpret_cast<unsigned long long*>(poll->host_state) : nullptr;
+  if (chunked) *reinterpret_cast<volatile unsigned long long*>(mirror) = 0;   // the caller zeroed state_dev too
 
   for (int it = 0; it < iterations; ++it)
   {
@@ -394,19 +400,24 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
     {
       // multi-GPU rig: sum the packed system over ranks before every rank solves it
       hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
-          hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+          hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
       VK_LAUNCH_CHECK();
       const int rr = reduce(system, 48, reduce_user, stream);
       if (rr != 0) return rr;
       hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, s, hessian, gradient, translation_enabled,
-          Twc_dev, state_dev, update_dev);
+          Twc_dev, state_dev, update_dev, mirror);
     }
     else
     {
       hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
-          hessian, gradient, Twc_dev, state_dev, update_dev);
+          hessian, gradient, Twc_dev, state_dev, update_dev, mirror);
     }
     VK_LAUNCH_CHECK();
+
+    // tracker.cpp:162: the reference leaves its loop once |update| < 1e-6. Steps enqueued
+    // after that point are no-ops, but each still costs two launches; so the host looks
+    // at the mirror every `chunk` steps and stops enqueuing when the loop has converged.
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(poll, it + 1, s)) break;
   }
   return VK_OK;
 }
@@ -416,7 +427,7 @@ int vk_icp_solve_update(const float* hessian, const float* gradient, int transla
 {
   VK_REQUIRE(hessian && gradient && Twc_dev);
   hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
-      translation_enabled, Twc_dev, state_dev, update_dev);
+      translation_enabled, Twc_dev, state_dev, update_dev, (unsigned long long*)nullptr);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

@@ -36,7 +36,8 @@ struct IntegrateParams
   const float* color;
   const float* normals;
   const float* mask;
-  int width, height;
+  int width, height;      // depth image
+  int cwidth, cheight;    // colour image (color_integrator.cu:183-184)
   vk_projection kd, kc;
   Rt Tdw, Tcw, Tcd;
   vk_light light;
@@ -45,7 +46,6 @@ struct IntegrateParams
   float max_distance_weight, max_color_weight;
 };
 
-constexpr int kWavesPerGroup = 4;
 constexpr int kTileF4 = 640;  // float4 per voxel block
 
 // light.h:53-60
@@ -58,257 +58,11 @@ __device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 n
   return l.intensity * cos_theta / distance_squared;
 }
 
-// Per-voxel depth sample gathered before the voxel tile arrives.
-struct DepthSample
-{
-  float depth;   // depth image value at the voxel's pixel (0 when not sampled)
-  float z;       // Xdp.z
-  bool valid;    // projects inside the image (depth_integrator.cu:46)
-};
-
-// VARIANT != 0 are timing-only ablations reached through vk_probe_integrate (their
-// results are wrong on purpose): 1 = no depth gather (depth = z + 1 cm), 2 = no per-voxel update,
-// 3 = no LDS staging either (load + store).
-template <bool DEPTH, int COLOR, int VARIANT = 0>
-__global__ __launch_bounds__(kWavesPerGroup * 64) void integrate_kernel(IntegrateParams P)
-{
-  __shared__ float4 tiles[kWavesPerGroup][kTileF4];
-
-  const int lane = lane_id();
-  const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wave = blockIdx.x * kWavesPerGroup + wave_in_group;
-  const int total_waves = gridDim.x * kWavesPerGroup;
-  const int count = P.counters[VK_CTR_VISIBLE];
-
-  float4* tile4 = tiles[wave_in_group];
-  float* tile = reinterpret_cast<float*>(tile4);
-
-  const int vx = lane & 7;
-  const int vy = lane >> 3;
-
-  // This wave owns blocks wave, wave + W, wave + 2W, ... Lane j fetches the hash
-  // entry of the j-th of them up front (two gathers per 64 blocks), so the block
-  // loop itself never waits on the visible list or the hash table: each
-  // iteration broadcasts its entry out of lane j with v_readlane.
-  for (int first = wave; first < count; first += 64 * total_waves)
-  {
-    const int mine = first + lane * total_waves;
-    int4 my_entry = make_int4(0, 0, -1, -1);
-    if (mine < count) my_entry = reinterpret_cast<const int4*>(P.entries)[P.visible[mine]];
-
-    for (int j = 0; j < 64; ++j)
-    {
-      const int i = first + j * total_waves;
-      if (i >= count) break;
-
-      const int e0 = __builtin_amdgcn_readlane(my_entry.x, j);
-      const int e1 = __builtin_amdgcn_readlane(my_entry.y, j);
-      const int data = __builtin_amdgcn_readlane(my_entry.z, j);
-      const int ox = (int16_t)(e0 & 0xffff), oy = (int16_t)((uint32_t)e0 >> 16), oz = (int16_t)(e1 & 0xffff);
-
-      // never-allocated origin block marked visible by the reference's quirk
-      // (SURVEY §2.5-1): the reference would index voxels[-512..]; skipped.
-      if (data < 0) continue;
-
-      float4* block4 = P.voxels4 + (size_t)data * kTileF4;
-
-    // ---- 1. project the lane's eight voxels and gather their depth pixels. This
-    // depends on the hash entry only, so the gathers fly together with the ten
-    // tile loads below instead of after them. The gather is unconditional (lanes
-    // that project outside the image read pixel 0 and ignore it): a branch
-    // around each load would force a wait at every merge point.
-    // depth_integrator.cu:35-52
-    const f3 block_offset = scale3(make3((float)ox, (float)oy, (float)oz), P.block_length);
-    DepthSample ds[8];
-    float du[8], dv[8];
-    if (DEPTH || COLOR == COLOR_LIGHT)
-    {
-#pragma unroll
-      for (int vz = 0; vz < 8; ++vz)
-      {
-        const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
-        const f3 Xdp = xform_point(P.Tdw, add3(block_offset, voxel_offset));
-        project(P.kd, Xdp, du[vz], dv[vz]);
-        ds[vz].z = Xdp.z;
-        ds[vz].valid = du[vz] >= 0 && du[vz] < P.width && dv[vz] >= 0 && dv[vz] < P.height;
-        ds[vz].depth = 0.0f;
-        if (DEPTH)
-        {
-          const int pixel = ds[vz].valid ? (int)dv[vz] * P.width + (int)du[vz] : 0;
-          ds[vz].depth = (VARIANT == 4) ? P.depth[(i & 1023) * 256 + vz * 64 + lane]   // coalesced stand-in
-                       : (VARIANT >= 1) ? ds[vz].z + 0.01f : P.depth[pixel];
-        }
-      }
-    }
-
-    // ---- 2. stage the tile: 10 x 1 KiB coalesced loads, then LDS
-    float4 r[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) r[k] = block4[k * 64 + lane];
-    if (VARIANT == 3)
-    {
-#pragma unroll
-      for (int k = 0; k < 10; ++k) block4[k * 64 + lane] = r[k];
-      continue;
-    }
-#pragma unroll
-    for (int k = 0; k < 10; ++k) tile4[k * 64 + lane] = r[k];
-    wave_lds_fence();   // float4-per-lane layout written, voxel-per-lane layout read
-
-    // ---- 3. update the eight z-slices. All sixteen LDS reads (distance +
-    // weight word per voxel) are issued before the first update so their latency
-    // overlaps instead of serialising behind eight branches.
-    bool dirty = false;
-    float old_d[8];
-    uint32_t old_w[8];
-#pragma unroll
-    for (int vz = 0; vz < 8; ++vz)
-    {
-      const float* vox = tile + (vz * 64 + lane) * 5;
-      old_d[vz] = vox[0];
-      old_w[vz] = __float_as_uint(vox[4]);
-    }
-
-#pragma unroll
-    for (int vz = 0; vz < 8; ++vz)
-    {
-      float* vox = tile + (vz * 64 + lane) * 5;  // 5 dwords per voxel
-      float distance_value = 0.0f;
-      bool have_distance = false;
-
-      if (VARIANT == 2)
-      {
-        vox[0] = old_d[vz] + 0.0f;   // ablation: LDS round trip only
-        dirty = true;
-      }
-      else if (DEPTH)
-      {
-        // depth_integrator.cu:54-78
-        const float depth = ds[vz].depth;
-        if (ds[vz].valid && !(depth < P.min_depth || depth > P.max_depth))
-        {
-          const float distance = depth - ds[vz].z;
-
-          if (distance > -P.truncation_length)
-          {
-            const float old_distance = old_d[vz];
-            const uint32_t weights = old_w[vz];
-            const int16_t dw = (int16_t)(weights & 0xffff);
-
-            const float prev_dist = dw * old_distance;
-            const float curr_dist = vmin(1.0f, distance / P.truncation_length);
-            const float dist_weight = dw + 1;
-            const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
-            distance_value = (prev_dist + curr_dist) / dist_weight;
-            have_distance = true;
-
-            vox[0] = distance_value;
-            old_w[vz] = (weights & 0xffff0000u) | (uint16_t)new_dw;
-            vox[4] = __uint_as_float(old_w[vz]);
-            dirty = true;
-          }
-        }
-      }
-
-      if (COLOR != COLOR_NONE)
-      {
-        const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
-        const f3 Xwp = add3(block_offset, voxel_offset);
-        const f3 Xcp = xform_point(P.Tcw, Xwp);
-        float cu, cv;
-        project(P.kc, Xcp, cu, cv);
-        const bool color_valid = cu >= 0 && cu < P.width && cv >= 0 && cv < P.height;
-
-        if (COLOR == COLOR_PLAIN)
-        {
-          // color_integrator.cu:100-134
-          if (color_valid)
-          {
-            const float dist = have_distance ? distance_value : old_d[vz];
-
-            if (fabsf(dist) < 1.0f)
-            {
-              const int image_index = (int)cv * P.width + (int)cu;
-              const uint32_t weights = old_w[vz];
-              const int16_t cw = (int16_t)(weights >> 16);
-              const float cwf = cw;
-              const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-              const f3 curr_color = make3(P.color[3 * image_index + 0], P.color[3 * image_index + 1],
-                  P.color[3 * image_index + 2]);
-              const float color_weight = cw + 1;
-              const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-              const f3 c = div3(add3(prev_color, curr_color), color_weight);
-              vox[1] = c.x;
-              vox[2] = c.y;
-              vox[3] = c.z;
-              vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-              dirty = true;
-            }
-          }
-        }
-
-        if (COLOR == COLOR_LIGHT)
-        {
-          // light_integrator.cu:197-248
-          if (ds[vz].valid && color_valid)
-          {
-            const int depth_index = (int)dv[vz] * P.width + (int)du[vz];
-            const int color_index = (int)cv * P.width + (int)cu;
-
-            if (P.mask[depth_index] > 0.5f)
-            {
-              const float dist = have_distance ? distance_value : old_d[vz];
-
-              if (fabsf(dist) < 1.0f)
-              {
-                f3 curr_color = make3(P.color[3 * color_index + 0], P.color[3 * color_index + 1],
-                    P.color[3 * color_index + 2]);
-                const f3 Xdn = make3(P.normals[3 * depth_index + 0], P.normals[3 * depth_index + 1],
-                    P.normals[3 * depth_index + 2]);
-                const f3 Xcn = xform_dir(P.Tcd, Xdn);
-                const float shading = light_shading(P.light, Xcp, Xcn);
-
-                if (shading > 0.05f)
-                {
-                  curr_color = div3(curr_color, shading);
-                  const uint32_t weights = old_w[vz];
-                  const int16_t cw = (int16_t)(weights >> 16);
-                  const float color_weight = cw + 1;
-                  const float cwf = cw;
-                  const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-                  const f3 c = div3(add3(prev_color, curr_color), color_weight);
-                  const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-                  vox[1] = c.x;
-                  vox[2] = c.y;
-                  vox[3] = c.z;
-                  vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-                  dirty = true;
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-
-    // ---- 4. stream the tile back (skipped when no voxel of the block changed)
-    if (__any(dirty))
-    {
-      wave_lds_fence();
-#pragma unroll
-      for (int k = 0; k < 10; ++k) r[k] = tile4[k * 64 + lane];
-#pragma unroll
-      for (int k = 0; k < 10; ++k) block4[k * 64 + lane] = r[k];
-    }
-    }  // blocks of this wave
-  }    // 64-block groups
-}
-
 // ---------------------------------------------------------------------------
-// Pipelined form. The kernel above moves a whole block per step: every wave of a
-// CU loads, then computes, then stores at about the same time, so the ~10 us of
-// per-voxel arithmetic does not overlap with the ~15 us of data movement (r01
-// ablations). Here the unit of work is HALF a block (four z
+// Software pipeline. Moving a whole block per step makes every wave of a CU load,
+// then compute, then store at about the same time, so the ~10 us of per-voxel
+// arithmetic does not overlap with the ~15 us of data movement (r01 ablations,
+// DESIGN.md section 4). The unit of work is therefore HALF a block (four z
 // slices = 5 KiB = 320 float4, five float4 per lane) and a wave keeps two units
 // in flight: while unit s is updated out of LDS, the tile loads and the depth
 // gathers of unit s+1 are already on their way into the other register set.
@@ -464,10 +218,10 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
       Xcp[k] = xform_point(P.Tcw, add3(u_off, voxel_offset));
       float cu, cv;
       project(P.kc, Xcp[k], cu, cv);
-      const bool color_valid = cu >= 0 && cu < P.width && cv >= 0 && cv < P.height;
+      const bool color_valid = cu >= 0 && cu < P.cwidth && cv >= 0 && cv < P.cheight;
       const bool valid = (u_valid >> k) & 1u;
       want[k] = color_valid && fabsf(dist[k]) < 1.0f && (COLOR == COLOR_PLAIN || valid);
-      color_index[k] = want[k] ? (int)cv * P.width + (int)cu : 0;
+      color_index[k] = want[k] ? (int)cv * P.cwidth + (int)cu : 0;
       depth_index[k] = (COLOR == COLOR_LIGHT && want[k]) ? (int)u_dv[k] * P.width + (int)u_du[k] : 0;
     }
 
@@ -633,6 +387,11 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
   if (need_depth && !f->depth) return VK_ERR_ARGUMENT;
   if (need_color && !f->color) return VK_ERR_ARGUMENT;
   if (need_light && (!f->normals || !mask || !light)) return VK_ERR_ARGUMENT;
+  const int cwidth = f->color_width > 0 ? f->color_width : f->width;
+  const int cheight = f->color_height > 0 ? f->color_height : f->height;
+  if (cwidth >= (1 << 24) || cheight >= (1 << 24)) return VK_ERR_ARGUMENT;
+  // light_integrator.cu:333-334 indexes the colour image with the depth image's size
+  if (need_light && (cwidth != f->width || cheight != f->height)) return VK_ERR_ARGUMENT;
 
   P.voxels4 = reinterpret_cast<float4*>(v->voxels);
   P.entries = v->hash_entries;
@@ -644,6 +403,8 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
   P.mask = mask;
   P.width = f->width;
   P.height = f->height;
+  P.cwidth = cwidth;
+  P.cheight = cheight;
   P.kd = f->depth_projection;
   P.kc = f->color_projection;
   P.Tdw = make_rt(f->depth_to_world.inv);  // Twd.Inverse(), depth_integrator.cu:104
@@ -671,27 +432,15 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
   return VK_OK;
 }
 
-// Persistent grid: 4 workgroups of 4 waves per CU (40 KiB LDS each, 160 KiB/CU),
-// capped by the largest possible visible count so small volumes do not launch
-// idle workgroups.
-int grid_for(const vk_volume* v)
-{
-  const int max_count = v->main_block_count + v->excess_block_count;
-  const int want = (max_count + kWavesPerGroup - 1) / kWavesPerGroup;
-  const int cap = kCUs * 4;
-  return want < cap ? (want > 0 ? want : 1) : cap;
-}
-
-bool g_integrate_pipelined = true;   // vk_probe_integrate(variant 10/11) flips it for A/B timing
-
-// 20 KiB of LDS per workgroup: up to 8 workgroups (32 waves) per CU by LDS, the
-// register budget decides; the grid is sized for 5 workgroups per CU.
-int g_pipe_groups_per_cu = 5;
-int pipe_grid_for(const vk_volume* v)
+// Persistent grid. 20 KiB of LDS per workgroup: up to 8 workgroups (32 waves) per CU
+// by LDS, the register budget decides; sized for 5 workgroups per CU (r01 sweep of
+// 2..8: profiles/r01_h_stage_timings_and_ablations.txt) and capped by the largest
+// possible visible count so small volumes do not launch idle workgroups.
+int pipe_grid_for(const vk_volume* v, int groups_per_cu)
 {
   const int max_count = v->main_block_count + v->excess_block_count;
   const int want = (max_count + kPipeWavesPerGroup - 1) / kPipeWavesPerGroup;
-  const int cap = kCUs * g_pipe_groups_per_cu;
+  const int cap = kCUs * groups_per_cu;
   return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
@@ -702,7 +451,7 @@ int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, 
   AheadParams A;
   A.partials = nullptr;
   bool with_bounds = false;
-  if (ahead && g_integrate_pipelined && ahead->scratch && ahead->bounds_width > 0 && ahead->bounds_height > 0 &&
+  if (ahead && ahead->scratch && ahead->bounds_width > 0 && ahead->bounds_height > 0 &&
       ahead->bounds_width * ahead->bounds_height <= kAheadMaxCells)
   {
     ahead->valid = 0;
@@ -714,18 +463,13 @@ int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, 
   if (with_bounds)
   {
     // 37.5 KiB of LDS per workgroup: four per CU
-    const int max_count = v->main_block_count + v->excess_block_count;
-    const int want = (max_count + kPipeWavesPerGroup - 1) / kPipeWavesPerGroup;
-    const int cap = kCUs * 4;
-    const int grid = (want < cap ? (want > 0 ? want : 1) : cap) + kBoundsGroups;
+    const int grid = pipe_grid_for(v, 4) + kBoundsGroups;
     hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, true>), dim3(grid),
         dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   }
-  else if (g_integrate_pipelined)
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false>), dim3(pipe_grid_for(v)),
-        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   else
-    hipLaunchKernelGGL((integrate_kernel<DEPTH, COLOR>), dim3(grid_for(v)), dim3(kWavesPerGroup * 64), 0, s, P);
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false>), dim3(pipe_grid_for(v, 5)),
+        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   VK_LAUNCH_CHECK();
   if (with_bounds) view_record(ahead, v, frame);
   return VK_OK;
@@ -817,6 +561,9 @@ int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const v
 int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold, float* mask, void* stream)
 {
   VK_REQUIRE(frame && frame->depth && frame->color && mask && frame->width > 0 && frame->height > 0);
+  // light_integrator.cu:277-293 walks the colour image with the depth image's size
+  VK_REQUIRE((frame->color_width <= 0 || frame->color_width == frame->width) &&
+             (frame->color_height <= 0 || frame->color_height == frame->height));
   const dim3 grid((frame->width + 15) / 16, (frame->height + 15) / 16);
   hipLaunchKernelGGL(frame_mask_kernel, grid, dim3(256), 0, vk_s(stream), frame->width, frame->height,
       frame->depth, frame->color, depth_threshold, mask);
@@ -853,30 +600,6 @@ int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p, const vk_fram
   if (color_mode == 0) return launch<true, COLOR_NONE>(P, v, frame, ahead, vk_s(stream));
   if (color_mode == 1) return launch<true, COLOR_PLAIN>(P, v, frame, ahead, vk_s(stream));
   return launch<true, COLOR_LIGHT>(P, v, frame, ahead, vk_s(stream));
-}
-
-int vk_probe_integrate(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int variant, void* stream)
-{
-  if (variant >= 10)   // 10 = block-at-a-time kernel, 11.. = pipelined with (variant - 10) workgroups per CU
-  {
-    g_integrate_pipelined = variant > 10;
-    if (variant > 10) g_pipe_groups_per_cu = variant - 10;
-    return VK_OK;
-  }
-  IntegrateParams P;
-  const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
-  if (rc != VK_OK) return rc;
-  const dim3 grid(grid_for(v)), block(kWavesPerGroup * 64);
-  switch (variant)
-  {
-    case 1: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 1>), grid, block, 0, vk_s(stream), P); break;
-    case 2: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 2>), grid, block, 0, vk_s(stream), P); break;
-    case 3: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 3>), grid, block, 0, vk_s(stream), P); break;
-    case 4: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 4>), grid, block, 0, vk_s(stream), P); break;
-    default: hipLaunchKernelGGL((integrate_kernel<true, COLOR_NONE, 0>), grid, block, 0, vk_s(stream), P); break;
-  }
-  VK_LAUNCH_CHECK();
-  return VK_OK;
 }
 
 }  // extern "C"

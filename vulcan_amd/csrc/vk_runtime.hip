@@ -88,6 +88,22 @@ int vk_free(void* ptr)
   return VK_OK;
 }
 
+int vk_malloc_host(void** ptr, size_t bytes)
+{
+  VK_REQUIRE(ptr);
+  *ptr = nullptr;
+  if (bytes == 0) return VK_OK;
+  VK_CHECK(hipHostMalloc(ptr, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+  return VK_OK;
+}
+
+int vk_free_host(void* ptr)
+{
+  if (!ptr) return VK_OK;
+  VK_CHECK(hipHostFree(ptr));
+  return VK_OK;
+}
+
 int vk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
 {
   if (bytes == 0) return VK_OK;

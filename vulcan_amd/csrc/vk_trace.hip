@@ -216,7 +216,6 @@ struct PointParams
   float* depths;
   float* colors;
   int image_width, image_height, bounds_width, bounds_height;
-  int variant;                // 0 = product; >0 = timing-only ablations (vk_probe_points)
 };
 
 // A voxel is 5 dwords {distance, r, g, b, (cw << 16 | dw)} at a 4-byte aligned
@@ -368,7 +367,6 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
   wrap_axis(i0x, lx[0], sx[0]); wrap_axis(i0x + 1, lx[1], sx[1]);
   wrap_axis(i0y, ly[0], sy[0]); wrap_axis(i0y + 1, ly[1], sy[1]);
   wrap_axis(i0z, lz[0], sz[0]); wrap_axis(i0z + 1, lz[1], sz[1]);
-  if (P.variant == 2) { sx[0] = sx[1] = sy[0] = sy[1] = sz[0] = sz[1] = 0; }
 
   int slot[8];  // pool slot of the block holding corner c, -1 = absent
 #pragma unroll
@@ -399,11 +397,6 @@ __device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& ca
     // absent blocks read voxel 0 of the pool and are overridden with Voxel::Empty() below
     const float* a0 = voxel_address(voxf, has0 ? slot[c0] : 0, has0 ? row_voxel + lx[0] : 0);
     const float* a1 = split ? voxel_address(voxf, has1 ? slot[c1] : 0, has1 ? row_voxel + lx[1] : 0) : a0 + 5;
-    if (P.variant == 3)   // timing only: every lane samples the same handful of cache lines
-    {
-      a0 = voxf + (size_t)(row_voxel + lx[0]) * 5;
-      a1 = a0 + 5;
-    }
 
     const float d0 = a0[0];
     // (w0, d1) when contiguous; a split lane reads (b0, w0) instead so the 8-byte
@@ -589,8 +582,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
           sample = (sdf <= 0.1f && sdf >= -0.5f);
         }
 
-        if (sample && P.variant != 1) interpolate(P, cache, bdir, bx, by, bz, data, wx, wy, wz, sdf, color);
-        if (P.variant == 1 && refine) sdf = 0.0f;
+        if (sample) interpolate(P, cache, bdir, bx, by, bz, data, wx, wy, wz, sdf, color);
 
         if (refine)
         {
@@ -752,8 +744,6 @@ int launch_block_bounds(PatchParams& P, float* bounds, float2* partials, bool me
   return VK_OK;
 }
 
-int g_points_variant = 0;   // set by vk_probe_points_variant (diagnostics only)
-
 int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
@@ -778,7 +768,6 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.image_height = image_height;
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
-  P.variant = g_points_variant;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
   const dim3 grid(8 * ((tiles + 7) / 8));   // padded so every XCD gets an equal band
   hipLaunchKernelGGL(compute_points_kernel, grid, dim3(256), 0, s, P);
@@ -879,12 +868,6 @@ int vk_frame_filter_depths(int image_width, int image_height, const float* src, 
   const dim3 grid((image_width + 63) / 64, (image_height + 3) / 4);
   hipLaunchKernelGGL(filter_depths_kernel, grid, dim3(256), 0, vk_s(stream), image_width, image_height, src, dst);
   VK_LAUNCH_CHECK();
-  return VK_OK;
-}
-
-int vk_probe_points_variant(int variant)
-{
-  g_points_variant = variant;
   return VK_OK;
 }
 

@@ -77,6 +77,14 @@ class Tracker
 
     ReduceHook reduce_hook_;
     void* reduce_user_;
+
+    // early exit of the device loop (vk_track_poll): pinned {iterations, converged} mirror
+    // and the number of steps enqueued between two looks at it (0 = enqueue all steps)
+    vk_track_poll poll_;
+
+  public:
+    int GetPollChunk() const { return poll_.chunk; }
+    void SetPollChunk(int steps) { poll_.chunk = steps; }
 };
 
 // Projective point-to-plane ICP on depth + normals.

@@ -101,6 +101,8 @@ vk_frame Frame::ToVk() const
   f.normals = normal_image ? reinterpret_cast<const float*>(normal_image->GetData()) : nullptr;
   f.width = depth_image ? depth_image->GetWidth() : (color_image ? color_image->GetWidth() : 0);
   f.height = depth_image ? depth_image->GetHeight() : (color_image ? color_image->GetHeight() : 0);
+  f.color_width = color_image ? color_image->GetWidth() : 0;     // color_integrator.cu:183-184
+  f.color_height = color_image ? color_image->GetHeight() : 0;
   f.depth_projection = depth_projection.ToVk();
   f.color_projection = color_projection.ToVk();
   f.depth_to_world = depth_to_world_transform.ToVk();

@@ -37,9 +37,14 @@ Tracker::Tracker() :
   pose_.Resize(1);
   state_.Resize(2);
   update_.Resize(6);
+  poll_.host_state = nullptr;
+  poll_.chunk = 4;
+  void* pinned = nullptr;
+  VK_ASSERT(vk_malloc_host(&pinned, 2 * sizeof(int32_t)));
+  poll_.host_state = static_cast<int32_t*>(pinned);
 }
 
-Tracker::~Tracker() {}
+Tracker::~Tracker() { vk_free_host(poll_.host_state); }
 
 std::shared_ptr<const Frame> Tracker::GetKeyframe() const { return keyframe_; }
 
@@ -186,7 +191,7 @@ void DepthTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_icp_track(&key, &Twm, &frm, pose_.GetData(), max_iterations_, translation_enabled_ ? 1 : 0,
       workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
 }
 
 void DepthTracker::ComputeSystem(const Frame& frame)
@@ -341,7 +346,7 @@ void ColorTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_color_tracker_track(&key, &frm, &frame_Tcd, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
   VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
 }
 
@@ -454,7 +459,7 @@ void LightTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_light_tracker_track(&key, &frm, &terms, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, Device::GetStream()));
+      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
   VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
 }
 

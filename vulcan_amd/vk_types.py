@@ -128,6 +128,7 @@ class Volume(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("normals", C.c_void_p),
                 ("width", C.c_int32), ("height", C.c_int32),
+                ("color_width", C.c_int32), ("color_height", C.c_int32),
                 ("depth_projection", Projection), ("color_projection", Projection),
                 ("depth_to_world", Transform), ("depth_to_color", Transform)]
 
@@ -157,6 +158,10 @@ class ColorView(C.Structure):
 
 class LightTerms(C.Structure):
     _fields_ = [("frame_mask", C.c_void_p), ("light", Light), ("frame_Tcd", Transform)]
+
+
+class TrackPoll(C.Structure):
+    _fields_ = [("host_state", C.c_void_p), ("chunk", C.c_int32)]
 
 
 class ColorPose(C.Structure):
