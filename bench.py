@@ -108,6 +108,32 @@ def spawn_ranks(args, argv):
     return rc
 
 
+def launch_selftest(args):
+    """What a rank does between being started and touching the GPU, on CPU: join the job
+    described by RANK / WORLD_SIZE / MASTER_*, check it is the job --gpus asked for, run the
+    rig's collective once over gloo, and let rank 0 print one JSON line."""
+    os.environ.setdefault("VK_DIST_BACKEND", "gloo")
+    import torch
+    from vulcan_amd import dist as vd
+    rank, local_rank, world = vd.init(backend="gloo")
+    if world != max(1, args.gpus):
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    if rank == args.selftest_fail_rank:
+        return 3                                   # rehearses a dying rank: the launcher must report it
+    system = torch.full((48,), float(rank + 1))
+    vd.allreduce_system(system)
+    slowest = vd.max_over_ranks(1.0 + rank)
+    frames = vd.sum_over_ranks(args.steps)
+    vd.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_selftest": True, "n_gpus": world, "system_sum": float(system[0]),
+                          "max_over_ranks": slowest, "frames_all_ranks": frames,
+                          "local_rank_env": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
+    vd.shutdown()
+    return 0
+
+
 # ------------------------------------------------------------------- frame loops ----
 
 class FrameLoop:
@@ -421,10 +447,16 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget (0 = skip)")
     ap.add_argument("--workload", default="rgbd", choices=["rgbd", "depth", "rgbd-icp"])
     ap.add_argument("--only", action="store_true", help="skip the other workloads, probes and the past-L3 pass")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU rehearsal of the N>1 launch path: ranks rendezvous over gloo, all-reduce one "
+                         "48-float buffer and exit without touching a GPU (tests/test_bench_launch.py)")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if args.selftest_launch:
+        sys.exit(launch_selftest(args))
 
     import torch
     from vulcan_amd import api, dist as vd, vk_types as T
@@ -481,7 +513,7 @@ def main():
             "memory_level": "infinity-cache assisted" if voxel_ws < L3_BYTES else "hbm",
             "voxel_working_set_bytes": voxel_ws,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-            "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9 * (1.0 / world) * world,
+            "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9,     # per GPU: integrate bytes / frame wall time
             "raycast": {"kernel": "compute_points_kernel + compute_normals_kernel (vk_trace_ahead)",
                         "avg_us": float(trace_ms.mean() * 1e3)},
         },
@@ -490,7 +522,8 @@ def main():
         if key_ in res:
             result["config"][key_] = res[key_]
 
-    if not args.only:
+    extras = not args.only and world == 1          # measured once, on a single GPU
+    if extras:
         pr = probes(loop, nvis[-1])
         result["roofline"].update(pr)
         if pr.get("measured_copy_GBps"):
@@ -498,7 +531,7 @@ def main():
     del loop
     torch.cuda.empty_cache()
 
-    if not args.only:
+    if extras:
         # the same kernel with the working set pushed out of the Infinity Cache
         pl3 = past_l3(wl, poses, min(args.warmup, 10), 6, nvis)
         pl3["frac"] = pl3["achieved"] / HBM_PEAK_GBS

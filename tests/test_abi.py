@@ -88,3 +88,32 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("expected VkError")
+
+
+# ---- libvk_comm.so (include/vk_comm.h): the rig's all-reduce ------------------------
+
+def test_comm_library_exports_and_loopback():
+    """Loads without RCCL or a GPU, exports exactly what vk_comm.h declares, validates
+    arguments, and a single-rank communicator is a loopback (the sum over one rank)."""
+    import numpy as np
+    from vulcan_amd import comm
+    text = open(os.path.join(ROOT, "include", "vk_comm.h")).read()
+    names = sorted(set(re.findall(r"VK_API\s+[\w\s\*]+?\b(vk_comm_\w+)\s*\(", text)))
+    assert names == sorted(comm.EXPORTS) and len(names) == 7
+    out = subprocess.run(["nm", "-D", "--defined-only", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
+    assert sorted(l.split()[-1] for l in out.splitlines() if " T vk_" in l) == names
+    assert "rccl" not in subprocess.run(["ldd", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout   # bound at run time
+    lib = comm.lib()
+    h = C.c_void_p()
+    assert lib.vk_comm_init(C.byref(h), None, 0, 0) == -1          # world < 1
+    assert lib.vk_comm_init(C.byref(h), None, 2, 2) == -1          # rank out of range
+    assert lib.vk_comm_init(C.byref(h), None, 0, 2) == -1          # world > 1 needs an id
+    assert lib.vk_comm_allreduce_system(None, None, 48, None) == -1
+    assert b"invalid argument" in lib.vk_comm_error_string(-1)
+    c = comm.Communicator(None, 0, 1)
+    r, w = C.c_int(-1), C.c_int(-1)
+    assert lib.vk_comm_rank(c.handle, C.byref(r), C.byref(w)) == 0 and (r.value, w.value) == (0, 1)
+    buf = np.arange(48, dtype=np.float32)
+    assert lib.vk_comm_reduce_hook(buf.ctypes.data_as(C.c_void_p), 48, c.handle, None) == 0
+    assert np.array_equal(buf, np.arange(48, dtype=np.float32))
+    c.close()

@@ -236,3 +236,72 @@ def test_two_tracers_share_a_volume(api, orc):
         for tracer, out in ((first, out_a), (second, out_b)):
             assert np.array_equal(tracer.bounds.cpu().numpy(), obounds), round_
             assert np.array_equal(out.depth.cpu().numpy(), odepth), round_
+
+
+# ------------------------------------------------- the rig step through libvk_comm --
+
+def test_rig_step_through_vk_comm(api, orc):
+    """configs[4] on the one GPU a test box has: the Gauss-Newton loop with the shipped C
+    hook (vk_comm_reduce_hook) between the system and the solve. With one rank the sum is the
+    identity, so the pose must equal the hook-less loop bit for bit — through the loopback
+    communicator and through a real one-rank RCCL communicator (ncclCommInitRank, ncclAllReduce
+    on the compute stream)."""
+    import torch
+    from vulcan_amd import comm
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160, 120)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start)
+    df.compute_normals()
+    tracker = api.DepthTracker()
+    tracker.keyframe = dk
+    plain = tracker.track(df)
+    steps_plain = int(tracker.state.cpu()[0])
+    for make in (lambda: comm.Communicator(None, 0, 1), lambda: comm.Communicator(comm.unique_id(), 0, 1)):
+        c = make()
+        buf = torch.arange(48, dtype=torch.float32, device="cuda")
+        c.allreduce_system(buf)
+        sync()
+        assert torch.equal(buf.cpu(), torch.arange(48, dtype=torch.float32))
+        df.depth_to_world = start
+        got = c.track(tracker, df)
+        sync()
+        assert bytes(got) == bytes(plain)
+        assert int(tracker.state.cpu()[0]) == steps_plain
+        assert c.time_allreduce(20) > 0
+        tracker.comm = None
+        c.close()
+    # and a python hook through the same C loop (what vulcan_amd.dist.allreduce_system plugs into)
+    calls = []
+    tracker.reduce_hook = lambda system: calls.append(system.data_ptr())
+    df.depth_to_world = start
+    got = tracker.track(df)
+    assert bytes(got) == bytes(plain) and len(calls) >= steps_plain
+
+
+def test_early_exit_matches_the_full_loop(api, orc):
+    """vk_track_poll: stopping the enqueue once the loop has converged gives the pose of the
+    full-length loop (steps after convergence are no-ops), and stops within one chunk."""
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160, 120)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start)
+    df.compute_normals()
+    poses, steps = [], []
+    for chunk in (0, 1, 3, 4, 50):
+        tracker = api.DepthTracker()
+        tracker.poll_chunk = chunk
+        tracker.keyframe = dk
+        df.depth_to_world = start
+        poses.append(bytes(tracker.track(df)))
+        sync()
+        st = tracker.state.cpu().numpy()
+        steps.append(int(st[0]))
+        assert st[1] == 1
+    assert len(set(poses)) == 1 and len(set(steps)) == 1

@@ -499,8 +499,17 @@ class _PollMixin:
         self._poll_desc.chunk = int(self.poll_chunk)
         return _ref(self._poll_desc)
 
+    comm = None                              # vulcan_amd.comm.Communicator: the rig's all-reduce, from C
+
     def _c_hook(self):
-        """The python reduce hook as a vk_icp_reduce_fn (or None)."""
+        """(vk_icp_reduce_fn, user): the communicator's C hook, or the python reduce hook
+        wrapped in a callback, or (None, None)."""
+        fn = self._c_hook_fn()
+        return fn, (self.comm.handle if self.comm is not None else None)
+
+    def _c_hook_fn(self):
+        if self.comm is not None:
+            return self.comm.hook_fn
         if self.reduce_hook is None:
             return None
         system, py_hook = self.system, self.reduce_hook
@@ -508,8 +517,8 @@ class _PollMixin:
         def _call(ptr, count, user, strm):
             py_hook(system)
             return 0
-        self._hook_keepalive = _REDUCE_FN(_call)
-        return self._hook_keepalive
+        self._hook_keepalive = _REDUCE_FN(_call)          # must outlive the C call
+        return C.cast(self._hook_keepalive, C.c_void_p)
 
     def __del__(self):
         host = getattr(self, "_poll_host", None)
@@ -591,7 +600,7 @@ class DepthTracker(_PollMixin):
         check(lib().vk_icp_track(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
                                  _ref(self._view(frame)), _ptr(self.pose), self.max_iterations,
                                  int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),
-                                 _ptr(self.state), _ptr(self.update), self._c_hook(), None, self._poll(), stream()),
+                                 _ptr(self.state), _ptr(self.update), *self._c_hook(), self._poll(), stream()),
               "vk_icp_track")
         out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out
@@ -704,11 +713,11 @@ class ColorTracker(_PollMixin):
         self.pose.copy_(torch.from_numpy(host).to(self.device))
         self.state.zero_()
         key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
-        hook = self._c_hook()
+        hook, hook_user = self._c_hook()
         check(lib().vk_color_tracker_track(_ref(kv), _ref(fv), _ref(frame.depth_to_color), _ref(key_Twc),
                                            _ptr(self.pose), self.max_iterations, int(self.translation_enabled),
                                            _ptr(self._workspace()), _ptr(self.system), _ptr(self.state),
-                                           _ptr(self.update), hook, None, self._poll(), stream()),
+                                           _ptr(self.update), hook, hook_user, self._poll(), stream()),
               "vk_color_tracker_track")
         out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out.depth_to_world
@@ -785,7 +794,7 @@ class LightTracker(ColorTracker):
         key_Twc = (self._keyframe.depth_to_color * self._keyframe.depth_to_world.inverse()).inverse()
         check(lib().vk_light_tracker_track(_ref(kv), _ref(fv), _ref(terms), _ref(key_Twc), _ptr(self.pose),
                                            self.max_iterations, int(self.translation_enabled), _ptr(self._workspace()),
-                                           _ptr(self.system), _ptr(self.state), _ptr(self.update), self._c_hook(), None,
+                                           _ptr(self.system), _ptr(self.state), _ptr(self.update), *self._c_hook(),
                                            self._poll(), stream()), "vk_light_tracker_track")
         out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out.depth_to_world

@@ -1,0 +1,117 @@
+"""ctypes binding of libvk_comm.so (include/vk_comm.h): the one collective of the hot path,
+the all-reduce of the packed ICP normal system of a rigid multi-camera rig, issued from C
+on the compute stream — no Python between Gauss-Newton iterations.
+
+    comm = Communicator.from_torch_group(rank, world)     # or Communicator(id_bytes, rank, world)
+    tracker.comm = comm                                   # api.DepthTracker / ColorTracker / LightTracker
+    tracker.track(frame)
+
+A host without torch.distributed distributes the 128-byte id itself (file, MPI, socket).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvk_comm.so")
+ID_BYTES = 128
+EXPORTS = ("vk_comm_unique_id", "vk_comm_init", "vk_comm_rank", "vk_comm_allreduce_system",
+           "vk_comm_reduce_hook", "vk_comm_destroy", "vk_comm_error_string")
+_LIB = None
+
+
+class CommError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CommError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        if "VK_RCCL_LIBRARY" not in os.environ:
+            # share the RCCL PyTorch already carries instead of loading a second copy
+            try:
+                import torch
+                bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+                if os.path.exists(bundled):
+                    os.environ["VK_RCCL_LIBRARY"] = bundled
+            except ImportError:
+                pass
+        h = C.CDLL(LIB_PATH)
+        P, I = C.c_void_p, C.c_int
+        h.vk_comm_unique_id.argtypes, h.vk_comm_unique_id.restype = [P], I
+        h.vk_comm_init.argtypes, h.vk_comm_init.restype = [C.POINTER(P), P, I, I], I
+        h.vk_comm_rank.argtypes, h.vk_comm_rank.restype = [P, C.POINTER(I), C.POINTER(I)], I
+        h.vk_comm_allreduce_system.argtypes, h.vk_comm_allreduce_system.restype = [P, P, I, P], I
+        h.vk_comm_reduce_hook.argtypes, h.vk_comm_reduce_hook.restype = [P, I, P, P], I
+        h.vk_comm_destroy.argtypes, h.vk_comm_destroy.restype = [P], I
+        h.vk_comm_error_string.argtypes, h.vk_comm_error_string.restype = [I], C.c_char_p
+        _LIB = h
+    return _LIB
+
+
+def check(code, what):
+    if code != 0:
+        raise CommError(f"{what}: {lib().vk_comm_error_string(code).decode()} [{code}]")
+
+
+def unique_id():
+    buf = C.create_string_buffer(ID_BYTES)
+    check(lib().vk_comm_unique_id(buf), "vk_comm_unique_id")
+    return buf.raw
+
+
+class Communicator:
+    def __init__(self, id_bytes, rank, world):
+        self.handle = C.c_void_p()
+        idbuf = None if id_bytes is None else C.create_string_buffer(bytes(id_bytes), ID_BYTES)
+        check(lib().vk_comm_init(C.byref(self.handle), idbuf, rank, world), "vk_comm_init")
+        self.rank, self.world = rank, world
+        # the C function itself, passed as vk_icp_reduce_fn: nothing of Python runs per iteration
+        self.hook_fn = C.cast(lib().vk_comm_reduce_hook, C.c_void_p)
+
+    @classmethod
+    def from_torch_group(cls, rank, world):
+        """Rank 0 creates the id; it travels through the default torch.distributed group."""
+        if world == 1:
+            return cls(None, 0, 1)
+        import torch
+        import torch.distributed as dist
+        lib()
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        raw = unique_id() if rank == 0 else bytes(ID_BYTES)
+        t = torch.tensor(list(raw), dtype=torch.uint8, device=device)
+        dist.broadcast(t, src=0)
+        return cls(bytes(t.cpu().tolist()), rank, world)
+
+    def allreduce_system(self, system, stream=None):
+        """In-place sum of a device float tensor over ranks on torch's current stream."""
+        if stream is None and system.is_cuda:
+            import torch
+            stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib().vk_comm_allreduce_system(self.handle, C.c_void_p(system.data_ptr()), system.numel(), stream),
+              "vk_comm_allreduce_system")
+        return system
+
+    def track(self, tracker, frame):
+        tracker.comm = self
+        return tracker.track(frame)
+
+    def time_allreduce(self, reps=200):
+        """Microseconds per 48-float all-reduce, enqueued back to back."""
+        import time
+        import torch
+        buf = torch.ones(48, dtype=torch.float32, device="cuda")
+        for _ in range(10):
+            self.allreduce_system(buf)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.allreduce_system(buf)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def close(self):
+        if self.handle:
+            check(lib().vk_comm_destroy(self.handle), "vk_comm_destroy")
+            self.handle = C.c_void_p()
