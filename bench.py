@@ -174,10 +174,12 @@ class FrameLoop:
             self.vols.append(dict(vol=vol, integ=integ, tracer=tracer, vdesc=vdesc, vref=C.byref(vdesc),
                                   pref=C.byref(integ.params), bref=C.byref(tracer.view_bounds),
                                   lref=C.byref(integ.light) if workload != "depth" else None))
-        self.mask = None
+        self.mask = self.records = None
         if workload != "depth":
             self.mask = torch.empty((H, W), dtype=torch.float32, device="cuda")
+            self.records = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
         self.m_ptr = None if self.mask is None else C.c_void_p(self.mask.data_ptr())
+        self.r_ptr = None if self.records is None else C.c_void_p(self.records.data_ptr())
         self.depth_threshold = 0.2                                  # light_integrator.cu:256
         self.tracker = None
         if workload == "rgbd-icp":
@@ -200,10 +202,10 @@ class FrameLoop:
         vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
         rc = lib.vk_volume_set_view(vv["vref"], self.fref, s)                       # volume.cu:430-437
         if self.mode == 2:
-            rc |= lib.vk_light_compute_frame_mask(self.fref, self.depth_threshold, self.m_ptr, s)   # light_integrator.cu:277-293
+            rc |= lib.vk_light_prepare(self.fref, self.depth_threshold, self.m_ptr, self.r_ptr, s)   # light_integrator.cu:277-293
         if ev:
             lib.vk_event_record(ev[0], s)
-        rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr,
+        rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr, self.r_ptr,
                                      vv["bref"], s)                                 # *_integrator.cu Integrate
         if ev:
             lib.vk_event_record(ev[1], s)

@@ -265,6 +265,16 @@ VK_API int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p,
 VK_API int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold,
     float* mask, void* stream);
 
+/* ref: src/light_integrator.cu:277-293 LightIntegrator::ComputeFrameMask plus the part
+ * of IntegrateColorKernel that depends on the PIXEL only (:215-225: the mask test and
+ * the pixel's normal rotated into the colour camera, Tcd * n). `records`: device
+ * float[h*w*4], 16-byte aligned, receives {Tcd * n (3), mask} per pixel, so the colour
+ * kernel gathers one record per voxel instead of a mask and three normal components
+ * and rotates nothing. `mask` is written as by vk_light_compute_frame_mask. Needs
+ * frame->normals. */
+VK_API int vk_light_prepare(const vk_frame* frame, float depth_threshold, float* mask,
+    float* records, void* stream);
+
 /* ref: src/light_integrator.cu:170-250,323-354 LightIntegrator::IntegrateColor */
 VK_API int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p,
     const vk_light* light, const float* mask, const vk_frame* frame, void* stream);
@@ -371,12 +381,14 @@ typedef struct vk_view_bounds {
 } vk_view_bounds;
 
 /* vk_integrate_depth / _depth_color / _depth_light (color_mode 0 / 1 / 2; `light`
- * and `mask` as in vk_integrate_depth_light for mode 2) which, when `ahead` is
- * given, also computes the raycast bounds of `frame`'s own view into
- * ahead->scratch and records the view in *ahead. ref: as those three. */
+ * and `mask` as in vk_integrate_depth_light for mode 2; `light_records`: optional
+ * output of vk_light_prepare for the same frame, NULL = gather mask and normals
+ * separately) which, when `ahead` is given, also computes the raycast bounds of
+ * `frame`'s own view into ahead->scratch and records the view in *ahead.
+ * ref: as those three. */
 VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
     const vk_frame* frame, int color_mode, const vk_light* light, const float* mask,
-    vk_view_bounds* ahead, void* stream);
+    const float* light_records, vk_view_bounds* ahead, void* stream);
 
 /* ref: src/tracer.cpp:41-47 Tracer::Trace, as vk_trace with the grid, depth range
  * and scratch taken from *ahead: when *ahead holds the bounds of this very view

@@ -317,7 +317,7 @@ def test_plain_entry_points_equal_the_ahead_ones(api, orc):
             out.normals = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
             v, f, o = api._ref(vol.desc()), api._ref(df.desc()), api._ref(out.desc())
             if ahead:
-                api.check(lib.vk_integrate_ahead(v, api._ref(params), f, mode, api._ref(light), api._ptr(mask),
+                api.check(lib.vk_integrate_ahead(v, api._ref(params), f, mode, api._ref(light), api._ptr(mask), None,
                                                  api._ref(tracer.view_bounds), api.stream()), "ahead")
                 assert tracer.view_bounds.valid == 1
                 api.check(lib.vk_trace_ahead(v, o, api._ref(tracer.view_bounds), api._ptr(out.depth), api._ptr(out.color),

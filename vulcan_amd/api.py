@@ -63,7 +63,8 @@ _SIGNATURES = {
     "vk_frame_filter_depths": ([_I, _I, _P, _P, _P], _I),
     "vk_trace_bounds_floats": ([_I, _I], _SZ),
     "vk_trace": ([_P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P], _I),
-    "vk_integrate_ahead": ([_P, _P, _P, _I, _P, _P, _P, _P], _I),
+    "vk_light_prepare": ([_P, _F, _P, _P, _P], _I),
+    "vk_integrate_ahead": ([_P, _P, _P, _I, _P, _P, _P, _P, _P], _I),
     "vk_trace_ahead": ([_P, _P, _P, _P, _P, _P, _P], _I),
     "vk_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
     "vk_color_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
@@ -99,8 +100,11 @@ class VkError(RuntimeError):
 def lib():
     """Load libvk_hip.so. torch is imported first so the HIP runtime it bundles
     (libamdhip64.so.7) is the one the library binds to."""
-    global _LIB
+    global _LIB, LIB_PATH
     if _LIB is None:
+        # VK_HIP_LIBRARY selects another build of the same ABI (the debug build that syncs and
+        # checks after every launch, libvk_hip_debug.so, or an experiment) — never a fallback
+        LIB_PATH = os.environ.get("VK_HIP_LIBRARY") or LIB_PATH
         if not os.path.exists(LIB_PATH):
             raise VkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
@@ -352,12 +356,12 @@ class Integrator:
         check(getattr(lib(), fn)(_ref(self.volume.desc()), _ref(self.params), *extra,
                                  _ref(frame.desc()), stream()), fn)
 
-    def _fused(self, frame, mode, light=None, mask=None):
+    def _fused(self, frame, mode, light=None, mask=None, records=None):
         """depth (+ colour) in one pass; when a Tracer is attached to the volume the
         same launch also prepares the raycast bounds of this frame's view."""
         vb = self.volume.view_bounds
         check(lib().vk_integrate_ahead(_ref(self.volume.desc()), _ref(self.params), _ref(frame.desc()), mode,
-                                       _ref(light) if light is not None else None, _ptr(mask),
+                                       _ref(light) if light is not None else None, _ptr(mask), _ptr(records),
                                        _ref(vb) if vb is not None else None, stream()), "vk_integrate_ahead")
 
 
@@ -383,6 +387,7 @@ class LightIntegrator(Integrator):
         self.light = T.Light.make(1.0, (0, 0, 0))    # light.h:14-18
         self.depth_threshold = 0.2                   # light_integrator.cu:256
         self.frame_mask = None
+        self.pixel_records = None
 
     def compute_frame_mask(self, frame):             # light_integrator.cu:277-293
         import torch
@@ -392,9 +397,21 @@ class LightIntegrator(Integrator):
                                                 _ptr(self.frame_mask), stream()), "vk_light_compute_frame_mask")
         return self.frame_mask
 
+    def prepare(self, frame):
+        """ComputeFrameMask + the per-pixel half of IntegrateColor (vk_light_prepare): the mask
+        and one {Tcd * normal, mask} record per pixel."""
+        import torch
+        shape = (frame.height, frame.width)
+        if self.frame_mask is None or tuple(self.frame_mask.shape) != shape:
+            self.frame_mask = torch.empty(shape, dtype=torch.float32, device=frame.device)
+        if self.pixel_records is None or tuple(self.pixel_records.shape[:2]) != shape:
+            self.pixel_records = torch.empty(shape + (4,), dtype=torch.float32, device=frame.device)
+        check(lib().vk_light_prepare(_ref(frame.desc()), self.depth_threshold, _ptr(self.frame_mask),
+                                     _ptr(self.pixel_records), stream()), "vk_light_prepare")
+
     def integrate(self, frame):                      # light_integrator.cu:270-275
-        self.compute_frame_mask(frame)
-        self._fused(frame, 2, self.light, self.frame_mask)
+        self.prepare(frame)
+        self._fused(frame, 2, self.light, self.frame_mask, self.pixel_records)
 
     def integrate_depth(self, frame):
         self._call("vk_integrate_depth", frame)

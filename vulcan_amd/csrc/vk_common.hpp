@@ -33,6 +33,11 @@ namespace vk
 constexpr int kWave = 64;       // CDNA4 wavefront
 constexpr int kCUs = 256;       // MI355X compute units
 
+// 8- and 12-byte loads of packed floats at 4-byte aligned addresses (gfx950 global
+// loads only need dword alignment): a 12-byte Vector3f is one dwordx3 load
+typedef float vf2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float vf3 __attribute__((ext_vector_type(3), aligned(4)));
+
 // ---- float3 in the reference's operation order (matrix.h) ------------------
 
 struct f3 { float x, y, z; };

@@ -15,9 +15,19 @@
 // (SURVEY.md §8d).
 #include "vk_bounds.hpp"
 
+#include <cstring>
+
 #ifndef VK_INTEGRATE_NT_STORES
 #define VK_INTEGRATE_NT_STORES 0
 #endif
+
+// Four waves per SIMD (<= 128 VGPRs) for every variant: the RGB-D kernel is bound by the
+// latency of its image gathers and division chains, and ran 42 us at three waves
+// (155 VGPRs), 39 us at four (r02 variants D/E/F, profiles/r02_b_light_variants.txt).
+// The register allocator reaches 128 by spilling two dwords outside the voxel loop.
+#define VK_INTEGRATE_WAVES __attribute__((amdgpu_waves_per_eu(4)))
+// voxels whose light-model colour update is in flight together (see unit_update)
+constexpr int kLightGroup = 2;
 
 using namespace vk;
 
@@ -36,6 +46,8 @@ struct IntegrateParams
   const float* color;
   const float* normals;
   const float* mask;
+  const float* records;   // optional: per depth pixel {Tcd * normal, mask} (vk_light_prepare)
+  bool same_camera;       // Tcw == Tdw, kc == kd, colour size == depth size
   int width, height;      // depth image
   int cwidth, cheight;    // colour image (color_integrator.cu:183-184)
   vk_projection kd, kc;
@@ -78,21 +90,22 @@ constexpr int kPipeWavesPerGroup = 4;
 // in scratch memory, which serialised every tile load behind a scratch store.
 #define UNIT_DECL(U)                                                                      \
   float4 U##_r0, U##_r1, U##_r2, U##_r3, U##_r4;   /* the half tile, five float4 per lane */ \
-  float U##_depth[4], U##_z[4], U##_du[4], U##_dv[4];                                      \
+  float U##_depth[4], U##_z[4];                                                            \
+  uint32_t U##_pix[4];   /* the voxel's pixel in the depth image, 0 when it has none */     \
   uint32_t U##_valid = 0;                                                                  \
   float4* U##_base = nullptr;                                                              \
   bool U##_skip = true;                                                                    \
   f3 U##_off = make3(0, 0, 0);                                                             \
   int U##_half = 0
-#define UNIT_ARGS(U) U##_r0, U##_r1, U##_r2, U##_r3, U##_r4, U##_depth, U##_z, U##_du, U##_dv, U##_valid, \
+#define UNIT_ARGS(U) U##_r0, U##_r1, U##_r2, U##_r3, U##_r4, U##_depth, U##_z, U##_pix, U##_valid, \
   U##_base, U##_skip, U##_off, U##_half
 #define UNIT_PARAMS float4& r0, float4& r1, float4& r2, float4& r3, float4& r4, float (&u_depth)[4],       \
-  float (&u_z)[4], float (&u_du)[4], float (&u_dv)[4], uint32_t& u_valid, float4*& u_base, bool& u_skip,  \
+  float (&u_z)[4], uint32_t (&u_pix)[4], uint32_t& u_valid, float4*& u_base, bool& u_skip,  \
   f3& u_off, int& u_half
 
 // unit s of the wave = half (s & 1) of its (s >> 1)-th block, whose hash entry sits
 // in lane (s >> 1) of my_entry
-template <bool DEPTH, int COLOR>
+template <bool DEPTH, int COLOR, bool SAME_CAM>
 __device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_entry, int s, int lane, UNIT_PARAMS)
 {
   const int j = s >> 1, half = s & 1;
@@ -109,7 +122,7 @@ __device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_ent
   u_base = P.voxels4 + (size_t)(data < 0 ? 0 : data) * kTileF4 + half * kHalfF4;
   u_valid = 0;
 
-  if (DEPTH || COLOR == COLOR_LIGHT)
+  if (DEPTH || COLOR == COLOR_LIGHT || (SAME_CAM && COLOR != COLOR_NONE))
   {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -117,19 +130,17 @@ __device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_ent
       const int vz = half * 4 + k;
       const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
       const f3 Xdp = xform_point(P.Tdw, add3(u_off, voxel_offset));
-      project(P.kd, Xdp, u_du[k], u_dv[k]);
+      float du, dv;
+      project(P.kd, Xdp, du, dv);
       u_z[k] = Xdp.z;
-      const bool valid = (u_du[k] >= 0) & (u_du[k] < P.width) & (u_dv[k] >= 0) & (u_dv[k] < P.height);
+      const bool valid = (du >= 0) & (du < P.width) & (dv >= 0) & (dv < P.height);
       u_valid |= (valid ? 1u : 0u) << k;
+      // 32-bit unsigned index: a signed 64-bit mad here made hipcc read a register
+      // pair whose upper half was a pending gather result (forced s_waitcnt vmcnt(0))
+      // (v_mad_u32_u24: row and width are < 2^24, checked on the host)
+      u_pix[k] = valid ? __umul24((uint32_t)f2i(dv), (uint32_t)P.width) + (uint32_t)f2i(du) : 0u;
       u_depth[k] = 0.0f;
-      if (DEPTH)
-      {
-        // 32-bit unsigned index: a signed 64-bit mad here made hipcc read a register
-        // pair whose upper half was a pending gather result (forced s_waitcnt vmcnt(0))
-        // (v_mad_u32_u24: row and width are < 2^24, checked on the host)
-        const uint32_t pixel = valid ? __umul24((uint32_t)f2i(u_dv[k]), (uint32_t)P.width) + (uint32_t)f2i(u_du[k]) : 0u;
-        u_depth[k] = P.depth[pixel];
-      }
+      if (DEPTH) u_depth[k] = P.depth[u_pix[k]];
     }
   }
 
@@ -140,8 +151,9 @@ __device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_ent
   r4 = u_base[4 * 64 + lane];
 }
 
-template <bool DEPTH, int COLOR>
-__device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, float4* tile4, UNIT_PARAMS)
+template <bool DEPTH, int COLOR, bool SAME_CAM, bool RECORDS>
+__device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, float4* tile4, uint8_t* changed,
+    UNIT_PARAMS)
 {
   float* tile = reinterpret_cast<float*>(tile4);
   const int vx = lane & 7, vy = lane >> 3;
@@ -152,6 +164,9 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
   tile4[2 * 64 + lane] = r2;
   tile4[3 * 64 + lane] = r3;
   tile4[4 * 64 + lane] = r4;
+  // one byte per 16-byte piece of the half tile (320 used): set by the lane that
+  // changes a dword of the piece, read at write-back by the lane that owns the piece
+  reinterpret_cast<uint2*>(changed)[lane] = make_uint2(0u, 0u);
   wave_lds_fence();   // float4-per-lane layout written, voxel-per-lane layout read
 
   float old_d[4];
@@ -195,8 +210,13 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
       {
         vox[0] = dist[k];
         vox[4] = __uint_as_float(old_w[k]);
+        // which 16-byte pieces now differ from what was read (dword j of voxel v sits in
+        // piece (5 v + j) / 4): a voxel in front of the band sits at distance 1 with a
+        // saturated weight and is "updated" to the very same bits
+        const int dword = (k * 64 + lane) * 5;
+        if (__float_as_uint(dist[k]) != __float_as_uint(old_d[k])) { changed[dword >> 2] = 1; dirty = true; }
+        if (old_w[k] != weights) { changed[(dword + 4) >> 2] = 1; dirty = true; }
       }
-      dirty |= update;
     }
   }
 
@@ -207,78 +227,126 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
     // voxel: (1) which voxels take colour and from which pixel, (2) the gathers,
     // (3) the running averages. Conditions are pure, so testing |dist| < 1 before the
     // mask (the reference tests the mask first) selects the same voxels.
-    f3 Xcp[4];
-    int color_index[4], depth_index[4];
-    bool want[4];
+    // G voxels at a time: per voxel the light model needs a 16-byte record, a colour, a
+    // normalisation and three divisions, ~35 registers; two at a time keep the kernel at
+    // 128 VGPRs = four waves per SIMD. The plain colour pass takes all four together.
+    constexpr int G = (COLOR == COLOR_LIGHT) ? kLightGroup : 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int g0 = 0; g0 < 4; g0 += G)
     {
-      const int vz = u_half * 4 + k;
-      const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
-      Xcp[k] = xform_point(P.Tcw, add3(u_off, voxel_offset));
-      float cu, cv;
-      project(P.kc, Xcp[k], cu, cv);
-      const bool color_valid = cu >= 0 && cu < P.cwidth && cv >= 0 && cv < P.cheight;
-      const bool valid = (u_valid >> k) & 1u;
-      want[k] = color_valid && fabsf(dist[k]) < 1.0f && (COLOR == COLOR_PLAIN || valid);
-      color_index[k] = want[k] ? (int)cv * P.cwidth + (int)cu : 0;
-      depth_index[k] = (COLOR == COLOR_LIGHT && want[k]) ? (int)u_dv[k] * P.width + (int)u_du[k] : 0;
-    }
+      if (g0 > 0) __builtin_amdgcn_sched_barrier(0);   // keep the next group's gathers below this group's work
 
-    if (COLOR == COLOR_LIGHT)
-    {
-      float m[4];
+      f3 Xcp[G];
+      uint32_t color_index[G], depth_index[G];
+      bool want[G];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = want[k] ? P.mask[depth_index[k]] : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) want[k] = want[k] && m[k] > 0.5f;
-    }
-
-    f3 pixel_color[4], pixel_normal[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      pixel_color[k] = make3(0, 0, 0);
-      pixel_normal[k] = make3(0, 0, 0);
-      if (want[k])
+      for (int i = 0; i < G; ++i)
       {
-        pixel_color[k] = make3(P.color[3 * color_index[k] + 0], P.color[3 * color_index[k] + 1],
-            P.color[3 * color_index[k] + 2]);
-        if (COLOR == COLOR_LIGHT)
-          pixel_normal[k] = make3(P.normals[3 * depth_index[k] + 0], P.normals[3 * depth_index[k] + 1],
-              P.normals[3 * depth_index[k] + 2]);
+        const int k = g0 + i;
+        const int vz = u_half * 4 + k;
+        const bool valid = (u_valid >> k) & 1u;
+        const f3 voxel_offset = scale3(make3(vx + 0.5f, vy + 0.5f, vz + 0.5f), P.voxel_length);
+        if (SAME_CAM)
+        {
+          // One camera (Tcd = identity, equal intrinsics and image size: fill_params checks
+          // Tcw == Tdw and kc == kd bit for bit): Tcw * Xwp and its projection are exactly
+          // what unit_issue computed for the depth image, so the colour pixel IS u_pix.
+          want[i] = valid && fabsf(dist[k]) < 1.0f;
+          color_index[i] = want[i] ? u_pix[k] : 0u;
+          if (COLOR == COLOR_LIGHT) Xcp[i] = xform_point(P.Tdw, add3(u_off, voxel_offset));
+        }
+        else
+        {
+          float cu, cv;
+          Xcp[i] = xform_point(P.Tcw, add3(u_off, voxel_offset));
+          project(P.kc, Xcp[i], cu, cv);
+          const bool color_valid = cu >= 0 && cu < P.cwidth && cv >= 0 && cv < P.cheight;
+          want[i] = color_valid && fabsf(dist[k]) < 1.0f && (COLOR == COLOR_PLAIN || valid);
+          color_index[i] = want[i] ? __umul24((uint32_t)f2i(cv), (uint32_t)P.cwidth) + (uint32_t)f2i(cu) : 0u;
+        }
+        depth_index[i] = SAME_CAM ? color_index[i] : ((COLOR == COLOR_LIGHT && want[i]) ? u_pix[k] : 0u);
       }
-    }
 
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      if (!want[k]) continue;
-      float* vox = tile + (k * 64 + lane) * 5;
-      f3 curr_color = pixel_color[k];
-
+      // light_integrator.cu:215-225: the frame mask and the pixel's normal in the colour
+      // camera's frame (Tcd * n). Neither depends on the voxel, so vk_light_prepare leaves
+      // both in one 16-byte record per pixel: one gather here instead of four.
+      f3 pixel_normal[G];   // already rotated by Tcd
       if (COLOR == COLOR_LIGHT)
       {
-        // light_integrator.cu:197-248
-        const f3 Xcn = xform_dir(P.Tcd, pixel_normal[k]);
-        const float shading = light_shading(P.light, Xcp[k], Xcn);
-        if (!(shading > 0.05f)) continue;
-        curr_color = div3(curr_color, shading);
+        if (RECORDS)
+        {
+          float4 rec[G];
+#pragma unroll
+          for (int i = 0; i < G; ++i) rec[i] = reinterpret_cast<const float4*>(P.records)[depth_index[i]];
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+          {
+            want[i] = want[i] && rec[i].w > 0.5f;
+            pixel_normal[i] = make3(rec[i].x, rec[i].y, rec[i].z);
+          }
+        }
+        else
+        {
+          float m[G];
+#pragma unroll
+          for (int i = 0; i < G; ++i) m[i] = want[i] ? P.mask[depth_index[i]] : 0.0f;
+#pragma unroll
+          for (int i = 0; i < G; ++i) want[i] = want[i] && m[i] > 0.5f;
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+          {
+            const vf3 n = *reinterpret_cast<const vf3*>(P.normals + 3 * (want[i] ? depth_index[i] : 0u));
+            pixel_normal[i] = xform_dir(P.Tcd, make3(n.x, n.y, n.z));
+          }
+        }
       }
 
-      // color_integrator.cu:100-134 / light_integrator.cu:233-246
-      const uint32_t weights = old_w[k];
-      const int16_t cw = (int16_t)(weights >> 16);
-      const float cwf = cw;
-      const f3 prev_color = scale3(make3(vox[1], vox[2], vox[3]), cwf);
-      const float color_weight = cw + 1;
-      const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-      const f3 c = div3(add3(prev_color, curr_color), color_weight);
-      vox[1] = c.x;
-      vox[2] = c.y;
-      vox[3] = c.z;
-      vox[4] = __uint_as_float((weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16));
-      dirty = true;
+      // a 12-byte packed colour is one dwordx3 load (4-byte alignment suffices on gfx950)
+      vf3 pixel_color[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        pixel_color[i] = *reinterpret_cast<const vf3*>(P.color + 3 * (want[i] ? color_index[i] : 0u));
+
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+      {
+        const int k = g0 + i;
+        if (!want[i]) continue;
+        float* vox = tile + (k * 64 + lane) * 5;
+        f3 curr_color = make3(pixel_color[i].x, pixel_color[i].y, pixel_color[i].z);
+
+        if (COLOR == COLOR_LIGHT)
+        {
+          // light_integrator.cu:197-248
+          const float shading = light_shading(P.light, Xcp[i], pixel_normal[i]);
+          if (!(shading > 0.05f)) continue;
+          curr_color = div3(curr_color, shading);
+        }
+
+        // color_integrator.cu:100-134 / light_integrator.cu:233-246
+        const uint32_t weights = old_w[k];
+        const int16_t cw = (int16_t)(weights >> 16);
+        const float cwf = cw;
+        const f3 stored = make3(vox[1], vox[2], vox[3]);
+        const f3 prev_color = scale3(stored, cwf);
+        const float color_weight = cw + 1;
+        const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
+        const f3 c = div3(add3(prev_color, curr_color), color_weight);
+        const uint32_t new_weights = (weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16);
+        vox[1] = c.x;
+        vox[2] = c.y;
+        vox[3] = c.z;
+        vox[4] = __uint_as_float(new_weights);
+        const int dword = (k * 64 + lane) * 5;
+        if ((__float_as_uint(c.x) ^ __float_as_uint(stored.x)) | (__float_as_uint(c.y) ^ __float_as_uint(stored.y)) |
+            (__float_as_uint(c.z) ^ __float_as_uint(stored.z)))
+        {
+          changed[(dword + 1) >> 2] = 1;   // dwords 1..3 touch at most these two pieces
+          changed[(dword + 3) >> 2] = 1;
+          dirty = true;
+        }
+        if (new_weights != weights) { changed[(dword + 4) >> 2] = 1; dirty = true; }
+      }
     }
   }
 
@@ -288,26 +356,21 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
     // third of a visible block is bit-for-bit unchanged (voxels behind the band are
     // never touched; voxels in front of it sit at distance 1 with a saturated
     // weight and are re-written with the same value), and a 64-byte line that no
-    // lane stores to stays clean in L2 and is never written to HBM.
-    float4 out[5];
+    // lane stores to stays clean in L2 and is never written to HBM. Which pieces
+    // changed comes from the `changed` bytes, not from a register copy of the tile as
+    // read: those 20 VGPRs are what kept the RGB-D kernel at three waves per SIMD.
     wave_lds_fence();   // other lanes' voxels make up this lane's float4s
-#pragma unroll
-    for (int k = 0; k < 5; ++k) out[k] = tile4[k * 64 + lane];
-    const float4 was[5] = {r0, r1, r2, r3, r4};
 #pragma unroll
     for (int k = 0; k < 5; ++k)
     {
-      const uint32_t differs = (__float_as_uint(out[k].x) ^ __float_as_uint(was[k].x)) |
-                               (__float_as_uint(out[k].y) ^ __float_as_uint(was[k].y)) |
-                               (__float_as_uint(out[k].z) ^ __float_as_uint(was[k].z)) |
-                               (__float_as_uint(out[k].w) ^ __float_as_uint(was[k].w));
-      if (differs == 0) continue;
+      if (changed[k * 64 + lane] == 0) continue;
+      const float4 out = tile4[k * 64 + lane];
       if (g_nt_stores)
       {
-        nf4 t; t.x = out[k].x; t.y = out[k].y; t.z = out[k].z; t.w = out[k].w;
+        nf4 t; t.x = out.x; t.y = out.y; t.z = out.z; t.w = out.w;
         __builtin_nontemporal_store(t, reinterpret_cast<nf4*>(&u_base[k * 64 + lane]));
       }
-      else u_base[k * 64 + lane] = out[k];
+      else u_base[k * 64 + lane] = out;
     }
   }
 }
@@ -322,13 +385,14 @@ struct AheadParams
   float2* partials;
 };
 
-template <bool DEPTH, int COLOR, bool AHEAD>
-__global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_kernel(IntegrateParams P, AheadParams A)
+template <bool DEPTH, int COLOR, bool AHEAD, bool SAME_CAM, bool RECORDS>
+__global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void integrate_pipelined_kernel(IntegrateParams P, AheadParams A)
 {
   // one LDS pool: four half-block tiles (20 KiB), or one bounds grid (37.5 KiB)
   constexpr int kTileInts = kPipeWavesPerGroup * kHalfF4 * 4;
   constexpr int kPoolInts = AHEAD ? (2 * kAheadMaxCells > kTileInts ? 2 * kAheadMaxCells : kTileInts) : kTileInts;
   __shared__ __attribute__((aligned(16))) int pool[kPoolInts];
+  __shared__ __attribute__((aligned(8))) uint8_t changed_bytes[kPipeWavesPerGroup][512];
 
   int group = (int)blockIdx.x, groups = (int)gridDim.x;
   if (AHEAD)
@@ -348,6 +412,7 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_k
   const int total_waves = groups * kPipeWavesPerGroup;
   const int count = P.counters[VK_CTR_VISIBLE];
   float4* tile4 = reinterpret_cast<float4*>(pool) + wave_in_group * kHalfF4;
+  uint8_t* changed = changed_bytes[wave_in_group];
 
   for (int first = wave; first < count; first += 64 * total_waves)
   {
@@ -361,24 +426,25 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) void integrate_pipelined_k
 
     UNIT_DECL(A);
     UNIT_DECL(B);
-    unit_issue<DEPTH, COLOR>(P, my_entry, 0, lane, UNIT_ARGS(A));
+    unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, 0, lane, UNIT_ARGS(A));
     int s = 0;
     for (; s + 2 < units; s += 2)   // steady state: two units per trip, next one always in flight
     {
-      unit_issue<DEPTH, COLOR>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
-      unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(A));
-      unit_issue<DEPTH, COLOR>(P, my_entry, s + 2, lane, UNIT_ARGS(A));
-      unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(B));
+      unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
+      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(A));
+      unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 2, lane, UNIT_ARGS(A));
+      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(B));
     }
     // units is even and >= 2: exactly two remain (s, s + 1)
-    unit_issue<DEPTH, COLOR>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
-    unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(A));
-    unit_update<DEPTH, COLOR>(P, lane, tile4, UNIT_ARGS(B));
+    unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
+    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(A));
+    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(B));
   }
 }
 
 int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, const vk_frame* f,
-    const vk_light* light, const float* mask, bool need_depth, bool need_color, bool need_light)
+    const vk_light* light, const float* mask, bool need_depth, bool need_color, bool need_light,
+    const float* records = nullptr)
 {
   if (!v || !p || !f) return VK_ERR_ARGUMENT;
   if (!v->voxels || !v->hash_entries || !v->visible_blocks || !v->counters) return VK_ERR_ARGUMENT;
@@ -401,6 +467,8 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
   P.color = f->color;
   P.normals = f->normals;
   P.mask = mask;
+  P.records = records;
+  if (records && (reinterpret_cast<uintptr_t>(records) & 15)) return VK_ERR_ARGUMENT;
   P.width = f->width;
   P.height = f->height;
   P.cwidth = cwidth;
@@ -420,6 +488,10 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
       Tcw[c * 4 + r] = acc;
     }
   P.Tcw = make_rt(Tcw);
+  // one camera for depth and colour: the colour projection of a voxel IS its depth projection
+  P.same_camera = cwidth == f->width && cheight == f->height &&
+      std::memcmp(Tcw, f->depth_to_world.inv, sizeof(Tcw)) == 0 &&
+      std::memcmp(&f->color_projection, &f->depth_projection, sizeof(vk_projection)) == 0;
   P.Tcd = make_rt(f->depth_to_color.m);
   if (light) P.light = *light; else { P.light.intensity = 1.0f; P.light.position[0] = P.light.position[1] = P.light.position[2] = 0.0f; }
   P.voxel_length = v->voxel_length;
@@ -445,8 +517,8 @@ int pipe_grid_for(const vk_volume* v, int groups_per_cu)
 }
 
 // `ahead` (optional): also compute the raycast bounds of the frame's own view
-template <bool DEPTH, int COLOR>
-int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, hipStream_t s)
+template <bool DEPTH, int COLOR, bool SAME_CAM, bool RECORDS>
+int launch_as(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, hipStream_t s)
 {
   AheadParams A;
   A.partials = nullptr;
@@ -464,15 +536,27 @@ int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, 
   {
     // 37.5 KiB of LDS per workgroup: four per CU
     const int grid = pipe_grid_for(v, 4) + kBoundsGroups;
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, true>), dim3(grid),
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, true, SAME_CAM, RECORDS>), dim3(grid),
         dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   }
   else
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false>), dim3(pipe_grid_for(v, 5)),
+    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false, SAME_CAM, RECORDS>), dim3(pipe_grid_for(v, 5)),
         dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
   VK_LAUNCH_CHECK();
   if (with_bounds) view_record(ahead, v, frame);
   return VK_OK;
+}
+
+template <bool DEPTH, int COLOR>
+int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, hipStream_t s)
+{
+  if (COLOR == COLOR_NONE) return launch_as<DEPTH, COLOR, false, false>(P, v, frame, ahead, s);
+  const bool records = COLOR == COLOR_LIGHT && P.records;
+  if (P.same_camera)
+    return records ? launch_as<DEPTH, COLOR, true, COLOR == COLOR_LIGHT>(P, v, frame, ahead, s)
+                   : launch_as<DEPTH, COLOR, true, false>(P, v, frame, ahead, s);
+  return records ? launch_as<DEPTH, COLOR, false, COLOR == COLOR_LIGHT>(P, v, frame, ahead, s)
+                 : launch_as<DEPTH, COLOR, false, false>(P, v, frame, ahead, s);
 }
 
 // ---------------------------------------------------------------- frame mask ----
@@ -480,9 +564,12 @@ int launch(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, 
 // ref: light_integrator.cu:17-103 ComputeFrameMaskKernel<16,3>. The reference
 // stages a 22x22 tile with a -1 halo offset and reads it with a +3 centre, so
 // pixel (x,y) looks at [x-1,x+5] x [y-1,y+5]; kept as is.
+// With `records` it also leaves, per pixel, what LightIntegrator's colour kernel would
+// otherwise gather and compute once per VOXEL that projects to the pixel
+// (light_integrator.cu:215-225): {Tcd * normal, mask} as one 16-byte record.
 __global__ __launch_bounds__(256) void frame_mask_kernel(int width, int height,
     const float* __restrict__ depths, const float* __restrict__ colors, float depth_threshold,
-    float* __restrict__ mask)
+    float* __restrict__ mask, const float* __restrict__ normals, Rt Tcd, float4* __restrict__ records)
 {
   constexpr int BD = 16, KS = 3, DIM = BD + 2 * KS;
   __shared__ float buffer[DIM * DIM];
@@ -507,9 +594,17 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(int width, int height,
     const int index = y * width + x;
     const float c0 = colors[3 * index + 0], c1 = colors[3 * index + 1], c2 = colors[3 * index + 2];
 
+    f3 Xcn = make3(0, 0, 0);
+    if (records)
+    {
+      const vf3 n = *reinterpret_cast<const vf3*>(normals + 3 * index);
+      Xcn = xform_dir(Tcd, make3(n.x, n.y, n.z));                     // light_integrator.cu:223
+    }
+
     if (c0 < 0.02f || c0 > 0.98f || c1 < 0.02f || c1 > 0.98f || c2 < 0.02f || c2 > 0.98f)
     {
       mask[index] = 0.0f;
+      if (records) records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, 0.0f);
       return;
     }
 
@@ -526,7 +621,9 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(int width, int height,
         dmax = fmaxf(depth, dmax);
       }
 
-    mask[index] = (dmax - dmin <= depth_threshold) ? 1.0f : 0.0f;
+    const float m = (dmax - dmin <= depth_threshold) ? 1.0f : 0.0f;
+    mask[index] = m;
+    if (records) records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
   }
 }
 
@@ -558,17 +655,30 @@ int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const v
   return launch<true, COLOR_PLAIN>(P, v, frame, nullptr, vk_s(stream));
 }
 
-int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold, float* mask, void* stream)
+static int light_prepare(const vk_frame* frame, float depth_threshold, float* mask, float* records, void* stream)
 {
   VK_REQUIRE(frame && frame->depth && frame->color && mask && frame->width > 0 && frame->height > 0);
+  VK_REQUIRE(!records || (frame->normals && (reinterpret_cast<uintptr_t>(records) & 15) == 0));
   // light_integrator.cu:277-293 walks the colour image with the depth image's size
   VK_REQUIRE((frame->color_width <= 0 || frame->color_width == frame->width) &&
              (frame->color_height <= 0 || frame->color_height == frame->height));
   const dim3 grid((frame->width + 15) / 16, (frame->height + 15) / 16);
   hipLaunchKernelGGL(frame_mask_kernel, grid, dim3(256), 0, vk_s(stream), frame->width, frame->height,
-      frame->depth, frame->color, depth_threshold, mask);
+      frame->depth, frame->color, depth_threshold, mask, frame->normals, make_rt(frame->depth_to_color.m),
+      reinterpret_cast<float4*>(records));
   VK_LAUNCH_CHECK();
   return VK_OK;
+}
+
+int vk_light_compute_frame_mask(const vk_frame* frame, float depth_threshold, float* mask, void* stream)
+{
+  return light_prepare(frame, depth_threshold, mask, nullptr, stream);
+}
+
+int vk_light_prepare(const vk_frame* frame, float depth_threshold, float* mask, float* records, void* stream)
+{
+  VK_REQUIRE(records);
+  return light_prepare(frame, depth_threshold, mask, records, stream);
 }
 
 int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p, const vk_light* light,
@@ -590,12 +700,12 @@ int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const v
 }
 
 int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int color_mode,
-    const vk_light* light, const float* mask, vk_view_bounds* ahead, void* stream)
+    const vk_light* light, const float* mask, const float* light_records, vk_view_bounds* ahead, void* stream)
 {
   IntegrateParams P;
   VK_REQUIRE(color_mode >= 0 && color_mode <= 2);
   const int rc = fill_params(P, v, p, frame, color_mode == 2 ? light : nullptr, color_mode == 2 ? mask : nullptr, true,
-      color_mode != 0, color_mode == 2);
+      color_mode != 0, color_mode == 2, color_mode == 2 ? light_records : nullptr);
   if (rc != VK_OK) return rc;
   if (color_mode == 0) return launch<true, COLOR_NONE>(P, v, frame, ahead, vk_s(stream));
   if (color_mode == 1) return launch<true, COLOR_PLAIN>(P, v, frame, ahead, vk_s(stream));

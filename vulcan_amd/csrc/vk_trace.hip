@@ -222,8 +222,6 @@ struct PointParams
 // address; gfx950 global loads only need dword alignment, so a voxel is read as
 // dwordx4 + dword, and the x-adjacent pair of a trilinear row as 10 contiguous
 // dwords, instead of the reference's five scalar loads per voxel.
-typedef float vf2 __attribute__((ext_vector_type(2), aligned(4)));
-typedef float vf3 __attribute__((ext_vector_type(3), aligned(4)));
 
 struct Corner
 {

@@ -93,6 +93,7 @@ class LightIntegrator : public Integrator
 
     Light light_;
     Image frame_mask_;
+    Image pixel_records_;           // {Tcd * normal, mask} per pixel as a 4w x h image (vk_light_prepare); not upstream
     float depth_threshold_;
 };
 

@@ -66,7 +66,7 @@ void DepthIntegrator::Integrate(const Frame& frame)
   const vk_volume v = volume_->ToVk();
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 0, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 0, nullptr, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
 }
 
 // ---- colour ------------------------------------------------------------------
@@ -78,7 +78,7 @@ void ColorIntegrator::Integrate(const Frame& frame)
   const vk_volume v = volume_->ToVk();
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 1, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 1, nullptr, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
 }
 
 void ColorIntegrator::IntegrateDepth(const Frame& frame)
@@ -111,12 +111,19 @@ void LightIntegrator::SetLight(const Light& light) { light_ = light; }
 
 void LightIntegrator::Integrate(const Frame& frame)
 {
-  ComputeFrameMask(frame);
+  // ComputeFrameMask (light_integrator.cu:277-293) plus the per-pixel half of IntegrateColor
+  // (:215-225): mask and Tcd * normal as one record per pixel for the fused voxel pass
+  VULCAN_ASSERT_MSG(frame.depth_image && frame.color_image && frame.normal_image, "missing depth, color or normal image");
+  const int w = frame.depth_image->GetWidth(), h = frame.depth_image->GetHeight();
+  frame_mask_.Resize(w, h);
+  pixel_records_.Resize(4 * w, h);
   const vk_volume v = volume_->ToVk();
   const vk_integrator p = ToVk();
   const vk_light l = light_.ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 2, &l, frame_mask_.GetData(), volume_->GetViewBounds(), Device::GetStream()));
+  VK_ASSERT(vk_light_prepare(&f, depth_threshold_, frame_mask_.GetData(), pixel_records_.GetData(), Device::GetStream()));
+  VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 2, &l, frame_mask_.GetData(), pixel_records_.GetData(),
+      volume_->GetViewBounds(), Device::GetStream()));
 }
 
 void LightIntegrator::ComputeFrameMask(const Frame& frame)
