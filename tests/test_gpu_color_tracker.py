@@ -128,28 +128,46 @@ def _pose_of(frame):
     return pose
 
 
-def test_track_follows_the_oracle_loop(api, orc, pair):
-    """Track() = BeginSolve + 20 x (system, solve, update) on the device; the oracle
-    runs the same loop with double sums, so poses agree to rounding, and the
-    photometric cost must drop."""
-    hk, hf, ks, fs, dk, df = pair
-    tracker = api.ColorTracker()
-    tracker.keyframe = dk
-    tracker.max_iterations = 8
-    moved = api.Frame(df.depth, df.depth_projection, hf.depth_to_world, color=df.color, normals=df.normals)
-    before = float((tracker.compute_residuals(moved).double() ** 2).sum())
-    got = tracker.track(moved)
-    sync()
-    after = float((tracker.compute_residuals(moved).double() ** 2).sum())
-    assert after < 0.5 * before
-    assert tracker.state.cpu().numpy()[0] >= 1
+def test_track_follows_the_oracle_loop(api, orc):
+    """Track() = BeginSolve + n x (system, solve, update) on the device; the oracle runs the
+    same loop with double sums. The keyframe and the frame show the SAME scene here (a curved
+    surface with the reference's test texture, seen from a slightly wrong pose): on the
+    reference's own pair of unrelated images (color_tracker_test.cu:12-148) Gauss-Newton
+    diverges until no pixel overlaps, and both sides ended in NaN poses that compared equal.
+    Float tree sums vs double sums differ by 2e-5 relative per system; three steps at a
+    condition number of ~1e3 keep the poses within 2e-4."""
+    k = cs.projection()
+    _, kc = cs.keyframe_images()
+    y, x = np.mgrid[0:cs.H, 0:cs.W]
+    depth = (1.0 + 0.05 * np.cos(3.0 * x / cs.W) * np.sin(2.0 * y / cs.H)).astype(np.float32)
+    hk = orc.HostFrame(depth, k, T.Transform.identity(), color=kc)
+    hk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf = orc.HostFrame(depth, k, start, color=kc, normals=hk.normals)
+    ks, fs = orc.ColorSide(hk, False), orc.ColorSide(hf, True)
+    dk = api.Frame(depth, k, T.Transform.identity(), color=kc, normals=hk.normals)
+    moved = api.Frame(depth, k, start, color=kc, normals=hk.normals)
 
-    pose = _pose_of(hf)
-    key_Twc = (hk.depth_to_color * hk.depth_to_world.inverse()).inverse()
-    orc.lib().orc_color_tracker_tcm(C.byref(hf.depth_to_color), C.byref(key_Twc), C.byref(pose))
-    for _ in range(8):
-        h, g = orc.color_system(ks, fs, pose.Tcm, True)
-        _, norm = orc.color_solve_update(h, g, hf.depth_to_color, key_Twc, pose, True)
-        if norm < 1e-6:
-            break
-    np.testing.assert_allclose(got.matrix(), pose.depth_to_world.matrix(), atol=2e-5)
+    for enabled in (True, False):
+        tracker = api.ColorTracker()
+        tracker.keyframe = dk
+        tracker.max_iterations = 3
+        tracker.translation_enabled = enabled
+        moved.depth_to_world = start
+        before = float((tracker.compute_residuals(moved).double() ** 2).sum())
+        got = tracker.track(moved)
+        sync()
+        after = float((tracker.compute_residuals(moved).double() ** 2).sum())
+        assert after < 0.5 * before
+        assert tracker.state.cpu().numpy().tolist() == [3, 0]
+
+        pose = T.ColorPose()
+        pose.depth_to_world = start
+        key_Twc = (hk.depth_to_color * hk.depth_to_world.inverse()).inverse()
+        orc.lib().orc_color_tracker_tcm(C.byref(hf.depth_to_color), C.byref(key_Twc), C.byref(pose))
+        for _ in range(3):
+            h, g = orc.color_system(ks, fs, pose.Tcm, enabled)
+            _, norm = orc.color_solve_update(h, g, hf.depth_to_color, key_Twc, pose, enabled)
+        assert np.all(np.isfinite(got.matrix()))
+        np.testing.assert_allclose(got.matrix(), pose.depth_to_world.matrix(), atol=2e-4)
+        np.testing.assert_allclose(got.inverse_matrix(), pose.depth_to_world.inverse_matrix(), atol=2e-4)

@@ -58,9 +58,6 @@ def main():
     out2 = torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda")
     col2 = torch.zeros((bench.H, bench.W, 3), dtype=torch.float32, device="cuda")
 
-    copy_src = torch.zeros(512 << 20, dtype=torch.uint8, device="cuda")
-    copy_dst = torch.zeros(512 << 20, dtype=torch.uint8, device="cuda")
-
     stages = {
         "set_view": lambda: vol.set_view(frame),
         "reset_vis": lambda: vol.reset_block_visibility(),
@@ -92,7 +89,6 @@ def main():
         "probe_rmw1": lambda: (api.lib().vk_probe_block_rmw_mode(1), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
         "probe_rmw2": lambda: (api.lib().vk_probe_block_rmw_mode(2), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
         "probe_rmw3": lambda: (api.lib().vk_probe_block_rmw_mode(3), api.check(api.lib().vk_probe_block_rmw(api._ref(vol.desc()), api.stream()), "probe"), api.lib().vk_probe_block_rmw_mode(0)),
-        "probe_copy": lambda: api.check(api.lib().vk_probe_stream_copy(api._ptr(copy_dst), api._ptr(copy_src), copy_src.numel(), api.stream()), "probe"),
     }
     only = [s for s in args.only.split(",") if s]
     for name, fn in stages.items():
@@ -116,10 +112,6 @@ def main():
         if name == "integrate":
             b = nvis * bench.BYTES_PER_BLOCK + bench.W * bench.H * 4 * (4 if args.color else 1)
             extra = f"  {b / (np.median(t) * 1e-6) / 1e9:7.0f} GB/s algorithmic"
-        if name == "probe_rmw":
-            extra = f"  {nvis * bench.BYTES_PER_BLOCK / (np.median(t) * 1e-6) / 1e9:7.0f} GB/s"
-        if name == "probe_copy":
-            extra = f"  {2 * copy_src.numel() / (np.median(t) * 1e-6) / 1e9:7.0f} GB/s (read + write)"
         print(f"{name:13s} median {np.median(t):8.1f} us  min {t.min():8.1f}  max {t.max():8.1f}{extra}")
 
 

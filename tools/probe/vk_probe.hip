@@ -1,6 +1,7 @@
 // vk_probe.hip — bandwidth probes (libvk_probe.so, see vk_probe.h). Measurement
 // tooling only: nothing in libvk_hip.so or vulcan_amd/ depends on it.
 #include "../../vulcan_amd/csrc/vk_common.hpp"
+#include "../../vulcan_amd/csrc/vk_raycast.hpp"
 #include "vk_probe.h"
 
 using namespace vk;
@@ -111,6 +112,26 @@ __global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ vox
   }
 }
 
+// the product's ray march with the counting hook compiled in (one wave per 8x8 tile)
+__global__ __launch_bounds__(256) void count_points_kernel(PointParams P)
+{
+  __shared__ int4 directories[4][kDirEntries];
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  int4* bdir = directories[wave];
+  bdir[lane] = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, -1);
+  wave_lds_fence();
+  const int tiles_x = (P.image_width + 15) / 16;
+  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= P.image_width || y >= P.image_height) return;
+  const int px = P.bounds_width * x / P.image_width;
+  const int py = P.bounds_height * y / P.image_height;
+  const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
+  march_ray<true, false>(P, bdir, x, y, bound);
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +160,41 @@ int vk_probe_stream_read(const void* src, size_t bytes, float* sink, void* strea
   const size_t n4 = bytes / 16;
   hipLaunchKernelGGL(read_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, vk_s(stream),
       reinterpret_cast<const float4*>(src), n4, sink);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
+    const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
+    int bounds_width, int bounds_height, uint8_t* touched, void* stream)
+{
+  VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors && touched);
+  VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
+  PointParams P;
+  P.entries = entries;
+  P.voxels = voxels;
+  P.bounds = bounds;
+  P.partials = nullptr;
+  P.bounds_out = nullptr;
+  P.K = (uint32_t)block_count;
+  P.block_length = block_length;
+  P.voxel_length = voxel_length;
+  P.trunc_length = trunc_length;
+  P.inv_block_length = 1.0 / (double)block_length;
+  P.inv_voxel_length = 1.0 / (double)voxel_length;
+  P.Twc = make_rt(Twc->m);
+  P.Tcw = make_rt(Twc->inv);
+  P.k = *projection;
+  P.depths = depths;
+  P.colors = colors;
+  P.image_width = image_width;
+  P.image_height = image_height;
+  P.bounds_width = bounds_width;
+  P.bounds_height = bounds_height;
+  P.touched = touched;
+  const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
+  hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

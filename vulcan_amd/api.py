@@ -503,7 +503,7 @@ class _PollMixin:
     """Early exit of the device-side Gauss-Newton loop (vk_track_poll): a pinned
     {iterations, converged} mirror the enqueuing call looks at every `poll_chunk` steps."""
 
-    poll_chunk = 4                           # 0: enqueue every step, never block
+    poll_chunk = int(os.environ.get("VK_TRACK_POLL_CHUNK", "4"))   # 0: enqueue every step, never block
 
     def _poll(self):
         if not self.poll_chunk:

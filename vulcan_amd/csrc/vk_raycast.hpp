@@ -1,0 +1,509 @@
+// vk_raycast.hpp — the per-pixel ray march through the hashed volume (ref:
+// src/tracer.cu:114-451 GetVoxel, GetInterpolatedDistance, ComputePointsKernel).
+//
+// One lane per pixel, one wave per 8x8 pixel tile. What differs from the reference's
+// thread-per-pixel kernel, with identical results:
+//  * a block is resolved against the global hash table about once per WAVE (per-wave
+//    block directory in LDS) instead of once per ray per step per corner;
+//  * the march only needs distances: a trilinear sample reads the eight corner
+//    distances and nothing else. The reference also assembles a colour at every
+//    sample and overwrites it at the next one (tracer.cu:392-393,412-413): only the
+//    LAST sample's colour reaches the image, so weights and colours are fetched once
+//    per ray, after the march, at that sample's position;
+//  * the eight corners are addressed from the block that holds the low corner, so a
+//    sample only ever leaves its block in the +x/+y/+z direction and corner c lives in
+//    neighbour (c & crossing mask) — no per-corner case analysis;
+//  * pools under 4 GiB (POOL32) address voxels by 32-bit offsets from a scalar base;
+//  * divisions by the two launch constants (block and voxel length) are exact
+//    without the division expansion (div_uniform below).
+// COUNT = true (tools/probe only) additionally marks every pool slot a ray reads.
+#pragma once
+
+#include "vk_common.hpp"
+
+#ifndef VK_RAY_SPECULATE
+#define VK_RAY_SPECULATE 0
+#endif
+
+namespace vk
+{
+
+struct PointParams
+{
+  const vk_hash_entry* entries;
+  const vk_voxel* voxels;
+  const float* bounds;        // merged grid (read when partials == nullptr)
+  const float2* partials;     // kBoundsGroups private grids (fused path), or nullptr
+  float2* bounds_out;         // fused path: the merged grid is written back here
+  uint32_t K;
+  float block_length, voxel_length, trunc_length;
+  double inv_block_length, inv_voxel_length;   // RN64(1 / length), see div_uniform
+  Rt Twc, Tcw;
+  vk_projection k;
+  float* depths;
+  float* colors;
+  int image_width, image_height, bounds_width, bounds_height;
+  uint8_t* touched;           // COUNT only: one byte per pool slot
+};
+
+// a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).
+// (double)a * inv_b is within 2^-52 (relative) of a / b; the quotient of two binary32
+// numbers is never closer than 2^-49 (relative) to the midpoint of two neighbouring
+// binary32 numbers [for 24-bit significands A, B and an odd 25-bit N, |A 2^j - B N| >= 1],
+// so rounding the double product to binary32 gives exactly RN32(a / b) — the value the
+// reference's `a / b` has. Three instructions instead of the ten of v_div_scale /
+// v_rcp / v_fma x4 / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ float div_uniform(float a, double inv_b)
+{
+  return (float)((double)a * inv_b);
+}
+
+// One-entry cache of the last hash lookup: consecutive march steps mostly stay in one
+// block, and the table is read-only during the kernel, so the cached answer is the
+// answer a fresh walk would give.
+struct BlockCache
+{
+  int bx, by, bz;
+  int data;    // pool slot of the block, -1 when absent / unallocated
+  bool valid;
+};
+
+// Per-wave block directory in LDS: 64 direct-mapped entries {bx, by, bz, slot}. The
+// reference walks the global hash table once per ray per step (and once per trilinear
+// corner near block faces). The 64 rays of a wave cross the same handful of blocks over
+// and over, so here a block is resolved against the global table about once per wave
+// and every later use, by any lane, is one LDS read.
+constexpr int kDirEntries = 64;
+constexpr int kMaxChain = 1 << 24;
+
+// Entry = the block's coordinates modulo 4 per axis: any 4x4x4 neighbourhood of blocks
+// (16 cm at 5 mm voxels, far more than one wave's 8x8 pixels see in a step) maps to 64
+// different entries, so the blocks a wave works on never evict one another.
+__device__ __forceinline__ int dir_index(int bx, int by, int bz)
+{
+  return (bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4);
+}
+
+// tracer.cu:364-371: walk the chain until the block matches or the chain ends; a hit
+// needs the match AND IsAllocated().
+__device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by, int bz)
+{
+  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
+  // a chain is at most the excess region long; the cap only guarantees that a wave
+  // leaves the loop if it is handed a corrupt table (a cycle would otherwise hang the GPU)
+  for (int guard = 0; !entry_is(entry, bx, by, bz) && entry.next != -1 && guard < kMaxChain; ++guard)
+    entry = load_entry(P.entries, (uint32_t)entry.next);
+  return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
+}
+
+// files a resolved block in the directory: one distinct block per trip, written by a
+// single lane so that an entry is never a mix of two lanes' stores
+__device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
+{
+  while (__any(pending))
+  {
+    const unsigned long long mask = __ballot(pending);
+    const int leader = __ffsll((long long)mask) - 1;
+    const int ubx = __builtin_amdgcn_readlane(bx, leader);
+    const int uby = __builtin_amdgcn_readlane(by, leader);
+    const int ubz = __builtin_amdgcn_readlane(bz, leader);
+    const int udata = __builtin_amdgcn_readlane(data, leader);
+    if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
+    if (bx == ubx && by == uby && bz == ubz) pending = false;
+  }
+  wave_lds_fence();   // later reads of the directory, by any lane, see these entries
+}
+
+// slot of block (bx, by, bz) for the lanes with `active` set; -1 = absent
+__device__ __forceinline__ int lookup_block(const PointParams& P, int4* dir, bool active, int bx, int by, int bz)
+{
+  const int4 e = dir[dir_index(bx, by, bz)];
+  int data = e.w;
+  const bool missed = active && !(e.x == bx && e.y == by && e.z == bz);
+  if (__any(missed))
+  {
+    // directory misses probe the global table, all lanes in parallel, then file their answers
+    if (missed) data = probe_table(P, bx, by, bz);
+    file_blocks(dir, missed, bx, by, bz, data);
+  }
+  return data;
+}
+
+__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
+{
+  if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
+  const int data = lookup_block(P, dir, true, bx, by, bz);
+  cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
+  return data;
+}
+
+// explicitly global pointers: the corner loads must not become flat loads
+typedef const float __attribute__((address_space(1)))* global_floats;
+typedef const vf3 __attribute__((address_space(1)))* global_vf3;
+
+// The eight voxels around a sample (tracer.cu:190-256), index dz*4 + dy*2 + dx: where
+// each one is, and the fractional position between them. POOL32: the pool is smaller
+// than 4 GiB, so a voxel is a 32-bit byte offset from the (scalar) pool base — one
+// 24-bit multiply-add per corner instead of a 64-bit one and a 64-bit add.
+template <bool POOL32>
+struct Corners
+{
+  uint32_t offset[8];      // POOL32: byte offset of the voxel in the pool
+  global_floats voxel[8];  // !POOL32: its address
+  uint32_t absent;         // bit c: corner c's block is not allocated -> Voxel::Empty()
+  float fx, fy, fz;        // w1 of tracer.cu:266-272
+
+  __device__ __forceinline__ float word(const PointParams& P, int c, int dword) const
+  {
+    if (POOL32)
+      return *(global_floats)((const char __attribute__((address_space(1)))*)(global_floats)reinterpret_cast<const float*>(P.voxels) +
+                              offset[c] + 4 * dword);
+    return voxel[c][dword];
+  }
+  __device__ __forceinline__ vf3 rgb(const PointParams& P, int c) const
+  {
+    if (POOL32)
+      return *(global_vf3)((const char __attribute__((address_space(1)))*)(global_floats)reinterpret_cast<const float*>(P.voxels) +
+                           offset[c] + 4);
+    return *(global_vf3)(voxel[c] + 1);
+  }
+};
+
+// (wx, wy, wz): the sample position in voxel units relative to block (bx, by, bz), i.e.
+// (p - b * block_length) / voxel_length as computed by the caller (tracer.cu:193-195);
+// `data`: that block's pool slot.
+//
+// tracer.cu:197-199: the low corner is voxel floor(w - 0.5) of the block, in [-1, 7];
+// index -1 / 8 along an axis means the neighbouring block (GetVoxel, :114-188). Seen from
+// the block that HOLDS the low corner (one block down along every axis whose index is
+// -1), the low corner has index l0 = i0 & 7 and the high corner (l0 + 1) & 7, and the
+// high corner sits in the next block up exactly when l0 == 7: corner (dx, dy, dz) is in
+// neighbour (dx & cx, dy & cy, dz & cz) of that base block.
+template <bool COUNT, bool POOL32>
+__device__ __forceinline__ Corners<POOL32> resolve_corners(const PointParams& P, int4* dir, int bx, int by, int bz,
+    int data, float wx, float wy, float wz)
+{
+  const int ix = f2i(floorf(wx - 0.5f));
+  const int iy = f2i(floorf(wy - 0.5f));
+  const int iz = f2i(floorf(wz - 0.5f));
+
+  // base block and in-block indices (>> is an arithmetic shift: -1 >> 3 == -1)
+  const int base_x = bx + (ix >> 3), base_y = by + (iy >> 3), base_z = bz + (iz >> 3);
+  const int l0x = ix & 7, l0y = iy & 7, l0z = iz & 7;
+  const int l1x = (ix + 1) & 7, l1y = (iy + 1) & 7, l1z = (iz + 1) & 7;
+  const bool cx = l0x == 7, cy = l0y == 7, cz = l0z == 7;
+  const bool moved = ((ix | iy | iz) >> 3) != 0;     // the base block is not (bx, by, bz)
+
+  // Pool slots of the up-to-eight blocks base + (m & 1, m >> 1 & 1, m >> 2); only the
+  // combinations some lane of the wave needs are looked up: one LDS read each, with the
+  // coordinates and the directory index of neighbour m put together from per-axis halves.
+  // Misses (a block the wave has not met yet: rare once the march is under way) are
+  // collected in a bit mask and resolved against the global table afterwards, in one place.
+  // (Measured and rejected, r02: looking up all eight once per base block and keeping
+  // them per lane from sample to sample — 40.6 us against 31.3: the eager lookups resolve
+  // blocks beyond the band that no sample ever reads.)
+  const int nx[2] = {base_x, base_x + 1}, ny[2] = {base_y, base_y + 1}, nz[2] = {base_z, base_z + 1};
+  const int dx[2] = {(nx[0] & 3) << 4, (nx[1] & 3) << 4};          // byte offsets into the int4 directory
+  const int dy[2] = {(ny[0] & 3) << 6, (ny[1] & 3) << 6};
+  const int dz[2] = {(nz[0] & 3) << 8, (nz[1] & 3) << 8};
+  const char* dir_bytes = reinterpret_cast<const char*>(dir);
+
+  int n[8];
+  uint32_t missing = 0;
+  n[0] = data;
+  if (__any(moved))
+  {
+    const int4 e = *reinterpret_cast<const int4*>(dir_bytes + (dx[0] | dy[0] | dz[0]));
+    const bool hit = e.x == nx[0] && e.y == ny[0] && e.z == nz[0];
+    n[0] = moved ? e.w : data;
+    missing |= (moved && !hit) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int m = 1; m < 8; ++m)
+  {
+    const bool need = ((m & 1) ? cx : true) && ((m & 2) ? cy : true) && ((m & 4) ? cz : true);
+    n[m] = -1;
+    if (__any(need))
+    {
+      const int4 e = *reinterpret_cast<const int4*>(dir_bytes + (dx[m & 1] | dy[(m >> 1) & 1] | dz[m >> 2]));
+      const bool hit = e.x == nx[m & 1] && e.y == ny[(m >> 1) & 1] && e.z == nz[m >> 2];
+      n[m] = e.w;
+      missing |= (need && !hit) ? (1u << m) : 0u;
+    }
+  }
+  while (__any(missing != 0))
+  {
+    const bool mine = missing != 0;
+    const int m = __ffs((int)missing) - 1;           // this lane's next missing neighbour
+    const int qx = base_x + (m & 1), qy = base_y + ((m >> 1) & 1), qz = base_z + ((m >> 2) & 1);
+    int found = -1;
+    if (mine) found = probe_table(P, qx, qy, qz);
+    file_blocks(dir, mine, qx, qy, qz, found);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) n[k] = (mine && m == k) ? found : n[k];
+    missing &= missing - 1;
+  }
+
+  // corner c is in block (c & crossing mask)
+  int slot[8];
+  slot[0] = n[0];
+  slot[1] = cx ? n[1] : n[0];
+  slot[2] = cy ? n[2] : n[0];
+  const int n13 = cy ? n[3] : n[1];
+  slot[3] = cx ? n13 : slot[2];
+  const int z0 = cz ? n[4] : n[0], z1 = cz ? n[5] : n[1], z2 = cz ? n[6] : n[2], z3 = cz ? n[7] : n[3];
+  slot[4] = z0;
+  slot[5] = cx ? z1 : z0;
+  slot[6] = cy ? z2 : z0;
+  const int z13 = cy ? z3 : z1;
+  slot[7] = cx ? z13 : slot[6];
+
+  Corners<POOL32> C;
+  const global_floats pool = (global_floats)reinterpret_cast<const float*>(P.voxels);
+  const int ox[2] = {l0x * 5, l1x * 5};
+  const int oy[2] = {l0y * 40, l1y * 40};
+  const int oz[2] = {l0z * 320, l1z * 320};
+  C.absent = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+  {
+    const int voxel = oz[c >> 2] + oy[(c >> 1) & 1] + ox[c & 1];        // in floats
+    const bool absent = slot[c] < 0;
+    const uint32_t s = absent ? 0u : (uint32_t)slot[c];                 // an absent block reads slot 0 and is overridden
+    C.absent |= absent ? (1u << c) : 0u;
+    if (POOL32) C.offset[c] = __umul24(s, (uint32_t)(VK_BLOCK_VOXELS * 20)) + (uint32_t)(4 * voxel);
+    else C.voxel[c] = pool + (size_t)s * (VK_BLOCK_VOXELS * 5) + voxel;  // a pool may hold tens of millions of blocks
+    if (COUNT) { if (!absent) P.touched[s] = 1; }
+  }
+
+  C.fx = wx - (ix + 0.5f);
+  C.fy = wy - (iy + 0.5f);
+  C.fz = wz - (iz + 0.5f);
+  return C;
+}
+
+// tracer.cu:266-280,312: trilinear distance (an absent block's voxels are Voxel::Empty(): 1)
+template <bool POOL32>
+__device__ __forceinline__ float corner_distance(const PointParams& P, const Corners<POOL32>& C)
+{
+  float d[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) d[c] = C.word(P, c, 0);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) d[c] = ((C.absent >> c) & 1u) ? 1.0f : d[c];
+  const float w1x = C.fx, w1y = C.fy, w1z = C.fz;
+  const float w0x = 1.0f - w1x, w0y = 1.0f - w1y, w0z = 1.0f - w1z;
+  const float n00 = d[0] * w0x + d[1] * w1x;
+  const float n01 = d[2] * w0x + d[3] * w1x;
+  const float n10 = d[4] * w0x + d[5] * w1x;
+  const float n11 = d[6] * w0x + d[7] * w1x;
+  const float n0 = n00 * w0y + n01 * w1y;
+  const float n1 = n10 * w0y + n11 * w1y;
+  return n0 * w0z + n1 * w1z;
+}
+
+// tracer.cu:282-310: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`, i.e. the colour
+// is the plain mean of the corners that carry colour. A voxel whose colour weight is 0
+// has never had its colour written (every colour update increments the weight), so its
+// colour is the initial (0,0,0): the 12 colour bytes are only fetched when the weight is
+// positive, and when no corner of any lane has one (depth-only volumes) nothing is.
+template <bool POOL32>
+__device__ __forceinline__ f3 corner_color(const PointParams& P, const Corners<POOL32>& C)
+{
+  int cw[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cw[c] = (int)(int16_t)(__float_as_uint(C.word(P, c, 4)) >> 16);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cw[c] = ((C.absent >> c) & 1u) ? 0 : cw[c];
+
+  int any_weight = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) any_weight |= (cw[c] > 0) ? 1 : 0;
+  f3 acc = make3(0.0f, 0.0f, 0.0f);
+  if (!__any(any_weight)) return acc;
+
+  const float w1x = C.fx, w1y = C.fy, w1z = C.fz;
+  const float w0x = 1.0f - w1x, w0y = 1.0f - w1y, w0z = 1.0f - w1z;
+  float total = 0.0f;
+  float cwt[8];
+  vf3 rgb[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+  {
+    rgb[c] = vf3{0.0f, 0.0f, 0.0f};
+    if (cw[c] > 0) rgb[c] = C.rgb(P, c);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+  {
+    const float fz = ((c >> 2) & 1) ? w1z : w0z;
+    const float fy = ((c >> 1) & 1) ? w1y : w0y;
+    const float fx = (c & 1) ? w1x : w0x;
+    const float prod = fz * fy * fx * (float)(cw[c] > 0 ? 1 : 0);
+    cwt[c] = (prod != 0.0f) ? 1.0f : 0.0f;   // NaN counts as true, as in C
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) total += cwt[c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc = add3(acc, scale3(make3(rgb[c].x, rgb[c].y, rgb[c].z), cwt[c]));
+  if (total > 0) acc = div3(acc, total);
+  return acc;
+}
+
+// ref: tracer.cu:317-451 for the pixel (x, y) of this lane; `bound` is its cell's
+// (near, far). Writes depth and colour.
+template <bool COUNT, bool POOL32>
+__device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int x, int y, float2 bound)
+{
+  float final_depth = 0;
+  f3 color = make3(0, 0, 0);
+
+  // where the last trilinear sample was taken (its colour is the pixel's colour)
+  bool sampled = false;
+  int sbx = 0, sby = 0, sbz = 0, sdata = -1;
+  float swx = 0, swy = 0, swz = 0;
+  bool capped = false;
+  if (bound.x < bound.y)
+  {
+    const f3 Xcp = unproject_d(P.k, x + 0.5f, y + 0.5f, bound.x);
+    const f3 Xwp = xform_point(P.Twc, Xcp);
+    const f3 dir = normalized3(xform_dir(P.Twc, Xcp));
+
+    f3 p = Xwp;
+    int iters = 0;
+    BlockCache cache;
+    cache.valid = false;
+    cache.bx = cache.by = cache.bz = 0;
+    cache.data = -1;
+
+    // The reference's loop body (tracer.cu:358-444) contains a second, nested lookup +
+    // interpolation for the step that follows the first sample behind the surface
+    // (:395-423). Here that step is one more trip through the same loop body with
+    // `refine` set, so the lanes of a wave share ONE lookup site and ONE sampling site
+    // whatever phase each ray is in.
+    bool refine = false;
+
+    for (;;)
+    {
+      const int bx = f2i(floorf(div_uniform(p.x, P.inv_block_length)));
+      const int by = f2i(floorf(div_uniform(p.y, P.inv_block_length)));
+      const int bz = f2i(floorf(div_uniform(p.z, P.inv_block_length)));
+      const int data = find_block(P, cache, bdir, bx, by, bz);
+      bool done = false;
+
+      if (data >= 0)
+      {
+        float sdf;
+        bool sample = refine;
+
+        // position in voxel units inside the block: tracer.cu:373-375 for the nearest-voxel
+        // read and, with the same expression, :193-195 for the sample
+        const float wx = div_uniform(p.x - bx * P.block_length, P.inv_voxel_length);
+        const float wy = div_uniform(p.y - by * P.block_length, P.inv_voxel_length);
+        const float wz = div_uniform(p.z - bz * P.block_length, P.inv_voxel_length);
+
+        // The reference reads the nearest voxel and, if its distance is in [-0.5, 0.1], the
+        // eight corners (tracer.cu:377-393): two dependent round trips to memory. A wave almost
+        // always has some lane that samples, so the sampling code runs on every trip anyway:
+        // here every lane resolves its corners and issues all nine loads together, and the
+        // nearest voxel then decides which value the lane uses.
+        float nearest = 0.0f;
+        if (!refine)
+        {
+          // int(w) can reach 8 on a block face: clamped, see DESIGN.md
+          const int vx = vmini(f2i(wx), 7);
+          const int vy = vmini(f2i(wy), 7);
+          const int vz = vmini(f2i(wz), 7);
+          const global_floats pool = (global_floats)reinterpret_cast<const float*>(P.voxels);
+          if (POOL32)
+            nearest = *(global_floats)((const char __attribute__((address_space(1)))*)pool +
+                                       (__umul24((uint32_t)data, (uint32_t)(VK_BLOCK_VOXELS * 20)) + (uint32_t)(20 * (vz * 64 + vy * 8 + vx))));
+          else
+            nearest = (pool + ((size_t)(uint32_t)data * VK_BLOCK_VOXELS + (size_t)(vz * 64 + vy * 8 + vx)) * 5)[0];
+          if (COUNT) P.touched[data] = 1;
+        }
+#if VK_RAY_SPECULATE
+        const Corners<POOL32> C = resolve_corners<COUNT, POOL32>(P, bdir, bx, by, bz, data, wx, wy, wz);
+        const float trilinear = corner_distance(P, C);
+        if (!refine) sample = (nearest <= 0.1f && nearest >= -0.5f);
+        sdf = sample ? trilinear : nearest;
+#else
+        if (!refine) sample = (nearest <= 0.1f && nearest >= -0.5f);
+        sdf = nearest;
+        if (sample)
+        {
+          const Corners<POOL32> C = resolve_corners<COUNT, POOL32>(P, bdir, bx, by, bz, data, wx, wy, wz);
+          sdf = corner_distance(P, C);
+        }
+#endif
+
+        if (sample)
+        {
+          sampled = true;
+          sbx = bx; sby = by; sbz = bz; sdata = data;
+          swx = wx; swy = wy; swz = wz;
+        }
+
+        if (refine)
+        {
+          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :417
+          done = true;
+        }
+        else if (sdf <= 0.0f)
+        {
+          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :397
+          refine = true;
+          continue;                                             // :399-418 happen next trip
+        }
+        else
+        {
+          p = add3(p, scale3(dir, vmax(P.voxel_length, P.trunc_length * sdf)));
+        }
+      }
+      else if (refine)
+      {
+        done = true;                                            // :410 false: no second sample
+      }
+      else
+      {
+        p = add3(p, scale3(dir, P.block_length));
+      }
+
+      const float depth = xform_point(P.Tcw, p).z;
+
+      if (done)
+      {
+        final_depth = depth;                                    // :420-422
+        break;
+      }
+
+      if (++iters >= 500)
+      {
+        capped = true;                                          // :437-442
+        break;
+      }
+
+      if (!(depth < bound.y)) break;
+    }
+  }
+
+  // the colour of the last sample (the reference computes one at every sample and keeps
+  // the last, tracer.cu:392-393,412-413)
+  if (__any(sampled))
+  {
+    if (sampled)
+    {
+      const Corners<POOL32> C = resolve_corners<COUNT, POOL32>(P, bdir, sbx, sby, sbz, sdata, swx, swy, swz);
+      color = corner_color(P, C);
+    }
+  }
+  if (capped) color = make3(1, 0, 0);
+
+  const int pixel = y * P.image_width + x;
+  P.depths[pixel] = final_depth;
+  P.colors[3 * pixel + 0] = color.x;
+  P.colors[3 * pixel + 1] = color.y;
+  P.colors[3 * pixel + 2] = color.z;
+}
+
+}  // namespace vk

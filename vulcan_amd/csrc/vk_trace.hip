@@ -8,6 +8,7 @@
 // straight into the 80x60 bounds grid with native integer atomic min/max
 // (positive floats order like their bit patterns), skipping the patch list.
 #include "vk_bounds.hpp"
+#include "vk_raycast.hpp"
 
 using namespace vk;
 
@@ -174,25 +175,6 @@ __device__ __forceinline__ float2 merged_bound(const float2* __restrict__ partia
   return b;
 }
 
-// The same merge for a wave-uniform cell, read through the scalar cache: the
-// partial grids were written by the previous kernel and are read-only here, so
-// they can be addressed as constant memory (s_load instead of 64-lane loads).
-typedef const float __attribute__((address_space(4)))* scalar_floats;
-
-__device__ __forceinline__ float2 merged_bound_uniform(const float2* partials, int cells, int cell)
-{
-  const scalar_floats base = (scalar_floats)reinterpret_cast<const float*>(partials);
-  float2 b = make_float2(base[2 * cell + 0], base[2 * cell + 1]);
-#pragma unroll
-  for (int g = 1; g < kBoundsGroups; ++g)
-  {
-    const size_t at = 2 * ((size_t)g * cells + cell);
-    b.x = vmin(base[at + 0], b.x);
-    b.y = vmax(base[at + 1], b.y);
-  }
-  return b;
-}
-
 __global__ __launch_bounds__(256) void merge_bounds_kernel(const float2* __restrict__ partials,
     float2* __restrict__ bounds, int cells)
 {
@@ -202,283 +184,58 @@ __global__ __launch_bounds__(256) void merge_bounds_kernel(const float2* __restr
 
 // ------------------------------------------------------------------- points ----
 
-struct PointParams
+// Wave-wide integer min / max ending in lane 63 (DPP row operations, no LDS): the
+// bounds are positive floats or the +-FLT_MAX initialisers, which order like their bit
+// patterns read as signed integers (see bound_cell).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_int(int v)
 {
-  const vk_hash_entry* entries;
-  const vk_voxel* voxels;
-  const float* bounds;        // merged grid (read when partials == nullptr)
-  const float2* partials;     // kBoundsGroups private grids (fused path), or nullptr
-  float2* bounds_out;         // fused path: the merged grid is written back here
-  uint32_t K;
-  float block_length, voxel_length, trunc_length;
-  Rt Twc, Tcw;
-  vk_projection k;
-  float* depths;
-  float* colors;
-  int image_width, image_height, bounds_width, bounds_height;
-};
-
-// A voxel is 5 dwords {distance, r, g, b, (cw << 16 | dw)} at a 4-byte aligned
-// address; gfx950 global loads only need dword alignment, so a voxel is read as
-// dwordx4 + dword, and the x-adjacent pair of a trilinear row as 10 contiguous
-// dwords, instead of the reference's five scalar loads per voxel.
-
-struct Corner
-{
-  float distance;
-  float r, g, b;
-  int color_weight;
-};
-
-__device__ __forceinline__ Corner empty_corner()   // Voxel::Empty(), voxel.h:31-39
-{
-  Corner c;
-  c.distance = 1.0f;
-  c.r = c.g = c.b = 0.0f;
-  c.color_weight = 0;
-  return c;
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);   // lanes outside the mask keep v
 }
 
-__device__ __forceinline__ int color_weight_of(float packed)
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_lane63(int v)
 {
-  return (int)(int16_t)(__float_as_uint(packed) >> 16);
+#define VK_STEP(CTRL, MASK) { const int o = dpp_int<CTRL, MASK>(v); v = MAX ? (o > v ? o : v) : (o < v ? o : v); }
+  VK_STEP(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  VK_STEP(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  VK_STEP(0x141, 0xf)   // row_half_mirror
+  VK_STEP(0x140, 0xf)   // row_mirror
+  VK_STEP(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+  VK_STEP(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef VK_STEP
+  return v;
 }
 
-// A voxel whose colour weight is 0 has never had its colour written (every
-// colour update increments the weight), so its colour is the initial (0,0,0):
-// the 12 colour bytes are only fetched when the weight is positive.
-
-// Address of voxel `voxel` (0..511) of pool slot `slot`; 64-bit throughout, a pool
-// may hold tens of millions of blocks (288 GB of HBM). Measured: 32-bit offsets for
-// pools under 4 GiB change nothing (the kernel is not bound by address arithmetic).
-__device__ __forceinline__ const float* voxel_address(const float* pool, int slot, int voxel)
+// min / max of one cell over the kBoundsGroups private grids, for a wave-uniform cell:
+// lane g reads group g's copy (one 8-byte load for the whole wave), twelve DPP steps fold
+// the 32 values. (64 s_loads + 64 compare/select pairs when each lane did all 32.)
+static_assert(kBoundsGroups == 32, "lane g of a wave reads group g & 31");
+__device__ __forceinline__ float2 merged_bound_wave(const float2* __restrict__ partials, int cells, int cell)
 {
-  return pool + ((size_t)slot * VK_BLOCK_VOXELS + (size_t)voxel) * 5;
-}
-
-// One-entry cache of the last hash lookup: consecutive march steps and the
-// eight trilinear corners mostly stay in one block, and the table is read-only
-// during the kernel, so the cached answer is the answer a fresh walk would give.
-struct BlockCache
-{
-  int bx, by, bz;
-  int data;    // pool slot of the block, -1 when absent / unallocated
-  bool valid;
-};
-
-// Per-wave block directory in LDS: 64 direct-mapped entries {bx, by, bz, slot}.
-// The reference walks the global hash table once per ray per step (and once per
-// trilinear corner near block faces). The 64 rays of a wave cross the same
-// handful of blocks over and over, so here a block is resolved against the
-// global table about once per wave and every later use, by any lane, is one LDS read. The
-// table is read-only during the kernel, so a cached answer is the answer a fresh
-// walk would give.
-constexpr int kDirEntries = 64;
-constexpr int kMaxChain = 1 << 24;
-
-// Entry = the block's coordinates modulo 4 per axis: any 4x4x4 neighbourhood of
-// blocks (16 cm at 5 mm voxels, far more than one wave's 8x8 pixels see in a
-// step) maps to 64 different entries, so the blocks a wave works on never evict
-// one another.
-__device__ __forceinline__ int dir_index(int bx, int by, int bz)
-{
-  return (bx & 3) | ((by & 3) << 2) | ((bz & 3) << 4);
-}
-
-// tracer.cu:364-371: walk the chain until the block matches or the chain ends;
-// a hit needs the match AND IsAllocated().
-__device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by, int bz)
-{
-  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
-  // a chain is at most the excess region long; the cap only guarantees that a wave
-  // leaves the loop if it is handed a corrupt table (a cycle would otherwise hang the GPU)
-  for (int guard = 0; !entry_is(entry, bx, by, bz) && entry.next != -1 && guard < kMaxChain; ++guard)
-    entry = load_entry(P.entries, (uint32_t)entry.next);
-  return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
-}
-
-// files a resolved block in the directory: one distinct block per trip, written
-// by a single lane so that an entry is never a mix of two lanes' stores
-__device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
-{
-  while (__any(pending))
-  {
-    const unsigned long long mask = __ballot(pending);
-    const int leader = __ffsll((long long)mask) - 1;
-    const int ubx = __builtin_amdgcn_readlane(bx, leader);
-    const int uby = __builtin_amdgcn_readlane(by, leader);
-    const int ubz = __builtin_amdgcn_readlane(bz, leader);
-    const int udata = __builtin_amdgcn_readlane(data, leader);
-    if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
-    if (bx == ubx && by == uby && bz == ubz) pending = false;
-  }
-  wave_lds_fence();   // later reads of the directory, by any lane, see these entries
-}
-
-__device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
-{
-  if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
-
-  const int4 e = dir[dir_index(bx, by, bz)];
-  int data = e.w;
-  const bool missed = !(e.x == bx && e.y == by && e.z == bz);
-
-  // directory misses probe the global table, all lanes in parallel, then file
-  // their answers
-  if (missed) data = probe_table(P, bx, by, bz);
-  file_blocks(dir, missed, bx, by, bz, data);
-
-  cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
-  return data;
-}
-
-// tracer.cu:114-188 GetVoxel: a corner index outside [0,8) moves one block over
-// along that axis (a single wrap, as in the reference)
-__device__ __forceinline__ void wrap_axis(int v, int& local, int& shift)
-{
-  shift = (v < 0) ? -1 : ((v >= VK_BLOCK_RESOLUTION) ? 1 : 0);
-  local = v - VK_BLOCK_RESOLUTION * shift;
-}
-
-// tracer.cu:190-315 GetInterpolatedDistance -> (sdf, colour)
-// (wx, wy, wz): the sample position in voxel units relative to block (bx, by, bz),
-// i.e. (p - b * block_length) / voxel_length as computed by the caller
-__device__ __forceinline__ void interpolate(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by,
-    int bz, int data, float wx, float wy, float wz, float& sdf, f3& color)
-{
-  const int i0x = f2i(floorf(wx - 0.5f));
-  const int i0y = f2i(floorf(wy - 0.5f));
-  const int i0z = f2i(floorf(wz - 0.5f));
-
-  Corner vv[8];  // index dz*4 + dy*2 + dx
-  const float* voxf = reinterpret_cast<const float*>(P.voxels);
-
-  // The eight corners touch at most 2x2x2 blocks. The reference has two code
-  // paths (all corners in this block: eight direct reads, tracer.cu:219-243;
-  // otherwise GetVoxel x8, each walking the hash table, :244-256). Here there is
-  // ONE path for every lane of the wave: per axis, sx/sy/sz say which way each of
-  // the two corners leaves the block (0 = stays; always 0 for interior samples)
-  // and lx/ly/lz are the wrapped voxel indices; a block is looked up only if it
-  // differs from this one AND from the block of a corner already resolved, so an
-  // interior sample costs no lookup and a face-crossing sample costs one.
-  int lx[2], ly[2], lz[2], sx[2], sy[2], sz[2];
-  wrap_axis(i0x, lx[0], sx[0]); wrap_axis(i0x + 1, lx[1], sx[1]);
-  wrap_axis(i0y, ly[0], sy[0]); wrap_axis(i0y + 1, ly[1], sy[1]);
-  wrap_axis(i0z, lz[0], sz[0]); wrap_axis(i0z + 1, lz[1], sz[1]);
-
-  int slot[8];  // pool slot of the block holding corner c, -1 = absent
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-  {
-    const int dx = c & 1, dy = (c >> 1) & 1, dz = (c >> 2) & 1;
-    if (dx && sx[1] == sx[0]) { slot[c] = slot[c ^ 1]; continue; }
-    if (dy && sy[1] == sy[0]) { slot[c] = slot[c ^ 2]; continue; }
-    if (dz && sz[1] == sz[0]) { slot[c] = slot[c ^ 4]; continue; }
-    if ((sx[dx] | sy[dy] | sz[dz]) == 0) { slot[c] = data; continue; }
-    BlockCache scratch;
-    scratch.valid = false;
-    slot[c] = find_block(P, scratch, dir, bx + sx[dx], by + sy[dy], bz + sz[dz]);
-  }
-
-  // Four rows of two x-neighbours. When both voxels of a row sit in the same
-  // block they are 10 contiguous dwords {d0 rgb0 w0 | d1 rgb1 w1}: d0, (w0,d1), w1
-  // = 3 loads for the row. Only lanes whose sample straddles a block face in x
-  // (1 in 8) fetch d1 separately (4th, exec-masked load).
-#pragma unroll
-  for (int row = 0; row < 4; ++row)
-  {
-    const int dy = row & 1, dz = row >> 1;
-    const int c0 = dz * 4 + dy * 2, c1 = c0 + 1;
-    const int row_voxel = lz[dz] * 64 + ly[dy] * 8;
-    const bool has0 = slot[c0] >= 0, has1 = slot[c1] >= 0;
-    const bool split = sx[0] != sx[1];   // x-neighbours in different blocks
-    // absent blocks read voxel 0 of the pool and are overridden with Voxel::Empty() below
-    const float* a0 = voxel_address(voxf, has0 ? slot[c0] : 0, has0 ? row_voxel + lx[0] : 0);
-    const float* a1 = split ? voxel_address(voxf, has1 ? slot[c1] : 0, has1 ? row_voxel + lx[1] : 0) : a0 + 5;
-
-    const float d0 = a0[0];
-    // (w0, d1) when contiguous; a split lane reads (b0, w0) instead so the 8-byte
-    // load never leaves its own voxel (the pool may end right after it)
-    const vf2 mid = *reinterpret_cast<const vf2*>(a0 + (split ? 3 : 4));
-    const float w0 = split ? mid.y : mid.x;
-    const float w1 = a1[4];
-    float d1 = mid.y;
-    if (split) d1 = a1[0];
-
-    vv[c0] = empty_corner();
-    vv[c1] = empty_corner();
-    if (has0)
-    {
-      vv[c0].distance = d0;
-      vv[c0].color_weight = color_weight_of(w0);
-      if (vv[c0].color_weight > 0)
-      {
-        const vf3 rgb = *reinterpret_cast<const vf3*>(a0 + 1);
-        vv[c0].r = rgb.x; vv[c0].g = rgb.y; vv[c0].b = rgb.z;
-      }
-    }
-    if (has1)
-    {
-      vv[c1].distance = d1;
-      vv[c1].color_weight = color_weight_of(w1);
-      if (vv[c1].color_weight > 0)
-      {
-        const vf3 rgb = *reinterpret_cast<const vf3*>(a1 + 1);
-        vv[c1].r = rgb.x; vv[c1].g = rgb.y; vv[c1].b = rgb.z;
-      }
-    }
-  }
-
-  const float w1x = wx - (i0x + 0.5f), w1y = wy - (i0y + 0.5f), w1z = wz - (i0z + 0.5f);
-  const float w0x = 1.0f - w1x, w0y = 1.0f - w1y, w0z = 1.0f - w1z;
-
-  const float n00 = vv[0].distance * w0x + vv[1].distance * w1x;
-  const float n01 = vv[2].distance * w0x + vv[3].distance * w1x;
-  const float n10 = vv[4].distance * w0x + vv[5].distance * w1x;
-  const float n11 = vv[6].distance * w0x + vv[7].distance * w1x;
-  const float n0 = n00 * w0y + n01 * w1y;
-  const float n1 = n10 * w0y + n11 * w1y;
-
-  // tracer.cu:282-289: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`, i.e. the
-  // colour is the plain mean of the corners that carry colour. When no corner of
-  // any lane in the wave has a colour weight (depth-only volumes) every weight is
-  // 0 and the result is (0,0,0): the whole block is skipped wave-uniformly.
-  float total = 0.0f;
-  f3 acc = make3(0.0f, 0.0f, 0.0f);
-  int any_weight = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) any_weight |= (vv[c].color_weight > 0) ? 1 : 0;
-
-  if (__any(any_weight))
-  {
-    float cwt[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-    {
-      const float fz = ((c >> 2) & 1) ? w1z : w0z;
-      const float fy = ((c >> 1) & 1) ? w1y : w0y;
-      const float fx = (c & 1) ? w1x : w0x;
-      const float prod = fz * fy * fx * (float)(vv[c].color_weight > 0 ? 1 : 0);
-      cwt[c] = (prod != 0.0f) ? 1.0f : 0.0f;   // NaN counts as true, as in C
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) total += cwt[c];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc = add3(acc, scale3(make3(vv[c].r, vv[c].g, vv[c].b), cwt[c]));
-    if (total > 0) acc = div3(acc, total);
-  }
-
-  sdf = n0 * w0z + n1 * w1z;
-  color = acc;
+  const float2 mine = partials[(size_t)(lane_id() & 31) * cells + cell];
+  const int lo = wave_minmax_lane63<false>(__float_as_int(mine.x));
+  const int hi = wave_minmax_lane63<true>(__float_as_int(mine.y));
+  return make_float2(__int_as_float(__builtin_amdgcn_readlane(lo, 63)), __int_as_float(__builtin_amdgcn_readlane(hi, 63)));
 }
 
 // ref: tracer.cu:317-451. One lane per pixel; a wave covers an 8x8 pixel tile
 // (one bounds cell at 640x480 / 80x60) so its rays start at the same depth, run
-// a similar number of steps and walk the same few blocks; a workgroup is 2x2
-// such tiles.
-__global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
+// a similar number of steps and walk the same few blocks. WAVES waves per workgroup:
+// 2x2 tiles (WAVES = 4) or a single tile (WAVES = 1).
+#ifndef VK_POINTS_WAVES
+#define VK_POINTS_WAVES 1
+#endif
+#ifndef VK_POINTS_ORDER
+#define VK_POINTS_ORDER 1
+#endif
+constexpr int kPointsWaves = VK_POINTS_WAVES;
+constexpr int kPointsTile = (kPointsWaves == 4) ? 16 : 8;     // pixels per workgroup edge
+
+template <bool POOL32>
+__global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(PointParams P)
 {
-  __shared__ int4 directories[4][kDirEntries];
+  __shared__ int4 directories[kPointsWaves][kDirEntries];
 
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -487,20 +244,29 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   wave_lds_fence();
 
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, each
-  // with its own L2, and neighbouring 16x16 tiles march through the same voxel
-  // blocks. Workgroup w therefore takes tile (w % 8) * chunk + w / 8, which gives
-  // every XCD one contiguous band of the image (placement only affects speed).
-  const int tiles_x = (P.image_width + 15) / 16, tiles_y = (P.image_height + 15) / 16;
+  // with its own L2, and neighbouring tiles march through the same voxel blocks.
+  // Workgroup w therefore takes tile (w % 8) * chunk + w / 8, which gives every XCD
+  // one contiguous band of the image (placement only affects speed).
+  const int tiles_x = (P.image_width + kPointsTile - 1) / kPointsTile, tiles_y = (P.image_height + kPointsTile - 1) / kPointsTile;
   const int tiles = tiles_x * tiles_y;
   const int chunk = (tiles + 7) / 8;
-  const int tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  int tile;
+  if (VK_POINTS_ORDER == 0) tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  else if (VK_POINTS_ORDER == 1)
+  {
+    // two half bands per XCD, k and k + 8 of 16: rays near the image border graze the
+    // surface and take more steps, so every XCD gets one outer and one inner strip
+    const int half = (chunk + 1) / 2;
+    const int i = blockIdx.x >> 3, k = blockIdx.x & 7;
+    tile = (i < half) ? k * half + i : (8 + k) * half + (i - half);
+  }
+  else tile = blockIdx.x;                                        // plain round robin
   const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int x = tile_x * kPointsTile + (kPointsWaves == 4 ? (wave & 1) * 8 : 0) + (lane & 7);
+  const int y = tile_y * kPointsTile + (kPointsWaves == 4 ? (wave >> 1) * 8 : 0) + (lane >> 3);
 
-  // This wave's bound first, while no store has been issued yet: with a
-  // wave-uniform cell (always, when a bounds cell is 8x8 pixels) the kBoundsGroups
-  // partial grids are then read through the scalar cache instead of by 64 lanes.
+  // This wave's bound first: with a wave-uniform cell (always, when a bounds cell is
+  // 8x8 pixels) the kBoundsGroups partial grids are merged by the wave as a whole.
   const bool inside = tile < tiles && x < P.image_width && y < P.image_height;
   const int px = P.bounds_width * vmini(x, P.image_width - 1) / P.image_width;
   const int py = P.bounds_height * vmini(y, P.image_height - 1) / P.image_height;
@@ -511,13 +277,13 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   {
     const int cells = P.bounds_width * P.bounds_height;
     const int first = __builtin_amdgcn_readfirstlane(cell);
-    if (__all(cell == first)) bound = merged_bound_uniform(P.partials, cells, first);
+    if (__all(cell == first)) bound = merged_bound_wave(P.partials, cells, first);
     else bound = merged_bound(P.partials, cells, cell);
 
     // publish the merged grid (Tracer::bounds_) — every cell, whether or not a
     // pixel maps to it
-    const int threads = gridDim.x * 256;
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += threads)
+    const int threads = gridDim.x * kPointsWaves * 64;
+    for (int c = blockIdx.x * kPointsWaves * 64 + threadIdx.x; c < cells; c += threads)
       P.bounds_out[c] = merged_bound(P.partials, cells, c);
   }
   else
@@ -526,110 +292,7 @@ __global__ __launch_bounds__(256) void compute_points_kernel(PointParams P)
   }
 
   if (!inside) return;
-
-  float final_depth = 0;
-  f3 color = make3(0, 0, 0);
-
-  if (bound.x < bound.y)
-  {
-    const f3 Xcp = unproject_d(P.k, x + 0.5f, y + 0.5f, bound.x);
-    const f3 Xwp = xform_point(P.Twc, Xcp);
-    const f3 dir = normalized3(xform_dir(P.Twc, Xcp));
-
-    f3 p = Xwp;
-    int iters = 0;
-    BlockCache cache;
-    cache.valid = false;
-    cache.bx = cache.by = cache.bz = 0;
-    cache.data = -1;
-
-    // The reference's loop body (tracer.cu:358-444) contains a second, nested
-    // lookup + interpolation for the step that follows the first sample behind
-    // the surface (:395-423). Here that step is one more trip through the same
-    // loop body with `refine` set, so the lanes of a wave share ONE lookup site
-    // and ONE interpolation site whatever phase each ray is in.
-    bool refine = false;
-
-    for (;;)
-    {
-      const int bx = f2i(floorf(p.x / P.block_length));
-      const int by = f2i(floorf(p.y / P.block_length));
-      const int bz = f2i(floorf(p.z / P.block_length));
-      const int data = find_block(P, cache, bdir, bx, by, bz);
-      bool done = false;
-
-      if (data >= 0)
-      {
-        float sdf;
-        bool sample = refine;
-
-        // position in voxel units inside the block: tracer.cu:373-375 for the
-        // nearest-voxel read and, with the same expression, :193-195 for the sample
-        const float wx = (p.x - bx * P.block_length) / P.voxel_length;
-        const float wy = (p.y - by * P.block_length) / P.voxel_length;
-        const float wz = (p.z - bz * P.block_length) / P.voxel_length;
-
-        if (!refine)
-        {
-          // int(w) can reach 8 on a block face: clamped, see DESIGN.md
-          const int vx = vmini(f2i(wx), 7);
-          const int vy = vmini(f2i(wy), 7);
-          const int vz = vmini(f2i(wz), 7);
-
-          sdf = voxel_address(reinterpret_cast<const float*>(P.voxels), data, vz * 64 + vy * 8 + vx)[0];
-          sample = (sdf <= 0.1f && sdf >= -0.5f);
-        }
-
-        if (sample) interpolate(P, cache, bdir, bx, by, bz, data, wx, wy, wz, sdf, color);
-
-        if (refine)
-        {
-          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :417
-          done = true;
-        }
-        else if (sdf <= 0.0f)
-        {
-          p = add3(p, scale3(dir, P.trunc_length * sdf));       // :397
-          refine = true;
-          continue;                                             // :399-418 happen next trip
-        }
-        else
-        {
-          p = add3(p, scale3(dir, vmax(P.voxel_length, P.trunc_length * sdf)));
-        }
-      }
-      else if (refine)
-      {
-        done = true;                                            // :410 false: no second sample
-      }
-      else
-      {
-        p = add3(p, scale3(dir, P.block_length));
-      }
-
-      const float depth = xform_point(P.Tcw, p).z;
-
-      if (done)
-      {
-        final_depth = depth;                                    // :420-422
-        break;
-      }
-
-      if (++iters >= 500)
-      {
-        color = make3(1, 0, 0);
-        break;
-      }
-
-      if (!(depth < bound.y)) break;
-    }
-  }
-
-  const int pixel = y * P.image_width + x;
-  P.depths[pixel] = final_depth;
-  P.colors[3 * pixel + 0] = color.x;
-  P.colors[3 * pixel + 1] = color.y;
-  P.colors[3 * pixel + 2] = color.z;
+  march_ray<false, POOL32>(P, bdir, x, y, bound);
 }
 
 // ------------------------------------------------------------------ normals ----
@@ -745,7 +408,8 @@ int launch_block_bounds(PatchParams& P, float* bounds, float2* partials, bool me
 int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
-    int image_width, int image_height, int bounds_width, int bounds_height, hipStream_t s)
+    int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
+    hipStream_t s)
 {
   PointParams P;
   P.entries = entries;
@@ -757,6 +421,9 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.block_length = block_length;
   P.voxel_length = voxel_length;
   P.trunc_length = trunc_length;
+  P.inv_block_length = 1.0 / (double)block_length;   // correctly rounded: vk_raycast.hpp div_uniform
+  P.inv_voxel_length = 1.0 / (double)voxel_length;
+  P.touched = nullptr;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
   P.k = *projection;
@@ -766,9 +433,15 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.image_height = image_height;
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
-  const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
-  const dim3 grid(8 * ((tiles + 7) / 8));   // padded so every XCD gets an equal band
-  hipLaunchKernelGGL(compute_points_kernel, grid, dim3(256), 0, s, P);
+  const int tiles = ((image_width + kPointsTile - 1) / kPointsTile) * ((image_height + kPointsTile - 1) / kPointsTile);
+  int chunk = (tiles + 7) / 8;
+  if (VK_POINTS_ORDER == 1) chunk = 2 * ((chunk + 1) / 2);
+  const dim3 grid(8 * chunk);   // padded so every XCD gets an equal share
+  // a pool under 4 GiB is addressed with 32-bit offsets from a scalar base
+  if (pool_bytes <= 0xffffffffull)
+    hipLaunchKernelGGL(compute_points_kernel<true>, grid, dim3(kPointsWaves * 64), 0, s, P);
+  else
+    hipLaunchKernelGGL(compute_points_kernel<false>, grid, dim3(kPointsWaves * 64), 0, s, P);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -850,7 +523,8 @@ int vk_trace_compute_points(const vk_hash_entry* entries, const vk_voxel* voxels
   VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
   VK_REQUIRE(block_length > 0 && voxel_length > 0);
   return launch_points(entries, voxels, bounds, nullptr, block_count, block_length, voxel_length, trunc_length,
-      Twc, projection, depths, colors, image_width, image_height, bounds_width, bounds_height, vk_s(stream));
+      Twc, projection, depths, colors, image_width, image_height, bounds_width, bounds_height,
+      ~0ull /* the free function is not told how large the pool is */, vk_s(stream));
 }
 
 int vk_frame_compute_normals(const float* depths, const vk_projection* projection, float* normals,
@@ -902,7 +576,8 @@ int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float m
   // tracer.cpp:78-95 ComputePoints (merges the private grids on the fly)
   if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
-           out_depth, out_color, frame->width, frame->height, bounds_width, bounds_height, s)) != VK_OK)
+           out_depth, out_color, frame->width, frame->height, bounds_width, bounds_height,
+           (unsigned long long)max_count * VK_BLOCK_VOXELS * sizeof(vk_voxel), s)) != VK_OK)
     return rc;
 
   // tracer.cpp:97-100 ComputeNormals
@@ -934,7 +609,8 @@ int vk_trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ah
 
   if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
-           out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height, s)) != VK_OK)
+           out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
+           (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s)) != VK_OK)
     return rc;
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
