@@ -340,8 +340,31 @@ def probes(loop, nvis_last):
     del a, b
     vref = loop.vols[0]["vref"]
     rmw = timed(lambda: pl.vk_probe_block_rmw(vref, 0, s), float(nvis_last) * 2 * 10240, reps=10)
-    return {"measured_copy_GBps": max(shapes.values()), "copy_shapes_GBps": shapes, "measured_read_GBps": read,
+    nhit = touched_blocks(pl, loop)
+    return {"raycast_blocks_touched": nhit,"measured_copy_GBps": max(shapes.values()), "copy_shapes_GBps": shapes, "measured_read_GBps": read,
             "measured_block_rmw_GBps": rmw, "copy_buffer_bytes": n}
+
+
+def touched_blocks(pl, loop):
+    """Nhit of SURVEY §8d: distinct voxel blocks the rays of the last raycast read, counted by
+    the product's own ray march compiled with its counting hook (tools/probe)."""
+    import torch
+    vv = loop.vols[0]
+    vol, tracer = vv["vol"], vv["tracer"]
+    touched = torch.zeros(vol.max, dtype=torch.uint8, device="cuda")
+    d2, c2 = torch.zeros_like(loop.key.depth), torch.zeros_like(loop.key.color)
+    F = C.c_float
+    pl.vk_probe_trace_touched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, F, F, F, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    rc = pl.vk_probe_trace_touched(vol.hash_entries.data_ptr(), vol.voxels.data_ptr(), tracer.bounds.data_ptr(), vol.main,
+                                   F(np.float32(8) * np.float32(VOXEL)), F(VOXEL), F(TRUNC), C.byref(loop.key.depth_to_world),
+                                   C.byref(loop.k), d2.data_ptr(), c2.data_ptr(), W, H, tracer.BOUNDS_W, tracer.BOUNDS_H,
+                                   touched.data_ptr(), None, loop.stream)
+    torch.cuda.synchronize()
+    if rc != 0 or not torch.equal(d2, loop.key.depth):
+        return None                      # the counting kernel must reproduce the product's image
+    return int(touched.sum())
 
 
 # ----------------------------------------------------------------- multi-GPU rig ----
@@ -530,6 +553,15 @@ def main():
         result["roofline"].update(pr)
         if pr.get("measured_copy_GBps"):
             result["roofline"]["frac_of_measured_copy_here"] = achieved / pr["measured_copy_GBps"]
+        nhit = result["roofline"].pop("raycast_blocks_touched", None)
+        if nhit:
+            # outputs W*H*(4+12) + bounds 4800*8 + compulsory voxel traffic Nhit * 10240
+            ray = result["roofline"]["raycast"]
+            ray["blocks_touched"] = nhit
+            ray["algorithmic_bytes"] = W * H * 16 + 4800 * 8 + nhit * 10240
+            ray["algorithmic_GBps"] = ray["algorithmic_bytes"] / (ray["avg_us"] * 1e-6) / 1e9
+            ray["bound"] = "latency / VALU issue (dependent hash -> voxel loads per march step), not bandwidth"
+            ray["traffic"] = pmc_traffic("raycast")
     del loop
     torch.cuda.empty_cache()
 
@@ -578,7 +610,7 @@ def pmc_traffic(workload):
     cannot be collected from inside an unprofiled run, so the newest measurement on file for
     this workload is reported; None when there is none."""
     import glob
-    tag = "integrate" if workload == "depth" else "integrate_rgbd"
+    tag = {"depth": "integrate", "raycast": "raycast"}.get(workload, "integrate_rgbd")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_traffic.json")))
     if not files:
         return None

@@ -29,11 +29,13 @@ VK_API int vk_probe_block_rmw(const vk_volume* v, int mode, void* stream);   /* 
 /* Nhit of SURVEY.md section 8d: the raycast kernel of the product (vk_raycast.hpp, the very same
  * code, instantiated with its counting hook) run over the whole image; `touched` (device,
  * one byte per pool slot, zeroed by the caller) receives 1 for every voxel block a ray read.
- * Arguments as vk_trace_compute_points (vk.h); depths / colors are written as usual. */
+ * Arguments as vk_trace_compute_points (vk.h); depths / colors are written as usual.
+ * `touched` NULL: the plain kernel (32-bit pool offsets) is run instead. `wave_clocks` (optional,
+ * device, 2 x 4 x workgroups u64): start and end of every wave on the 100 MHz wall clock. */
 VK_API int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
     const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
-    int bounds_width, int bounds_height, uint8_t* touched, void* stream);
+    int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, void* stream);
 
 #ifdef __cplusplus
 }

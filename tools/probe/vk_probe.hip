@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ vox
 }
 
 // the product's ray march with the counting hook compiled in (one wave per 8x8 tile)
-__global__ __launch_bounds__(256) void count_points_kernel(PointParams P)
+__global__ __launch_bounds__(256) void count_points_kernel(PointParams P, unsigned long long* wave_clocks)
 {
+  const unsigned long long t0 = wall_clock64();
   __shared__ int4 directories[4][kDirEntries];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -125,11 +126,20 @@ __global__ __launch_bounds__(256) void count_points_kernel(PointParams P)
   const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
   const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  if (x >= P.image_width || y >= P.image_height) return;
-  const int px = P.bounds_width * x / P.image_width;
-  const int py = P.bounds_height * y / P.image_height;
-  const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
-  march_ray<true, false>(P, bdir, x, y, bound);
+  if (x < P.image_width && y < P.image_height)
+  {
+    const int px = P.bounds_width * x / P.image_width;
+    const int py = P.bounds_height * y / P.image_height;
+    const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
+    if (P.touched) march_ray<true, false>(P, bdir, x, y, bound);
+    else march_ray<false, true>(P, bdir, x, y, bound);
+  }
+  // per-wave start / end on the 100 MHz wall clock (distribution of wave lifetimes)
+  if (wave_clocks && lane == 0)
+  {
+    wave_clocks[2 * (blockIdx.x * 4 + wave) + 0] = t0;
+    wave_clocks[2 * (blockIdx.x * 4 + wave) + 1] = wall_clock64();
+  }
 }
 
 }  // namespace
@@ -167,9 +177,9 @@ int vk_probe_stream_read(const void* src, size_t bytes, float* sink, void* strea
 int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
     const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
-    int bounds_width, int bounds_height, uint8_t* touched, void* stream)
+    int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, void* stream)
 {
-  VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors && touched);
+  VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors && (touched || wave_clocks));
   VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
   PointParams P;
   P.entries = entries;
@@ -194,7 +204,7 @@ int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels,
   P.bounds_height = bounds_height;
   P.touched = touched;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
-  hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P);
+  hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P, wave_clocks);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

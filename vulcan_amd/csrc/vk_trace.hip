@@ -223,12 +223,11 @@ __device__ __forceinline__ float2 merged_bound_wave(const float2* __restrict__ p
 // (one bounds cell at 640x480 / 80x60) so its rays start at the same depth, run
 // a similar number of steps and walk the same few blocks. WAVES waves per workgroup:
 // 2x2 tiles (WAVES = 4) or a single tile (WAVES = 1).
-#ifndef VK_POINTS_WAVES
+// (r02 variants, rocprofv3 averages of 120 launches: 2x2 tiles per workgroup in one band per
+// XCD 31.25 us; single tiles 31.46; two half bands per XCD 31.06 / 30.71 with single tiles;
+// plain round robin 32.21.)
 #define VK_POINTS_WAVES 1
-#endif
-#ifndef VK_POINTS_ORDER
 #define VK_POINTS_ORDER 1
-#endif
 constexpr int kPointsWaves = VK_POINTS_WAVES;
 constexpr int kPointsTile = (kPointsWaves == 4) ? 16 : 8;     // pixels per workgroup edge
 
