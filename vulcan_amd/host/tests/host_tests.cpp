@@ -914,11 +914,28 @@ TEST(DepthTracker, ReduceHook)   // the hook sits between the sums an
     DepthTracker tracker;
     tracker.SetKeyframe(keyframe);
     tracker.SetMaxIterations(5);
+    tracker.SetPollChunk(0);      // enqueue every step: one hook call per step, converged or not
     g_hook_calls = 0;
     if (hooked) tracker.SetReduceHook(DoublingHook, nullptr);
     tracker.Track(frame);
     poses[hooked] = frame.depth_to_world_transform.GetMatrix();
     ASSERT_EQ(hooked ? 5 : 0, g_hook_calls);
+    if (hooked)
+    {
+      // default: the loop looks at the convergence mirror every 4 steps and stops enqueuing
+      // once |update| < 1e-6 (vk_track_poll) — same pose, no launches after convergence
+      Frame again = *keyframe;
+      again.depth_to_world_transform = start;
+      DepthTracker chunked;
+      chunked.SetKeyframe(keyframe);
+      chunked.SetMaxIterations(5);
+      chunked.SetReduceHook(DoublingHook, nullptr);
+      g_hook_calls = 0;
+      chunked.Track(again);
+      ASSERT_TRUE(g_hook_calls == 4 || g_hook_calls == 5);
+      const Matrix4f M = again.depth_to_world_transform.GetMatrix();
+      for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_EQ(poses[1](r, c), M(r, c));
+    }
   }
   for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) ASSERT_EQ(poses[0](r, c), poses[1](r, c));   // x2 is exact
 }
