@@ -183,17 +183,31 @@ class FrameLoop:
         self.depth_threshold = 0.2                                  # light_integrator.cu:256
         self.tracker = None
         if workload == "rgbd-icp":
+            # PyramidTracker<DepthTracker>::Track through its one C entry point, descriptors built once
             self.tracker = api.PyramidTracker()
-        self.iterations = []
+            t = self.tracker.tracker
+            self.key_view, self.frame_view = t._view(self.key), t._view(self.frame)
+            n = int(self.lib.vk_icp_pyramid_floats(W, H, W, H))
+            self.pyramid = torch.empty(n, dtype=torch.float32, device="cuda")
+            self.track_args = (C.byref(self.key_view), None, C.byref(self.frame_view), C.c_void_p(t.pose.data_ptr()),
+                               C.c_void_p(self.pyramid.data_ptr()), C.c_void_p(t._workspace(self.frame).data_ptr()),
+                               C.c_void_p(t.system.data_ptr()), C.c_void_p(t.state.data_ptr()),
+                               C.c_void_p(t.update.data_ptr()), None, None, t._poll())
+            self.pose_dev = C.c_void_p(t.pose.data_ptr())
+            self.tracked = T.Transform()
 
     def step(self, i, ev=None, v=0):
         lib, s, vv = self.lib, self.stream, self.vols[v]
         if self.tracker is not None and i > 0:
             # tracker -> SetView -> Integrate -> Trace (apps/vulcan/vulcan.cu:300-325): the frame
-            # starts from the previous pose and is tracked against the previous raycast
-            self.frame.depth_to_world = self.poses[i - 1]
-            self.tracker.keyframe = self.key
-            self.tracker.track(self.frame)
+            # starts from the previous pose and is tracked against the previous raycast (whose
+            # pose is poses[i - 1]); the tracked pose is read back, as Tracker::EndSolve does
+            a = self.track_args
+            rc = lib.vk_transform_upload(self.pose_dev, C.byref(self.poses[i - 1]), s)
+            rc |= lib.vk_icp_pyramid_track(a[0], C.byref(self.poses[i - 1]), *a[2:], s)
+            rc |= lib.vk_memcpy_d2h(C.byref(self.tracked), self.pose_dev, 128, s)
+            if rc:
+                raise self.api.VkError(f"frame {i}: tracking returned {rc}")
         pose = self.poses[i]                       # ground truth keeps the map consistent
         self.frame.depth_to_world = pose
         self.key.depth_to_world = pose

@@ -459,6 +459,11 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
  * it over ranks here (ncclAllReduce on `stream`). Returns 0 on success. */
 typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* stream);
 
+/* *dst_dev = *src_host, stream-ordered and without a host synchronisation (the 128
+ * bytes travel as kernel arguments): how a tracker's device-side pose is seeded
+ * from frame.depth_to_world_transform (ref: src/tracker.cpp:70-76 BeginSolve). */
+VK_API int vk_transform_upload(vk_transform* dst_dev, const vk_transform* src_host, void* stream);
+
 /* Early exit for the device-side Gauss-Newton loops. The reference leaves its loop
  * as soon as |update| < 1e-6 (tracker.cpp:162) because its host sees every update.
  * The loops here are enqueued without a host round trip; steps after convergence
@@ -469,7 +474,8 @@ typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* 
  * call blocks for at most one chunk, and no launch follows convergence by more
  * than chunk-1 steps. NULL (or chunk <= 0): enqueue every step, never block. */
 typedef struct vk_track_poll {
-  int32_t* host_state;   /* pinned int32[2], 8-byte aligned, written by the device */
+  int32_t* host_state;   /* pinned int32[4], 8-byte aligned, zeroed once by the caller: [0..1] the
+                            device's word {steps, converged | call tag}, [2] the library's call counter */
   int32_t  chunk;        /* steps enqueued between two looks at host_state         */
 } vk_track_poll;
 
@@ -478,12 +484,31 @@ typedef struct vk_track_poll {
  * partial-sum launch and one launch that finishes the sums, solves the 6x6
  * system and updates *Twc_dev (three launches when `reduce` is given). `system`:
  * device float[48]; `state_dev`: device int[2] {iterations run, converged}, the
- * caller zeroes it; `workspace`: vk_icp_workspace_floats(w, h) floats. */
+ * caller zeroes it; `workspace`: vk_icp_workspace_floats(w, h) floats. Without a
+ * `reduce` hook a step is ONE launch: every workgroup first finishes the previous step
+ * itself (sums its partials, solves, updates the pose — redundantly, hence identically,
+ * workgroup 0 publishes) and then evaluates its pixels at the new pose; one more launch
+ * finishes the last step. */
 VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     const vk_icp_view* frame, vk_transform* Twc_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev,
     float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll,
     void* stream);
+
+/* ref: src/pyramid_tracker.cpp:52-90 PyramidTracker<DepthTracker>::Track — the half-
+ * resolution level of both frames (Frame::Downsample, src/frame.cpp:38-58: nearest
+ * depth and normals, intrinsics / 2; ONE launch for the four images), vk_icp_track
+ * with 15 steps on it, then 20 steps at full resolution from the pose the half
+ * level left. The quarter level upstream builds and never tracks (:64-77) is not
+ * built. `pyramid`: device float[vk_icp_pyramid_floats(...)] for the half-resolution
+ * images; `workspace`: vk_icp_workspace_floats of the FULL frame size; the other
+ * buffers as in vk_icp_track. state_dev is reset before each level and holds the
+ * full-resolution level's {steps, converged} afterwards. Image sizes must be even. */
+VK_API size_t vk_icp_pyramid_floats(int key_width, int key_height, int frame_width, int frame_height);
+VK_API int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, vk_transform* Twc_dev, float* pyramid, float* workspace,
+    float* system, int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce,
+    void* reduce_user, const vk_track_poll* poll, void* stream);
 
 /* ------------------------------------------------------------ colour tracker -- */
 

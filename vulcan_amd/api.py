@@ -74,6 +74,9 @@ _SIGNATURES = {
     "vk_icp_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_solve_update": ([_P, _P, _I, _P, _P, _P, _P], _I),
     "vk_icp_track": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_transform_upload": ([_P, _P, _P], _I),
+    "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
+    "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_compute_residuals": ([_P, _P, _P, _P, _P], _I),
@@ -510,7 +513,8 @@ class _PollMixin:
             return None
         if getattr(self, "_poll_desc", None) is None:
             host = C.c_void_p()
-            check(lib().vk_malloc_host(C.byref(host), 8), "vk_malloc_host")
+            check(lib().vk_malloc_host(C.byref(host), 16), "vk_malloc_host")
+            C.memset(host, 0, 16)
             self._poll_host = host
             self._poll_desc = T.TrackPoll(host.value, 0)
         self._poll_desc.chunk = int(self.poll_chunk)
@@ -609,8 +613,7 @@ class DepthTracker(_PollMixin):
         """Tracker::Track (tracker.cpp:53-63): <= max_iterations Gauss-Newton steps,
         all enqueued without a host sync; one 128-byte readback of the pose at the end."""
         import torch
-        host = np.frombuffer(bytes(frame.depth_to_world), dtype=np.uint8).copy()
-        self.pose.copy_(torch.from_numpy(host).to(self.device))
+        check(lib().vk_transform_upload(_ptr(self.pose), _ref(frame.depth_to_world), stream()), "vk_transform_upload")
         self.state.zero_()
         # one C call enqueues the iterations (2 launches each, 3 with a reduce hook) and
         # stops enqueuing once the loop has converged
@@ -827,9 +830,11 @@ class PyramidTracker:
         self.keyframe = None
 
     def track(self, frame):
+        t = self.tracker
+        if isinstance(t, DepthTracker):
+            return self._track_depth(frame)
         half_frame = frame.downsample()
         half_key = self.keyframe.downsample()
-        t = self.tracker
         t.max_iterations, t.translation_enabled = 15, True
         t.keyframe = half_key
         t.track(half_frame)
@@ -837,6 +842,25 @@ class PyramidTracker:
         frame.depth_to_world = half_frame.depth_to_world
         t.keyframe = self.keyframe
         return t.track(frame)
+
+
+    def _track_depth(self, frame):
+        """PyramidTracker<DepthTracker>::Track as ONE call (vk_icp_pyramid_track): both levels
+        are enqueued from C, the pose stays on the device in between, one readback at the end."""
+        import torch
+        t, key = self.tracker, self.keyframe
+        n = int(lib().vk_icp_pyramid_floats(key.width, key.height, frame.width, frame.height))
+        if getattr(self, "_pyramid", None) is None or self._pyramid.numel() < n:
+            self._pyramid = torch.empty(n, dtype=torch.float32, device=t.device)
+        check(lib().vk_transform_upload(_ptr(t.pose), _ref(frame.depth_to_world), stream()), "vk_transform_upload")
+        t.max_iterations, t.translation_enabled, t.keyframe = 20, True, key
+        check(lib().vk_icp_pyramid_track(_ref(t._view(key)), _ref(key.depth_to_world), _ref(t._view(frame)),
+                                         _ptr(t.pose), _ptr(self._pyramid), _ptr(t._workspace(frame)), _ptr(t.system),
+                                         _ptr(t.state), _ptr(t.update), *t._c_hook(), t._poll(), stream()),
+              "vk_icp_pyramid_track")
+        out = T.Transform.from_buffer_copy(t.pose.cpu().numpy().tobytes())
+        frame.depth_to_world = out
+        return out
 
 
 class Detector:

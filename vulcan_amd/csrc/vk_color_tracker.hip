@@ -375,7 +375,7 @@ __device__ __forceinline__ void derive_tcm(const vk_transform& frame_Tcd, const 
 template <int N>
 __device__ __forceinline__ void color_solve_update_n(const float* hessian, const float* gradient,
     const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
-    float* update_out, unsigned long long* mirror)
+    float* update_out, Mirror mirror)
 {
   float update[6];
   solve_step<N>(hessian, gradient, update);
@@ -401,7 +401,7 @@ __device__ __forceinline__ void color_solve_update_n(const float* hessian, const
 
 __device__ void color_solve_update(const float* hessian, const float* gradient, int translation_enabled,
     const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
-    float* update_out, unsigned long long* mirror)
+    float* update_out, Mirror mirror)
 {
   if (state && state[1]) return;  // converged earlier: tracker.cpp:162
   if (translation_enabled) color_solve_update_n<6>(hessian, gradient, frame_Tcd, key_Twc, pose, state, update_out, mirror);
@@ -414,14 +414,14 @@ struct PoseArgs
   vk_color_pose* pose;      // null: sums only
   int32_t* state;
   float* update_out;
-  unsigned long long* mirror;   // pinned host {iterations, converged}, or null (vk_track_poll)
+  Mirror mirror;   // pinned host {iterations, converged}, or null (vk_track_poll)
 };
 
 // second stage; with a pose it also solves and updates (one workgroup)
 __global__ __launch_bounds__(256) void color_final_kernel(const float* __restrict__ workspace, int partials,
     int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient, PoseArgs A)
 {
-  __shared__ float slices[8][kSysStride];
+  __shared__ float slices[kSysSlices][kSysStride];
   __shared__ float sums[48];
   if (A.state && A.state[1]) return;
   sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
@@ -603,7 +603,7 @@ static int system_impl(const vk_color_view* keyframe, const vk_color_view* frame
   A.pose = nullptr;
   A.state = nullptr;
   A.update_out = nullptr;
-  A.mirror = nullptr;
+  A.mirror = Mirror{nullptr, 0};
   hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
       translation_enabled, hessian, gradient, A);
   VK_LAUNCH_CHECK();
@@ -637,7 +637,7 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
   A.pose = pose_dev;
   A.state = state_dev;
   A.update_out = update_dev;
-  A.mirror = nullptr;
+  A.mirror = Mirror{nullptr, 0};
   hipLaunchKernelGGL(color_solve_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
       translation_enabled, A);
   VK_LAUNCH_CHECK();
@@ -669,10 +669,9 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
   A.state = state_dev;
   A.update_out = update_dev;
   const bool chunked = polling(poll);
-  A.mirror = chunked ? reinterpret_cast<unsigned long long*>(poll->host_state) : nullptr;
-  if (chunked) *reinterpret_cast<volatile unsigned long long*>(A.mirror) = 0;
+  A.mirror = begin_mirror(poll);
   PoseArgs sums_only = A;
-  sums_only.mirror = nullptr;
+  sums_only.mirror = Mirror{nullptr, 0};
   sums_only.pose = nullptr;
   sums_only.state = nullptr;
   sums_only.update_out = nullptr;
@@ -701,7 +700,7 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
     }
     VK_LAUNCH_CHECK();
     // stop enqueuing once the loop has converged (tracker.cpp:162), see vk_icp_track
-    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(poll, it + 1, s)) break;
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(A.mirror, it + 1, s)) break;
   }
   return VK_OK;
 }

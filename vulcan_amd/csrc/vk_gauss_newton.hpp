@@ -49,7 +49,8 @@ __device__ __forceinline__ void outer_products(const float (&J)[6], float r, flo
 }
 
 // First stage: the workgroup's 27 sums -> workspace[blockIdx.x]. Called by every
-// thread of a kSysThreads-wide workgroup.
+// thread of a WAVES * 64 wide workgroup.
+template <int WAVES = kSysWaves>
 __device__ __forceinline__ void store_partial(const float (&acc)[27], float (*lds)[kSysStride], float* workspace)
 {
   const int lane = lane_id();
@@ -68,39 +69,51 @@ __device__ __forceinline__ void store_partial(const float (&acc)[27], float (*ld
     if (threadIdx.x < 27)
     {
 #pragma unroll
-      for (int w = 0; w < kSysWaves; ++w) v += lds[w][threadIdx.x];
+      for (int w = 0; w < WAVES; ++w) v += lds[w][threadIdx.x];
     }
     workspace[(size_t)blockIdx.x * kSysStride + threadIdx.x] = v;
   }
 }
 
-// Second stage: fixed-order sum of the per-workgroup partials (8 slices x 32
-// components, then the slices in order) into hessian[36] (packed lower triangle
-// first, rest 0) and gradient[6], and into sums[48] in LDS for a solve that
-// follows. Every thread of the (>= 256-wide) workgroup must call it; ends with a
-// barrier.
+// Second stage: fixed-order sum of the per-workgroup partials into hessian[36] (packed
+// lower triangle first, rest 0) and gradient[6] (either may be null), and into sums[48]
+// in LDS for a solve that follows. Slice s of kSysSlices adds partials s, s + 32, s + 64,
+// ... in that order, then the slices are added in order: the result depends on the
+// partials alone, not on how many threads call (256 or 1024: both are used), so every
+// caller gets the same bits. Every thread of the workgroup must call it; ends with a
+// barrier. The loads of a slice are issued sixteen at a time: with one L2 round trip per
+// term this was the longest part of a Gauss-Newton step (a 640x480 image has 300
+// partials, 1280x960 has 1200).
+constexpr int kSysSlices = 32;
+
 __device__ __forceinline__ void sum_partials(const float* workspace, int partials, int translation_enabled,
     float* hessian, float* gradient, float (*slices)[kSysStride], float* sums)
 {
   const int c = threadIdx.x & 31;
-  const int s = threadIdx.x >> 5;
-
-  if (threadIdx.x < 256)
+  for (int s = threadIdx.x >> 5; s < kSysSlices; s += blockDim.x >> 5)
   {
-    // slice s adds partials s, s + 8, s + 16, ... in that order; the loads of eight
-    // terms are issued together (a 640x480 image has 300 partials, 1280x960 has 1200:
-    // one L2 round trip per term made this the longest part of an iteration)
     float v = 0.0f;
     int j = s;
-    for (; j + 56 < partials; j += 64)
+    for (; j + 15 * kSysSlices < partials; j += 16 * kSysSlices)
     {
-      float t[8];
+      float t[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = workspace[(size_t)(j + 8 * u) * kSysStride + c];
+      for (int u = 0; u < 16; ++u) t[u] = workspace[(size_t)(j + kSysSlices * u) * kSysStride + c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];
+      for (int u = 0; u < 16; ++u) v += t[u];
     }
-    for (; j < partials; j += 8) v += workspace[(size_t)j * kSysStride + c];
+    {
+      // the tail, still issued together: terms past the end read partial 0 and add 0
+      float t[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+      {
+        const int k = j + kSysSlices * u;
+        t[u] = workspace[(size_t)(k < partials ? k : 0) * kSysStride + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v += (j + kSysSlices * u < partials) ? t[u] : 0.0f;
+    }
     slices[s][c] = v;
   }
   __syncthreads();
@@ -112,8 +125,8 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
       float g = 0.0f;
       const int n = translation_enabled ? 6 : 3;
       if ((int)threadIdx.x < n)
-        for (int k = 0; k < 8; ++k) g += slices[k][threadIdx.x];
-      gradient[threadIdx.x] = g;
+        for (int k = 0; k < kSysSlices; ++k) g += slices[k][threadIdx.x];
+      if (gradient) gradient[threadIdx.x] = g;
       sums[36 + threadIdx.x] = g;
     }
     else
@@ -124,8 +137,8 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
       const int n = translation_enabled ? 21 : 6;
       float h = 0.0f;
       if (out < n)
-        for (int k = 0; k < 8; ++k) h += slices[k][6 + out];
-      hessian[out] = h;
+        for (int k = 0; k < kSysSlices; ++k) h += slices[k][6 + out];
+      if (hessian) hessian[out] = h;
       sums[out] = h;
     }
   }
@@ -259,12 +272,20 @@ __device__ __forceinline__ void rigid_from(const float (&M)[16], float (&out_m)[
 }
 
 // tracker.cpp:160-162: record the step and stop once it is shorter than 1e-6.
-// `mirror` (optional): pinned host memory that receives {iterations, converged} as
+// `mirror` (optional): pinned host memory that receives {iterations, converged, epoch} as
 // ONE 64-bit system-scope store after every step, so a host that enqueues the loop
-// in chunks can stop enqueuing once it has converged (vk_track_poll, vk.h).
+// in chunks can stop enqueuing once it has converged (vk_track_poll, vk.h). The epoch
+// (bits 48..63) names the Track call the word belongs to: the launches of one call may
+// still be running when the next call starts to look at the mirror.
+struct Mirror
+{
+  unsigned long long* word;
+  uint32_t epoch;
+};
+
 template <int N>
 __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* state, float* update_out,
-    unsigned long long* mirror = nullptr)
+    Mirror mirror = Mirror{nullptr, 0})
 {
   float sq = 0.0f;
 #pragma unroll
@@ -280,8 +301,9 @@ __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* s
     const int converged = (sqrtf(sq) < 1E-6f) ? 1 : state[1];
     state[0] = iterations;
     state[1] = converged;
-    if (mirror)
-      __hip_atomic_store(mirror, ((unsigned long long)(uint32_t)converged << 32) | (uint32_t)iterations,
+    if (mirror.word)
+      __hip_atomic_store(mirror.word, ((unsigned long long)(mirror.epoch & 0xffffu) << 48) |
+          ((unsigned long long)(uint32_t)(converged & 1) << 32) | (uint32_t)iterations,
           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -292,24 +314,48 @@ __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* s
 // that many steps or a converged loop. Returns true when the loop has converged (stop
 // enqueuing). The spin is bounded by the stream itself: once the stream has drained
 // nothing more will be written.
-inline bool wait_for_steps(const vk_track_poll* poll, int target, hipStream_t s)
+inline bool wait_for_steps(const Mirror& mirror, int target, hipStream_t s)
 {
-  const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(poll->host_state);
+  const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(mirror.word);
+  const unsigned long long tag = (unsigned long long)(mirror.epoch & 0xffffu);
   for (unsigned spin = 0;; ++spin)
   {
     const unsigned long long v = *word;
-    if ((v >> 32) != 0) return true;
-    if ((int)(uint32_t)v >= target) return false;
+    if ((v >> 48) == tag)                          // a word of THIS call (earlier calls' launches may still write theirs)
+    {
+      if ((v >> 32) & 1u) return true;
+      if ((int)(uint32_t)v >= target) return false;
+    }
     if ((spin & 1023u) == 1023u && hipStreamQuery(s) != hipErrorNotReady)
     {
       const unsigned long long last = *word;      // drained: the mirror is final
-      return (last >> 32) != 0;
+      return (last >> 48) == tag && ((last >> 32) & 1u);
     }
   }
 }
 
 inline bool polling(const vk_track_poll* poll) { return poll && poll->host_state && poll->chunk > 0; }
 
+// the mirror of one Track call: a fresh epoch, kept in the pinned block itself (word 2)
+inline Mirror begin_mirror(const vk_track_poll* poll)
+{
+  Mirror m{nullptr, 0};
+  if (!polling(poll)) return m;
+  volatile int32_t* host = poll->host_state;
+  const uint32_t epoch = ((uint32_t)host[2] + 1u) & 0xffffu;
+  host[2] = (int32_t)(epoch ? epoch : 1u);        // never 0: a zeroed block matches no call
+  m.word = reinterpret_cast<unsigned long long*>(poll->host_state);
+  m.epoch = (uint32_t)host[2];
+  return m;
+}
+
+
+// The depth tracker's workgroups are 256 lanes x 4 pixels (one partial per 1024 pixels, as
+// for the 1024 x 1 shape the photometric trackers use): a lane adds up its four pixels'
+// products before the wave reduction, so the 27 x 6 DPP steps, the LDS hop and the
+// barrier are paid once per four pixels (r02: 12.6 -> see profiles/r02_icp_steps.txt).
+constexpr int kIcpThreads = 256;
+constexpr int kIcpPixels = kSysThreads / kIcpThreads;
 
 inline int partial_count(int width, int height)
 {

@@ -43,9 +43,32 @@ __device__ __forceinline__ Rt rt_from_colmajor(const float* m)
 
 // ref: depth_tracker.cu:18-94 Evaluate<translation_enabled>; returns false when
 // the pixel contributes nothing (residual 0, Jacobian 0).
+// what a frame pixel contributes that does not depend on the pose being solved for: its
+// depth and normal (loaded before the pose is known, in the one-launch-per-step kernel)
+struct FramePixel
+{
+  float depth;
+  f3 normal;
+};
+
+__device__ __forceinline__ FramePixel load_frame_pixel(const View& frm, int frame_x, int frame_y)
+{
+  FramePixel px;
+  px.depth = 0.0f;
+  px.normal = make3(0, 0, 0);
+  if (frame_x < frm.width && frame_y < frm.height)
+  {
+    const int frame_index = frame_y * frm.width + frame_x;
+    px.depth = frm.depths[frame_index];
+    const vf3 n = *reinterpret_cast<const vf3*>(frm.normals + 3 * frame_index);
+    px.normal = make3(n.x, n.y, n.z);
+  }
+  return px;
+}
+
 template <bool TRANSLATION>
 __device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int frame_x, int frame_y,
-    float& residual, float J[6])
+    const FramePixel& px, float& residual, float J[6])
 {
   residual = 0.0f;
 #pragma unroll
@@ -55,8 +78,7 @@ __device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int 
   const View& key = P.key;
   if (!(frame_x < frm.width && frame_y < frm.height)) return false;
 
-  const int frame_index = frame_y * frm.width + frame_x;
-  const float frame_depth = frm.depths[frame_index];
+  const float frame_depth = px.depth;
   if (!(frame_depth > 0)) return false;
 
   const f3 Xcp = unproject_d(frm.k, frame_x + 0.5f, frame_y + 0.5f, frame_depth);
@@ -70,11 +92,9 @@ __device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int 
   const float keyframe_depth = key.depths[keyframe_index];
   if (!(keyframe_depth > 0)) return false;
 
-  f3 frame_normal = make3(frm.normals[3 * frame_index + 0], frm.normals[3 * frame_index + 1],
-      frm.normals[3 * frame_index + 2]);
-  frame_normal = xform_dir(Twc, frame_normal);
-  f3 keyframe_normal = make3(key.normals[3 * keyframe_index + 0], key.normals[3 * keyframe_index + 1],
-      key.normals[3 * keyframe_index + 2]);
+  const f3 frame_normal = xform_dir(Twc, px.normal);
+  const vf3 kn = *reinterpret_cast<const vf3*>(key.normals + 3 * keyframe_index);   // one 12-byte load
+  f3 keyframe_normal = make3(kn.x, kn.y, kn.z);
   keyframe_normal = xform_dir(P.Twm, keyframe_normal);
 
   if (!(sqnorm3(keyframe_normal) > 0.0f && dot3(frame_normal, keyframe_normal) > 0.5f)) return false;
@@ -95,6 +115,13 @@ __device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int 
     J[5] = keyframe_normal.z;
   }
   return true;
+}
+
+template <bool TRANSLATION>
+__device__ __forceinline__ bool evaluate(const IcpParams& P, const Rt& Twc, int frame_x, int frame_y,
+    float& residual, float J[6])
+{
+  return evaluate<TRANSLATION>(P, Twc, frame_x, frame_y, load_frame_pixel(P.frm, frame_x, frame_y), residual, J);
 }
 
 // ref: depth_tracker.cu:97-118
@@ -123,7 +150,7 @@ __global__ __launch_bounds__(256) void jacobian_kernel(IcpParams P, float* __res
 }
 
 __device__ void solve_update(const float* hessian, const float* gradient, int translation_enabled,
-    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror);
+    vk_transform* Twc, int32_t* state, float* update_out, Mirror mirror);
 
 // ref: depth_tracker.cu:144-268. Slot layout of a partial: [0,6) J^T r,
 // [6,27) packed lower triangle of J^T J in (r, c<=r) row-major order.
@@ -133,37 +160,66 @@ __device__ void solve_update(const float* hessian, const float* gradient, int tr
 // multi-XCD part the agent-scope release/acquire fences that publish the partials
 // write back and invalidate whole L2s, once per workgroup: the fused iteration
 // took 2.5x as long as the two launches.
+// this lane's four pixels: kIcpThreads apart, so that every load is coalesced
+__device__ __forceinline__ int lane_pixel(int k) { return blockIdx.x * kSysThreads + k * kIcpThreads + (int)threadIdx.x; }
+
+// the 27 products of the lane's pixels, added pixel by pixel
 template <bool TRANSLATION>
-__global__ __launch_bounds__(kSysThreads) void system_partial_kernel(IcpParams P, float* __restrict__ workspace)
+__device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& Twc, const FramePixel (&px)[kIcpPixels],
+    float (&acc)[27])
 {
-  __shared__ float lds[kSysWaves][kSysStride];
+  const int total = P.frm.width * P.frm.height;
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < kIcpPixels; ++k)
+  {
+    const int pixel = lane_pixel(k);
+    float r, J[6], one[27];
+    if (pixel < total && evaluate<TRANSLATION>(P, Twc, pixel % P.frm.width, pixel / P.frm.width, px[k], r, J))
+    {
+      outer_products(J, r, one);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += one[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void load_pixels(const IcpParams& P, FramePixel (&px)[kIcpPixels])
+{
+  const int total = P.frm.width * P.frm.height;
+#pragma unroll
+  for (int k = 0; k < kIcpPixels; ++k)
+  {
+    const int pixel = lane_pixel(k);
+    px[k] = load_frame_pixel(P.frm, pixel % P.frm.width, pixel < total ? pixel / P.frm.width : P.frm.height);
+  }
+}
+
+template <bool TRANSLATION>
+__global__ __launch_bounds__(kIcpThreads) void system_partial_kernel(IcpParams P, float* __restrict__ workspace)
+{
+  __shared__ float lds[kIcpThreads / 64][kSysStride];
 
   // tracker.cpp:162: once the update norm fell below 1e-6 the reference leaves its
   // loop; here the remaining (already enqueued) iterations turn into empty launches
   if (P.state && P.state[1]) return;
 
   const Rt Twc = P.Twc_dev ? rt_from_colmajor(P.Twc_dev->m) : P.Twc;
-  const int total = P.frm.width * P.frm.height;
-  const int pixel = blockIdx.x * kSysThreads + (int)threadIdx.x;
-
+  FramePixel px[kIcpPixels];
+  load_pixels(P, px);
   float acc[27];
-#pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-
-  float r, J[6];
-  if (pixel < total && evaluate<TRANSLATION>(P, Twc, pixel % P.frm.width, pixel / P.frm.width, r, J))
-    outer_products(J, r, acc);
-
-  store_partial(acc, lds, workspace);
+  accumulate_pixels<TRANSLATION>(P, Twc, px, acc);
+  store_partial<kIcpThreads / 64>(acc, lds, workspace);
 }
 
 // Second stage: one workgroup. With `Twc` non-null it also solves and updates the
 // pose, so a Gauss-Newton iteration is two launches.
 __global__ __launch_bounds__(256) void system_final_kernel(const float* __restrict__ workspace,
     int partials, int translation_enabled, float* __restrict__ hessian, float* __restrict__ gradient,
-    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
+    vk_transform* Twc, int32_t* state, float* update_out, Mirror mirror)
 {
-  __shared__ float slices[8][kSysStride];
+  __shared__ float slices[kSysSlices][kSysStride];
   __shared__ float sums[48];   // hessian[36] | gradient[6]: the solve reads them from LDS
   if (state && state[1]) return;   // converged: the system was not recomputed, keep the last one
   sum_partials(workspace, partials, translation_enabled, hessian, gradient, slices, sums);
@@ -174,11 +230,11 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
 
 // ref: tracker.cpp:124-163 + depth_tracker.cpp:22-86. One lane; 6x6 is too
 // small to spread.
+// the new pose (out_m, out_i) from the system and the old pose matrix
 template <int N>
-__device__ __forceinline__ void solve_update_n(const float* hessian, const float* gradient,
-    vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
+__device__ __forceinline__ void pose_step(const float* hessian, const float* gradient, const float (&old_m)[16],
+    float (&out_m)[16], float (&out_i)[16], float (&update)[6])
 {
-  float update[6];
   solve_step<N>(hessian, gradient, update);
 
   // depth_tracker.cpp:33-53, including Tinc(1,2) = +update[0]
@@ -188,19 +244,26 @@ __device__ __forceinline__ void solve_update_n(const float* hessian, const float
   Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
   Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
 
-  float old_m[16], M[16], out_m[16], out_i[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) old_m[i] = Twc->m[i];
+  float M[16];
   matmul4(Tinc, old_m, M);
   rigid_from(M, out_m, out_i);
+}
+
+template <int N>
+__device__ __forceinline__ void solve_update_n(const float* hessian, const float* gradient,
+    vk_transform* Twc, int32_t* state, float* update_out, Mirror mirror)
+{
+  float update[6], old_m[16], out_m[16], out_i[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) old_m[i] = Twc->m[i];
+  pose_step<N>(hessian, gradient, old_m, out_m, out_i, update);
 #pragma unroll
   for (int i = 0; i < 16; ++i) { Twc->m[i] = out_m[i]; Twc->inv[i] = out_i[i]; }
-
   finish_step<N>(update, state, update_out, mirror);
 }
 
 __device__ void solve_update(const float* hessian, const float* gradient,
-    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, Mirror mirror)
 {
   if (state && state[1]) return;  // converged earlier: tracker.cpp:162
   if (translation_enabled) solve_update_n<6>(hessian, gradient, Twc, state, update_out, mirror);
@@ -208,10 +271,135 @@ __device__ void solve_update(const float* hessian, const float* gradient,
 }
 
 __global__ void solve_update_kernel(const float* __restrict__ hessian, const float* __restrict__ gradient,
-    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, unsigned long long* mirror)
+    int translation_enabled, vk_transform* Twc, int32_t* state, float* update_out, Mirror mirror)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0)
     solve_update(hessian, gradient, translation_enabled, Twc, state, update_out, mirror);
+}
+
+// ---- one launch per Gauss-Newton step ------------------------------------------
+//
+// system_partial_kernel + system_final_kernel cost two dependent launches per step
+// (4.8 + 4.5 us at 640x480, most of it launch and dependency latency, r01). Joining
+// them with an in-kernel hand-off ("last workgroup finishes") was measured 2.5x slower:
+// agent-scope fences flush whole L2s on this multi-XCD part. Here the kernel boundary
+// stays the only synchronisation, but there is one per step instead of two: step i
+// first FINISHES step i - 1 — every workgroup sums the previous partials and solves the
+// 6x6 system itself, redundantly and therefore identically (same instructions, same
+// inputs: bit-identical poses in all workgroups) — and then evaluates its 1024 pixels
+// at the new pose. Workgroup 0 alone publishes the pose, the system, the state.
+// Poses and partials are double-buffered so that no workgroup reads what another one
+// of the same launch writes.
+struct StepParams
+{
+  const float* partials_in;    // previous step's partials, null on the first step
+  float* partials_out;
+  const vk_transform* pose_in; // the pose the previous step was evaluated at
+  vk_transform* pose_out;      // written by workgroup 0 (steps after the first)
+  int partials;
+  float* hessian;
+  float* gradient;
+  int32_t* state;
+  float* update_out;
+  Mirror mirror;
+};
+
+__device__ __forceinline__ int load_relaxed(const int32_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool TRANSLATION>
+__global__ __launch_bounds__(kIcpThreads) void fused_step_kernel(IcpParams P, StepParams S)
+{
+  __shared__ float lds[kIcpThreads / 64][kSysStride];
+  __shared__ float slices[kSysSlices][kSysStride];
+  __shared__ float sums[48];
+  __shared__ float pose_m[16];
+  __shared__ int stop;
+
+  // tracker.cpp:162: converged in an earlier step -> the remaining launches are empty
+  if (load_relaxed(S.state + 1)) return;
+
+  // this lane's pixels of the frame do not depend on the pose: their loads are issued
+  // first and land while the previous step is being finished
+  FramePixel px[kIcpPixels];
+  load_pixels(P, px);
+
+  Rt Twc;
+  if (S.partials_in)
+  {
+    const bool publish = blockIdx.x == 0;
+    sum_partials(S.partials_in, S.partials, TRANSLATION, publish ? S.hessian : nullptr,
+        publish ? S.gradient : nullptr, slices, sums);
+    if (threadIdx.x == 0)
+    {
+      constexpr int N = TRANSLATION ? 6 : 3;
+      float update[6], old_m[16], out_m[16], out_i[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) old_m[i] = S.pose_in->m[i];
+      pose_step<N>(sums, sums + 36, old_m, out_m, out_i, update);
+      float sq = 0.0f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sq += update[i] * update[i];
+      stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pose_m[i] = out_m[i];
+      if (publish)
+      {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { S.pose_out->m[i] = out_m[i]; S.pose_out->inv[i] = out_i[i]; }
+        finish_step<N>(update, S.state, S.update_out, S.mirror);
+      }
+    }
+    __syncthreads();
+    if (stop) return;             // this step converged: nothing further is evaluated
+    Twc = rt_from_colmajor(pose_m);
+  }
+  else
+  {
+    Twc = rt_from_colmajor(S.pose_in->m);
+  }
+
+  float acc[27];
+  accumulate_pixels<TRANSLATION>(P, Twc, px, acc);
+  store_partial<kIcpThreads / 64>(acc, lds, S.partials_out);
+}
+
+// after the last step: finish it (or, if the loop converged earlier, do nothing) and leave
+// the pose where the caller wants it
+__global__ __launch_bounds__(256) void fused_finish_kernel(StepParams S, int translation_enabled,
+    const vk_transform* pose_a, const vk_transform* pose_b, vk_transform* result)
+{
+  __shared__ float slices[kSysSlices][kSysStride];
+  __shared__ float sums[48];
+  const bool converged = S.state[1] != 0;
+  if (!converged)
+  {
+    sum_partials(S.partials_in, S.partials, translation_enabled, S.hessian, S.gradient, slices, sums);
+    if (threadIdx.x == 0)
+    {
+      float update[6], old_m[16], out_m[16], out_i[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) old_m[i] = S.pose_in->m[i];
+      if (translation_enabled) pose_step<6>(sums, sums + 36, old_m, out_m, out_i, update);
+      else pose_step<3>(sums, sums + 36, old_m, out_m, out_i, update);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { result->m[i] = out_m[i]; result->inv[i] = out_i[i]; }
+      if (translation_enabled) finish_step<6>(update, S.state, S.update_out, S.mirror);
+      else finish_step<3>(update, S.state, S.update_out, S.mirror);
+    }
+  }
+  else if (threadIdx.x < 32)
+  {
+    // the pose of the converging step sits in the buffer that step wrote: step i writes buffer i & 1
+    const vk_transform* last = (S.state[0] & 1) ? pose_b : pose_a;
+    if (last != result)
+    {
+      const float v = threadIdx.x < 16 ? last->m[threadIdx.x] : last->inv[threadIdx.x - 16];
+      if (threadIdx.x < 16) result->m[threadIdx.x] = v; else result->inv[threadIdx.x - 16] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ pyramid ----
@@ -273,6 +461,32 @@ __global__ __launch_bounds__(256) void downsample3_kernel(int src_w, int dst_w, 
   }
 }
 
+// One pyramid level of BOTH sides of a depth-tracking problem in one launch (blockIdx.z:
+// keyframe / frame): nearest depth and nearest normals, exactly Image::Downsample(nearest)
+// and ColorImage::Downsample(nearest) of Frame::Downsample (frame.cpp:49-51). The colour
+// image Frame::Downsample also halves is not an input of DepthTracker and is not touched.
+struct LevelParams
+{
+  const float* src_depth[2];
+  const float* src_normals[2];
+  float* dst_depth[2];
+  float* dst_normals[2];
+  int src_w[2], dst_w[2], dst_h[2];
+};
+
+__global__ __launch_bounds__(256) void pyramid_level_kernel(LevelParams L)
+{
+  const int side = blockIdx.z;
+  const int dst_x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dst_y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dst_x >= L.dst_w[side] || dst_y >= L.dst_h[side]) return;
+  const int src = (2 * dst_y) * L.src_w[side] + 2 * dst_x;
+  const int dst = dst_y * L.dst_w[side] + dst_x;
+  L.dst_depth[side][dst] = L.src_depth[side][src];
+  const vf3 n = *reinterpret_cast<const vf3*>(L.src_normals[side] + 3 * src);
+  *reinterpret_cast<vf3*>(L.dst_normals[side] + 3 * dst) = n;
+}
+
 int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
     const vk_icp_view* frame, const vk_transform* Twc)
 {
@@ -301,9 +515,9 @@ int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
 void launch_partials(const IcpParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
 {
   if (translation_enabled)
-    hipLaunchKernelGGL(system_partial_kernel<true>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+    hipLaunchKernelGGL(system_partial_kernel<true>, dim3(partials), dim3(kIcpThreads), 0, s, P, workspace);
   else
-    hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+    hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kIcpThreads), 0, s, P, workspace);
 }
 
 }  // namespace
@@ -343,7 +557,9 @@ int vk_icp_compute_jacobian(const vk_icp_view* keyframe, const vk_transform* Twm
 size_t vk_icp_workspace_floats(int width, int height)
 {
   if (width <= 0 || height <= 0) return 0;
-  return (size_t)partial_count(width, height) * kSysStride;
+  // two sets of per-workgroup partials (double-buffered by the one-launch-per-step loop)
+  // and a second pose buffer
+  return 2 * (size_t)partial_count(width, height) * kSysStride + sizeof(vk_transform) / sizeof(float);
 }
 
 int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
@@ -366,7 +582,7 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
       translation_enabled, hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr,
-      (unsigned long long*)nullptr);
+      Mirror{nullptr, 0});
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -389,37 +605,142 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
   const int partials = partial_count(frame->width, frame->height);
   hipStream_t s = vk_s(stream);
   const bool chunked = polling(poll);
-  unsigned long long* mirror = chunked ? reinterpret_cast<unsigned long long*>(poll->host_state) : nullptr;
-  if (chunked) *reinterpret_cast<volatile unsigned long long*>(mirror) = 0;   // the caller zeroed state_dev too
+  const Mirror mirror = begin_mirror(poll);
+
+  if (!reduce)
+  {
+    // one launch per step (fused_step_kernel) + one to finish the last step
+    float* buffers[2] = {workspace, workspace + (size_t)partials * kSysStride};
+    vk_transform* poses[2] = {Twc_dev, reinterpret_cast<vk_transform*>(workspace + 2 * (size_t)partials * kSysStride)};
+    StepParams S;
+    S.partials = partials;
+    S.hessian = hessian;
+    S.gradient = gradient;
+    S.state = state_dev;
+    S.update_out = update_dev;
+    S.mirror = mirror;
+    int it = 0;
+    for (; it < iterations; ++it)
+    {
+      S.partials_in = it ? buffers[(it - 1) & 1] : nullptr;
+      S.partials_out = buffers[it & 1];
+      S.pose_in = poses[it ? (it - 1) & 1 : 0];
+      S.pose_out = poses[it & 1];
+      if (translation_enabled)
+        hipLaunchKernelGGL(fused_step_kernel<true>, dim3(partials), dim3(kIcpThreads), 0, s, P, S);
+      else
+        hipLaunchKernelGGL(fused_step_kernel<false>, dim3(partials), dim3(kIcpThreads), 0, s, P, S);
+      VK_LAUNCH_CHECK();
+      // Launch `it` solves step `it`. Every `chunk` steps the host looks at the mirror
+      // (tracker.cpp:162) — at the state one chunk BACK, so that a chunk of launches is
+      // always queued behind the one being waited for and the GPU never idles while the host
+      // reacts (waiting for the newest step cost a ~13 us bubble per look, r02 timeline).
+      if (chunked && it >= 2 * poll->chunk && it % poll->chunk == 0 && wait_for_steps(mirror, it - poll->chunk, s)) { ++it; break; }
+    }
+    S.partials_in = buffers[(iterations - 1) & 1];
+    S.pose_in = poses[(iterations - 1) & 1];
+    hipLaunchKernelGGL(fused_finish_kernel, dim3(1), dim3(256), 0, s, S, translation_enabled, poses[0], poses[1], Twc_dev);
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
 
   for (int it = 0; it < iterations; ++it)
   {
     launch_partials(P, translation_enabled, partials, workspace, s);
 
-    if (reduce)
-    {
-      // multi-GPU rig: sum the packed system over ranks before every rank solves it
-      hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
-          hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr, (unsigned long long*)nullptr);
-      VK_LAUNCH_CHECK();
-      const int rr = reduce(system, 48, reduce_user, stream);
-      if (rr != 0) return rr;
-      hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, s, hessian, gradient, translation_enabled,
-          Twc_dev, state_dev, update_dev, mirror);
-    }
-    else
-    {
-      hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
-          hessian, gradient, Twc_dev, state_dev, update_dev, mirror);
-    }
+    // multi-GPU rig: sum the packed system over ranks before every rank solves it
+    hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
+        hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr, Mirror{nullptr, 0});
+    VK_LAUNCH_CHECK();
+    const int rr = reduce(system, 48, reduce_user, stream);
+    if (rr != 0) return rr;
+    hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, s, hessian, gradient, translation_enabled,
+        Twc_dev, state_dev, update_dev, mirror);
     VK_LAUNCH_CHECK();
 
     // tracker.cpp:162: the reference leaves its loop once |update| < 1e-6. Steps enqueued
-    // after that point are no-ops, but each still costs two launches; so the host looks
+    // after that point are no-ops, but each still costs its launches; so the host looks
     // at the mirror every `chunk` steps and stops enqueuing when the loop has converged.
-    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(poll, it + 1, s)) break;
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(mirror, it + 1, s)) break;
   }
   return VK_OK;
+}
+
+// the pose travels in the dispatch packet: no staging copy, no host synchronisation
+__global__ void store_transform_kernel(vk_transform* dst, vk_transform value)
+{
+  if (threadIdx.x < 32)
+  {
+    const float v = threadIdx.x < 16 ? value.m[threadIdx.x] : value.inv[threadIdx.x - 16];
+    if (threadIdx.x < 16) dst->m[threadIdx.x] = v; else dst->inv[threadIdx.x - 16] = v;
+  }
+}
+
+int vk_transform_upload(vk_transform* dst_dev, const vk_transform* src_host, void* stream)
+{
+  VK_REQUIRE(dst_dev && src_host);
+  hipLaunchKernelGGL(store_transform_kernel, dim3(1), dim3(64), 0, vk_s(stream), dst_dev, *src_host);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+size_t vk_icp_pyramid_floats(int key_width, int key_height, int frame_width, int frame_height)
+{
+  if (key_width <= 0 || key_height <= 0 || frame_width <= 0 || frame_height <= 0) return 0;
+  if ((key_width | key_height | frame_width | frame_height) & 1) return 0;
+  return 4 * ((size_t)(key_width / 2) * (key_height / 2) + (size_t)(frame_width / 2) * (frame_height / 2));
+}
+
+int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, float* pyramid, float* workspace, float* system, int32_t* state_dev,
+    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
+{
+  VK_REQUIRE(keyframe && Twm && frame && Twc_dev && pyramid && workspace && system && state_dev);
+  VK_REQUIRE(keyframe->depths && keyframe->normals && frame->depths && frame->normals);
+  VK_REQUIRE(vk_icp_pyramid_floats(keyframe->width, keyframe->height, frame->width, frame->height) > 0);
+  hipStream_t s = vk_s(stream);
+
+  // pyramid_tracker.cpp:58-62: half-resolution frame and keyframe (the quarter level is built
+  // upstream but never tracked: :64-77 are commented out)
+  vk_icp_view half[2] = {*keyframe, *frame};
+  LevelParams L;
+  float* at = pyramid;
+  const vk_icp_view* full[2] = {keyframe, frame};
+  for (int side = 0; side < 2; ++side)
+  {
+    const int w = full[side]->width / 2, h = full[side]->height / 2;
+    L.src_depth[side] = full[side]->depths;
+    L.src_normals[side] = full[side]->normals;
+    L.dst_depth[side] = at;
+    L.dst_normals[side] = at + (size_t)w * h;
+    at += 4 * (size_t)w * h;
+    L.src_w[side] = full[side]->width;
+    L.dst_w[side] = w;
+    L.dst_h[side] = h;
+    half[side].depths = L.dst_depth[side];
+    half[side].normals = L.dst_normals[side];
+    half[side].width = w;
+    half[side].height = h;
+    // frame.cpp:53-56: focal length and centre / 2 (Vector2f / 2 multiplies by 1 / 2, matrix.h:279-295)
+    half[side].projection.fx = full[side]->projection.fx * 0.5f;
+    half[side].projection.fy = full[side]->projection.fy * 0.5f;
+    half[side].projection.cx = full[side]->projection.cx * 0.5f;
+    half[side].projection.cy = full[side]->projection.cy * 0.5f;
+  }
+  const int gw = half[0].width > half[1].width ? half[0].width : half[1].width;
+  const int gh = half[0].height > half[1].height ? half[0].height : half[1].height;
+  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2), dim3(256), 0, s, L);
+  VK_LAUNCH_CHECK();
+
+  // :79-83 half level, 15 steps; :85-89 full level, 20 steps, from the pose the half level left.
+  // Tracker::CreateState (tracker.cpp:107-110) starts every Track at iteration 0.
+  VK_CHECK(hipMemsetAsync(state_dev, 0, 2 * sizeof(int32_t), s));
+  int rc = vk_icp_track(&half[0], Twm, &half[1], Twc_dev, 15, 1, workspace, system, state_dev, update_dev,
+      reduce, reduce_user, poll, stream);
+  if (rc != VK_OK) return rc;
+  VK_CHECK(hipMemsetAsync(state_dev, 0, 2 * sizeof(int32_t), s));
+  return vk_icp_track(keyframe, Twm, frame, Twc_dev, 20, 1, workspace, system, state_dev, update_dev,
+      reduce, reduce_user, poll, stream);
 }
 
 int vk_icp_solve_update(const float* hessian, const float* gradient, int translation_enabled,
@@ -427,7 +748,7 @@ int vk_icp_solve_update(const float* hessian, const float* gradient, int transla
 {
   VK_REQUIRE(hessian && gradient && Twc_dev);
   hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
-      translation_enabled, Twc_dev, state_dev, update_dev, (unsigned long long*)nullptr);
+      translation_enabled, Twc_dev, state_dev, update_dev, Mirror{nullptr, 0});
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

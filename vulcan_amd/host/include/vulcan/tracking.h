@@ -101,10 +101,15 @@ class DepthTracker : public Tracker
     // host form of the pose update (ref: depth_tracker.cpp:22-86)
     void ApplyUpdate(Frame& frame, const Vector6f& x) const override;
 
+    // PyramidTracker<DepthTracker>::Track as one call into the C ABI (vk_icp_pyramid_track)
+    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame);
+
   protected:
     int GetResidualCount(const Frame& frame) const override;
     void ComputeSystem(const Frame& frame) override;
     void TrackOnDevice(Frame& frame) override;
+
+    Buffer<float> pyramid_;       // half-resolution depth + normals of keyframe and frame
 };
 
 // Photometric tracking: one intensity residual per keyframe pixel, sampled
@@ -190,6 +195,8 @@ class PyramidTracker
     void Track(Frame& frame);
 
   protected:
+    void TrackLevels(Frame& frame);   // the generic two-level loop (pyramid_tracker.cpp:52-90)
+
     std::shared_ptr<Tracker> tracker_;
     std::shared_ptr<const Frame> keyframe_;
     std::shared_ptr<Frame> half_keyframe_;

@@ -40,8 +40,9 @@ Tracker::Tracker() :
   poll_.host_state = nullptr;
   poll_.chunk = 4;
   void* pinned = nullptr;
-  VK_ASSERT(vk_malloc_host(&pinned, 2 * sizeof(int32_t)));
+  VK_ASSERT(vk_malloc_host(&pinned, 4 * sizeof(int32_t)));
   poll_.host_state = static_cast<int32_t*>(pinned);
+  for (int i = 0; i < 4; ++i) poll_.host_state[i] = 0;
 }
 
 Tracker::~Tracker() { vk_free_host(poll_.host_state); }
@@ -102,7 +103,7 @@ void Tracker::BeginSolve(const Frame& frame)
   ResizeBuffers(frame);
   iteration_ = 0;
   const vk_transform pose = frame.depth_to_world_transform.ToVk();
-  pose_.CopyFromHost(&pose);
+  VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
   VK_ASSERT(vk_memset(state_.GetData(), 0, 2 * sizeof(int), Device::GetStream()));
 }
 
@@ -192,6 +193,29 @@ void DepthTracker::TrackOnDevice(Frame& frame)
   VK_ASSERT(vk_icp_track(&key, &Twm, &frm, pose_.GetData(), max_iterations_, translation_enabled_ ? 1 : 0,
       workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
       reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
+}
+
+void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame)
+{
+  keyframe_ = keyframe;
+  max_iterations_ = 20;          // what pyramid_tracker.cpp:85-86 leaves behind
+  translation_enabled_ = true;
+  ValidateKeyframe();
+  ValidateFrame(frame);
+  ResizeBuffers(frame);
+  const vk_icp_view key = ViewOf(*keyframe_), frm = ViewOf(frame);
+  const size_t floats = vk_icp_pyramid_floats(key.width, key.height, frm.width, frm.height);
+  VULCAN_ASSERT_MSG(floats > 0, "pyramid tracking needs even image sizes");
+  if (floats > pyramid_.GetSize()) pyramid_.Resize(floats);
+  const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
+  const vk_transform pose = frame.depth_to_world_transform.ToVk();
+  VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
+  HookAdapter adapter = { reduce_hook_, reduce_user_ };
+  VK_ASSERT(vk_icp_pyramid_track(&key, &Twm, &frm, pose_.GetData(), pyramid_.GetData(), workspace_.GetData(),
+      system_.GetData(), state_.GetData(), update_.GetData(), reduce_hook_ ? CallReduceHook : nullptr, &adapter,
+      &poll_, Device::GetStream()));
+  iteration_ = max_iterations_;
+  EndSolve(frame);
 }
 
 void DepthTracker::ComputeSystem(const Frame& frame)
@@ -499,6 +523,22 @@ void PyramidTracker<Tracker>::SetKeyframe(std::shared_ptr<const Frame> keyframe)
 // upstream (:69-77 commented out); it is not built here.
 template <typename Tracker>
 void PyramidTracker<Tracker>::Track(Frame& frame)
+{
+  TrackLevels(frame);
+}
+
+// the depth tracker's two levels are one call into the C ABI: nothing but the final pose
+// crosses the host boundary
+template <>
+void PyramidTracker<DepthTracker>::Track(Frame& frame)
+{
+  VULCAN_DEBUG(keyframe_);
+  tracker_->TrackPyramid(keyframe_, frame);
+  ++iter_;
+}
+
+template <typename Tracker>
+void PyramidTracker<Tracker>::TrackLevels(Frame& frame)
 {
   VULCAN_DEBUG(keyframe_);
 
