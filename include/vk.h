@@ -675,6 +675,28 @@ VK_API int vk_detect(const vk_detector* detector, const float* points,
     int32_t count, float* inliers, vk_detect_state* state_dev, void* workspace,
     void* stream);
 
+/* --------------------------------------------------------------- extraction -- */
+
+/* ref: include/vulcan/extractor.h:10-136, src/extractor.cu — Extractor::Extract(DeviceMesh&):
+ * the triangle mesh of the zero level set. Upstream stops after the vertices
+ * (ExtractVertexIndicesKernel / ExtractFacesKernel are empty, extractor.cu:392-430), works one
+ * block per launch with blocking copies in between, drops the far faces of every block and
+ * has no test; this entry point is the finished extractor (conventions kept, gaps filled:
+ * vulcan_amd/csrc/vk_extract.hip). Blocks come from the visible list as upstream
+ * (extractor.cu:455-457) or, with `all_allocated`, from the whole table. `interpolate` = 0
+ * places a vertex at its edge's midpoint as upstream's active code does (:361), 1 where
+ * the linearly interpolated distance is 0.
+ * points: device float[3 * point_capacity]; faces: device int32[3 * face_capacity];
+ * counts_dev: device int32[4] = {points, faces, cubes skipped because a vertex they need
+ * belongs to a block that is not listed, blocks listed}. Counts are the full totals even when
+ * a capacity is too small (nothing is written past a capacity). Order: blocks in list order,
+ * cubes by z*64 + y*8 + x, vertices by axis, faces in table order — reproducible.
+ * workspace: device, vk_extract_workspace_bytes(main, excess) bytes. Four launches, no readback. */
+VK_API size_t vk_extract_workspace_bytes(int32_t main_block_count, int32_t excess_block_count);
+VK_API int vk_extract_mesh(const vk_volume* v, int all_allocated, int interpolate, float* points,
+    int32_t point_capacity, int32_t* faces, int32_t face_capacity, int32_t* counts_dev,
+    void* workspace, void* stream);
+
 #ifdef __cplusplus
 }  /* extern "C" */
 #endif

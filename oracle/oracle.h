@@ -124,6 +124,12 @@ void orc_light_tracker_compute_system(const vk_color_view* keyframe, const vk_co
 void orc_detect(const vk_detector* detector, const float* points, int count,
     float* inliers, vk_detect_state* state);
 
+/* mesh extraction (oracle_extract.c). PARITY UNPINNED: upstream's extractor is unfinished
+ * and has no test (tests/extractor_test.cpp is empty). */
+int orc_extract_mesh(const vk_volume* v, int all_allocated, int interpolate, float* points, int point_capacity,
+    int32_t* faces, int face_capacity, int32_t* counts);
+int orc_mc_triangles(int state, signed char* edges15);
+
 uint32_t orc_kat_hash(int bx, int by, int bz, uint32_t K);
 void orc_kat_project(const vk_projection* k, float x, float y, float z, float* uv);
 void orc_kat_unproject(const vk_projection* k, float u, float v, float d, float* xyz);

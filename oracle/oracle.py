@@ -328,6 +328,27 @@ def pyramid_track(key, frame):
     return icp_track(key, frame, 20, True)
 
 
+def extract_mesh(vol, all_allocated=False, interpolate=True):
+    """orc_extract_mesh: (points [n, 3] float32, faces [m, 3] int32, cubes skipped)."""
+    counts = np.zeros(4, dtype=np.int32)
+    pc, fc = 1, 1
+    for _ in range(2):
+        points = np.zeros((pc, 3), dtype=np.float32)
+        faces = np.zeros((fc, 3), dtype=np.int32)
+        rc = lib().orc_extract_mesh(C.byref(vol.desc()), int(all_allocated), int(interpolate), _p(points), pc,
+                                    _p(faces), fc, _p(counts))
+        if rc == 0:
+            return points[:counts[0]].copy(), faces[:counts[1]].copy(), int(counts[2])
+        pc, fc = max(int(counts[0]), 1), max(int(counts[1]), 1)
+    raise RuntimeError("orc_extract_mesh: capacities did not settle")
+
+
+def mc_triangles(state):
+    edges = np.zeros(15, dtype=np.int8)
+    n = lib().orc_mc_triangles(int(state), _p(edges))
+    return edges[:3 * n].reshape(n, 3).copy()
+
+
 def detect(points, params):
     """orc_detect: returns (DetectState, inlier points [m,3])."""
     pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)

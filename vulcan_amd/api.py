@@ -88,6 +88,8 @@ _SIGNATURES = {
     "vk_light_tracker_compute_jacobian": ([_P, _P, _P, _P, _I, _P, _P], _I),
     "vk_light_tracker_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_light_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_extract_workspace_bytes": ([C.c_int32, C.c_int32], _SZ),
+    "vk_extract_mesh": ([_P, _I, _I, _P, C.c_int32, _P, C.c_int32, _P, _P, _P], _I),
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
     "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
@@ -861,6 +863,49 @@ class PyramidTracker:
         out = T.Transform.from_buffer_copy(t.pose.cpu().numpy().tobytes())
         frame.depth_to_world = out
         return out
+
+
+class Mesh:
+    """vulcan::DeviceMesh (mesh.h:16-21): points [n, 3] float32, faces [m, 3] int32 on the device."""
+
+    def __init__(self, points, faces):
+        self.points, self.faces = points, faces
+
+    def host(self):
+        return self.points.cpu().numpy(), self.faces.cpu().numpy()
+
+
+class Extractor:
+    """vulcan::Extractor (extractor.h:116-134): the whole volume in four launches."""
+
+    def __init__(self, volume):
+        import torch
+        self.volume = volume
+        self.all_allocated = False       # upstream walks the visible blocks (extractor.cu:455-457)
+        self.interpolate = True
+        n = int(lib().vk_extract_workspace_bytes(volume.main, volume.excess))
+        self.workspace = torch.empty(n, dtype=torch.uint8, device=volume.device)
+        self.counts = torch.zeros(4, dtype=torch.int32, device=volume.device)
+
+    def extract(self, point_capacity=None, face_capacity=None):
+        """Extractor::Extract(DeviceMesh&). Capacities default to upstream's ResizeMesh bound
+        for the visible blocks (extractor.cu:700-716: 3 points per voxel, 5 faces per cube),
+        capped; a second call with the reported totals follows when they did not suffice."""
+        import torch
+        v = self.volume
+        blocks = v.max if self.all_allocated else max(v.visible_count, 1)
+        pc = point_capacity if point_capacity is not None else min(blocks * 1536, 1 << 24)
+        fc = face_capacity if face_capacity is not None else min(blocks * 5 * 512, 1 << 25)
+        for _ in range(2):
+            points = torch.empty((pc, 3), dtype=torch.float32, device=v.device)
+            faces = torch.empty((fc, 3), dtype=torch.int32, device=v.device)
+            check(lib().vk_extract_mesh(_ref(v.desc()), int(self.all_allocated), int(self.interpolate), _ptr(points), pc,
+                                        _ptr(faces), fc, _ptr(self.counts), _ptr(self.workspace), stream()), "vk_extract_mesh")
+            np_, nf, self.skipped, self.blocks = (int(c) for c in self.counts.cpu())
+            if np_ <= pc and nf <= fc:
+                return Mesh(points[:np_], faces[:nf])
+            pc, fc = max(np_, 1), max(nf, 1)
+        raise VkError("vk_extract_mesh: capacities did not settle")
 
 
 class Detector:

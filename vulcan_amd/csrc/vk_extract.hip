@@ -1,0 +1,480 @@
+// vk_extract.hip — triangle mesh of the zero level set of the hashed TSDF volume for
+// gfx950 (ref: src/extractor.cu, include/vulcan/extractor.h, mesh.h).
+//
+// The reference's extractor is a per-block prototype that stops after the vertices:
+// ExtractCubeStateKernel classifies the cubes of ONE block per launch (with two blocking
+// copies per stage and per block, extractor.cu:478-482,680-693), ExtractVertexEdgesKernel
+// lists the cut edges among the three that leave each cube's minimum corner,
+// ExtractVertexPointsKernel puts a vertex on each, and ExtractVertexIndicesKernel /
+// ExtractFacesKernel are empty (:392-430). What it fixes is kept: corner c of a cube is
+// voxel (x + (c & 1), y + (c >> 1 & 1), z + (c >> 2)); bit c of the cube state is set when
+// that voxel's distance is > 0; a cube with a corner of distance weight 0 is empty
+// (:185-210); a cube owns the vertices of its edges 0 (+x), 3 (+y), 8 (+z) (:16-118).
+// What it leaves open is finished (the tests hold a CPU statement of it): corners
+// beyond a block's far faces come from the neighbouring blocks, voxels sit where the
+// integrators put them, vertices divide their edge where the interpolated distance is 0,
+// faces come from a derived triangle table (tools/gen_mc_table.py).
+//
+// Shape here: every listed block is one workgroup; the whole volume is four launches,
+// nothing is read back. A workgroup stages the block's 9x9x9 corner lattice (its 512 voxels
+// plus the near faces of up to seven neighbours, resolved through the hash table) in LDS;
+// pass 1 classifies the 512 cubes and counts vertices / triangles per block, an ordered
+// scan over the blocks turns counts into offsets, pass 2 writes points and faces. Vertex
+// indices of neighbouring cubes — also across block borders — are recomputed from the
+// packed per-cube record pass 1 leaves behind, not looked up in a 3-ints-per-voxel map.
+#include "vk_common.hpp"
+
+#define VK_MC_QUALIFIER __device__ const
+#include "vk_mc_table.inc"
+
+using namespace vk;
+
+namespace
+{
+
+constexpr int kExtractThreads = 256;
+constexpr int kLattice = 9 * 9 * 9;
+
+struct ExtractParams
+{
+  vk_volume v;
+  int all_allocated;
+  int interpolate;
+  int total;                 // main + excess entries
+  // workspace
+  int32_t* list;             // [total]  hash entry index of listed block i
+  int32_t* listed;           // [total]  pool slot -> position in the list, -1
+  int32_t* list_count;       // [1]
+  uint32_t* cube_info;       // [total * 512]  see pack_info
+  uint16_t* tri_offset;      // [total * 512]  first triangle of the cube within its block
+  int32_t* block_counts;     // [total * 2]    vertices, triangles of listed block i
+  int32_t* block_offsets;    // [total * 2]    exclusive scan of block_counts
+  // output
+  float* points;
+  int32_t* faces;
+  int32_t point_capacity, face_capacity;
+  int32_t* counts;           // [4] points, faces, cubes skipped, blocks listed
+};
+
+// owner cube (offset from the cube) and axis of each of the twelve edges: edge e of cube
+// (x, y, z) is the axis-th owned edge of cube (x, y, z) + offset
+__device__ const signed char d_edge_owner[12][4] = {
+  {0, 0, 0, 0}, {1, 0, 0, 1}, {0, 1, 0, 0}, {0, 0, 0, 1},
+  {0, 0, 1, 0}, {1, 0, 1, 1}, {0, 1, 1, 0}, {0, 0, 1, 1},
+  {0, 0, 0, 2}, {1, 0, 0, 2}, {1, 1, 0, 2}, {0, 1, 0, 2},
+};
+
+// per-cube record: state (8) | vertex flags x, y, z (3) | emits faces (1) | skipped (1) |
+// first vertex of the cube within its block (11 bits: < 1536)
+__device__ __forceinline__ uint32_t pack_info(uint32_t state, uint32_t flags, bool emit, bool skipped, uint32_t voff)
+{
+  return state | (flags << 8) | ((emit ? 1u : 0u) << 11) | ((skipped ? 1u : 0u) << 12) | (voff << 13);
+}
+__device__ __forceinline__ uint32_t info_state(uint32_t i) { return i & 0xffu; }
+__device__ __forceinline__ uint32_t info_flags(uint32_t i) { return (i >> 8) & 7u; }
+__device__ __forceinline__ bool info_emit(uint32_t i) { return (i >> 11) & 1u; }
+__device__ __forceinline__ uint32_t info_voff(uint32_t i) { return i >> 13; }
+
+// extractor.cu:455-457 takes the visible blocks ("TODO: replace with all allocated blocks");
+// all_allocated walks the table instead. One workgroup, ordered: the list (and with it the
+// vertex and face order) does not depend on timing.
+__global__ __launch_bounds__(1024) void build_list_kernel(ExtractParams P)
+{
+  __shared__ int wave_count[16];
+  __shared__ int running;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int n = P.all_allocated ? P.total : min(P.v.counters[VK_CTR_VISIBLE], P.total);
+
+  for (int base = 0; base < n; base += 1024)
+  {
+    const int i = base + (int)threadIdx.x;
+    int entry = -1, slot = -1;
+    if (i < n)
+    {
+      entry = P.all_allocated ? i : P.v.visible_blocks[i];
+      slot = P.v.hash_entries[entry].data;      // the unallocated origin block can sit in the visible list
+    }
+    const bool keep = slot >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    int offset = running;
+    for (int w = 0; w < wave; ++w) offset += wave_count[w];
+    if (keep)
+    {
+      P.list[offset + before] = entry;
+      P.listed[slot] = offset + before;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int sum = 0;
+      for (int w = 0; w < 16; ++w) sum += wave_count[w];
+      running += sum;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *P.list_count = running; P.counts[3] = running; }
+}
+
+// chain walk of volume.cu:183-190 / tracer.cu:364-371: the block's pool slot, -1 when absent
+__device__ __forceinline__ int find_slot(const vk_hash_entry* entries, uint32_t K, int bx, int by, int bz)
+{
+  Entry entry = load_entry(entries, block_hash(bx, by, bz, K));
+  for (int guard = 0; !entry_is(entry, bx, by, bz) && entry.next != -1 && guard < (1 << 24); ++guard)
+    entry = load_entry(entries, (uint32_t)entry.next);
+  return entry_is(entry, bx, by, bz) ? entry.data : -1;
+}
+
+// The block's 9^3 corner lattice in LDS: distance and whether the voxel is known
+// (allocated block, distance weight != 0: extractor.cu:202-205).
+struct Lattice
+{
+  float distance[kLattice];
+  uint8_t known[kLattice + 3];
+  int slot[8];        // pool slots of block + (m & 1, m >> 1 & 1, m >> 2)
+  int owner[8];       // their positions in the list, -1
+};
+
+__device__ __forceinline__ void stage_lattice(const ExtractParams& P, const Entry& entry, Lattice& L)
+{
+  if (threadIdx.x < 8)
+  {
+    const int m = threadIdx.x;
+    const int slot = (m == 0) ? entry.data
+                   : find_slot(P.v.hash_entries, (uint32_t)P.v.main_block_count, entry.ox + (m & 1), entry.oy + ((m >> 1) & 1), entry.oz + (m >> 2));
+    L.slot[m] = slot;
+    L.owner[m] = slot >= 0 ? P.listed[slot] : -1;
+  }
+  __syncthreads();
+  const float* pool = reinterpret_cast<const float*>(P.v.voxels);
+  for (int i = threadIdx.x; i < kLattice; i += kExtractThreads)
+  {
+    const int hx = i % 9, hy = (i / 9) % 9, hz = i / 81;
+    const int slot = L.slot[(hx >> 3) | ((hy >> 3) << 1) | ((hz >> 3) << 2)];
+    float d = 0.0f;
+    bool known = false;
+    if (slot >= 0)
+    {
+      const float* voxel = pool + ((size_t)slot * VK_BLOCK_VOXELS + (hz & 7) * 64 + (hy & 7) * 8 + (hx & 7)) * 5;
+      d = voxel[0];
+      known = (__float_as_uint(voxel[4]) & 0xffffu) != 0u;     // distance_weight
+    }
+    L.distance[i] = d;
+    L.known[i] = known ? 1 : 0;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int lattice_index(int x, int y, int z) { return z * 81 + y * 9 + x; }
+
+// workgroup-wide exclusive prefix of two counters over the 512 cubes in cube order (thread t
+// holds cubes t and t + 256); totals in *total_a / *total_b
+__device__ __forceinline__ void scan_cubes(int (&a)[2], int (&b)[2], int (&off_a)[2], int (&off_b)[2], int* scratch /* 2 * 8 ints */,
+    int& total_a, int& total_b)
+{
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  // half h covers cubes [256 h, 256 h + 256): scan each half over the 256 threads, then add half 0's total to half 1
+  int incl_a[2], incl_b[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+    int va = a[h], vb = b[h];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const int ta = __shfl_up(va, d), tb = __shfl_up(vb, d);
+      if (lane >= d) { va += ta; vb += tb; }
+    }
+    incl_a[h] = va; incl_b[h] = vb;
+    if (lane == 63) { scratch[h * 8 + wave] = va; scratch[h * 8 + 4 + wave] = vb; }
+  }
+  __syncthreads();
+  int half_a[2] = {0, 0}, half_b[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+    int before_a = 0, before_b = 0;
+    for (int w = 0; w < 4; ++w)
+    {
+      if (w < wave) { before_a += scratch[h * 8 + w]; before_b += scratch[h * 8 + 4 + w]; }
+      half_a[h] += scratch[h * 8 + w];
+      half_b[h] += scratch[h * 8 + 4 + w];
+    }
+    off_a[h] = before_a + incl_a[h] - a[h];
+    off_b[h] = before_b + incl_b[h] - b[h];
+  }
+  off_a[1] += half_a[0];
+  off_b[1] += half_b[0];
+  total_a = half_a[0] + half_a[1];
+  total_b = half_b[0] + half_b[1];
+  __syncthreads();
+}
+
+// pass 1: classify the cubes of listed block blockIdx.x
+__global__ __launch_bounds__(kExtractThreads) void classify_kernel(ExtractParams P)
+{
+  __shared__ Lattice L;
+  __shared__ int scratch[16];
+  const int block = blockIdx.x;
+  if (block >= *P.list_count) return;
+  const Entry entry = load_entry(P.v.hash_entries, (uint32_t)P.list[block]);
+  stage_lattice(P, entry, L);
+
+  int verts[2], tris[2];
+  uint32_t state[2], flags[2];
+  bool emit[2], skipped[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+    const int cube = h * 256 + (int)threadIdx.x;
+    const int x = cube & 7, y = (cube >> 3) & 7, z = cube >> 6;
+    uint32_t s = 0;
+    bool all_known = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+      const int i = lattice_index(x + (c & 1), y + ((c >> 1) & 1), z + (c >> 2));
+      const bool known = L.known[i] != 0;
+      all_known = all_known && known;
+      s |= (known && L.distance[i] > 0.0f) ? (1u << c) : 0u;       // extractor.cu:198-200
+    }
+    // the three owned edges: corner 0 -> corner 1 (+x), 2 (+y), 4 (+z)
+    const int i0 = lattice_index(x, y, z);
+    const bool k0 = L.known[i0] != 0;
+    const bool p0 = L.distance[i0] > 0.0f;
+    uint32_t f = 0;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis)
+    {
+      const int ic = lattice_index(x + (axis == 0), y + (axis == 1), z + (axis == 2));
+      const bool cut = k0 && L.known[ic] != 0 && (p0 != (L.distance[ic] > 0.0f));
+      f |= cut ? (1u << axis) : 0u;
+    }
+    // faces: a valid, non-empty cube whose every vertex belongs to a listed block
+    bool e = all_known && s != 0u && s != 255u;
+    bool skip = false;
+    if (e)
+    {
+      const int n = vk_mc_count[s];
+      for (int k = 0; k < 3 * n; ++k)
+      {
+        const int edge = vk_mc_edges[s][k];
+        const int ox = x + d_edge_owner[edge][0], oy = y + d_edge_owner[edge][1], oz = z + d_edge_owner[edge][2];
+        if (L.owner[(ox >> 3) | ((oy >> 3) << 1) | ((oz >> 3) << 2)] < 0) skip = true;
+      }
+      if (skip) e = false;
+    }
+    state[h] = all_known ? s : 0u;      // a cube with an unknown corner is empty (:212)
+    flags[h] = f;
+    emit[h] = e;
+    skipped[h] = skip;
+    verts[h] = __popc(f);
+    tris[h] = e ? (int)vk_mc_count[s] : 0;
+  }
+
+  int voff[2], toff[2], total_v, total_t;
+  scan_cubes(verts, tris, voff, toff, scratch, total_v, total_t);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+    const size_t at = (size_t)block * 512 + h * 256 + threadIdx.x;
+    P.cube_info[at] = pack_info(state[h], flags[h], emit[h], skipped[h], (uint32_t)voff[h]);
+    P.tri_offset[at] = (uint16_t)toff[h];
+  }
+  int skipped_here = (skipped[0] ? 1 : 0) + (skipped[1] ? 1 : 0);
+  for (int d = 32; d > 0; d >>= 1) skipped_here += __shfl_down(skipped_here, d);
+  if (lane_id() == 0 && skipped_here) atomicAdd(&P.counts[2], skipped_here);
+  if (threadIdx.x == 0)
+  {
+    P.block_counts[2 * block + 0] = total_v;
+    P.block_counts[2 * block + 1] = total_t;
+  }
+}
+
+// ordered exclusive scan of the per-block counts (one workgroup)
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(ExtractParams P)
+{
+  __shared__ int wave_sum[16][2];
+  __shared__ int running[2];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  if (threadIdx.x < 2) running[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = *P.list_count;
+  for (int base = 0; base < n; base += 1024)
+  {
+    const int i = base + (int)threadIdx.x;
+    const int a = i < n ? P.block_counts[2 * i + 0] : 0;
+    const int b = i < n ? P.block_counts[2 * i + 1] : 0;
+    int va = a, vb = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const int ta = __shfl_up(va, d), tb = __shfl_up(vb, d);
+      if (lane >= d) { va += ta; vb += tb; }
+    }
+    if (lane == 63) { wave_sum[wave][0] = va; wave_sum[wave][1] = vb; }
+    __syncthreads();
+    int before_a = running[0], before_b = running[1];
+    for (int w = 0; w < wave; ++w) { before_a += wave_sum[w][0]; before_b += wave_sum[w][1]; }
+    if (i < n)
+    {
+      P.block_offsets[2 * i + 0] = before_a + va - a;
+      P.block_offsets[2 * i + 1] = before_b + vb - b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      int sa = 0, sb = 0;
+      for (int w = 0; w < 16; ++w) { sa += wave_sum[w][0]; sb += wave_sum[w][1]; }
+      running[0] += sa;
+      running[1] += sb;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { P.counts[0] = running[0]; P.counts[1] = running[1]; }
+}
+
+// global index of the vertex on the axis-th owned edge of a cube, from its record
+__device__ __forceinline__ int vertex_index(const ExtractParams& P, int list_index, int cube, int axis)
+{
+  const uint32_t info = P.cube_info[(size_t)list_index * 512 + cube];
+  const uint32_t flags = info_flags(info);
+  return P.block_offsets[2 * list_index] + (int)info_voff(info) + __popc(flags & ((1u << axis) - 1u));
+}
+
+// pass 2: points and faces of listed block blockIdx.x
+__global__ __launch_bounds__(kExtractThreads) void emit_kernel(ExtractParams P)
+{
+  __shared__ Lattice L;
+  const int block = blockIdx.x;
+  if (block >= *P.list_count) return;
+  const Entry entry = load_entry(P.v.hash_entries, (uint32_t)P.list[block]);
+  stage_lattice(P, entry, L);
+  const int first_vertex = P.block_offsets[2 * block + 0];
+  const int first_face = P.block_offsets[2 * block + 1];
+  const float length = P.v.voxel_length;
+  const float block_length = VK_BLOCK_RESOLUTION * length;
+
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+  {
+    const int cube = h * 256 + (int)threadIdx.x;
+    const int x = cube & 7, y = (cube >> 3) & 7, z = cube >> 6;
+    const uint32_t info = P.cube_info[(size_t)block * 512 + cube];
+    const uint32_t flags = info_flags(info);
+
+    // vertices: depth_integrator.cu:35-38 puts voxel (x, y, z) of block o at
+    // block_length * o + voxel_length * (xyz + 0.5)
+    if (flags)
+    {
+      const float d0 = L.distance[lattice_index(x, y, z)];
+      const float px = block_length * (float)entry.ox + length * ((float)x + 0.5f);
+      const float py = block_length * (float)entry.oy + length * ((float)y + 0.5f);
+      const float pz = block_length * (float)entry.oz + length * ((float)z + 0.5f);
+      int out = first_vertex + (int)info_voff(info);
+#pragma unroll
+      for (int axis = 0; axis < 3; ++axis)
+      {
+        if (!((flags >> axis) & 1u)) continue;
+        const float dc = L.distance[lattice_index(x + (axis == 0), y + (axis == 1), z + (axis == 2))];
+        const float t = P.interpolate ? d0 / (d0 - dc) : 0.5f;
+        float p[3] = {px, py, pz};
+        p[axis] = p[axis] + t * length;
+        if (out < P.point_capacity)
+        {
+          P.points[3 * out + 0] = p[0];
+          P.points[3 * out + 1] = p[1];
+          P.points[3 * out + 2] = p[2];
+        }
+        ++out;
+      }
+    }
+
+    // faces
+    if (info_emit(info))
+    {
+      const uint32_t state = info_state(info);
+      const int n = vk_mc_count[state];
+      int out = first_face + (int)P.tri_offset[(size_t)block * 512 + cube];
+      for (int t = 0; t < n; ++t, ++out)
+      {
+        int index[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+        {
+          const int edge = vk_mc_edges[state][3 * t + k];
+          const int ox = x + d_edge_owner[edge][0], oy = y + d_edge_owner[edge][1], oz = z + d_edge_owner[edge][2];
+          const int owner = L.owner[(ox >> 3) | ((oy >> 3) << 1) | ((oz >> 3) << 2)];
+          index[k] = vertex_index(P, owner, (oz & 7) * 64 + (oy & 7) * 8 + (ox & 7), d_edge_owner[edge][3]);
+        }
+        if (out < P.face_capacity)
+        {
+          P.faces[3 * out + 0] = index[0];
+          P.faces[3 * out + 1] = index[1];
+          P.faces[3 * out + 2] = index[2];
+        }
+      }
+    }
+  }
+}
+
+inline size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" {
+
+size_t vk_extract_workspace_bytes(int32_t main_block_count, int32_t excess_block_count)
+{
+  if (main_block_count <= 0 || excess_block_count < 0) return 0;
+  const size_t total = (size_t)main_block_count + (size_t)excess_block_count;
+  return align_up(total * 4) * 2 + align_up(4) + align_up(total * 512 * 4) + align_up(total * 512 * 2) +
+         align_up(total * 8) * 2;
+}
+
+int vk_extract_mesh(const vk_volume* v, int all_allocated, int interpolate, float* points, int32_t point_capacity,
+    int32_t* faces, int32_t face_capacity, int32_t* counts_dev, void* workspace, void* stream)
+{
+  VK_REQUIRE(v && points && faces && counts_dev && workspace);
+  VK_REQUIRE(v->voxels && v->hash_entries && v->visible_blocks && v->counters);
+  VK_REQUIRE(v->main_block_count > 0 && v->excess_block_count >= 0 && point_capacity >= 0 && face_capacity >= 0);
+  hipStream_t s = vk_s(stream);
+  ExtractParams P;
+  P.v = *v;
+  P.all_allocated = all_allocated ? 1 : 0;
+  P.interpolate = interpolate ? 1 : 0;
+  P.total = v->main_block_count + v->excess_block_count;
+  const size_t total = (size_t)P.total;
+  char* at = static_cast<char*>(workspace);
+  P.list = reinterpret_cast<int32_t*>(at);            at += align_up(total * 4);
+  P.listed = reinterpret_cast<int32_t*>(at);          at += align_up(total * 4);
+  P.list_count = reinterpret_cast<int32_t*>(at);      at += align_up(4);
+  P.cube_info = reinterpret_cast<uint32_t*>(at);      at += align_up(total * 512 * 4);
+  P.tri_offset = reinterpret_cast<uint16_t*>(at);     at += align_up(total * 512 * 2);
+  P.block_counts = reinterpret_cast<int32_t*>(at);    at += align_up(total * 8);
+  P.block_offsets = reinterpret_cast<int32_t*>(at);
+  P.points = points;
+  P.faces = faces;
+  P.point_capacity = point_capacity;
+  P.face_capacity = face_capacity;
+  P.counts = counts_dev;
+
+  VK_CHECK(hipMemsetAsync(P.listed, 0xff, total * 4, s));
+  VK_CHECK(hipMemsetAsync(counts_dev, 0, 4 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(build_list_kernel, dim3(1), dim3(1024), 0, s, P);
+  VK_LAUNCH_CHECK();
+  // the list length stays on the device: one workgroup per possible block, the surplus leaves at once
+  hipLaunchKernelGGL(classify_kernel, dim3(P.total), dim3(kExtractThreads), 0, s, P);
+  VK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, P);
+  VK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(emit_kernel, dim3(P.total), dim3(kExtractThreads), 0, s, P);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+}  // extern "C"

@@ -1,9 +1,12 @@
 // image.h — single-channel float image and packed float3 image in device memory
-// (ref: include/vulcan/image.h). The reference's OpenCV Load/Save are replaced
-// by CopyFromHost / CopyToHost; Resize discards contents when the pixel count
-// changes (image.h:85-97).
+// (ref: include/vulcan/image.h). Resize discards contents when the pixel count changes
+// (image.h:85-97). Load / Save keep the reference's signatures (image.h:100-133,228-253)
+// for the two formats that need no OpenCV — binary PGM (8 / 16 bit) and binary PPM —
+// with cv::Mat::convertTo's arithmetic: Load = pixel * scale, Save = saturate(round-half-
+// even(v * alpha + beta)).
 #pragma once
 
+#include <string>
 #include <vulcan/device.h>
 #include <vulcan/matrix.h>
 
@@ -92,6 +95,12 @@ class Image : public detail::ImageStorage<float>
 
     // 3x3 smoothed central differences, zero padding (ref: image.cu:21-99,166-179)
     void GetGradients(Image& gx, Image& gy) const;
+
+    // ref: image.h:100-111 — grey PGM (an RGB PPM is reduced to grey first, as RGB2GRAY does)
+    void Load(const std::string& file, float scale = 1);
+
+    // ref: image.cu:213-221 — bits = 8 (CV_8UC1) or 16 (CV_16UC1)
+    void Save(const std::string& file, int bits = 8, float alpha = 1, float beta = 0) const;
 };
 
 class ColorImage : public detail::ImageStorage<Vector3f>
@@ -107,6 +116,12 @@ class ColorImage : public detail::ImageStorage<Vector3f>
 
     // intensity = (r + g + b) / 3 (ref: image.cu:10-19,235-247)
     void ConvertTo(Image& image) const;
+
+    // ref: image.h:228-240 — PPM in R, G, B order (a grey PGM is replicated to three channels)
+    void Load(const std::string& file, float scale = 1);
+
+    // ref: image.cu:264-273
+    void Save(const std::string& file, int bits = 8, float alpha = 1, float beta = 0) const;
 };
 
 } // namespace vulcan

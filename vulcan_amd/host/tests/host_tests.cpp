@@ -1236,6 +1236,135 @@ TEST(Detector, Detect)   // Filter + 1.5-sigma removal + mean of |x| (detector.c
   ASSERT_TRUE(std::isnan(missing[0]) && std::isnan(missing[1]) && std::isnan(missing[2]));
 }
 
+// ---- mesh extraction, export, sequences (upstream's extractor_test.cpp,
+// exporter_test.cpp and mesh_test.cpp are empty) ---------------------------------------------
+
+#include <fstream>
+#include <sstream>
+#include <sys/stat.h>
+
+static std::shared_ptr<Volume> FusedPlane(Frame& frame)
+{
+  const int w = 160, h = 120;
+  frame.depth_projection.SetFocalLength(136, 136);
+  frame.depth_projection.SetCenterPoint(80, 60);
+  frame.color_projection = frame.depth_projection;
+  frame.depth_image = MakeDepth(w, h, [](int, int) { return 1.5f; });
+  frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.1f + 0.005f * x, 0.2f + 0.006f * y, 0.3f); });
+  auto volume = std::make_shared<Volume>(8192, 2048);
+  volume->SetVoxelLength(0.008f);
+  for (int i = 0; i < 6; ++i) volume->SetView(frame);
+  DepthIntegrator integrator(volume);
+  for (int i = 0; i < 3; ++i) integrator.Integrate(frame);
+  return volume;
+}
+
+TEST(Extractor, Extract)   // extractor.h:116-134; faces are what upstream leaves unwritten (extractor.cu:392-430)
+{
+  Frame frame;
+  auto volume = FusedPlane(frame);
+  Extractor extractor(volume);
+  extractor.SetAllAllocated(true);
+  Mesh mesh;
+  extractor.Extract(mesh);
+  ASSERT_TRUE(mesh.points.size() > 5000 && mesh.faces.size() > 10000);
+  ASSERT_EQ(0, extractor.GetSkippedCubes());
+  for (const Vector3f& p : mesh.points) ASSERT_NEAR(1.5f, p[2], 0.3f * 0.008f);     // on the plane
+  int towards_camera = 0;
+  for (const Vector3i& f : mesh.faces)
+  {
+    for (int k = 0; k < 3; ++k) ASSERT_TRUE(f[k] >= 0 && f[k] < (int)mesh.points.size());
+    const Vector3f a = mesh.points[f[1]] - mesh.points[f[0]], b = mesh.points[f[2]] - mesh.points[f[0]];
+    if (a[0] * b[1] - a[1] * b[0] < 0) ++towards_camera;        // normal z < 0: towards free space
+  }
+  ASSERT_TRUE(towards_camera > 0.999 * mesh.faces.size());
+
+  // upstream's block source (the visible list) and vertex rule (edge midpoints)
+  extractor.SetAllAllocated(false);
+  extractor.SetInterpolate(false);
+  Mesh visible;
+  extractor.Extract(visible);
+  ASSERT_TRUE(!visible.faces.empty() && visible.faces.size() <= mesh.faces.size());
+  for (const Vector3f& p : visible.points) ASSERT_NEAR(1.5f, p[2], 0.5f * 0.008f + 1e-6f);
+}
+
+TEST(Exporter, Export)   // exporter.cpp:19-71, byte for byte
+{
+  Mesh mesh;
+  mesh.points = { Vector3f(0.1f, -0.25f, 0.35f), Vector3f(1.5f, 2.0f, 0.85f), Vector3f(1e-7f, 123456.789f, 1.35f), Vector3f(0, 0, 0.6f) };
+  mesh.faces = { Vector3i(0, 1, 2), Vector3i(2, 1, 3) };
+  const std::string file = "/tmp/vulcan_host_test.ply";
+  Exporter exporter(file);
+  ASSERT_TRUE(exporter.GetFile() == file);
+  exporter.Export(mesh);
+  std::ifstream in(file);
+  std::stringstream text;
+  text << in.rdbuf();
+  const std::string want =
+      "ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+      "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 2\n"
+      "property list uchar int vertex_indices\nend_header\n"
+      "0.1 -0.25 0.35 0 0 0\n1.5 2 0.85 127 127 127\n1e-07 123457 1.35 255 255 255\n0 0 0.6 63 63 63\n"
+      "3 0 1 2\n3 2 1 3\n";
+  ASSERT_TRUE(text.str() == want);
+}
+
+TEST(Sequence, RoundTrip)   // image.h:100-133,228-253 Load / Save on PGM / PPM; sequence.h
+{
+  const int w = 64, h = 48;
+  const std::string dir = "/tmp/vulcan_host_test_sequence";
+  mkdir(dir.c_str(), 0755);
+  Projection k;
+  k.SetFocalLength(54.4162f, 54.43847f);
+  k.SetCenterPoint(31.12701f, 23.47798f);
+  std::vector<Transform> poses;
+  {
+    SequenceWriter writer(dir, w, h, k, k, 0.0002f);
+    for (int i = 0; i < 3; ++i)
+    {
+      Frame frame;
+      frame.depth_image = MakeDepth(w, h, [i](int x, int y) { return 0.5f + 0.01f * x + 0.02f * y + 0.1f * i; });
+      frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(x / 64.0f, y / 48.0f, 0.5f); });
+      frame.depth_to_world_transform = Transform::Translate(0.1f * i, -0.2f, 0.3f) * Transform::Rotate(0.9998719f, 0.0085884f, -0.0104268f, 0.0085884f);
+      poses.push_back(frame.depth_to_world_transform);
+      writer.Append(frame);
+    }
+    ASSERT_EQ(3, writer.GetFrameCount());
+  }
+  SequenceReader reader(dir);
+  ASSERT_EQ(3, reader.GetFrameCount()); ASSERT_EQ(w, reader.GetWidth()); ASSERT_EQ(h, reader.GetHeight());
+  for (int i = 0; i < 3; ++i)
+  {
+    Frame frame;
+    reader.Read(i, frame);
+    ASSERT_EQ(w, frame.depth_image->GetWidth()); ASSERT_EQ(h, frame.color_image->GetHeight());
+    const std::vector<float> d = Download(*frame.depth_image);
+    const std::vector<Vector3f> c = Download(*frame.color_image);
+    for (int y = 0; y < h; y += 5)
+      for (int x = 0; x < w; x += 7)
+      {
+        ASSERT_NEAR(0.5f + 0.01f * x + 0.02f * y + 0.1f * i, d[y * w + x], 0.0001f + 1e-6f);     // half a depth unit
+        ASSERT_NEAR(x / 64.0f, c[y * w + x][0], 0.5f / 255 + 1e-6f);
+      }
+    ASSERT_FLOAT_EQ(54.4162f, frame.depth_projection.GetFocalLength()[0]);
+    for (int r = 0; r < 4; ++r) for (int cc = 0; cc < 4; ++cc)
+    {
+      ASSERT_EQ(poses[i].GetMatrix()(r, cc), frame.depth_to_world_transform.GetMatrix()(r, cc));
+      ASSERT_EQ(poses[i].GetInverseMatrix()(r, cc), frame.depth_to_world_transform.GetInverseMatrix()(r, cc));
+    }
+  }
+  // Save: saturate(round-half-even(v * alpha + beta)) as cv::Mat::convertTo
+  Image ramp(6, 1);
+  const float values[6] = {-3.0f, 0.4999f, 0.5f, 1.5f, 2.5f, 300.0f};
+  ramp.CopyFromHost(values);
+  ramp.Save(dir + "/ramp.pgm", 8);
+  Image back;
+  back.Load(dir + "/ramp.pgm");
+  const std::vector<float> r = Download(back);
+  const float want[6] = {0, 0, 0, 2, 2, 255};
+  for (int i = 0; i < 6; ++i) ASSERT_EQ(want[i], r[i]);
+}
+
 int main(int argc, char** argv)
 {
   int count = 0;
