@@ -675,6 +675,20 @@ VK_API int vk_detect(const vk_detector* detector, const float* points,
     int32_t count, float* inliers, vk_detect_state* state_dev, void* workspace,
     void* stream);
 
+/* --------------------------------------------------------------- compaction -- */
+
+/* ref: include/vulcan/util.cuh:52-140 PrefixSum<N> (both overloads) — the stream-compaction
+ * primitive behind visible-block, patch and detector compaction. For every element i with
+ * counts[i] > 0, offsets[i] is the first of counts[i] private, consecutive slots of a packed
+ * output; elements with counts[i] == 0 get -1 (util.cuh:93-94); *total_dev is increased by
+ * the sum (it is the reference's `total` argument: zero it to start a new output). The
+ * reference leaves the order of the workgroups' ranges to its atomicAdd; here the ranges
+ * are in input order (stable). counts, offsets: device int32[count]; workspace: device,
+ * vk_compact_workspace_bytes(count). Three launches, no readback. */
+VK_API size_t vk_compact_workspace_bytes(int32_t count);
+VK_API int vk_compact_offsets(const int32_t* counts, int32_t count, int32_t* offsets,
+    int32_t* total_dev, void* workspace, void* stream);
+
 /* --------------------------------------------------------------- extraction -- */
 
 /* ref: include/vulcan/extractor.h:10-136, src/extractor.cu — Extractor::Extract(DeviceMesh&):

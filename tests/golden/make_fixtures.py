@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/scenes_160x120.npz: reduced-size golden vectors for the synthetic
+scenes of SURVEY.md §8(d), produced by the CPU oracle (oracle/, the restated reference
+kernels — the reference itself cannot be built or run here: CUDA + OpenCV).
+
+  python tests/golden/make_fixtures.py            # regenerate (needs liboracle.so)
+
+Inputs are closed-form (tests/scenes.py) and are not stored. Per scene the file holds the
+raycast depth / colour / normal images and bounds grid, the visible count and pool pointers,
+and SHA-256 digests of the volume's buffers (the voxel pool is 50 MB). tests/test_golden.py
+checks the oracle against the file on the CPU; tests/test_gpu_golden.py checks the device
+against it without building or loading the oracle."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 160, 120
+MAIN, EXCESS, VOXEL, TRUNC = 4096, 1024, 0.008, 0.04
+FILE = os.path.join(HERE, "scenes_160x120.npz")
+
+
+def scene_inputs(name):
+    """(depth, colour, projection, pose) of scene `name` — closed form, shared with the tests."""
+    import scenes
+    from vulcan_amd import vk_types as T
+    k = T.Projection.make(136.0, 136.0, 80.0, 60.0)
+    if name == "plane":            # scene A
+        return scenes.plane(W, H, 1.5), scenes.constant_color(W, H), k, T.Transform.identity()
+    if name == "sphere":           # scene B, scaled to the reduced image: r < 50 px
+        y, x = np.mgrid[0:H, 0:W]
+        u = x.astype(np.float32) + np.float32(0.5) - np.float32(0.5 * W)
+        v = y.astype(np.float32) + np.float32(0.5) - np.float32(0.5 * H)
+        rr = (u * u + v * v).astype(np.float64)
+        depth = np.where(np.sqrt(rr) < 50, 4.0 - 1.5 * np.sqrt(np.maximum(50.0 * 50.0 - rr, 0.0)) / 50.0, 0.0)
+        return depth.astype(np.float32), scenes.checker_color(W, H, 0.1, 0.9), k, scenes.tracer_test_pose()
+    if name == "ripple":           # scene C
+        return (scenes.ripple(W, H) * np.float32(1.3)).astype(np.float32), scenes.checker_color(W, H, 0.1, 0.9), k, \
+            T.Transform.translate(0.001, -0.002, 0.003) * T.Transform.rotate(0.9998719, 0.0085884, -0.0104268, 0.0085884)
+    if name == "ramp":             # scene D
+        return scenes.ramp(W, H), scenes.constant_color(W, H, (0.4, 0.5, 0.6)), k, T.Transform.translate(-10.73, 2.11, -33.54)
+    raise KeyError(name)
+
+
+SCENES = ("plane", "sphere", "ripple", "ramp")
+
+
+def digest(array):
+    return hashlib.sha256(np.ascontiguousarray(array).tobytes()).hexdigest()
+
+
+def run_scene(backend, name):
+    """backend: an object with the oracle's or the device's operations (tests build one each)."""
+    depth, color, k, pose = scene_inputs(name)
+    return backend(depth, color, k, pose)
+
+
+def oracle_backend(depth, color, k, pose):
+    from oracle import oracle as orc
+    from vulcan_amd import vk_types as T
+    hv = orc.HostVolume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
+    hf = orc.HostFrame(depth, k, pose, color=color)
+    hf.compute_normals()
+    for _ in range(5):
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+    orc.integrate_depth(hv, hf)
+    orc.integrate_color(hv, hf)
+    odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+    points, faces, skipped = orc.extract_mesh(hv, True, True)
+    key = orc.HostFrame(odepth, k, pose, normals=onormals)
+    moved = orc.HostFrame(depth, k, T.Transform.translate(0.002, -0.001, 0.001) * pose, normals=hf.normals)
+    residuals = orc.icp_residuals(key, moved)
+    return dict(frame_normals=hf.normals, depth=odepth, color=ocolor, normals=onormals, bounds=obounds,
+                counters=hv.counters.copy(), visible=np.sort(hv.visible()),
+                voxels_sha256=digest(hv.voxels), entries_sha256=digest(hv.hash_entries),
+                visibility_sha256=digest(hv.block_visibility),
+                mesh_points_sha256=digest(points), mesh_faces_sha256=digest(faces),
+                mesh_counts=np.array([len(points), len(faces), skipped], dtype=np.int32),
+                icp_residuals=residuals)
+
+
+def main():
+    from oracle import oracle as orc
+    orc.build()
+    orc.set_threads(8)
+    out = {}
+    for name in SCENES:
+        for key, value in run_scene(oracle_backend, name).items():
+            out[f"{name}/{key}"] = np.asarray(value)
+    np.savez_compressed(FILE, **out)
+    print(f"{FILE}: {os.path.getsize(FILE) / 1e6:.2f} MB, {len(out)} arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -37,11 +37,22 @@ def test_pod_sizes(orc):
 
 
 def test_hash_known_answers(orc):
+    """hash.h / volume.cu:168-180: ((bx*P1) ^ (by*P2) ^ (bz*P3)) % K in uint32 — recomputed here
+    with Python integers, so the stored codes are checked twice."""
     f = orc.lib().orc_kat_hash
     f.restype = C.c_uint32
+    P1, P2, P3 = 73856093, 19349669, 83492791
     for case in kats()["hash"]:
         bx, by, bz = case["block"]
+        by_hand = (((bx * P1) & 0xffffffff) ^ ((by * P2) & 0xffffffff) ^ ((bz * P3) & 0xffffffff)) % case["K"]
+        assert by_hand == case["code"]
         assert f(bx, by, bz, C.c_uint32(case["K"])) == case["code"]
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        bx, by, bz = (int(v) for v in rng.integers(-3000, 3000, 3))
+        K = int(rng.integers(1, 200000))
+        by_hand = (((bx * P1) & 0xffffffff) ^ ((by * P2) & 0xffffffff) ^ ((bz * P3) & 0xffffffff)) % K
+        assert f(bx, by, bz, C.c_uint32(K)) == by_hand
 
 
 def test_projection_known_answer(orc):
@@ -50,6 +61,11 @@ def test_projection_known_answer(orc):
         uv = (C.c_float * 2)()
         x, y, z = case["point"]
         orc.lib().orc_kat_project(C.byref(k), C.c_float(x), C.c_float(y), C.c_float(z), uv)
+        # projection.h:63-70 in numpy float32: inv_w = 1 / z; u = inv_w * fx * x + cx
+        F = np.float32
+        inv_w = F(1) / F(z)
+        assert F(F(F(inv_w * F(k.fx)) * F(x)) + F(k.cx)) == F(case["uv"][0])
+        assert F(F(F(inv_w * F(k.fy)) * F(y)) + F(k.cy)) == F(case["uv"][1])
         assert np.float32(uv[0]) == np.float32(case["uv"][0])
         assert np.float32(uv[1]) == np.float32(case["uv"][1])
         xyz = (C.c_float * 3)()

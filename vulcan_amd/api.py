@@ -88,6 +88,8 @@ _SIGNATURES = {
     "vk_light_tracker_compute_jacobian": ([_P, _P, _P, _P, _I, _P, _P], _I),
     "vk_light_tracker_compute_system": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P], _I),
     "vk_light_tracker_track": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_compact_workspace_bytes": ([C.c_int32], _SZ),
+    "vk_compact_offsets": ([_P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_extract_workspace_bytes": ([C.c_int32, C.c_int32], _SZ),
     "vk_extract_mesh": ([_P, _I, _I, _P, C.c_int32, _P, C.c_int32, _P, _P, _P], _I),
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
