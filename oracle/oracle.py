@@ -18,6 +18,8 @@ POLICY_SERIAL, POLICY_MAXKEY = 0, 1
 
 
 def build(force=False):
+    if os.environ.get("ORACLE_LIBRARY"):
+        return os.environ["ORACLE_LIBRARY"]
     so = os.path.join(_HERE, "liboracle.so")
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     srcs.append(os.path.join(_HERE, "..", "include", "vk.h"))
@@ -29,7 +31,9 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        # ORACLE_LIBRARY: another build of the same sources (the AddressSanitizer / UBSan build,
+        # `make -C oracle asan`)
+        so = os.environ.get("ORACLE_LIBRARY") or os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             so = build()
         _LIB = C.CDLL(so)

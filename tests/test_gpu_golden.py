@@ -62,3 +62,21 @@ def test_device_reproduces_the_golden_vectors(api, name):
     for i in (T.VK_CTR_PENDING_ALL, T.VK_CTR_PENDING_EXCESS, T.VK_CTR_REQUESTS, T.VK_CTR_PATCHES):
         got["counters"][i] = want[i]
     compare(got, golden, name)
+
+
+def test_debug_build_reproduces_the_golden_vectors():
+    """libvk_hip_debug.so (VK_DEBUG_SYNC: device synchronisation + error check after every
+    launch, ref: device.h:48-52) is the same ABI and must give the same bits. Run in a child
+    process, because a process binds one build of the library."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    lib = os.path.join(root, "vulcan_amd", "lib", "libvk_hip_debug.so")
+    assert os.path.exists(lib), "run __graft_entry__.build() first"
+    env = dict(os.environ, VK_HIP_LIBRARY=lib)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "from vulcan_amd import api; import test_gpu_golden as t, numpy as np; "
+            "assert api.lib() and api.LIB_PATH.endswith('libvk_hip_debug.so'); "
+            "[t.test_device_reproduces_the_golden_vectors(api, n) for n in ('plane', 'ripple')]; print('debug build ok')"
+            % (root, HERE))
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "debug build ok" in p.stdout, p.stdout[-3000:]

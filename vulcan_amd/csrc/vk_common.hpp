@@ -22,8 +22,20 @@
     if (!(cond)) return VK_ERR_ARGUMENT;                \
   } while (0)
 
-// Launch errors are picked up with hipGetLastError (no device sync).
+// Launch errors are picked up with hipGetLastError (no device sync). The debug build
+// (-DVK_DEBUG_SYNC: libvk_hip_debug.so, `make debug`) also waits for the device after every
+// launch and reports what the kernel itself raised, at the launch that raised it — the
+// reference's CUDA_LAUNCH does this whenever NDEBUG is not defined (device.h:48-52).
+#ifdef VK_DEBUG_SYNC
+#define VK_LAUNCH_CHECK()                               \
+  do {                                                  \
+    VK_CHECK(hipGetLastError());                        \
+    VK_CHECK(hipDeviceSynchronize());                   \
+    VK_CHECK(hipGetLastError());                        \
+  } while (0)
+#else
 #define VK_LAUNCH_CHECK() VK_CHECK(hipGetLastError())
+#endif
 
 static inline hipStream_t vk_s(void* stream) { return reinterpret_cast<hipStream_t>(stream); }
 
