@@ -608,7 +608,12 @@ def main():
         result["other_workloads"] = others
 
     if world > 1:
-        result["collective"] = rig_collective(rank, world, vd)
+        # the rig step is reported next to the headline, never instead of it: a failure here
+        # (every rank sees the same exception or none: the calls are collective) is recorded
+        try:
+            result["collective"] = rig_collective(rank, world, vd)
+        except Exception as e:     # noqa: BLE001
+            result["collective"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:400]}
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:   # the CPU leg is reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(wl, poses, args.cpu_seconds)
