@@ -69,6 +69,16 @@ def sphere_room_depth(k):
     return (RADIUS / np.sqrt(rx * rx + ry * ry + 1.0)).astype(np.float32)
 
 
+_REAL_STDOUT = None
+
+
+def emit(result):
+    """The one JSON line, on the process's original stdout."""
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 # --------------------------------------------------------------------- launching ----
 
 def free_port():
@@ -127,9 +137,9 @@ def launch_selftest(args):
     frames = vd.sum_over_ranks(args.steps)
     vd.barrier()
     if rank == 0:
-        print(json.dumps({"launch_selftest": True, "n_gpus": world, "system_sum": float(system[0]),
-                          "max_over_ranks": slowest, "frames_all_ranks": frames,
-                          "local_rank_env": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
+        emit({"launch_selftest": True, "n_gpus": world, "system_sum": float(system[0]),
+              "max_over_ranks": slowest, "frames_all_ranks": frames,
+              "local_rank_env": int(os.environ.get("LOCAL_RANK", "-1"))})
     vd.shutdown()
     return 0
 
@@ -494,6 +504,12 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
+    # stdout carries ONE json line and nothing else: gloo and RCCL print banners on fd 1, so
+    # everything written there from here on goes to stderr and the line is written to the real one
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     if args.selftest_launch:
         sys.exit(launch_selftest(args))
 
@@ -619,7 +635,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(wl, poses, args.cpu_seconds)
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     vd.shutdown()
 
 
