@@ -699,8 +699,10 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
           hessian, gradient, A);
     }
     VK_LAUNCH_CHECK();
-    // stop enqueuing once the loop has converged (tracker.cpp:162), see vk_icp_track
-    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(A.mirror, it + 1, s)) break;
+    // stop enqueuing once the loop has converged (tracker.cpp:162), see vk_icp_track: the look is
+    // at the state one chunk back, so a chunk of launches is always queued behind it
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 >= 2 * poll->chunk && it + 1 < iterations &&
+        wait_for_steps(A.mirror, it + 1 - poll->chunk, s)) break;
   }
   return VK_OK;
 }

@@ -661,7 +661,8 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
     // tracker.cpp:162: the reference leaves its loop once |update| < 1e-6. Steps enqueued
     // after that point are no-ops, but each still costs its launches; so the host looks
     // at the mirror every `chunk` steps and stops enqueuing when the loop has converged.
-    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 < iterations && wait_for_steps(mirror, it + 1, s)) break;
+    if (chunked && (it + 1) % poll->chunk == 0 && it + 1 >= 2 * poll->chunk && it + 1 < iterations &&
+        wait_for_steps(mirror, it + 1 - poll->chunk, s)) break;
   }
   return VK_OK;
 }
