@@ -479,16 +479,25 @@ typedef struct vk_track_poll {
   int32_t  chunk;        /* steps enqueued between two looks at host_state         */
 } vk_track_poll;
 
-/* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker — `iterations`
- * Gauss-Newton steps enqueued back to back with no host round trip: per step one
- * partial-sum launch and one launch that finishes the sums, solves the 6x6
- * system and updates *Twc_dev (three launches when `reduce` is given). `system`:
- * device float[48]; `state_dev`: device int[2] {iterations run, converged}, the
- * caller zeroes it; `workspace`: vk_icp_workspace_floats(w, h) floats. Without a
- * `reduce` hook a step is ONE launch: every workgroup first finishes the previous step
- * itself (sums its partials, solves, updates the pose — redundantly, hence identically,
- * workgroup 0 publishes) and then evaluates its pixels at the new pose; one more launch
- * finishes the last step. */
+/* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker — up to `iterations`
+ * Gauss-Newton steps without a host round trip, ending early once |update| < 1e-6
+ * (tracker.cpp:162). `system`: device float[48]; `state_dev`: device int[2]
+ * {steps run, converged}, the caller zeroes it (a state that says "converged" makes
+ * the call a no-op); `workspace`: vk_icp_workspace_floats(w, h) floats.
+ *
+ * Without a `reduce` hook the whole loop is ONE launch: the workgroups exchange
+ * their 27 sums inside the launch after every step, each adds all of them in a fixed
+ * order and solves the 6x6 system itself (redundantly, hence identically), workgroup 0
+ * publishes pose, system and state at the end (a loop of more than 32 steps continues in
+ * further launches of 32). `poll` is not
+ * needed for an early exit on this path (its mirror still receives the final state).
+ * Should the device be unable to hold the launch's workgroups at the same time — not
+ * expected: the grid is sized from the occupancy query — the launch gives up after two
+ * seconds and leaves state_dev[1] = VK_TRACK_ABORTED.
+ *
+ * With a `reduce` hook (multi-GPU rig) a step is three launches — partial sums, sum,
+ * [the hook's all-reduce], solve — and `poll` stops the enqueuing after convergence. */
+#define VK_TRACK_ABORTED (-1)
 VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     const vk_icp_view* frame, vk_transform* Twc_dev, int iterations,
     int translation_enabled, float* workspace, float* system, int32_t* state_dev,
@@ -499,8 +508,8 @@ VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
  * resolution level of both frames (Frame::Downsample, src/frame.cpp:38-58: nearest
  * depth and normals, intrinsics / 2; ONE launch for the four images), vk_icp_track
  * with 15 steps on it, then 20 steps at full resolution from the pose the half
- * level left. The quarter level upstream builds and never tracks (:64-77) is not
- * built. `pyramid`: device float[vk_icp_pyramid_floats(...)] for the half-resolution
+ * level left (one launch per level when there is no `reduce` hook). The quarter level
+ * upstream builds and never tracks (:64-77) is not built. `pyramid`: device float[vk_icp_pyramid_floats(...)] for the half-resolution
  * images; `workspace`: vk_icp_workspace_floats of the FULL frame size; the other
  * buffers as in vk_icp_track. state_dev is reset before each level and holds the
  * full-resolution level's {steps, converged} afterwards. Image sizes must be even. */

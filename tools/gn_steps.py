@@ -37,6 +37,7 @@ for i in range(frames):
 torch.cuda.synchronize()
 ms = np.array([loop.elapsed_ms(e0, e1) for e0, e1 in ev[10:]])
 print(f"track: median {1e3 * np.median(ms):.1f} us, full-level steps run {np.median(steps[9:]):.0f} of 20 "
-      f"-> {1e3 * np.median(ms) / (15 + np.median(steps[9:])):.2f} us per step over both levels (incl. pyramid + 2 finish launches)")
+      f"-> {1e3 * np.median(ms) / (15 + np.median(steps[9:])):.2f} us per step over both levels (incl. the pyramid launch)")
+print("per frame (us, full-level steps):", [(round(1e3 * float(m)), int(n)) for m, n in zip(ms[:16], steps[9:25])])
 err = np.abs(loop.tracked.matrix() - poses[frames - 2].matrix()).max()
 print(f"last tracked pose vs the keyframe's pose: max |diff| {err:.2e}")

@@ -3,11 +3,11 @@
 import collections, csv, glob, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for f in sorted(glob.glob(sys.argv[1] + "/g*/p_counter_collection.csv")):
+for f in sorted(glob.glob(sys.argv[1] + "/g*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:34]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for f in sorted(glob.glob(sys.argv[1] + "/g*/p_kernel_trace.csv")):
+for f in sorted(glob.glob(sys.argv[1] + "/g*/**/*kernel_trace.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:34]
         dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)

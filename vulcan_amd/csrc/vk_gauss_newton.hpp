@@ -75,6 +75,42 @@ __device__ __forceinline__ void store_partial(const float (&acc)[27], float (*ld
   }
 }
 
+// number of interleaved slices of the second stage (see sum_partials)
+constexpr int kSysSlices = 32;
+
+// The slices added in order into hessian[36] / gradient[6] (either may be null) and sums[48]
+// (LDS). Every thread of the workgroup must call it, after a barrier that follows the
+// writes of `slices`; ends with a barrier.
+__device__ __forceinline__ void finish_sums(float (*slices)[kSysStride], int translation_enabled,
+    float* hessian, float* gradient, float* sums)
+{
+  if (threadIdx.x < 36 + 6)
+  {
+    if (threadIdx.x < 6)
+    {
+      float g = 0.0f;
+      const int n = translation_enabled ? 6 : 3;
+      if ((int)threadIdx.x < n)
+        for (int k = 0; k < kSysSlices; ++k) g += slices[k][threadIdx.x];
+      if (gradient) gradient[threadIdx.x] = g;
+      sums[36 + threadIdx.x] = g;
+    }
+    else
+    {
+      // depth_tracker.cu:199-214: with translation disabled the packed triangle
+      // is that of the 3x3 rotation block (6 values)
+      const int out = threadIdx.x - 6;
+      const int n = translation_enabled ? 21 : 6;
+      float h = 0.0f;
+      if (out < n)
+        for (int k = 0; k < kSysSlices; ++k) h += slices[k][6 + out];
+      if (hessian) hessian[out] = h;
+      sums[out] = h;
+    }
+  }
+  __syncthreads();
+}
+
 // Second stage: fixed-order sum of the per-workgroup partials into hessian[36] (packed
 // lower triangle first, rest 0) and gradient[6] (either may be null), and into sums[48]
 // in LDS for a solve that follows. Slice s of kSysSlices adds partials s, s + 32, s + 64,
@@ -84,8 +120,6 @@ __device__ __forceinline__ void store_partial(const float (&acc)[27], float (*ld
 // barrier. The loads of a slice are issued sixteen at a time: with one L2 round trip per
 // term this was the longest part of a Gauss-Newton step (a 640x480 image has 300
 // partials, 1280x960 has 1200).
-constexpr int kSysSlices = 32;
-
 __device__ __forceinline__ void sum_partials(const float* workspace, int partials, int translation_enabled,
     float* hessian, float* gradient, float (*slices)[kSysStride], float* sums)
 {
@@ -117,32 +151,136 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
     slices[s][c] = v;
   }
   __syncthreads();
+  finish_sums(slices, translation_enabled, hessian, gradient, sums);
+}
 
-  if (threadIdx.x < 36 + 6)
+// ---- partials exchanged INSIDE a launch (the whole Gauss-Newton loop as one kernel) ----
+//
+// A step of the loop is: every workgroup evaluates its pixels at the current pose, all
+// workgroups' sums are added, the 6x6 system is solved, the pose moves. With one launch per
+// step the kernel boundary is the exchange, and on this part a kernel boundary costs
+// ~4.5 us plus cold caches for the images every step. Here the workgroups of ONE launch
+// exchange their sums through memory and every workgroup then adds all of them and solves,
+// redundantly and identically — so after the exchange nobody waits for anybody.
+//
+// The exchange uses no fences (an agent-scope release / acquire writes back and
+// invalidates a whole L2 per workgroup on this multi-XCD part: measured 2.5x slower than
+// ending the kernel, r01) and no atomic read-modify-write (hundreds of workgroups on one
+// counter serialise). Each of a workgroup's 27 sums travels as ONE 64-bit word
+// {tag, value}, written and read with relaxed agent-scope atomics — which are coherent
+// across the XCDs by themselves (they bypass the non-coherent L2 path). A reader takes a
+// value only if its tag names this launch and step, and otherwise asks again; value and
+// tag cannot be torn apart because they are one atomic object, and no second round trip
+// ("data, wait, then flag") is needed: the chain per step is one store and one load
+// across the fabric (~1 us each on this part; measured alternative with separate flags
+// and L2-cached slots: one fabric trip more per step, 1 us slower). Nothing is ever
+// invalidated, so the images stay in L2 across steps.
+//
+// Tag = epoch (22 bits, unique per launch, never 0) << 10 | step + 1. Slots are double
+// buffered by step parity: a workgroup writes step i + 2 only after it has read every
+// workgroup's step i + 1, which they wrote after reading all of step i.
+//
+// Every workgroup of the launch must be resident at the same time (the host sizes the grid
+// from the occupancy query); should that ever not hold — or a workgroup die — the readers
+// give up after kExchangeTimeout and the launch ends with state[1] = VK_TRACK_ABORTED
+// instead of spinning for ever.
+constexpr unsigned long long kExchangeTimeout = 200000000ull;   // wall_clock64 ticks (100 MHz): 2 s
+constexpr int kExchangeSteps = 1023;                              // ten tag bits name the step
+
+__device__ __forceinline__ uint32_t exchange_tag(uint32_t epoch, int step) { return (epoch << 10) | (uint32_t)(step + 1); }
+
+// floats of an exchange area for `count` workgroups: two parities x count x kSysStride words of 64 bits
+inline size_t exchange_floats(int count) { return 4 * (size_t)count * kSysStride; }
+
+struct Exchange
+{
+  unsigned long long* words;   // [2][count][kSysStride]
+  int count;                   // workgroups of the launch
+  uint32_t epoch;
+};
+
+template <int WAVES>
+__device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*lds)[kSysStride],
+    const Exchange& E, int step)
+{
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 27; ++i)
   {
-    if (threadIdx.x < 6)
-    {
-      float g = 0.0f;
-      const int n = translation_enabled ? 6 : 3;
-      if ((int)threadIdx.x < n)
-        for (int k = 0; k < kSysSlices; ++k) g += slices[k][threadIdx.x];
-      if (gradient) gradient[threadIdx.x] = g;
-      sums[36 + threadIdx.x] = g;
-    }
-    else
-    {
-      // depth_tracker.cu:199-214: with translation disabled the packed triangle
-      // is that of the 3x3 rotation block (6 values)
-      const int out = threadIdx.x - 6;
-      const int n = translation_enabled ? 21 : 6;
-      float h = 0.0f;
-      if (out < n)
-        for (int k = 0; k < kSysSlices; ++k) h += slices[k][6 + out];
-      if (hessian) hessian[out] = h;
-      sums[out] = h;
-    }
+    const float v = wave_sum_lane63(acc[i]);
+    if (lane == 63) lds[wave][i] = v;
   }
   __syncthreads();
+  if (threadIdx.x < 27)
+  {
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += lds[w][threadIdx.x];
+    __hip_atomic_store(E.words + ((size_t)(step & 1) * E.count + blockIdx.x) * kSysStride + threadIdx.x,
+        ((unsigned long long)exchange_tag(E.epoch, step) << 32) | (unsigned long long)__float_as_uint(v),
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The counterpart of sum_partials for exchanged sums: same slices, same order within a
+// slice, so the result depends on the published values alone. THREADS = workgroup size.
+// A thread owns 32 / (THREADS / 32) slices of one component and keeps sixteen requests in
+// flight; a word whose tag is not yet this step's is asked for again. Returns false (for
+// every thread of the workgroup) if some workgroup's sums did not arrive in time.
+template <int THREADS>
+__device__ __forceinline__ bool gather_partials(const Exchange& E, int step, int translation_enabled,
+    float* hessian, float* gradient, float (*slices)[kSysStride], float* sums, int* failed)
+{
+  constexpr int PASS = THREADS / 32;            // slices covered by the workgroup at once
+  constexpr int M = kSysSlices / PASS;          // slices per thread
+  static_assert(M >= 1 && 16 % M == 0, "workgroup of 256, 512 or 1024 threads");
+  const uint32_t tag = exchange_tag(E.epoch, step);
+  const unsigned long long* words = E.words + (size_t)(step & 1) * E.count * kSysStride;
+  const int c = threadIdx.x & 31;
+  const int s0 = threadIdx.x >> 5;
+  const unsigned long long deadline = (unsigned long long)wall_clock64() + kExchangeTimeout;
+  float v[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) v[m] = 0.0f;
+  bool ok = true;
+  if (c < 27)
+  {
+    const int items = M * ((E.count + kSysSlices - 1) / kSysSlices);
+    for (int i0 = 0; i0 < items && ok; i0 += 16)
+    {
+      unsigned long long w[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+      {
+        const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);     // slice s0 + m * PASS, term u
+        w[q] = k < E.count ? __hip_atomic_load(words + (size_t)k * kSysStride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+      {
+        const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);
+        if (k < E.count && ok)
+        {
+          unsigned long long word = w[q];
+          while ((uint32_t)(word >> 32) != tag)
+          {
+            if ((unsigned long long)wall_clock64() > deadline) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+            word = __hip_atomic_load(words + (size_t)k * kSysStride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (ok) v[q % M] += __uint_as_float((uint32_t)word);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) slices[s0 + m * PASS][c] = v[m];
+  if (!ok) *failed = 1;      // LDS flag, zeroed by the caller before the loop; any writer writes 1
+  __syncthreads();
+  if (*failed) return false;
+  finish_sums(slices, translation_enabled, hessian, gradient, sums);
+  return true;
 }
 
 // LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
@@ -350,12 +488,23 @@ inline Mirror begin_mirror(const vk_track_poll* poll)
 }
 
 
-// The depth tracker's workgroups are 256 lanes x 4 pixels (one partial per 1024 pixels, as
-// for the 1024 x 1 shape the photometric trackers use): a lane adds up its four pixels'
-// products before the wave reduction, so the 27 x 6 DPP steps, the LDS hop and the
-// barrier are paid once per four pixels (r02: 12.6 -> see profiles/r02_icp_steps.txt).
-constexpr int kIcpThreads = 256;
-constexpr int kIcpPixels = kSysThreads / kIcpThreads;
+// The depth tracker's workgroups: kIcpThreads lanes x kIcpPixels pixels each (a lane adds up
+// its pixels' products before the wave reduction, so the 27 x 6 DPP steps, the LDS hop and
+// the barrier are paid once per kIcpPixels pixels), one partial per kIcpGroup pixels.
+#ifndef VK_ICP_THREADS
+#define VK_ICP_THREADS 512
+#endif
+#ifndef VK_ICP_PIXELS
+#define VK_ICP_PIXELS 4
+#endif
+constexpr int kIcpThreads = VK_ICP_THREADS;
+constexpr int kIcpPixels = VK_ICP_PIXELS;
+constexpr int kIcpGroup = kIcpThreads * kIcpPixels;
+
+inline int icp_group_count(int width, int height)
+{
+  return (width * height + kIcpGroup - 1) / kIcpGroup;
+}
 
 inline int partial_count(int width, int height)
 {

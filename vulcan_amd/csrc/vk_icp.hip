@@ -8,6 +8,11 @@
 // Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
 // summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
 // solve + SE(3) update can run on the device so an iteration needs no readback.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "vk_gauss_newton.hpp"
 
 using namespace vk;
@@ -160,23 +165,93 @@ __device__ void solve_update(const float* hessian, const float* gradient, int tr
 // multi-XCD part the agent-scope release/acquire fences that publish the partials
 // write back and invalidate whole L2s, once per workgroup: the fused iteration
 // took 2.5x as long as the two launches.
-// this lane's four pixels: kIcpThreads apart, so that every load is coalesced
-__device__ __forceinline__ int lane_pixel(int k) { return blockIdx.x * kSysThreads + k * kIcpThreads + (int)threadIdx.x; }
+// this lane's pixels: kIcpThreads apart, so that every load is coalesced
+__device__ __forceinline__ int lane_pixel(int group, int k) { return group * kIcpGroup + k * kIcpThreads + (int)threadIdx.x; }
 
-// the 27 products of the lane's pixels, added pixel by pixel
+// evaluate() in two halves, so that a lane with several pixels can have all its keyframe
+// loads in flight at once: everything up to the keyframe pixel's address ...
+struct Candidate
+{
+  f3 Xwp, frame_normal;
+  float ku, kv;
+  int keyframe_index;   // 0 when the pixel has no candidate (the load is issued all the same)
+  bool ok;
+};
+
+__device__ __forceinline__ Candidate prepare_pixel(const IcpParams& P, const Rt& Twc, int frame_x, int frame_y,
+    bool inside, const FramePixel& px)
+{
+  Candidate c;
+  c.ok = false;
+  c.keyframe_index = 0;
+  c.ku = c.kv = 0.0f;
+  c.Xwp = c.frame_normal = make3(0, 0, 0);
+  if (!inside || !(px.depth > 0)) return c;
+  const f3 Xcp = unproject_d(P.frm.k, frame_x + 0.5f, frame_y + 0.5f, px.depth);
+  c.Xwp = xform_point(Twc, Xcp);
+  const f3 Xmp = xform_point(P.Tmw, c.Xwp);
+  project(P.key.k, Xmp, c.ku, c.kv);
+  if (!(c.ku >= 0 && c.ku < P.key.width && c.kv >= 0 && c.kv < P.key.height)) return c;
+  c.keyframe_index = (int)c.kv * P.key.width + (int)c.ku;
+  c.frame_normal = xform_dir(Twc, px.normal);
+  c.ok = true;
+  return c;
+}
+
+// ... and everything after the keyframe's depth and normal have arrived (same operations
+// in the same order as evaluate())
 template <bool TRANSLATION>
-__device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& Twc, const FramePixel (&px)[kIcpPixels],
-    float (&acc)[27])
+__device__ __forceinline__ bool finish_pixel(const IcpParams& P, const Candidate& c, float keyframe_depth, const vf3& kn,
+    float& residual, float J[6])
+{
+  if (!c.ok || !(keyframe_depth > 0)) return false;
+  f3 keyframe_normal = make3(kn.x, kn.y, kn.z);
+  keyframe_normal = xform_dir(P.Twm, keyframe_normal);
+  if (!(sqnorm3(keyframe_normal) > 0.0f && dot3(c.frame_normal, keyframe_normal) > 0.5f)) return false;
+  const f3 Ymp = unproject_d(P.key.k, floorf(c.ku) + 0.5f, floorf(c.kv) + 0.5f, keyframe_depth);
+  const f3 Ywp = xform_point(P.Twm, Ymp);
+  const f3 delta = sub3(c.Xwp, Ywp);
+  if (!(sqnorm3(delta) < 0.05f)) return false;
+  residual = dot3(delta, keyframe_normal);
+  J[0] = keyframe_normal.z * c.Xwp.y - keyframe_normal.y * c.Xwp.z;
+  J[1] = keyframe_normal.x * c.Xwp.z - keyframe_normal.z * c.Xwp.x;
+  J[2] = keyframe_normal.y * c.Xwp.x - keyframe_normal.x * c.Xwp.y;
+  J[3] = J[4] = J[5] = 0.0f;
+  if (TRANSLATION)
+  {
+    J[3] = keyframe_normal.x;
+    J[4] = keyframe_normal.y;
+    J[5] = keyframe_normal.z;
+  }
+  return true;
+}
+
+// the 27 products of the lane's pixels of one group, added pixel by pixel onto acc
+template <bool TRANSLATION>
+__device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& Twc, int group,
+    const FramePixel (&px)[kIcpPixels], float (&acc)[27])
 {
   const int total = P.frm.width * P.frm.height;
-#pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+  Candidate cand[kIcpPixels];
+  float key_depth[kIcpPixels];
+  vf3 key_normal[kIcpPixels];
 #pragma unroll
   for (int k = 0; k < kIcpPixels; ++k)
   {
-    const int pixel = lane_pixel(k);
+    const int pixel = lane_pixel(group, k);
+    cand[k] = prepare_pixel(P, Twc, pixel % P.frm.width, pixel / P.frm.width, pixel < total, px[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kIcpPixels; ++k)
+  {
+    key_depth[k] = P.key.depths[cand[k].keyframe_index];
+    key_normal[k] = *reinterpret_cast<const vf3*>(P.key.normals + 3 * cand[k].keyframe_index);
+  }
+#pragma unroll
+  for (int k = 0; k < kIcpPixels; ++k)
+  {
     float r, J[6], one[27];
-    if (pixel < total && evaluate<TRANSLATION>(P, Twc, pixel % P.frm.width, pixel / P.frm.width, px[k], r, J))
+    if (finish_pixel<TRANSLATION>(P, cand[k], key_depth[k], key_normal[k], r, J))
     {
       outer_products(J, r, one);
 #pragma unroll
@@ -185,13 +260,13 @@ __device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& 
   }
 }
 
-__device__ __forceinline__ void load_pixels(const IcpParams& P, FramePixel (&px)[kIcpPixels])
+__device__ __forceinline__ void load_pixels(const IcpParams& P, int group, FramePixel (&px)[kIcpPixels])
 {
   const int total = P.frm.width * P.frm.height;
 #pragma unroll
   for (int k = 0; k < kIcpPixels; ++k)
   {
-    const int pixel = lane_pixel(k);
+    const int pixel = lane_pixel(group, k);
     px[k] = load_frame_pixel(P.frm, pixel % P.frm.width, pixel < total ? pixel / P.frm.width : P.frm.height);
   }
 }
@@ -207,9 +282,11 @@ __global__ __launch_bounds__(kIcpThreads) void system_partial_kernel(IcpParams P
 
   const Rt Twc = P.Twc_dev ? rt_from_colmajor(P.Twc_dev->m) : P.Twc;
   FramePixel px[kIcpPixels];
-  load_pixels(P, px);
+  load_pixels(P, blockIdx.x, px);
   float acc[27];
-  accumulate_pixels<TRANSLATION>(P, Twc, px, acc);
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+  accumulate_pixels<TRANSLATION>(P, Twc, blockIdx.x, px, acc);
   store_partial<kIcpThreads / 64>(acc, lds, workspace);
 }
 
@@ -277,26 +354,28 @@ __global__ void solve_update_kernel(const float* __restrict__ hessian, const flo
     solve_update(hessian, gradient, translation_enabled, Twc, state, update_out, mirror);
 }
 
-// ---- one launch per Gauss-Newton step ------------------------------------------
+// ---- the whole Gauss-Newton loop in one launch ------------------------------------
 //
-// system_partial_kernel + system_final_kernel cost two dependent launches per step
-// (4.8 + 4.5 us at 640x480, most of it launch and dependency latency, r01). Joining
-// them with an in-kernel hand-off ("last workgroup finishes") was measured 2.5x slower:
-// agent-scope fences flush whole L2s on this multi-XCD part. Here the kernel boundary
-// stays the only synchronisation, but there is one per step instead of two: step i
-// first FINISHES step i - 1 — every workgroup sums the previous partials and solves the
-// 6x6 system itself, redundantly and therefore identically (same instructions, same
-// inputs: bit-identical poses in all workgroups) — and then evaluates its 1024 pixels
-// at the new pose. Workgroup 0 alone publishes the pose, the system, the state.
-// Poses and partials are double-buffered so that no workgroup reads what another one
-// of the same launch writes.
-struct StepParams
+// History: two launches per step (r01: partials, then sum + solve), one launch per step
+// (r02: every workgroup finishes the previous step itself), and now one launch per LOOP:
+// the workgroups exchange their sums inside the launch (vk_gauss_newton.hpp, "partials
+// exchanged inside a launch"), every workgroup adds all of them in the fixed order and
+// solves the 6x6 system itself — same instructions, same inputs, bit-identical poses
+// everywhere — and goes on to the next step at the new pose. What that removes per step:
+// the launch (~4.5 us on this part), the cold start of the caches (the images now stay
+// in L2 for the whole loop; the frame pixels of a lane stay in its registers), the
+// empty launches after convergence and the host's polling for it (tracker.cpp:162 is a
+// `break` again). Workgroup 0 alone publishes pose, system and state, once, at the end.
+struct LoopParams
 {
-  const float* partials_in;    // previous step's partials, null on the first step
-  float* partials_out;
-  const vk_transform* pose_in; // the pose the previous step was evaluated at
-  vk_transform* pose_out;      // written by workgroup 0 (steps after the first)
-  int partials;
+  Exchange exchange;             // {tag, value} words of the launch's workgroups
+#ifdef VK_LOOP_TIMING
+  unsigned long long* timing;
+#endif
+  vk_transform* pose;            // in: the pose to start from; out: the pose after the loop
+  int groups;                    // 1024-pixel groups of the frame (gridDim.x <= groups)
+  int iterations;
+  int fresh_state;               // 1: the loop starts at {0 steps, not converged} whatever `state` holds
   float* hessian;
   float* gradient;
   int32_t* state;
@@ -304,40 +383,65 @@ struct StepParams
   Mirror mirror;
 };
 
-__device__ __forceinline__ int load_relaxed(const int32_t* p)
-{
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <bool TRANSLATION>
-__global__ __launch_bounds__(kIcpThreads) void fused_step_kernel(IcpParams P, StepParams S)
+__global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, LoopParams L)
 {
+  constexpr int N = TRANSLATION ? 6 : 3;
   __shared__ float lds[kIcpThreads / 64][kSysStride];
   __shared__ float slices[kSysSlices][kSysStride];
   __shared__ float sums[48];
   __shared__ float pose_m[16];
-  __shared__ int stop;
+  __shared__ float result[16 + 16 + 6];   // workgroup 0: matrix, inverse, update of the last step
+  __shared__ int stop, failed;
 
-  // tracker.cpp:162: converged in an earlier step -> the remaining launches are empty
-  if (load_relaxed(S.state + 1)) return;
+  // tracker.cpp:162 / Tracker::CreateState: a state that already says "converged" ends the call
+  const int steps_before = L.fresh_state ? 0 : L.state[0];
+  if (!L.fresh_state && L.state[1]) return;   // uniform over the grid: nobody waits for anybody
 
-  // this lane's pixels of the frame do not depend on the pose: their loads are issued
-  // first and land while the previous step is being finished
+  // with one group per workgroup the lane's frame pixels never change: loaded once
+  const bool resident = (int)gridDim.x >= L.groups;
   FramePixel px[kIcpPixels];
-  load_pixels(P, px);
+  if (resident) load_pixels(P, blockIdx.x, px);
 
-  Rt Twc;
-  if (S.partials_in)
+  if (threadIdx.x < 16) pose_m[threadIdx.x] = L.pose->m[threadIdx.x];
+  if (threadIdx.x == 0) { stop = 0; failed = 0; }
+  __syncthreads();
+
+  const bool publisher = blockIdx.x == 0;
+  int steps = 0;
+  for (int it = 0; it < L.iterations; ++it)
   {
-    const bool publish = blockIdx.x == 0;
-    sum_partials(S.partials_in, S.partials, TRANSLATION, publish ? S.hessian : nullptr,
-        publish ? S.gradient : nullptr, slices, sums);
+#ifdef VK_LOOP_TIMING
+#define VK_STAMP(k) if (blockIdx.x == 0 && threadIdx.x == 0 && L.timing) L.timing[it * 8 + (k)] = wall_clock64()
+#else
+#define VK_STAMP(k)
+#endif
+    VK_STAMP(0);
+    const Rt Twc = rt_from_colmajor(pose_m);
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+    for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
+    {
+      if (!resident) load_pixels(P, group, px);
+      accumulate_pixels<TRANSLATION>(P, Twc, group, px, acc);
+    }
+
+    VK_STAMP(1);
+    publish_partial<kIcpThreads / 64>(acc, lds, L.exchange, it);
+    VK_STAMP(2);
+    VK_STAMP(3);
+    if (!gather_partials<kIcpThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
+            publisher ? L.gradient : nullptr, slices, sums, &failed))
+      break;
+    steps = it + 1;
+    VK_STAMP(4);
+
     if (threadIdx.x == 0)
     {
-      constexpr int N = TRANSLATION ? 6 : 3;
       float update[6], old_m[16], out_m[16], out_i[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) old_m[i] = S.pose_in->m[i];
+      for (int i = 0; i < 16; ++i) old_m[i] = pose_m[i];
       pose_step<N>(sums, sums + 36, old_m, out_m, out_i, update);
       float sq = 0.0f;
 #pragma unroll
@@ -345,61 +449,68 @@ __global__ __launch_bounds__(kIcpThreads) void fused_step_kernel(IcpParams P, St
       stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) pose_m[i] = out_m[i];
-      if (publish)
+      if (publisher)
       {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { S.pose_out->m[i] = out_m[i]; S.pose_out->inv[i] = out_i[i]; }
-        finish_step<N>(update, S.state, S.update_out, S.mirror);
+        for (int i = 0; i < 16; ++i) { result[i] = out_m[i]; result[16 + i] = out_i[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) result[32 + i] = update[i];
       }
     }
     __syncthreads();
-    if (stop) return;             // this step converged: nothing further is evaluated
-    Twc = rt_from_colmajor(pose_m);
-  }
-  else
-  {
-    Twc = rt_from_colmajor(S.pose_in->m);
+    VK_STAMP(5);
+    if (stop) break;             // tracker.cpp:162
   }
 
-  float acc[27];
-  accumulate_pixels<TRANSLATION>(P, Twc, px, acc);
-  store_partial<kIcpThreads / 64>(acc, lds, S.partials_out);
+  if (failed)
+  {
+    // some workgroup's sums never came (see kExchangeTimeout): every workgroup ends up here
+    if (threadIdx.x == 0) L.state[1] = VK_TRACK_ABORTED;
+    return;
+  }
+  if (!publisher || steps == 0) return;
+  if (threadIdx.x < 32)
+  {
+    const float v = result[threadIdx.x];
+    if (threadIdx.x < 16) L.pose->m[threadIdx.x] = v; else L.pose->inv[threadIdx.x - 16] = v;
+  }
+  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = result[32 + threadIdx.x];
+  if (threadIdx.x == 0)
+  {
+    const int iterations = steps_before + steps;
+    L.state[0] = iterations;
+    L.state[1] = stop;
+    if (L.mirror.word)
+      __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
+          ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
+          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-// after the last step: finish it (or, if the loop converged earlier, do nothing) and leave
-// the pose where the caller wants it
-__global__ __launch_bounds__(256) void fused_finish_kernel(StepParams S, int translation_enabled,
-    const vk_transform* pose_a, const vk_transform* pose_b, vk_transform* result)
+// how many workgroups of the loop kernel the device holds at once (they all have to)
+template <bool TRANSLATION>
+int loop_capacity()
 {
-  __shared__ float slices[kSysSlices][kSysStride];
-  __shared__ float sums[48];
-  const bool converged = S.state[1] != 0;
-  if (!converged)
+  static int capacity[16] = {0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return 0;
+  if (capacity[device] == 0)
   {
-    sum_partials(S.partials_in, S.partials, translation_enabled, S.hessian, S.gradient, slices, sums);
-    if (threadIdx.x == 0)
-    {
-      float update[6], old_m[16], out_m[16], out_i[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) old_m[i] = S.pose_in->m[i];
-      if (translation_enabled) pose_step<6>(sums, sums + 36, old_m, out_m, out_i, update);
-      else pose_step<3>(sums, sums + 36, old_m, out_m, out_i, update);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { result->m[i] = out_m[i]; result->inv[i] = out_i[i]; }
-      if (translation_enabled) finish_step<6>(update, S.state, S.update_out, S.mirror);
-      else finish_step<3>(update, S.state, S.update_out, S.mirror);
-    }
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, track_loop_kernel<TRANSLATION>, kIcpThreads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+      return 0;
+    capacity[device] = per_cu * cus > 0 ? per_cu * cus : -1;
   }
-  else if (threadIdx.x < 32)
-  {
-    // the pose of the converging step sits in the buffer that step wrote: step i writes buffer i & 1
-    const vk_transform* last = (S.state[0] & 1) ? pose_b : pose_a;
-    if (last != result)
-    {
-      const float v = threadIdx.x < 16 ? last->m[threadIdx.x] : last->inv[threadIdx.x - 16];
-      if (threadIdx.x < 16) result->m[threadIdx.x] = v; else result->inv[threadIdx.x - 16] = v;
-    }
-  }
+  return capacity[device] > 0 ? capacity[device] : 0;
+}
+
+uint32_t next_loop_epoch()
+{
+  static std::atomic<uint32_t> counter{0};
+  uint32_t e;
+  do { e = (counter.fetch_add(1) + 1u) & 0x3fffffu; } while (e == 0);
+  return e;
 }
 
 // ------------------------------------------------------------------ pyramid ----
@@ -520,6 +631,58 @@ void launch_partials(const IcpParams& P, int translation_enabled, int partials, 
     hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kIcpThreads), 0, s, P, workspace);
 }
 
+// the non-rig loop: one launch (track_loop_kernel)
+int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int translation_enabled, int groups,
+    float* workspace, float* hessian, float* gradient, int32_t* state_dev, float* update_dev, Mirror mirror,
+    bool fresh_state, hipStream_t s)
+{
+  VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
+  const int capacity = translation_enabled ? loop_capacity<true>() : loop_capacity<false>();
+  if (capacity <= 0) return VK_ERR_ARGUMENT;
+  const int grid = groups < capacity ? groups : capacity;
+  LoopParams L;
+  L.pose = Twc_dev;
+  L.groups = groups;
+  L.hessian = hessian;
+  L.gradient = gradient;
+  L.state = state_dev;
+  L.update_out = update_dev;
+  L.mirror = mirror;
+  // ten tag bits name the step: a longer loop continues in another launch (which returns at
+  // once if the state says the loop has converged)
+  for (int done = 0; done < iterations; done += kExchangeSteps)
+  {
+    L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
+    L.exchange.count = grid;
+    L.exchange.epoch = next_loop_epoch();
+#ifdef VK_LOOP_TIMING
+    {
+      static unsigned long long* timing = nullptr;
+      if (!timing) { (void)hipHostMalloc((void**)&timing, 64 * 8 * 8, hipHostMallocMapped); memset(timing, 0, 64 * 8 * 8); }
+      if (getenv("VK_LOOP_TIMING_DUMP") && timing[0])
+      {
+        (void)hipStreamSynchronize(s);
+        for (int k = 0; k < 32 && timing[k * 8]; ++k)
+          fprintf(stderr, "step %2d: pixels %5.2f publish %5.2f flags %5.2f sum %5.2f solve %5.2f | total %5.2f us\n", k,
+              (timing[k * 8 + 1] - timing[k * 8 + 0]) / 100.0, (timing[k * 8 + 2] - timing[k * 8 + 1]) / 100.0,
+              (timing[k * 8 + 3] - timing[k * 8 + 2]) / 100.0, (timing[k * 8 + 4] - timing[k * 8 + 3]) / 100.0,
+              (timing[k * 8 + 5] - timing[k * 8 + 4]) / 100.0, (timing[k * 8 + 5] - timing[k * 8 + 0]) / 100.0);
+        memset(timing, 0, 64 * 8 * 8);
+      }
+      L.timing = timing;
+    }
+#endif
+    L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
+    L.fresh_state = (fresh_state && done == 0) ? 1 : 0;
+    if (translation_enabled)
+      hipLaunchKernelGGL(track_loop_kernel<true>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
+    else
+      hipLaunchKernelGGL(track_loop_kernel<false>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
+    VK_LAUNCH_CHECK();
+  }
+  return VK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -557,9 +720,9 @@ int vk_icp_compute_jacobian(const vk_icp_view* keyframe, const vk_transform* Twm
 size_t vk_icp_workspace_floats(int width, int height)
 {
   if (width <= 0 || height <= 0) return 0;
-  // two sets of per-workgroup partials (double-buffered by the one-launch-per-step loop)
-  // and a second pose buffer
-  return 2 * (size_t)partial_count(width, height) * kSysStride + sizeof(vk_transform) / sizeof(float);
+  // the in-launch exchange of the loop kernel (the rig's launch-per-stage loop uses the first
+  // icp_group_count * kSysStride floats of it)
+  return exchange_floats(icp_group_count(width, height)) + sizeof(vk_transform) / sizeof(float);
 }
 
 int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
@@ -577,7 +740,7 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
   if (rc != VK_OK) return rc;
   VK_REQUIRE(workspace && hessian && gradient);
   P.Twc_dev = Twc_dev;
-  const int partials = partial_count(frame->width, frame->height);
+  const int partials = icp_group_count(frame->width, frame->height);
   launch_partials(P, translation_enabled, partials, workspace, vk_s(stream));
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
@@ -602,47 +765,14 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
   P.state = state_dev;
   float* hessian = system;
   float* gradient = system + 36;
-  const int partials = partial_count(frame->width, frame->height);
+  const int partials = icp_group_count(frame->width, frame->height);
   hipStream_t s = vk_s(stream);
   const bool chunked = polling(poll);
   const Mirror mirror = begin_mirror(poll);
 
   if (!reduce)
-  {
-    // one launch per step (fused_step_kernel) + one to finish the last step
-    float* buffers[2] = {workspace, workspace + (size_t)partials * kSysStride};
-    vk_transform* poses[2] = {Twc_dev, reinterpret_cast<vk_transform*>(workspace + 2 * (size_t)partials * kSysStride)};
-    StepParams S;
-    S.partials = partials;
-    S.hessian = hessian;
-    S.gradient = gradient;
-    S.state = state_dev;
-    S.update_out = update_dev;
-    S.mirror = mirror;
-    int it = 0;
-    for (; it < iterations; ++it)
-    {
-      S.partials_in = it ? buffers[(it - 1) & 1] : nullptr;
-      S.partials_out = buffers[it & 1];
-      S.pose_in = poses[it ? (it - 1) & 1 : 0];
-      S.pose_out = poses[it & 1];
-      if (translation_enabled)
-        hipLaunchKernelGGL(fused_step_kernel<true>, dim3(partials), dim3(kIcpThreads), 0, s, P, S);
-      else
-        hipLaunchKernelGGL(fused_step_kernel<false>, dim3(partials), dim3(kIcpThreads), 0, s, P, S);
-      VK_LAUNCH_CHECK();
-      // Launch `it` solves step `it`. Every `chunk` steps the host looks at the mirror
-      // (tracker.cpp:162) — at the state one chunk BACK, so that a chunk of launches is
-      // always queued behind the one being waited for and the GPU never idles while the host
-      // reacts (waiting for the newest step cost a ~13 us bubble per look, r02 timeline).
-      if (chunked && it >= 2 * poll->chunk && it % poll->chunk == 0 && wait_for_steps(mirror, it - poll->chunk, s)) { ++it; break; }
-    }
-    S.partials_in = buffers[(iterations - 1) & 1];
-    S.pose_in = poses[(iterations - 1) & 1];
-    hipLaunchKernelGGL(fused_finish_kernel, dim3(1), dim3(256), 0, s, S, translation_enabled, poses[0], poses[1], Twc_dev);
-    VK_LAUNCH_CHECK();
-    return VK_OK;
-  }
+    return launch_loop(P, Twc_dev, iterations, translation_enabled, partials, workspace, hessian, gradient,
+        state_dev, update_dev, mirror, /*fresh_state*/ false, s);
 
   for (int it = 0; it < iterations; ++it)
   {
@@ -735,6 +865,25 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
 
   // :79-83 half level, 15 steps; :85-89 full level, 20 steps, from the pose the half level left.
   // Tracker::CreateState (tracker.cpp:107-110) starts every Track at iteration 0.
+  if (!reduce)
+  {
+    // one launch per level; the loop kernel starts from a fresh state by itself
+    const vk_icp_view* views[2][2] = {{&half[0], &half[1]}, {keyframe, frame}};
+    const int steps[2] = {15, 20};
+    const Mirror mirror = begin_mirror(poll);
+    vk_transform identity;
+    for (int i = 0; i < 16; ++i) identity.m[i] = identity.inv[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (int level = 0; level < 2; ++level)
+    {
+      IcpParams P;
+      const int rc = fill_icp(P, views[level][0], Twm, views[level][1], &identity);
+      if (rc != VK_OK) return rc;
+      const int rl = launch_loop(P, Twc_dev, steps[level], 1, icp_group_count(views[level][1]->width, views[level][1]->height),
+          workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ true, s);
+      if (rl != VK_OK) return rl;
+    }
+    return VK_OK;
+  }
   VK_CHECK(hipMemsetAsync(state_dev, 0, 2 * sizeof(int32_t), s));
   int rc = vk_icp_track(&half[0], Twm, &half[1], Twc_dev, 15, 1, workspace, system, state_dev, update_dev,
       reduce, reduce_user, poll, stream);
