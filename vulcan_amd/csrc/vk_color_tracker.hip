@@ -371,13 +371,30 @@ __device__ __forceinline__ void derive_tcm(const vk_transform& frame_Tcd, const 
   for (int i = 0; i < 16; ++i) { pose->Tcm.m[i] = out_m[i]; pose->Tcm.inv[i] = out_i[i]; }
 }
 
-// ref: tracker.cpp:124-163 + color_tracker.cpp:34-96, one lane
-template <int N>
-__device__ __forceinline__ void color_solve_update_n(const float* hessian, const float* gradient,
-    const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
-    float* update_out, Mirror mirror)
+// color_tracker.cu:312-320 on arrays: Tcm from the frame's and the keyframe's poses
+__device__ __forceinline__ void derive_tcm_arrays(const vk_transform& frame_Tcd, const vk_transform& key_Twc,
+    const float (&twd_m)[16], const float (&twd_i)[16], float (&out_m)[16], float (&out_i)[16])
 {
-  float update[6];
+  float tcd_m[16], tcd_i[16], twc_m[16], twc_i[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+  {
+    tcd_m[i] = frame_Tcd.m[i];  tcd_i[i] = frame_Tcd.inv[i];
+    twc_m[i] = key_Twc.m[i];  twc_i[i] = key_Twc.inv[i];
+  }
+  float tcw_m[16], tcw_i[16];
+  matmul4(tcd_m, twd_i, tcw_m);    // frame_Tcw.m   = Tcd.m * (Twd^-1).m
+  matmul4(twd_m, tcd_i, tcw_i);    // frame_Tcw.inv = (Twd^-1).inv * Tcd.inv
+  matmul4(tcw_m, twc_m, out_m);
+  matmul4(twc_i, tcw_i, out_i);
+}
+
+// ref: tracker.cpp:124-163 + color_tracker.cpp:34-96 on arrays: the update from the system,
+// the new depth_to_world (m, inv) from the old inverse
+template <int N>
+__device__ __forceinline__ void color_pose_step(const float* hessian, const float* gradient, const float (&old_i)[16],
+    float (&twd_m)[16], float (&twd_i)[16], float (&update)[6])
+{
   solve_step<N>(hessian, gradient, update);
 
   // color_tracker.cpp:45-65: a proper skew matrix (DepthTracker's has Tinc(1,2) = +u0)
@@ -387,13 +404,23 @@ __device__ __forceinline__ void color_solve_update_n(const float* hessian, const
   Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
   Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
 
-  float old_i[16], M[16], out_m[16], out_i[16];
+  float M[16];
+  matmul4(Tinc, old_i, M);             // :67  M = Tinc * Twd^-1
+  rigid_from(M, twd_i, twd_m);         // :69-95 world -> depth, re-orthonormalised; .Inverse() swaps the two
+}
+
+// one lane
+template <int N>
+__device__ __forceinline__ void color_solve_update_n(const float* hessian, const float* gradient,
+    const vk_transform& frame_Tcd, const vk_transform& key_Twc, vk_color_pose* pose, int32_t* state,
+    float* update_out, Mirror mirror)
+{
+  float update[6], old_i[16], twd_m[16], twd_i[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) old_i[i] = pose->depth_to_world.inv[i];
-  matmul4(Tinc, old_i, M);             // :67  M = Tinc * Twd^-1
-  rigid_from(M, out_m, out_i);         // :69-95 world -> depth, re-orthonormalised
+  color_pose_step<N>(hessian, gradient, old_i, twd_m, twd_i, update);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { pose->depth_to_world.m[i] = out_i[i]; pose->depth_to_world.inv[i] = out_m[i]; }   // .Inverse()
+  for (int i = 0; i < 16; ++i) { pose->depth_to_world.m[i] = twd_m[i]; pose->depth_to_world.inv[i] = twd_i[i]; }
 
   derive_tcm(frame_Tcd, key_Twc, pose);
   finish_step<N>(update, state, update_out, mirror);
@@ -439,6 +466,165 @@ __global__ void color_solve_kernel(const float* __restrict__ hessian, const floa
 __global__ void color_prepare_kernel(PoseArgs A)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0) derive_tcm(A.frame_Tcd, A.key_Twc, A.pose);
+}
+
+// ---- the whole Gauss-Newton loop of the photometric trackers in one launch ----------
+//
+// As track_loop_kernel of the depth tracker (vk_icp.hip; the exchange is described in
+// vk_gauss_newton.hpp): every workgroup evaluates its keyframe pixels, the workgroups
+// exchange their 27 sums inside the launch, every workgroup adds all of them, solves and
+// moves depth_to_world and Tcm itself, in LDS; workgroup 0 publishes once, at the end.
+#ifndef VK_COLOR_THREADS
+#define VK_COLOR_THREADS 1024
+#endif
+constexpr int kColorThreads = VK_COLOR_THREADS;
+constexpr int kColorPixels = kSysThreads / kColorThreads;     // a group is kSysThreads keyframe pixels
+
+struct ColorLoopParams
+{
+  Exchange exchange;
+  vk_transform frame_Tcd, key_Twc;
+  vk_color_pose* pose;     // in: depth_to_world; out: depth_to_world and Tcm after the loop
+  int groups;
+  int iterations;
+  int fresh_state;
+  float* hessian;
+  float* gradient;
+  int32_t* state;
+  float* update_out;
+  Mirror mirror;
+};
+
+template <bool LIGHT, bool TRANSLATION>
+__global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P, ColorLoopParams L)
+{
+  constexpr int N = TRANSLATION ? 6 : 3;
+  __shared__ float lds[kColorThreads / 64][kSysStride];
+  __shared__ float slices[kSysSlices][kSysStride];
+  __shared__ float sums[48];
+  __shared__ float twd[32];      // depth_to_world: matrix, inverse
+  __shared__ float tcm[32];      // Tcm: matrix, inverse
+  __shared__ float last_update[6];
+  __shared__ int stop, failed;
+
+  const int steps_before = L.fresh_state ? 0 : L.state[0];
+  if (!L.fresh_state && L.state[1]) return;   // uniform over the grid
+
+  if (threadIdx.x < 32)
+    twd[threadIdx.x] = threadIdx.x < 16 ? L.pose->depth_to_world.m[threadIdx.x] : L.pose->depth_to_world.inv[threadIdx.x - 16];
+  if (threadIdx.x == 0) { stop = 0; failed = 0; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    // Tracker::BeginSolve: Tcm of the pose the loop starts from
+    float m[16], i[16], out_m[16], out_i[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { m[k] = twd[k]; i[k] = twd[16 + k]; }
+    derive_tcm_arrays(L.frame_Tcd, L.key_Twc, m, i, out_m, out_i);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { tcm[k] = out_m[k]; tcm[16 + k] = out_i[k]; }
+  }
+  __syncthreads();
+
+  const bool publisher = blockIdx.x == 0;
+  const int total = P.key.width * P.key.height;
+  int steps = 0;
+  for (int it = 0; it < L.iterations; ++it)
+  {
+    const Rt Tcm = rt_of(tcm);
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
+    for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
+    {
+#pragma unroll
+      for (int k = 0; k < kColorPixels; ++k)
+      {
+        const int pixel = group * kSysThreads + k * kColorThreads + (int)threadIdx.x;
+        float r, J[6], one[27];
+        if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
+        {
+          outer_products(J, r, one);
+#pragma unroll
+          for (int i = 0; i < 27; ++i) acc[i] += one[i];
+        }
+      }
+    }
+
+    publish_partial<kColorThreads / 64>(acc, lds, L.exchange, it);
+    if (!gather_partials<kColorThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
+            publisher ? L.gradient : nullptr, slices, sums, &failed))
+      break;
+    steps = it + 1;
+
+    if (threadIdx.x == 0)
+    {
+      float update[6], old_i[16], m[16], i[16], out_m[16], out_i[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) old_i[k] = twd[16 + k];
+      color_pose_step<N>(sums, sums + 36, old_i, m, i, update);
+      derive_tcm_arrays(L.frame_Tcd, L.key_Twc, m, i, out_m, out_i);
+      float sq = 0.0f;
+#pragma unroll
+      for (int k = 0; k < N; ++k) sq += update[k] * update[k];
+      stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { twd[k] = m[k]; twd[16 + k] = i[k]; tcm[k] = out_m[k]; tcm[16 + k] = out_i[k]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) last_update[k] = update[k];
+    }
+    __syncthreads();
+    if (stop) break;             // tracker.cpp:162
+  }
+
+  if (failed)
+  {
+    if (threadIdx.x == 0) L.state[1] = VK_TRACK_ABORTED;
+    return;
+  }
+  if (!publisher) return;
+  // the derived Tcm is part of the pose even when no step ran (color_prepare_kernel's job)
+  if (threadIdx.x < 32)
+  {
+    const float v = tcm[threadIdx.x];
+    if (threadIdx.x < 16) L.pose->Tcm.m[threadIdx.x] = v; else L.pose->Tcm.inv[threadIdx.x - 16] = v;
+  }
+  if (steps == 0) return;
+  if (threadIdx.x < 32)
+  {
+    const float v = twd[threadIdx.x];
+    if (threadIdx.x < 16) L.pose->depth_to_world.m[threadIdx.x] = v; else L.pose->depth_to_world.inv[threadIdx.x - 16] = v;
+  }
+  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = last_update[threadIdx.x];
+  if (threadIdx.x == 0)
+  {
+    const int iterations = steps_before + steps;
+    L.state[0] = iterations;
+    L.state[1] = stop;
+    if (L.mirror.word)
+      __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
+          ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
+          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <bool LIGHT, bool TRANSLATION>
+int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iterations, float* workspace, hipStream_t s)
+{
+  const int capacity = resident_workgroups(color_loop_kernel<LIGHT, TRANSLATION>, kColorThreads);
+  if (capacity <= 0) return VK_ERR_ARGUMENT;
+  const int grid = L.groups < capacity ? L.groups : capacity;
+  for (int done = 0; done < iterations; done += kExchangeSteps)
+  {
+    L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
+    L.exchange.count = grid;
+    L.exchange.epoch = vk_next_loop_epoch();
+    L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
+    hipLaunchKernelGGL((color_loop_kernel<LIGHT, TRANSLATION>), dim3(grid), dim3(kColorThreads), 0, s, P, L);
+    VK_LAUNCH_CHECK();
+    L.fresh_state = 0;
+  }
+  return VK_OK;
 }
 
 // -------------------------------------------------------------- host side ----
@@ -675,6 +861,28 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
   sums_only.pose = nullptr;
   sums_only.state = nullptr;
   sums_only.update_out = nullptr;
+
+  if (!reduce)
+  {
+    // the whole loop in one launch (color_loop_kernel)
+    VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
+    ColorLoopParams L;
+    L.frame_Tcd = *frame_Tcd;
+    L.key_Twc = *keyframe_Twc;
+    L.pose = pose_dev;
+    L.groups = partials;
+    L.fresh_state = 0;
+    L.hessian = hessian;
+    L.gradient = gradient;
+    L.state = state_dev;
+    L.update_out = update_dev;
+    L.mirror = A.mirror;
+    if (light)
+      return translation_enabled ? launch_color_loop_of<true, true>(P, L, iterations, workspace, s)
+                                 : launch_color_loop_of<true, false>(P, L, iterations, workspace, s);
+    return translation_enabled ? launch_color_loop_of<false, true>(P, L, iterations, workspace, s)
+                               : launch_color_loop_of<false, false>(P, L, iterations, workspace, s);
+  }
 
   hipLaunchKernelGGL(color_prepare_kernel, dim3(1), dim3(64), 0, s, A);
   VK_LAUNCH_CHECK();

@@ -199,6 +199,35 @@ struct Exchange
   uint32_t epoch;
 };
 
+}  // namespace vk
+
+// process-wide source of launch tags (vk_runtime.hip): 22 bits, never 0
+uint32_t vk_next_loop_epoch();
+
+namespace vk
+{
+
+// How many workgroups of `kernel` (THREADS wide, static LDS only) the current device holds
+// at once: the grid of a loop kernel must not exceed it. 0 on error.
+template <typename Kernel>
+inline int resident_workgroups(Kernel kernel, int threads)
+{
+  struct Entry { const void* kernel; int device; int capacity; };
+  static Entry cache[32];
+  static int used = 0;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].kernel == reinterpret_cast<const void*>(kernel) && cache[i].device == device) return cache[i].capacity;
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+    return 0;
+  const int capacity = per_cu * cus > 0 ? per_cu * cus : 0;
+  if (used < 32) cache[used++] = Entry{reinterpret_cast<const void*>(kernel), device, capacity};   // benign if two threads race: same values
+  return capacity;
+}
+
 template <int WAVES>
 __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*lds)[kSysStride],
     const Exchange& E, int step)

@@ -8,7 +8,6 @@
 // Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
 // summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
 // solve + SE(3) update can run on the device so an iteration needs no readback.
-#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -487,32 +486,6 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   }
 }
 
-// how many workgroups of the loop kernel the device holds at once (they all have to)
-template <bool TRANSLATION>
-int loop_capacity()
-{
-  static int capacity[16] = {0};
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return 0;
-  if (capacity[device] == 0)
-  {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, track_loop_kernel<TRANSLATION>, kIcpThreads, 0) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
-      return 0;
-    capacity[device] = per_cu * cus > 0 ? per_cu * cus : -1;
-  }
-  return capacity[device] > 0 ? capacity[device] : 0;
-}
-
-uint32_t next_loop_epoch()
-{
-  static std::atomic<uint32_t> counter{0};
-  uint32_t e;
-  do { e = (counter.fetch_add(1) + 1u) & 0x3fffffu; } while (e == 0);
-  return e;
-}
-
 // ------------------------------------------------------------------ pyramid ----
 
 // ref: image.cu:101-131
@@ -637,7 +610,8 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     bool fresh_state, hipStream_t s)
 {
   VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
-  const int capacity = translation_enabled ? loop_capacity<true>() : loop_capacity<false>();
+  const int capacity = translation_enabled ? resident_workgroups(track_loop_kernel<true>, kIcpThreads)
+                                           : resident_workgroups(track_loop_kernel<false>, kIcpThreads);
   if (capacity <= 0) return VK_ERR_ARGUMENT;
   const int grid = groups < capacity ? groups : capacity;
   LoopParams L;
@@ -654,7 +628,7 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
   {
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
     L.exchange.count = grid;
-    L.exchange.epoch = next_loop_epoch();
+    L.exchange.epoch = vk_next_loop_epoch();
 #ifdef VK_LOOP_TIMING
     {
       static unsigned long long* timing = nullptr;
@@ -720,9 +694,10 @@ int vk_icp_compute_jacobian(const vk_icp_view* keyframe, const vk_transform* Twm
 size_t vk_icp_workspace_floats(int width, int height)
 {
   if (width <= 0 || height <= 0) return 0;
-  // the in-launch exchange of the loop kernel (the rig's launch-per-stage loop uses the first
-  // icp_group_count * kSysStride floats of it)
-  return exchange_floats(icp_group_count(width, height)) + sizeof(vk_transform) / sizeof(float);
+  // the in-launch exchange of the loop kernels, sized for the photometric trackers' groups of
+  // kSysThreads pixels (the depth tracker's groups are larger, so it has fewer of them; the
+  // rig's launch-per-stage loops use the first partial_count * kSysStride floats)
+  return exchange_floats(partial_count(width, height)) + sizeof(vk_transform) / sizeof(float);
 }
 
 int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,

@@ -5,6 +5,28 @@
 #include "vk_common.hpp"
 
 #include <string.h>
+#include <time.h>
+
+#include <atomic>
+
+// Launch tags of the loop kernels (vk_gauss_newton.hpp, "partials exchanged inside a
+// launch"): one counter for the whole library, so that two trackers that are handed the
+// same memory one after the other never use the same tag. It starts at a value taken from
+// the clock and the library's load address: a second copy of the library in the same
+// process (the debug build next to the release build) then counts from somewhere else.
+uint32_t vk_next_loop_epoch()
+{
+  static std::atomic<uint32_t> counter{[] {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    uint64_t x = (uint64_t)t.tv_nsec ^ ((uint64_t)t.tv_sec << 20) ^ (uint64_t)reinterpret_cast<uintptr_t>(&vk_next_loop_epoch);
+    x ^= x >> 33;  x *= 0xff51afd7ed558ccdull;  x ^= x >> 33;
+    return (uint32_t)x;
+  }()};
+  uint32_t e;
+  do { e = (counter.fetch_add(1) + 1u) & 0x3fffffu; } while (e == 0);
+  return e;
+}
 
 extern "C" {
 

@@ -22,9 +22,9 @@ class ImageStorage
 {
   public:
 
-    ImageStorage() : size_(0, 0), data_(nullptr) {}
+    ImageStorage() : size_(0, 0), data_(nullptr), capacity_(0) {}
 
-    ImageStorage(int w, int h) : size_(0, 0), data_(nullptr) { Resize(w, h); }
+    ImageStorage(int w, int h) : size_(0, 0), data_(nullptr), capacity_(0) { Resize(w, h); }
 
     ~ImageStorage() { vk_free(data_); }
 
@@ -47,14 +47,18 @@ class ImageStorage
     void Resize(const Vector2i& size)
     {
       VULCAN_DEBUG(size[0] >= 0 && size[1] >= 0);
-      const int old_total = GetTotal();
       size_ = size;
-      if (GetTotal() == old_total) return;
+      // upstream frees and allocates whenever the pixel count changes (image.h:85-97); a
+      // pyramid tracker alternates between two sizes every frame, and on this runtime a free
+      // is a device-wide synchronisation: the storage only ever grows
+      if ((size_t)GetTotal() <= capacity_) return;
       VK_ASSERT(vk_free(data_));
       data_ = nullptr;
+      capacity_ = 0;
       void* ptr = nullptr;
       VK_ASSERT(vk_malloc(&ptr, GetBytes()));
       data_ = static_cast<Pixel*>(ptr);
+      capacity_ = (size_t)GetTotal();
     }
 
     void CopyFromHost(const Pixel* pixels)
@@ -78,6 +82,8 @@ class ImageStorage
     Vector2i size_;
 
     Pixel* data_;
+
+    size_t capacity_;   // pixels allocated (>= GetTotal())
 };
 
 } // namespace detail

@@ -72,6 +72,10 @@ class Tracker
     Buffer<float> system_;        // hessian = [0,36), gradient = [36,42)
     Buffer<float> workspace_;     // per-workgroup partial sums
     Buffer<vk_transform> pose_;   // device copy of the pose being refined
+
+    // where BeginSolve puts the pose and EndSolve reads it back from (a tracker whose device loop
+    // keeps a larger pose record points this at the record's depth_to_world)
+    virtual vk_transform* DevicePose() { return pose_.GetData(); }
     Buffer<int> state_;           // {iterations run, converged}
     Buffer<float> update_;        // last 6-vector
 
@@ -148,6 +152,8 @@ class ColorTracker : public Tracker
     Image frame_gradient_x_;
     Image frame_gradient_y_;
     Buffer<vk_color_pose> color_pose_;   // depth_to_world + derived Tcm, on the device
+
+    vk_transform* DevicePose() override { return &color_pose_.GetData()->depth_to_world; }
 };
 
 // ColorTracker with a shading model: where the frame mask is set the residual is
@@ -200,6 +206,7 @@ class PyramidTracker
     std::shared_ptr<Tracker> tracker_;
     std::shared_ptr<const Frame> keyframe_;
     std::shared_ptr<Frame> half_keyframe_;
+    std::shared_ptr<Frame> half_frame_;      // upstream: a local of Track (pyramid_tracker.cpp:58); kept so its images are reused
     std::shared_ptr<Frame> quarter_keyframe_;
     int iter_;
 };

@@ -103,14 +103,14 @@ void Tracker::BeginSolve(const Frame& frame)
   ResizeBuffers(frame);
   iteration_ = 0;
   const vk_transform pose = frame.depth_to_world_transform.ToVk();
-  VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
+  VK_ASSERT(vk_transform_upload(DevicePose(), &pose, Device::GetStream()));
   VK_ASSERT(vk_memset(state_.GetData(), 0, 2 * sizeof(int), Device::GetStream()));
 }
 
 void Tracker::EndSolve(Frame& frame)
 {
   vk_transform pose;
-  pose_.CopyToHost(&pose);  // the only readback of the solve
+  VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));  // the only readback of the solve
   frame.depth_to_world_transform = Transform::FromVk(pose);
 }
 
@@ -365,13 +365,11 @@ void ColorTracker::TrackOnDevice(Frame& frame)
   const vk_color_view key = KeyframeView(), frm = FrameView(frame);
   const vk_transform frame_Tcd = frame.depth_to_color_transform.ToVk();
   const vk_transform key_Twc = GetKeyframeTwc();
-  // pose_ was filled by BeginSolve: it is the first member of the colour pose
-  VK_ASSERT(vk_memcpy_d2d(color_pose_.GetData(), pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
+  // BeginSolve put the pose into color_pose_->depth_to_world (DevicePose)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_color_tracker_track(&key, &frm, &frame_Tcd, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
       reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
-  VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
 }
 
 // ref: color_tracker.cpp:34-96 (host form; Track() uses the device form)
@@ -479,12 +477,10 @@ void LightTracker::TrackOnDevice(Frame& frame)
   const vk_color_view key = KeyframeView(), frm = FrameView(frame);
   const vk_light_terms terms = GetTerms(frame);
   const vk_transform key_Twc = GetKeyframeTwc();
-  VK_ASSERT(vk_memcpy_d2d(color_pose_.GetData(), pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_light_tracker_track(&key, &frm, &terms, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
       reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
-  VK_ASSERT(vk_memcpy_d2d(pose_.GetData(), color_pose_.GetData(), sizeof(vk_transform), Device::GetStream()));
 }
 
 // ---- PyramidTracker ---------------------------------------------------------------
@@ -493,6 +489,7 @@ template <typename Tracker>
 PyramidTracker<Tracker>::PyramidTracker() :
   tracker_(std::shared_ptr<Tracker>(new Tracker())),
   half_keyframe_(std::make_shared<Frame>()),
+  half_frame_(std::make_shared<Frame>()),
   quarter_keyframe_(std::make_shared<Frame>()),
   iter_(0)
 {
@@ -502,6 +499,7 @@ template <typename Tracker>
 PyramidTracker<Tracker>::PyramidTracker(std::shared_ptr<Tracker> tracker) :
   tracker_(tracker),
   half_keyframe_(std::make_shared<Frame>()),
+  half_frame_(std::make_shared<Frame>()),
   quarter_keyframe_(std::make_shared<Frame>()),
   iter_(0)
 {
@@ -542,7 +540,7 @@ void PyramidTracker<Tracker>::TrackLevels(Frame& frame)
 {
   VULCAN_DEBUG(keyframe_);
 
-  Frame half_frame;
+  Frame& half_frame = *half_frame_;
   frame.Downsample(half_frame);
   keyframe_->Downsample(*half_keyframe_);
 
