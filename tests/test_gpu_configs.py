@@ -305,3 +305,33 @@ def test_early_exit_matches_the_full_loop(api, orc):
         steps.append(int(st[0]))
         assert st[1] == 1
     assert len(set(poses)) == 1 and len(set(steps)) == 1
+
+
+def test_loop_kernel_is_reproducible_and_continues_past_one_launch(api, orc):
+    """The depth tracker's loop is one launch whose workgroups exchange their sums inside it
+    (vk_icp_track without a reduce hook). Twice the same call gives the same bits; a loop longer
+    than the 1023 steps one launch can tag continues in a further launch and ends where the
+    converged loop ended; with the rig's hook (launch per stage, same order of summation) the
+    pose is the same bit for bit."""
+    w, h = 640, 480
+    k = T.Projection.make(547.0, 547.0, 320, 240)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start)
+    df.compute_normals()
+    results = []
+    for iterations, hook in ((20, False), (20, False), (1100, False), (20, True)):
+        tracker = api.DepthTracker()
+        tracker.keyframe = dk
+        tracker.max_iterations = iterations
+        if hook:
+            tracker.reduce_hook = lambda system: None
+        df.depth_to_world = start
+        pose = bytes(tracker.track(df))
+        sync()
+        st = tracker.state.cpu().numpy()
+        assert st[1] == 1 and 0 < st[0] < 20
+        results.append((pose, int(st[0]), tracker.system.cpu().numpy().tobytes()))
+    assert len(set(results)) == 1

@@ -392,8 +392,8 @@ __device__ __forceinline__ void derive_tcm_arrays(const vk_transform& frame_Tcd,
 // ref: tracker.cpp:124-163 + color_tracker.cpp:34-96 on arrays: the update from the system,
 // the new depth_to_world (m, inv) from the old inverse
 template <int N>
-__device__ __forceinline__ void color_pose_step(const float* hessian, const float* gradient, const float (&old_i)[16],
-    float (&twd_m)[16], float (&twd_i)[16], float (&update)[6])
+__device__ __forceinline__ void color_pose_matrix(const float* hessian, const float* gradient, const float (&old_i)[16],
+    float (&M)[16], float (&update)[6])
 {
   solve_step<N>(hessian, gradient, update);
 
@@ -404,8 +404,15 @@ __device__ __forceinline__ void color_pose_step(const float* hessian, const floa
   Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
   Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
 
-  float M[16];
   matmul4(Tinc, old_i, M);             // :67  M = Tinc * Twd^-1
+}
+
+template <int N>
+__device__ __forceinline__ void color_pose_step(const float* hessian, const float* gradient, const float (&old_i)[16],
+    float (&twd_m)[16], float (&twd_i)[16], float (&update)[6])
+{
+  float M[16];
+  color_pose_matrix<N>(hessian, gradient, old_i, M, update);
   rigid_from(M, twd_i, twd_m);         // :69-95 world -> depth, re-orthonormalised; .Inverse() swaps the two
 }
 
@@ -477,8 +484,13 @@ __global__ void color_prepare_kernel(PoseArgs A)
 #ifndef VK_COLOR_THREADS
 #define VK_COLOR_THREADS 1024
 #endif
+#ifndef VK_COLOR_PIXELS
+#define VK_COLOR_PIXELS 1
+#endif
 constexpr int kColorThreads = VK_COLOR_THREADS;
-constexpr int kColorPixels = kSysThreads / kColorThreads;     // a group is kSysThreads keyframe pixels
+constexpr int kColorPixels = VK_COLOR_PIXELS;                 // keyframe pixels per lane
+constexpr int kColorGroup = kColorThreads * kColorPixels;     // ... and per workgroup
+static_assert(kColorGroup >= kSysThreads, "the workspace is sized for groups of at least kSysThreads pixels");
 
 struct ColorLoopParams
 {
@@ -493,6 +505,7 @@ struct ColorLoopParams
   int32_t* state;
   float* update_out;
   Mirror mirror;
+  VK_LOOP_TIMING_FIELD
 };
 
 template <bool LIGHT, bool TRANSLATION>
@@ -505,6 +518,7 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
   __shared__ float twd[32];      // depth_to_world: matrix, inverse
   __shared__ float tcm[32];      // Tcm: matrix, inverse
   __shared__ float last_update[6];
+  __shared__ float last_M[16];   // workgroup 0: Tinc * Twd^-1 of the last step
   __shared__ int stop, failed;
 
   const int steps_before = L.fresh_state ? 0 : L.state[0];
@@ -531,6 +545,7 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
   int steps = 0;
   for (int it = 0; it < L.iterations; ++it)
   {
+    VK_STAMP(0);
     const Rt Tcm = rt_of(tcm);
     float acc[27];
 #pragma unroll
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
 #pragma unroll
       for (int k = 0; k < kColorPixels; ++k)
       {
-        const int pixel = group * kSysThreads + k * kColorThreads + (int)threadIdx.x;
+        const int pixel = group * kColorGroup + k * kColorThreads + (int)threadIdx.x;
         float r, J[6], one[27];
         if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
         {
@@ -551,29 +566,43 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
       }
     }
 
+    VK_STAMP(1);
     publish_partial<kColorThreads / 64>(acc, lds, L.exchange, it);
+    VK_STAMP(2);
+    VK_STAMP(3);
     if (!gather_partials<kColorThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
             publisher ? L.gradient : nullptr, slices, sums, &failed))
       break;
     steps = it + 1;
+    VK_STAMP(4);
 
     if (threadIdx.x == 0)
     {
-      float update[6], old_i[16], m[16], i[16], out_m[16], out_i[16];
+      // A step needs depth_to_world^-1 (the next update multiplies it) and Tcm's matrix (the
+      // pixels); depth_to_world itself and Tcm^-1 — three more 4x4 products per step — are made
+      // once, after the loop, from the last step's M. (The unused halves are dead code here.)
+      float update[6], old_i[16], M[16], m[16], i[16], out_m[16], out_i[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) old_i[k] = twd[16 + k];
-      color_pose_step<N>(sums, sums + 36, old_i, m, i, update);
+      color_pose_matrix<N>(sums, sums + 36, old_i, M, update);
+      rigid_from(M, i, m);
       derive_tcm_arrays(L.frame_Tcd, L.key_Twc, m, i, out_m, out_i);
       float sq = 0.0f;
 #pragma unroll
       for (int k = 0; k < N; ++k) sq += update[k] * update[k];
       stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { twd[k] = m[k]; twd[16 + k] = i[k]; tcm[k] = out_m[k]; tcm[16 + k] = out_i[k]; }
+      for (int k = 0; k < 16; ++k) { twd[16 + k] = i[k]; tcm[k] = out_m[k]; }
+      if (publisher)
+      {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) last_update[k] = update[k];
+        for (int k = 0; k < 16; ++k) last_M[k] = M[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) last_update[k] = update[k];
+      }
     }
     __syncthreads();
+    VK_STAMP(5);
     if (stop) break;             // tracker.cpp:162
   }
 
@@ -583,6 +612,20 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
     return;
   }
   if (!publisher) return;
+  if (steps > 0)
+  {
+    if (threadIdx.x == 0)
+    {
+      float M[16], m[16], i[16], out_m[16], out_i[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) M[k] = last_M[k];
+      rigid_from(M, i, m);
+      derive_tcm_arrays(L.frame_Tcd, L.key_Twc, m, i, out_m, out_i);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { twd[k] = m[k]; twd[16 + k] = i[k]; tcm[k] = out_m[k]; tcm[16 + k] = out_i[k]; }
+    }
+    __syncthreads();
+  }
   // the derived Tcm is part of the pose even when no step ran (color_prepare_kernel's job)
   if (threadIdx.x < 32)
   {
@@ -619,6 +662,7 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
     L.exchange.count = grid;
     L.exchange.epoch = vk_next_loop_epoch();
+    VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     hipLaunchKernelGGL((color_loop_kernel<LIGHT, TRANSLATION>), dim3(grid), dim3(kColorThreads), 0, s, P, L);
     VK_LAUNCH_CHECK();
@@ -870,7 +914,7 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
     L.frame_Tcd = *frame_Tcd;
     L.key_Twc = *keyframe_Twc;
     L.pose = pose_dev;
-    L.groups = partials;
+    L.groups = (keyframe->width * keyframe->height + kColorGroup - 1) / kColorGroup;
     L.fresh_state = 0;
     L.hessian = hessian;
     L.gradient = gradient;

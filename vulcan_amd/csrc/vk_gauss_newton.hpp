@@ -7,6 +7,12 @@
 
 #include "vk_common.hpp"
 
+#ifdef VK_LOOP_TIMING
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#endif
+
 namespace vk
 {
 
@@ -153,6 +159,35 @@ __device__ __forceinline__ void sum_partials(const float* workspace, int partial
   __syncthreads();
   finish_sums(slices, translation_enabled, hessian, gradient, sums);
 }
+
+// Development aid (-DVK_LOOP_TIMING): workgroup 0 of a loop kernel stamps the wall clock at six
+// points of every step; with VK_LOOP_TIMING_DUMP set the host prints the previous launch's
+// stamps before the next launch. Compiled out of the product.
+#ifdef VK_LOOP_TIMING
+#define VK_STAMP(k) if (blockIdx.x == 0 && threadIdx.x == 0 && L.timing) L.timing[it * 8 + (k)] = wall_clock64()
+inline unsigned long long* loop_timing_attach(hipStream_t s)
+{
+  static unsigned long long* timing = nullptr;
+  if (!timing) { (void)hipHostMalloc((void**)&timing, 64 * 8 * 8, hipHostMallocMapped); memset(timing, 0, 64 * 8 * 8); }
+  if (getenv("VK_LOOP_TIMING_DUMP"))
+  {
+    (void)hipStreamSynchronize(s);
+    for (int k = 0; k < 32 && timing[k * 8]; ++k)
+      fprintf(stderr, "step %2d: pixels %5.2f publish %5.2f flags %5.2f sum %5.2f solve %5.2f | total %5.2f us\n", k,
+          (timing[k * 8 + 1] - timing[k * 8 + 0]) / 100.0, (timing[k * 8 + 2] - timing[k * 8 + 1]) / 100.0,
+          (timing[k * 8 + 3] - timing[k * 8 + 2]) / 100.0, (timing[k * 8 + 4] - timing[k * 8 + 3]) / 100.0,
+          (timing[k * 8 + 5] - timing[k * 8 + 4]) / 100.0, (timing[k * 8 + 5] - timing[k * 8 + 0]) / 100.0);
+    memset(timing, 0, 64 * 8 * 8);
+  }
+  return timing;
+}
+#define VK_LOOP_TIMING_ATTACH(L, s) (L).timing = loop_timing_attach(s)
+#define VK_LOOP_TIMING_FIELD unsigned long long* timing;
+#else
+#define VK_STAMP(k)
+#define VK_LOOP_TIMING_ATTACH(L, s)
+#define VK_LOOP_TIMING_FIELD
+#endif
 
 // ---- partials exchanged INSIDE a launch (the whole Gauss-Newton loop as one kernel) ----
 //

@@ -8,10 +8,6 @@
 // Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
 // summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
 // solve + SE(3) update can run on the device so an iteration needs no readback.
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-
 #include "vk_gauss_newton.hpp"
 
 using namespace vk;
@@ -307,9 +303,10 @@ __global__ __launch_bounds__(256) void system_final_kernel(const float* __restri
 // ref: tracker.cpp:124-163 + depth_tracker.cpp:22-86. One lane; 6x6 is too
 // small to spread.
 // the new pose (out_m, out_i) from the system and the old pose matrix
+// M = Tinc(update) * old pose matrix; the new pose is rigid_from(M)
 template <int N>
-__device__ __forceinline__ void pose_step(const float* hessian, const float* gradient, const float (&old_m)[16],
-    float (&out_m)[16], float (&out_i)[16], float (&update)[6])
+__device__ __forceinline__ void pose_matrix(const float* hessian, const float* gradient, const float (&old_m)[16],
+    float (&M)[16], float (&update)[6])
 {
   solve_step<N>(hessian, gradient, update);
 
@@ -320,8 +317,15 @@ __device__ __forceinline__ void pose_step(const float* hessian, const float* gra
   Tinc[2] = -update[1];  Tinc[6] = +update[0]; Tinc[10] = 1.0f;       Tinc[14] = +update[5];
   Tinc[3] = 0.0f;        Tinc[7] = 0.0f;       Tinc[11] = 0.0f;       Tinc[15] = 1.0f;
 
-  float M[16];
   matmul4(Tinc, old_m, M);
+}
+
+template <int N>
+__device__ __forceinline__ void pose_step(const float* hessian, const float* gradient, const float (&old_m)[16],
+    float (&out_m)[16], float (&out_i)[16], float (&update)[6])
+{
+  float M[16];
+  pose_matrix<N>(hessian, gradient, old_m, M, update);
   rigid_from(M, out_m, out_i);
 }
 
@@ -368,9 +372,7 @@ __global__ void solve_update_kernel(const float* __restrict__ hessian, const flo
 struct LoopParams
 {
   Exchange exchange;             // {tag, value} words of the launch's workgroups
-#ifdef VK_LOOP_TIMING
-  unsigned long long* timing;
-#endif
+  VK_LOOP_TIMING_FIELD
   vk_transform* pose;            // in: the pose to start from; out: the pose after the loop
   int groups;                    // 1024-pixel groups of the frame (gridDim.x <= groups)
   int iterations;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   __shared__ float slices[kSysSlices][kSysStride];
   __shared__ float sums[48];
   __shared__ float pose_m[16];
-  __shared__ float result[16 + 16 + 6];   // workgroup 0: matrix, inverse, update of the last step
+  __shared__ float result[16 + 6];        // workgroup 0: M (see below) and update of the last step
   __shared__ int stop, failed;
 
   // tracker.cpp:162 / Tracker::CreateState: a state that already says "converged" ends the call
@@ -410,11 +412,6 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   int steps = 0;
   for (int it = 0; it < L.iterations; ++it)
   {
-#ifdef VK_LOOP_TIMING
-#define VK_STAMP(k) if (blockIdx.x == 0 && threadIdx.x == 0 && L.timing) L.timing[it * 8 + (k)] = wall_clock64()
-#else
-#define VK_STAMP(k)
-#endif
     VK_STAMP(0);
     const Rt Twc = rt_from_colmajor(pose_m);
     float acc[27];
@@ -438,10 +435,13 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
 
     if (threadIdx.x == 0)
     {
-      float update[6], old_m[16], out_m[16], out_i[16];
+      // the pixels only ever need the pose's matrix; its inverse (a second 4x4 product per
+      // step) is made once, after the loop, from the last step's M
+      float update[6], old_m[16], M[16], out_m[16], unused_i[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) old_m[i] = pose_m[i];
-      pose_step<N>(sums, sums + 36, old_m, out_m, out_i, update);
+      pose_matrix<N>(sums, sums + 36, old_m, M, update);
+      rigid_from(M, out_m, unused_i);
       float sq = 0.0f;
 #pragma unroll
       for (int i = 0; i < N; ++i) sq += update[i] * update[i];
@@ -451,9 +451,9 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
       if (publisher)
       {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { result[i] = out_m[i]; result[16 + i] = out_i[i]; }
+        for (int i = 0; i < 16; ++i) result[i] = M[i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) result[32 + i] = update[i];
+        for (int i = 0; i < 6; ++i) result[16 + i] = update[i];
       }
     }
     __syncthreads();
@@ -468,12 +468,16 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
     return;
   }
   if (!publisher || steps == 0) return;
-  if (threadIdx.x < 32)
+  if (threadIdx.x == 0)
   {
-    const float v = result[threadIdx.x];
-    if (threadIdx.x < 16) L.pose->m[threadIdx.x] = v; else L.pose->inv[threadIdx.x - 16] = v;
+    float M[16], out_m[16], out_i[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M[i] = result[i];
+    rigid_from(M, out_m, out_i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { L.pose->m[i] = out_m[i]; L.pose->inv[i] = out_i[i]; }
   }
-  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = result[32 + threadIdx.x];
+  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = result[16 + threadIdx.x];
   if (threadIdx.x == 0)
   {
     const int iterations = steps_before + steps;
@@ -629,23 +633,7 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
     L.exchange.count = grid;
     L.exchange.epoch = vk_next_loop_epoch();
-#ifdef VK_LOOP_TIMING
-    {
-      static unsigned long long* timing = nullptr;
-      if (!timing) { (void)hipHostMalloc((void**)&timing, 64 * 8 * 8, hipHostMallocMapped); memset(timing, 0, 64 * 8 * 8); }
-      if (getenv("VK_LOOP_TIMING_DUMP") && timing[0])
-      {
-        (void)hipStreamSynchronize(s);
-        for (int k = 0; k < 32 && timing[k * 8]; ++k)
-          fprintf(stderr, "step %2d: pixels %5.2f publish %5.2f flags %5.2f sum %5.2f solve %5.2f | total %5.2f us\n", k,
-              (timing[k * 8 + 1] - timing[k * 8 + 0]) / 100.0, (timing[k * 8 + 2] - timing[k * 8 + 1]) / 100.0,
-              (timing[k * 8 + 3] - timing[k * 8 + 2]) / 100.0, (timing[k * 8 + 4] - timing[k * 8 + 3]) / 100.0,
-              (timing[k * 8 + 5] - timing[k * 8 + 4]) / 100.0, (timing[k * 8 + 5] - timing[k * 8 + 0]) / 100.0);
-        memset(timing, 0, 64 * 8 * 8);
-      }
-      L.timing = timing;
-    }
-#endif
+    VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.fresh_state = (fresh_state && done == 0) ? 1 : 0;
     if (translation_enabled)
