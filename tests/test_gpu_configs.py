@@ -307,14 +307,15 @@ def test_early_exit_matches_the_full_loop(api, orc):
     assert len(set(poses)) == 1 and len(set(steps)) == 1
 
 
-def test_loop_kernel_is_reproducible_and_continues_past_one_launch(api, orc):
+@pytest.mark.parametrize("w,h", [(640, 480), (1280, 960)])
+def test_loop_kernel_is_reproducible_and_continues_past_one_launch(api, orc, w, h):
     """The depth tracker's loop is one launch whose workgroups exchange their sums inside it
     (vk_icp_track without a reduce hook). Twice the same call gives the same bits; a loop longer
     than the 1023 steps one launch can tag continues in a further launch and ends where the
     converged loop ended; with the rig's hook (launch per stage, same order of summation) the
-    pose is the same bit for bit."""
-    w, h = 640, 480
-    k = T.Projection.make(547.0, 547.0, 320, 240)
+    pose is the same bit for bit — also at 1280x960, where the image has more pixel groups than
+    the device holds workgroups and a workgroup publishes several groups."""
+    k = T.Projection.make(547.0 * w / 640, 547.0 * w / 640, w / 2, h / 2)
     key_depth = curved_depth(w, h)
     hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
     dk.compute_normals()

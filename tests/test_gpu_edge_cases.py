@@ -372,11 +372,12 @@ def test_reduce_hook_between_system_and_solve(api, orc):
             tracker.track(frame)
             sync()
             poses.append(np.array(frame.depth_to_world.m[:], dtype=np.float32))
-        # one call per step that was ENQUEUED: the loop looks at the convergence mirror every
-        # poll_chunk steps and stops enqueuing once |update| < 1e-6 (vk_track_poll)
+        # one call per step that was ENQUEUED: every poll_chunk steps the loop looks at the
+        # convergence mirror — at the state one chunk back, so that a chunk of launches is always
+        # queued behind the look — and stops enqueuing once |update| < 1e-6 (vk_track_poll)
         steps, converged = (int(v) for v in tracker.state.cpu().numpy())
         chunk = tracker.poll_chunk or 6
-        expected = min(6, -(-steps // chunk) * chunk) if converged else 6
+        expected = min(6, (-(-steps // chunk) + 1) * chunk) if converged else 6
         assert len(calls) == expected and steps <= len(calls)
         assert np.array_equal(poses[0].view(np.uint32), poses[1].view(np.uint32))
         assert not np.array_equal(poses[0], np.array(start.m[:], dtype=np.float32))

@@ -509,7 +509,7 @@ struct ColorLoopParams
 };
 
 template <bool LIGHT, bool TRANSLATION>
-__global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P, ColorLoopParams L)
+__global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loop_kernel(ColorParams P, ColorLoopParams L)
 {
   constexpr int N = TRANSLATION ? 6 : 3;
   __shared__ float lds[kColorThreads / 64][kSysStride];
@@ -547,11 +547,11 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
   {
     VK_STAMP(0);
     const Rt Tcm = rt_of(tcm);
-    float acc[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
     for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
     {
+      float acc[27];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
 #pragma unroll
       for (int k = 0; k < kColorPixels; ++k)
       {
@@ -564,10 +564,9 @@ __global__ __launch_bounds__(kColorThreads) void color_loop_kernel(ColorParams P
           for (int i = 0; i < 27; ++i) acc[i] += one[i];
         }
       }
+      VK_STAMP(1);
+      publish_partial<kColorThreads / 64>(acc, lds, L.exchange, it, group);
     }
-
-    VK_STAMP(1);
-    publish_partial<kColorThreads / 64>(acc, lds, L.exchange, it);
     VK_STAMP(2);
     VK_STAMP(3);
     if (!gather_partials<kColorThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
@@ -660,7 +659,7 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
   for (int done = 0; done < iterations; done += kExchangeSteps)
   {
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
-    L.exchange.count = grid;
+    L.exchange.count = L.groups;
     L.exchange.epoch = vk_next_loop_epoch();
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;

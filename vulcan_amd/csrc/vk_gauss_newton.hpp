@@ -230,7 +230,7 @@ inline size_t exchange_floats(int count) { return 4 * (size_t)count * kSysStride
 struct Exchange
 {
   unsigned long long* words;   // [2][count][kSysStride]
-  int count;                   // workgroups of the launch
+  int count;                   // pixel groups of the image = slots per parity (a workgroup fills one or more)
   uint32_t epoch;
 };
 
@@ -263,9 +263,14 @@ inline int resident_workgroups(Kernel kernel, int threads)
   return capacity;
 }
 
+// One slot per pixel GROUP, not per workgroup: a workgroup that is given several groups (more
+// groups than the device holds workgroups) publishes each group's sums separately, so what is
+// added up — and therefore every bit of the result — does not depend on the size of the grid,
+// i.e. on the device's CU count or the kernel's occupancy, and equals the launch-per-stage
+// path's partials.
 template <int WAVES>
 __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*lds)[kSysStride],
-    const Exchange& E, int step)
+    const Exchange& E, int step, int group)
 {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -281,10 +286,11 @@ __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*
     float v = 0.0f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += lds[w][threadIdx.x];
-    __hip_atomic_store(E.words + ((size_t)(step & 1) * E.count + blockIdx.x) * kSysStride + threadIdx.x,
+    __hip_atomic_store(E.words + ((size_t)(step & 1) * E.count + group) * kSysStride + threadIdx.x,
         ((unsigned long long)exchange_tag(E.epoch, step) << 32) | (unsigned long long)__float_as_uint(v),
         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  __syncthreads();   // lds may be written again (the workgroup's next group)
 }
 
 // The counterpart of sum_partials for exchanged sums: same slices, same order within a

@@ -414,17 +414,16 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   {
     VK_STAMP(0);
     const Rt Twc = rt_from_colmajor(pose_m);
-    float acc[27];
-#pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
     for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
     {
+      float acc[27];
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
       if (!resident) load_pixels(P, group, px);
       accumulate_pixels<TRANSLATION>(P, Twc, group, px, acc);
+      VK_STAMP(1);
+      publish_partial<kIcpThreads / 64>(acc, lds, L.exchange, it, group);
     }
-
-    VK_STAMP(1);
-    publish_partial<kIcpThreads / 64>(acc, lds, L.exchange, it);
     VK_STAMP(2);
     VK_STAMP(3);
     if (!gather_partials<kIcpThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
@@ -631,7 +630,7 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
   for (int done = 0; done < iterations; done += kExchangeSteps)
   {
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
-    L.exchange.count = grid;
+    L.exchange.count = groups;
     L.exchange.epoch = vk_next_loop_epoch();
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
