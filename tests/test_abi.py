@@ -48,7 +48,7 @@ def test_version_and_errors_without_gpu():
     assert lib.vk_volume_initialize(None, None) == -1              # VK_ERR_ARGUMENT, no device touched
     assert lib.vk_integrate_depth(None, None, None, None) == -1
     assert lib.vk_trace_compute_points(None, None, None, 0, 0.0, 0.0, 0.0, None, None, None, None, 0, 0, 0, 0, None) == -1
-    assert lib.vk_icp_workspace_floats(640, 480) == 4 * 300 * 32 + 32     # two parities of 300 x 32 {tag, value} words + a pose
+    assert lib.vk_icp_workspace_floats(640, 480) == 4 * 1200 * 32 + 32     # two parities of 1200 slots (256-pixel groups) x 32 {tag, value} words + a pose
     n = C.c_int(-5)
     lib.vk_device_count(C.byref(n))
     assert n.value >= 0

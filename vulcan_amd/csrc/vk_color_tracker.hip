@@ -59,6 +59,7 @@ struct ColorParams
   Rt Tcm;
   const vk_transform* Tcm_dev;  // optional device override of Tcm
   const int32_t* state;         // optional {iterations, converged}: a converged solve skips the pass
+  int group_pixels;             // keyframe pixels per partial sum (group_pixels_for)
   // light tracker only
   const float* mask;
   vk_light light;
@@ -324,27 +325,46 @@ __global__ __launch_bounds__(256) void color_jacobian_kernel(ColorParams P, floa
   for (int i = 0; i < 6; ++i) out[i] = J[i];
 }
 
+// One workgroup of kColorThreads lanes per group of keyframe pixels (group_pixels_for,
+// vk_gauss_newton.hpp).
+#ifndef VK_COLOR_THREADS
+#define VK_COLOR_THREADS 512
+#endif
+constexpr int kColorThreads = VK_COLOR_THREADS;
+
+// the 27 products of this lane's pixels of one group, added pixel by pixel onto acc
+template <bool LIGHT, bool TRANSLATION>
+__device__ __forceinline__ void accumulate_group(const ColorParams& P, const Rt& Tcm, int group, float (&acc)[27])
+{
+  const int total = P.key.width * P.key.height;
+  const int first = group * P.group_pixels;
+  for (int p = (int)threadIdx.x; p < P.group_pixels; p += kColorThreads)
+  {
+    const int pixel = first + p;
+    float r, J[6], one[27];
+    if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
+    {
+      outer_products(J, r, one);
+#pragma unroll
+      for (int i = 0; i < 27; ++i) acc[i] += one[i];
+    }
+  }
+}
+
 // ref: color_tracker.cu:206-343, first stage (see vk_gauss_newton.hpp)
 template <bool LIGHT, bool TRANSLATION>
-__global__ __launch_bounds__(kSysThreads) void color_partial_kernel(ColorParams P, float* __restrict__ workspace)
+__global__ __launch_bounds__(kColorThreads) void color_partial_kernel(ColorParams P, float* __restrict__ workspace)
 {
-  __shared__ float lds[kSysWaves][kSysStride];
+  __shared__ float lds[kColorThreads / 64][kSysStride];
 
   if (P.state && P.state[1]) return;   // tracker.cpp:162, see system_partial_kernel
 
   const Rt Tcm = P.Tcm_dev ? rt_of(P.Tcm_dev->m) : P.Tcm;
-  const int total = P.key.width * P.key.height;
-  const int pixel = blockIdx.x * kSysThreads + (int)threadIdx.x;
-
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-
-  float r, J[6];
-  if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
-    outer_products(J, r, acc);
-
-  store_partial(acc, lds, workspace);
+  accumulate_group<LIGHT, TRANSLATION>(P, Tcm, blockIdx.x, acc);
+  store_partial<kColorThreads / 64>(acc, lds, workspace);
 }
 
 // ------------------------------------------------------------ pose update ----
@@ -481,17 +501,6 @@ __global__ void color_prepare_kernel(PoseArgs A)
 // vk_gauss_newton.hpp): every workgroup evaluates its keyframe pixels, the workgroups
 // exchange their 27 sums inside the launch, every workgroup adds all of them, solves and
 // moves depth_to_world and Tcm itself, in LDS; workgroup 0 publishes once, at the end.
-#ifndef VK_COLOR_THREADS
-#define VK_COLOR_THREADS 1024
-#endif
-#ifndef VK_COLOR_PIXELS
-#define VK_COLOR_PIXELS 1
-#endif
-constexpr int kColorThreads = VK_COLOR_THREADS;
-constexpr int kColorPixels = VK_COLOR_PIXELS;                 // keyframe pixels per lane
-constexpr int kColorGroup = kColorThreads * kColorPixels;     // ... and per workgroup
-static_assert(kColorGroup >= kSysThreads, "the workspace is sized for groups of at least kSysThreads pixels");
-
 struct ColorLoopParams
 {
   Exchange exchange;
@@ -541,7 +550,6 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
   __syncthreads();
 
   const bool publisher = blockIdx.x == 0;
-  const int total = P.key.width * P.key.height;
   int steps = 0;
   for (int it = 0; it < L.iterations; ++it)
   {
@@ -549,21 +557,11 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
     const Rt Tcm = rt_of(tcm);
     for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
     {
+      if (group != (int)blockIdx.x) __syncthreads();   // the previous group's sums have left the LDS
       float acc[27];
 #pragma unroll
       for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-#pragma unroll
-      for (int k = 0; k < kColorPixels; ++k)
-      {
-        const int pixel = group * kColorGroup + k * kColorThreads + (int)threadIdx.x;
-        float r, J[6], one[27];
-        if (pixel < total && evaluate_any<LIGHT, TRANSLATION, true>(P, Tcm, pixel % P.key.width, pixel / P.key.width, r, J))
-        {
-          outer_products(J, r, one);
-#pragma unroll
-          for (int i = 0; i < 27; ++i) acc[i] += one[i];
-        }
-      }
+      accumulate_group<LIGHT, TRANSLATION>(P, Tcm, group, acc);
       VK_STAMP(1);
       publish_partial<kColorThreads / 64>(acc, lds, L.exchange, it, group);
     }
@@ -687,6 +685,7 @@ int fill_color(ColorParams& P, const vk_color_view* keyframe, const vk_color_vie
   P.Tcm = make_rt(Tcm->m);
   P.Tcm_dev = nullptr;
   P.state = nullptr;
+  P.group_pixels = group_pixels_for(keyframe->width * keyframe->height);
   P.mask = nullptr;
   P.light.intensity = 1.0f;
   P.light.position[0] = P.light.position[1] = P.light.position[2] = 0.0f;
@@ -707,9 +706,9 @@ template <bool LIGHT>
 void launch_partials_of(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
 {
   if (translation_enabled)
-    hipLaunchKernelGGL((color_partial_kernel<LIGHT, true>), dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+    hipLaunchKernelGGL((color_partial_kernel<LIGHT, true>), dim3(partials), dim3(kColorThreads), 0, s, P, workspace);
   else
-    hipLaunchKernelGGL((color_partial_kernel<LIGHT, false>), dim3(partials), dim3(kSysThreads), 0, s, P, workspace);
+    hipLaunchKernelGGL((color_partial_kernel<LIGHT, false>), dim3(partials), dim3(kColorThreads), 0, s, P, workspace);
 }
 
 void launch_color_partials(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
@@ -823,7 +822,7 @@ static int system_impl(const vk_color_view* keyframe, const vk_color_view* frame
   if (light && (rc = fill_light(P, terms)) != VK_OK) return rc;
   VK_REQUIRE(workspace && hessian && gradient);
   P.Tcm_dev = Tcm_dev;
-  const int partials = partial_count(keyframe->width, keyframe->height);
+  const int partials = group_count_for(keyframe->width * keyframe->height, P.group_pixels);
   launch_color_partials(P, translation_enabled, partials, workspace, vk_s(stream));
   VK_LAUNCH_CHECK();
   PoseArgs A;
@@ -888,7 +887,7 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
   P.state = state_dev;
   float* hessian = system;
   float* gradient = system + 36;
-  const int partials = partial_count(keyframe->width, keyframe->height);
+  const int partials = group_count_for(keyframe->width * keyframe->height, P.group_pixels);
   hipStream_t s = vk_s(stream);
 
   PoseArgs A;
@@ -913,7 +912,7 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
     L.frame_Tcd = *frame_Tcd;
     L.key_Twc = *keyframe_Twc;
     L.pose = pose_dev;
-    L.groups = (keyframe->width * keyframe->height + kColorGroup - 1) / kColorGroup;
+    L.groups = partials;
     L.fresh_state = 0;
     L.hessian = hessian;
     L.gradient = gradient;

@@ -268,6 +268,7 @@ inline int resident_workgroups(Kernel kernel, int threads)
 // added up — and therefore every bit of the result — does not depend on the size of the grid,
 // i.e. on the device's CU count or the kernel's occupancy, and equals the launch-per-stage
 // path's partials.
+// A caller that publishes several groups puts a barrier between two calls (lds is reused).
 template <int WAVES>
 __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*lds)[kSysStride],
     const Exchange& E, int step, int group)
@@ -290,7 +291,6 @@ __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*
         ((unsigned long long)exchange_tag(E.epoch, step) << 32) | (unsigned long long)__float_as_uint(v),
         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();   // lds may be written again (the workgroup's next group)
 }
 
 // The counterpart of sum_partials for exchanged sums: same slices, same order within a
@@ -319,27 +319,43 @@ __device__ __forceinline__ bool gather_partials(const Exchange& E, int step, int
     const int items = M * ((E.count + kSysSlices - 1) / kSysSlices);
     for (int i0 = 0; i0 < items && ok; i0 += 16)
     {
+      // sixteen requests in flight; whatever came back with an older tag is asked for again,
+      // all of those together (one round trip per attempt, however many are missing), and
+      // the values are added only once all sixteen are there — in their fixed order
       unsigned long long w[16];
+      unsigned missing = 0;
 #pragma unroll
       for (int q = 0; q < 16; ++q)
       {
         const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);     // slice s0 + m * PASS, term u
-        w[q] = k < E.count ? __hip_atomic_load(words + (size_t)k * kSysStride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (k < E.count) missing |= 1u << q;
       }
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
+      // (Measured and rejected: letting only the lane of a slot's first word poll while the
+      // slot is missing, the others asking again once it has arrived — a quarter of the polling
+      // requests, but one more round trip for most words: 256 -> 278 us per depth Track.)
+      for (;;)
       {
-        const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);
-        if (k < E.count && ok)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
         {
-          unsigned long long word = w[q];
-          while ((uint32_t)(word >> 32) != tag)
-          {
-            if ((unsigned long long)wall_clock64() > deadline) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(2);
-            word = __hip_atomic_load(words + (size_t)k * kSysStride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (ok) v[q % M] += __uint_as_float((uint32_t)word);
+          const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);
+          if (missing & (1u << q))
+            w[q] = __hip_atomic_load(words + (size_t)k * kSysStride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if ((missing & (1u << q)) && (uint32_t)(w[q] >> 32) == tag) missing &= ~(1u << q);
+        if (!missing) break;
+        if ((unsigned long long)wall_clock64() > deadline) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (ok)
+      {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+        {
+          const int k = s0 + (q % M) * PASS + kSysSlices * ((i0 + q) / M);
+          if (k < E.count) v[q % M] += __uint_as_float((uint32_t)w[q]);
         }
       }
     }
@@ -558,9 +574,38 @@ inline Mirror begin_mirror(const vk_track_poll* poll)
 }
 
 
-// The depth tracker's workgroups: kIcpThreads lanes x kIcpPixels pixels each (a lane adds up
-// its pixels' products before the wave reduction, so the 27 x 6 DPP steps, the LDS hop and
-// the barrier are paid once per kIcpPixels pixels), one partial per kIcpGroup pixels.
+// ---- how an image's pixels are grouped into partial sums --------------------------
+//
+// One workgroup adds up one GROUP of consecutive pixels (a lane takes pixels lane, lane +
+// width of the workgroup, ... of the group, in that order). The group size depends on the
+// image alone — never on the device — so the partial sums, and with them every bit of the
+// result, are the same on any GPU and in both loops (launch per stage with a reduce hook, or
+// everything in one launch): the smallest multiple of kGroupQuantum pixels that gives at
+// most kTargetGroups groups. At most that many workgroups exchange their sums in the
+// one-launch loops (the cost of the exchange grows with the square of their number), and
+// there are enough of them to use the whole device at every pyramid level:
+// 640x480 -> 240 groups of 1280 pixels, 320x240 -> 150 of 512, 1280x960 -> 253 of 4864.
+// (Measured on the light tracker, shipped-app loop: groups of 1024 pixels — 75 / 300 of
+// them — 1290 frames/s; this rule 1640.)
+constexpr int kTargetGroups = 256;
+constexpr int kGroupQuantum = 256;
+
+inline int group_pixels_for(int total)
+{
+  int target = kTargetGroups, quantum = kGroupQuantum;
+#ifdef VK_LOOP_TIMING
+  if (const char* e = getenv("VK_TARGET_GROUPS")) target = atoi(e);     // development sweeps only
+  if (const char* e = getenv("VK_GROUP_QUANTUM")) quantum = atoi(e);
+#endif
+  const int per_group = (total + target - 1) / target;
+  const int rounded = (per_group + quantum - 1) / quantum * quantum;
+  return rounded < quantum ? quantum : rounded;
+}
+
+inline int group_count_for(int total, int group_pixels) { return (total + group_pixels - 1) / group_pixels; }
+
+// The depth tracker's workgroups are kIcpThreads lanes wide; a lane works on up to
+// kIcpPixels of its pixels at a time (their keyframe loads are in flight together).
 #ifndef VK_ICP_THREADS
 #define VK_ICP_THREADS 512
 #endif
@@ -569,16 +614,5 @@ inline Mirror begin_mirror(const vk_track_poll* poll)
 #endif
 constexpr int kIcpThreads = VK_ICP_THREADS;
 constexpr int kIcpPixels = VK_ICP_PIXELS;
-constexpr int kIcpGroup = kIcpThreads * kIcpPixels;
-
-inline int icp_group_count(int width, int height)
-{
-  return (width * height + kIcpGroup - 1) / kIcpGroup;
-}
-
-inline int partial_count(int width, int height)
-{
-  return (width * height + kSysThreads - 1) / kSysThreads;
-}
 
 }  // namespace vk

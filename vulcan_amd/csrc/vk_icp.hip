@@ -29,6 +29,7 @@ struct IcpParams
   Rt Twm, Tmw, Twc;
   const vk_transform* Twc_dev;  // optional device override of Twc
   const int32_t* state;         // optional {iterations, converged}: a converged solve skips the pass
+  int group_pixels;             // frame pixels per partial sum (group_pixels_for)
 };
 
 __device__ __forceinline__ Rt rt_from_colmajor(const float* m)
@@ -160,8 +161,14 @@ __device__ void solve_update(const float* hessian, const float* gradient, int tr
 // multi-XCD part the agent-scope release/acquire fences that publish the partials
 // write back and invalidate whole L2s, once per workgroup: the fused iteration
 // took 2.5x as long as the two launches.
-// this lane's pixels: kIcpThreads apart, so that every load is coalesced
-__device__ __forceinline__ int lane_pixel(int group, int k) { return group * kIcpGroup + k * kIcpThreads + (int)threadIdx.x; }
+// pixel `trip` of this lane within a group (kIcpThreads apart, so that every load is
+// coalesced); -1 beyond the group or the image
+__device__ __forceinline__ int lane_pixel(const IcpParams& P, int group, int trip)
+{
+  const int within = trip * kIcpThreads + (int)threadIdx.x;
+  const int pixel = group * P.group_pixels + within;
+  return (within < P.group_pixels && pixel < P.frm.width * P.frm.height) ? pixel : -1;
+}
 
 // evaluate() in two halves, so that a lane with several pixels can have all its keyframe
 // loads in flight at once: everything up to the keyframe pixel's address ...
@@ -221,20 +228,21 @@ __device__ __forceinline__ bool finish_pixel(const IcpParams& P, const Candidate
   return true;
 }
 
-// the 27 products of the lane's pixels of one group, added pixel by pixel onto acc
+// the 27 products of kIcpPixels of the lane's pixels of one group (trips first ...), added
+// pixel by pixel onto acc
 template <bool TRANSLATION>
-__device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& Twc, int group,
+__device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& Twc, int group, int first,
     const FramePixel (&px)[kIcpPixels], float (&acc)[27])
 {
-  const int total = P.frm.width * P.frm.height;
   Candidate cand[kIcpPixels];
   float key_depth[kIcpPixels];
   vf3 key_normal[kIcpPixels];
 #pragma unroll
   for (int k = 0; k < kIcpPixels; ++k)
   {
-    const int pixel = lane_pixel(group, k);
-    cand[k] = prepare_pixel(P, Twc, pixel % P.frm.width, pixel / P.frm.width, pixel < total, px[k]);
+    const int pixel = lane_pixel(P, group, first + k);
+    const int safe = pixel < 0 ? 0 : pixel;
+    cand[k] = prepare_pixel(P, Twc, safe % P.frm.width, safe / P.frm.width, pixel >= 0, px[k]);
   }
 #pragma unroll
   for (int k = 0; k < kIcpPixels; ++k)
@@ -255,14 +263,26 @@ __device__ __forceinline__ void accumulate_pixels(const IcpParams& P, const Rt& 
   }
 }
 
-__device__ __forceinline__ void load_pixels(const IcpParams& P, int group, FramePixel (&px)[kIcpPixels])
+__device__ __forceinline__ void load_pixels(const IcpParams& P, int group, int first, FramePixel (&px)[kIcpPixels])
 {
-  const int total = P.frm.width * P.frm.height;
 #pragma unroll
   for (int k = 0; k < kIcpPixels; ++k)
   {
-    const int pixel = lane_pixel(group, k);
-    px[k] = load_frame_pixel(P.frm, pixel % P.frm.width, pixel < total ? pixel / P.frm.width : P.frm.height);
+    const int pixel = lane_pixel(P, group, first + k);
+    px[k] = load_frame_pixel(P.frm, pixel < 0 ? 0 : pixel % P.frm.width, pixel < 0 ? P.frm.height : pixel / P.frm.width);
+  }
+}
+
+// a group's trips, kIcpPixels at a time
+template <bool TRANSLATION>
+__device__ __forceinline__ void accumulate_group(const IcpParams& P, const Rt& Twc, int group, float (&acc)[27])
+{
+  const int trips = (P.group_pixels + kIcpThreads - 1) / kIcpThreads;
+  for (int first = 0; first < trips; first += kIcpPixels)
+  {
+    FramePixel px[kIcpPixels];
+    load_pixels(P, group, first, px);
+    accumulate_pixels<TRANSLATION>(P, Twc, group, first, px, acc);
   }
 }
 
@@ -276,12 +296,10 @@ __global__ __launch_bounds__(kIcpThreads) void system_partial_kernel(IcpParams P
   if (P.state && P.state[1]) return;
 
   const Rt Twc = P.Twc_dev ? rt_from_colmajor(P.Twc_dev->m) : P.Twc;
-  FramePixel px[kIcpPixels];
-  load_pixels(P, blockIdx.x, px);
   float acc[27];
 #pragma unroll
   for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-  accumulate_pixels<TRANSLATION>(P, Twc, blockIdx.x, px, acc);
+  accumulate_group<TRANSLATION>(P, Twc, blockIdx.x, acc);
   store_partial<kIcpThreads / 64>(acc, lds, workspace);
 }
 
@@ -399,10 +417,11 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   const int steps_before = L.fresh_state ? 0 : L.state[0];
   if (!L.fresh_state && L.state[1]) return;   // uniform over the grid: nobody waits for anybody
 
-  // with one group per workgroup the lane's frame pixels never change: loaded once
-  const bool resident = (int)gridDim.x >= L.groups;
+  // with one group of at most kIcpPixels trips per workgroup the lane's frame pixels never
+  // change: loaded once, kept in registers over all steps
+  const bool resident = (int)gridDim.x >= L.groups && P.group_pixels <= kIcpPixels * kIcpThreads;
   FramePixel px[kIcpPixels];
-  if (resident) load_pixels(P, blockIdx.x, px);
+  if (resident) load_pixels(P, blockIdx.x, 0, px);
 
   if (threadIdx.x < 16) pose_m[threadIdx.x] = L.pose->m[threadIdx.x];
   if (threadIdx.x == 0) { stop = 0; failed = 0; }
@@ -416,11 +435,12 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
     const Rt Twc = rt_from_colmajor(pose_m);
     for (int group = blockIdx.x; group < L.groups; group += gridDim.x)
     {
+      if (group != (int)blockIdx.x) __syncthreads();   // the previous group's sums have left the LDS
       float acc[27];
 #pragma unroll
       for (int i = 0; i < 27; ++i) acc[i] = 0.0f;
-      if (!resident) load_pixels(P, group, px);
-      accumulate_pixels<TRANSLATION>(P, Twc, group, px, acc);
+      if (resident) accumulate_pixels<TRANSLATION>(P, Twc, group, 0, px, acc);
+      else accumulate_group<TRANSLATION>(P, Twc, group, acc);
       VK_STAMP(1);
       publish_partial<kIcpThreads / 64>(acc, lds, L.exchange, it, group);
     }
@@ -596,6 +616,7 @@ int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
   P.Twc = make_rt(Twc->m);
   P.Twc_dev = nullptr;
   P.state = nullptr;
+  P.group_pixels = group_pixels_for(frame->width * frame->height);
   return VK_OK;
 }
 
@@ -681,10 +702,10 @@ int vk_icp_compute_jacobian(const vk_icp_view* keyframe, const vk_transform* Twm
 size_t vk_icp_workspace_floats(int width, int height)
 {
   if (width <= 0 || height <= 0) return 0;
-  // the in-launch exchange of the loop kernels, sized for the photometric trackers' groups of
-  // kSysThreads pixels (the depth tracker's groups are larger, so it has fewer of them; the
-  // rig's launch-per-stage loops use the first partial_count * kSysStride floats)
-  return exchange_floats(partial_count(width, height)) + sizeof(vk_transform) / sizeof(float);
+  // the in-launch exchange of the loop kernels (two parities of one slot per pixel group; the
+  // rig's launch-per-stage loops use the first `groups` * kSysStride floats), sized for the
+  // smallest groups any tracker forms: 256 pixels
+  return exchange_floats((width * height + 255) / 256) + sizeof(vk_transform) / sizeof(float);
 }
 
 int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
@@ -702,7 +723,7 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
   if (rc != VK_OK) return rc;
   VK_REQUIRE(workspace && hessian && gradient);
   P.Twc_dev = Twc_dev;
-  const int partials = icp_group_count(frame->width, frame->height);
+  const int partials = group_count_for(frame->width * frame->height, P.group_pixels);
   launch_partials(P, translation_enabled, partials, workspace, vk_s(stream));
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
@@ -727,7 +748,7 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
   P.state = state_dev;
   float* hessian = system;
   float* gradient = system + 36;
-  const int partials = icp_group_count(frame->width, frame->height);
+  const int partials = group_count_for(frame->width * frame->height, P.group_pixels);
   hipStream_t s = vk_s(stream);
   const bool chunked = polling(poll);
   const Mirror mirror = begin_mirror(poll);
@@ -840,7 +861,7 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
       IcpParams P;
       const int rc = fill_icp(P, views[level][0], Twm, views[level][1], &identity);
       if (rc != VK_OK) return rc;
-      const int rl = launch_loop(P, Twc_dev, steps[level], 1, icp_group_count(views[level][1]->width, views[level][1]->height),
+      const int rl = launch_loop(P, Twc_dev, steps[level], 1, group_count_for(views[level][1]->width * views[level][1]->height, P.group_pixels),
           workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ true, s);
       if (rl != VK_OK) return rl;
     }
