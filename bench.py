@@ -212,10 +212,11 @@ class FrameLoop:
             # tracker -> SetView -> Integrate -> Trace (apps/vulcan/vulcan.cu:300-325): the frame
             # starts from the previous pose and is tracked against the previous raycast (whose
             # pose is poses[i - 1]); the tracked pose is read back, as Tracker::EndSolve does
-            a = self.track_args
+            a, t = self.track_args, self.tracker.tracker
             rc = lib.vk_transform_upload(self.pose_dev, C.byref(self.poses[i - 1]), s)
             rc |= lib.vk_icp_pyramid_track(a[0], C.byref(self.poses[i - 1]), *a[2:], s)
-            rc |= lib.vk_memcpy_d2h(C.byref(self.tracked), self.pose_dev, 128, s)
+            rc |= lib.vk_track_wait(a[-1], s)                       # Tracker::EndSolve: the pose, from pinned memory
+            C.memmove(C.byref(self.tracked), t._pose_host, 128)
             if rc:
                 raise self.api.VkError(f"frame {i}: tracking returned {rc}")
         pose = self.poses[i]                       # ground truth keeps the map consistent

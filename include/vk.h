@@ -475,9 +475,19 @@ VK_API int vk_transform_upload(vk_transform* dst_dev, const vk_transform* src_ho
  * than chunk-1 steps. NULL (or chunk <= 0): enqueue every step, never block. */
 typedef struct vk_track_poll {
   int32_t* host_state;   /* pinned int32[4], 8-byte aligned, zeroed once by the caller: [0..1] the
-                            device's word {steps, converged | call tag}, [2] the library's call counter */
-  int32_t  chunk;        /* steps enqueued between two looks at host_state         */
+                            device's word {steps, converged | call tag}, [2] the library's call counter,
+                            [3] the tag of the last call whose pose has arrived in host_pose             */
+  int32_t  chunk;        /* steps enqueued between two looks at host_state (0: never look)               */
+  vk_transform* host_pose;  /* optional, pinned (vk_malloc_host): every Track also leaves its final pose
+                            here (for the colour trackers: depth_to_world); see vk_track_wait            */
 } vk_track_poll;
+
+/* ref: src/tracker.cpp:78-82 Tracker::EndSolve — the pose of the last Track issued with `poll` is in
+ * poll->host_pose when this returns VK_OK. It watches one word of pinned memory that the last kernel
+ * of the Track writes after the pose (a few microseconds after the kernel is done) instead of copying
+ * the pose and synchronising the stream. VK_ERR_UNSUPPORTED: `stream` drained without the pose having
+ * been left (a Track that failed, or none was issued with this `poll`). */
+VK_API int vk_track_wait(const vk_track_poll* poll, void* stream);
 
 /* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker — up to `iterations`
  * Gauss-Newton steps without a host round trip, ending early once |update| < 1e-6
@@ -580,8 +590,10 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
     vk_color_pose* pose_dev, int32_t* state_dev, float* update_dev, void* stream);
 
 /* ref: src/tracker.cpp:53-63 Tracker::Track for ColorTracker: derive Tcm from
- * pose_dev->depth_to_world, then `iterations` Gauss-Newton steps of two launches
- * each (three with `reduce`), no host round trip. Buffers as in vk_icp_track. */
+ * pose_dev->depth_to_world, then up to `iterations` Gauss-Newton steps without a host
+ * round trip — one launch for the whole loop, as vk_icp_track (three launches per step
+ * with `reduce`). Buffers, early exit and VK_TRACK_ABORTED as in vk_icp_track; `workspace`:
+ * vk_icp_workspace_floats(keyframe w, h). */
 VK_API int vk_color_tracker_track(const vk_color_view* keyframe, const vk_color_view* frame,
     const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc, vk_color_pose* pose_dev,
     int iterations, int translation_enabled, float* workspace, float* system,

@@ -336,3 +336,42 @@ def test_loop_kernel_is_reproducible_and_continues_past_one_launch(api, orc, w, 
         assert st[1] == 1 and 0 < st[0] < 20
         results.append((pose, int(st[0]), tracker.system.cpu().numpy().tobytes()))
     assert len(set(results)) == 1
+
+
+def test_track_wait_hands_over_the_device_pose(api, orc):
+    """vk_track_wait (Tracker::EndSolve): the pose a Track leaves in pinned host memory is the pose
+    on the device, for the one-launch loop, the rig's launch-per-stage loop and the colour tracker;
+    waiting without a Track that could have left one reports it instead of blocking."""
+    import color_scenes as cs
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160, 120)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start)
+    df.compute_normals()
+    for hook in (False, True):
+        tracker = api.DepthTracker()
+        tracker.keyframe = dk
+        if hook:
+            tracker.reduce_hook = lambda system: None
+        df.depth_to_world = start
+        got = tracker.track(df)
+        sync()
+        assert bytes(got) == tracker.pose.cpu().numpy().tobytes()
+        assert bytes(got) != bytes(start)
+    # a poll block no Track has used: the stream drains, nothing arrives
+    fresh = api.DepthTracker()
+    fresh._poll()
+    assert api.lib().vk_track_wait(C.byref(fresh._poll_desc), api.stream()) == -2      # VK_ERR_UNSUPPORTED
+
+    kc = cs.keyframe_images()[1][:h, :w].copy()
+    key = api.Frame(key_depth, k, T.Transform.identity(), color=kc, normals=dk.normals)
+    moved = api.Frame(key_depth, k, start, color=kc, normals=dk.normals)
+    ct = api.ColorTracker()
+    ct.keyframe = key
+    ct.max_iterations = 3
+    got = ct.track(moved)
+    sync()
+    assert bytes(got) == ct.pose.cpu().numpy().tobytes()[:128]

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "vk_transform_upload": ([_P, _P, _P], _I),
     "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_track_wait": ([_P, _P], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_compute_residuals": ([_P, _P, _P, _P, _P], _I),
@@ -513,16 +514,21 @@ class _PollMixin:
     poll_chunk = int(os.environ.get("VK_TRACK_POLL_CHUNK", "4"))   # 0: enqueue every step, never block
 
     def _poll(self):
-        if not self.poll_chunk:
-            return None
         if getattr(self, "_poll_desc", None) is None:
-            host = C.c_void_p()
+            host, pose = C.c_void_p(), C.c_void_p()
             check(lib().vk_malloc_host(C.byref(host), 16), "vk_malloc_host")
+            check(lib().vk_malloc_host(C.byref(pose), C.sizeof(T.Transform)), "vk_malloc_host")
             C.memset(host, 0, 16)
-            self._poll_host = host
-            self._poll_desc = T.TrackPoll(host.value, 0)
-        self._poll_desc.chunk = int(self.poll_chunk)
+            self._poll_host, self._pose_host = host, pose
+            self._poll_desc = T.TrackPoll(host.value, 0, pose.value)
+        self._poll_desc.chunk = int(self.poll_chunk)          # 0: enqueue every step, never look
         return _ref(self._poll_desc)
+
+    def _wait_pose(self):
+        """Tracker::EndSolve (tracker.cpp:78-82): the pose of the Track just issued, picked up from
+        pinned memory (vk_track_wait) instead of a copy + stream synchronisation."""
+        check(lib().vk_track_wait(_ref(self._poll_desc), stream()), "vk_track_wait")
+        return T.Transform.from_buffer_copy(C.string_at(self._pose_host, C.sizeof(T.Transform)))
 
     comm = None                              # vulcan_amd.comm.Communicator: the rig's all-reduce, from C
 
@@ -626,7 +632,7 @@ class DepthTracker(_PollMixin):
                                  int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),
                                  _ptr(self.state), _ptr(self.update), *self._c_hook(), self._poll(), stream()),
               "vk_icp_track")
-        out = T.Transform.from_buffer_copy(self.pose.cpu().numpy().tobytes())
+        out = self._wait_pose()
         frame.depth_to_world = out
         return out
 
@@ -743,9 +749,9 @@ class ColorTracker(_PollMixin):
                                            _ptr(self._workspace()), _ptr(self.system), _ptr(self.state),
                                            _ptr(self.update), hook, hook_user, self._poll(), stream()),
               "vk_color_tracker_track")
-        out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
-        frame.depth_to_world = out.depth_to_world
-        return out.depth_to_world
+        out = self._wait_pose()
+        frame.depth_to_world = out
+        return out
 
 
 class LightTracker(ColorTracker):
@@ -820,9 +826,9 @@ class LightTracker(ColorTracker):
                                            self.max_iterations, int(self.translation_enabled), _ptr(self._workspace()),
                                            _ptr(self.system), _ptr(self.state), _ptr(self.update), *self._c_hook(),
                                            self._poll(), stream()), "vk_light_tracker_track")
-        out = T.ColorPose.from_buffer_copy(self.pose.cpu().numpy().tobytes())
-        frame.depth_to_world = out.depth_to_world
-        return out.depth_to_world
+        out = self._wait_pose()
+        frame.depth_to_world = out
+        return out
 
 
 class PyramidTracker:
@@ -862,7 +868,7 @@ class PyramidTracker:
                                          _ptr(t.pose), _ptr(self._pyramid), _ptr(t._workspace(frame)), _ptr(t.system),
                                          _ptr(t.state), _ptr(t.update), *t._c_hook(), t._poll(), stream()),
               "vk_icp_pyramid_track")
-        out = T.Transform.from_buffer_copy(t.pose.cpu().numpy().tobytes())
+        out = t._wait_pose()
         frame.depth_to_world = out
         return out
 

@@ -490,6 +490,11 @@ __global__ void color_solve_kernel(const float* __restrict__ hessian, const floa
     color_solve_update(hessian, gradient, translation_enabled, A.frame_Tcd, A.key_Twc, A.pose, A.state, A.update_out, A.mirror);
 }
 
+__global__ void color_publish_pose_kernel(Mirror mirror, const vk_color_pose* pose)
+{
+  publish_host_pose(mirror, &pose->depth_to_world);
+}
+
 __global__ void color_prepare_kernel(PoseArgs A)
 {
   if (threadIdx.x == 0 && blockIdx.x == 0) derive_tcm(A.frame_Tcd, A.key_Twc, A.pose);
@@ -509,6 +514,7 @@ struct ColorLoopParams
   int groups;
   int iterations;
   int fresh_state;
+  int last_launch;         // 1: this launch ends the Track (it leaves the pose for vk_track_wait)
   float* hessian;
   float* gradient;
   int32_t* state;
@@ -531,7 +537,11 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
   __shared__ int stop, failed;
 
   const int steps_before = L.fresh_state ? 0 : L.state[0];
-  if (!L.fresh_state && L.state[1]) return;   // uniform over the grid
+  if (!L.fresh_state && L.state[1])           // uniform over the grid
+  {
+    if (blockIdx.x == 0 && L.last_launch) publish_host_pose(L.mirror, &L.pose->depth_to_world);
+    return;
+  }
 
   if (threadIdx.x < 32)
     twd[threadIdx.x] = threadIdx.x < 16 ? L.pose->depth_to_world.m[threadIdx.x] : L.pose->depth_to_world.inv[threadIdx.x - 16];
@@ -629,22 +639,29 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
     const float v = tcm[threadIdx.x];
     if (threadIdx.x < 16) L.pose->Tcm.m[threadIdx.x] = v; else L.pose->Tcm.inv[threadIdx.x - 16] = v;
   }
-  if (steps == 0) return;
-  if (threadIdx.x < 32)
+  if (steps > 0)
   {
-    const float v = twd[threadIdx.x];
-    if (threadIdx.x < 16) L.pose->depth_to_world.m[threadIdx.x] = v; else L.pose->depth_to_world.inv[threadIdx.x - 16] = v;
+    if (threadIdx.x < 32)
+    {
+      const float v = twd[threadIdx.x];
+      if (threadIdx.x < 16) L.pose->depth_to_world.m[threadIdx.x] = v; else L.pose->depth_to_world.inv[threadIdx.x - 16] = v;
+    }
+    if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = last_update[threadIdx.x];
+    if (threadIdx.x == 0)
+    {
+      const int iterations = steps_before + steps;
+      L.state[0] = iterations;
+      L.state[1] = stop;
+      if (L.mirror.word)
+        __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
+            ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
+            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = last_update[threadIdx.x];
-  if (threadIdx.x == 0)
+  if (L.last_launch)
   {
-    const int iterations = steps_before + steps;
-    L.state[0] = iterations;
-    L.state[1] = stop;
-    if (L.mirror.word)
-      __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
-          ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
-          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    publish_host_pose(L.mirror, &L.pose->depth_to_world);
   }
 }
 
@@ -661,6 +678,7 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
     L.exchange.epoch = vk_next_loop_epoch();
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
+    L.last_launch = done + kExchangeSteps >= iterations ? 1 : 0;
     hipLaunchKernelGGL((color_loop_kernel<LIGHT, TRANSLATION>), dim3(grid), dim3(kColorThreads), 0, s, P, L);
     VK_LAUNCH_CHECK();
     L.fresh_state = 0;
@@ -831,7 +849,7 @@ static int system_impl(const vk_color_view* keyframe, const vk_color_view* frame
   A.pose = nullptr;
   A.state = nullptr;
   A.update_out = nullptr;
-  A.mirror = Mirror{nullptr, 0};
+  A.mirror = Mirror{nullptr, 0, nullptr};
   hipLaunchKernelGGL(color_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
       translation_enabled, hessian, gradient, A);
   VK_LAUNCH_CHECK();
@@ -865,7 +883,7 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
   A.pose = pose_dev;
   A.state = state_dev;
   A.update_out = update_dev;
-  A.mirror = Mirror{nullptr, 0};
+  A.mirror = Mirror{nullptr, 0, nullptr};
   hipLaunchKernelGGL(color_solve_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
       translation_enabled, A);
   VK_LAUNCH_CHECK();
@@ -899,7 +917,7 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
   const bool chunked = polling(poll);
   A.mirror = begin_mirror(poll);
   PoseArgs sums_only = A;
-  sums_only.mirror = Mirror{nullptr, 0};
+  sums_only.mirror = Mirror{nullptr, 0, nullptr};
   sums_only.pose = nullptr;
   sums_only.state = nullptr;
   sums_only.update_out = nullptr;
@@ -953,6 +971,11 @@ static int track_impl(const vk_color_view* keyframe, const vk_color_view* frame,
     // at the state one chunk back, so a chunk of launches is always queued behind it
     if (chunked && (it + 1) % poll->chunk == 0 && it + 1 >= 2 * poll->chunk && it + 1 < iterations &&
         wait_for_steps(A.mirror, it + 1 - poll->chunk, s)) break;
+  }
+  if (A.mirror.host_pose)
+  {
+    hipLaunchKernelGGL(color_publish_pose_kernel, dim3(1), dim3(64), 0, s, A.mirror, pose_dev);
+    VK_LAUNCH_CHECK();
   }
   return VK_OK;
 }

@@ -505,11 +505,29 @@ struct Mirror
 {
   unsigned long long* word;
   uint32_t epoch;
+  vk_transform* host_pose;   // optional (vk_track_poll::host_pose): where the final pose is left for vk_track_wait
 };
+
+// The last thing a Track does when the caller gave a host_pose: the pose goes to pinned host
+// memory and then host_state[3] takes the call's tag (system-scope release), so that the
+// host can pick the pose up by watching one word instead of a copy + stream synchronisation.
+// Called by the first 32 lanes of ONE wave (the release of lane 0 then covers all 32 stores).
+__device__ __forceinline__ void publish_host_pose(const Mirror& mirror, const vk_transform* pose)
+{
+  if (!mirror.word || !mirror.host_pose) return;
+  if (threadIdx.x < 32)
+  {
+    const float v = threadIdx.x < 16 ? pose->m[threadIdx.x] : pose->inv[threadIdx.x - 16];
+    if (threadIdx.x < 16) mirror.host_pose->m[threadIdx.x] = v; else mirror.host_pose->inv[threadIdx.x - 16] = v;
+  }
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(mirror.word) + 3, mirror.epoch & 0xffffu, __ATOMIC_RELEASE,
+        __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 template <int N>
 __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* state, float* update_out,
-    Mirror mirror = Mirror{nullptr, 0})
+    Mirror mirror = Mirror{nullptr, 0, nullptr})
 {
   float sq = 0.0f;
 #pragma unroll
@@ -563,16 +581,16 @@ inline bool polling(const vk_track_poll* poll) { return poll && poll->host_state
 // the mirror of one Track call: a fresh epoch, kept in the pinned block itself (word 2)
 inline Mirror begin_mirror(const vk_track_poll* poll)
 {
-  Mirror m{nullptr, 0};
-  if (!polling(poll)) return m;
+  Mirror m{nullptr, 0, nullptr};
+  if (!poll || !poll->host_state) return m;
   volatile int32_t* host = poll->host_state;
   const uint32_t epoch = ((uint32_t)host[2] + 1u) & 0xffffu;
   host[2] = (int32_t)(epoch ? epoch : 1u);        // never 0: a zeroed block matches no call
   m.word = reinterpret_cast<unsigned long long*>(poll->host_state);
   m.epoch = (uint32_t)host[2];
+  m.host_pose = poll->host_pose;
   return m;
 }
-
 
 // ---- how an image's pixels are grouped into partial sums --------------------------
 //

@@ -395,6 +395,7 @@ struct LoopParams
   int groups;                    // 1024-pixel groups of the frame (gridDim.x <= groups)
   int iterations;
   int fresh_state;               // 1: the loop starts at {0 steps, not converged} whatever `state` holds
+  int last_launch;               // 1: this launch ends the Track (it leaves the pose for vk_track_wait)
   float* hessian;
   float* gradient;
   int32_t* state;
@@ -415,7 +416,11 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
 
   // tracker.cpp:162 / Tracker::CreateState: a state that already says "converged" ends the call
   const int steps_before = L.fresh_state ? 0 : L.state[0];
-  if (!L.fresh_state && L.state[1]) return;   // uniform over the grid: nobody waits for anybody
+  if (!L.fresh_state && L.state[1])           // uniform over the grid: nobody waits for anybody
+  {
+    if (blockIdx.x == 0 && L.last_launch) publish_host_pose(L.mirror, L.pose);
+    return;
+  }
 
   // with one group of at most kIcpPixels trips per workgroup the lane's frame pixels never
   // change: loaded once, kept in registers over all steps
@@ -486,26 +491,34 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
     if (threadIdx.x == 0) L.state[1] = VK_TRACK_ABORTED;
     return;
   }
-  if (!publisher || steps == 0) return;
-  if (threadIdx.x == 0)
+  if (!publisher) return;
+  if (steps > 0)
   {
-    float M[16], out_m[16], out_i[16];
+    if (threadIdx.x == 0)
+    {
+      float M[16], out_m[16], out_i[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) M[i] = result[i];
-    rigid_from(M, out_m, out_i);
+      for (int i = 0; i < 16; ++i) M[i] = result[i];
+      rigid_from(M, out_m, out_i);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { L.pose->m[i] = out_m[i]; L.pose->inv[i] = out_i[i]; }
+      for (int i = 0; i < 16; ++i) { L.pose->m[i] = out_m[i]; L.pose->inv[i] = out_i[i]; }
+    }
+    if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = result[16 + threadIdx.x];
+    if (threadIdx.x == 0)
+    {
+      const int iterations = steps_before + steps;
+      L.state[0] = iterations;
+      L.state[1] = stop;
+      if (L.mirror.word)
+        __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
+            ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
+            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
-  if (threadIdx.x < 6 && L.update_out) L.update_out[threadIdx.x] = result[16 + threadIdx.x];
-  if (threadIdx.x == 0)
+  if (L.last_launch)
   {
-    const int iterations = steps_before + steps;
-    L.state[0] = iterations;
-    L.state[1] = stop;
-    if (L.mirror.word)
-      __hip_atomic_store(L.mirror.word, ((unsigned long long)(L.mirror.epoch & 0xffffu) << 48) |
-          ((unsigned long long)(uint32_t)(stop & 1) << 32) | (uint32_t)iterations,
-          __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();   // lane 0's pose stores are visible to the 32 lanes that copy them out
+    publish_host_pose(L.mirror, L.pose);
   }
 }
 
@@ -628,10 +641,16 @@ void launch_partials(const IcpParams& P, int translation_enabled, int partials, 
     hipLaunchKernelGGL(system_partial_kernel<false>, dim3(partials), dim3(kIcpThreads), 0, s, P, workspace);
 }
 
+// the rig's launch-per-stage loop ends with this when the caller wants the pose in host memory
+__global__ void publish_pose_kernel(Mirror mirror, const vk_transform* pose)
+{
+  publish_host_pose(mirror, pose);
+}
+
 // the non-rig loop: one launch (track_loop_kernel)
 int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int translation_enabled, int groups,
     float* workspace, float* hessian, float* gradient, int32_t* state_dev, float* update_dev, Mirror mirror,
-    bool fresh_state, hipStream_t s)
+    bool fresh_state, bool ends_track, hipStream_t s)
 {
   VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
   const int capacity = translation_enabled ? resident_workgroups(track_loop_kernel<true>, kIcpThreads)
@@ -656,6 +675,7 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.fresh_state = (fresh_state && done == 0) ? 1 : 0;
+    L.last_launch = (ends_track && done + kExchangeSteps >= iterations) ? 1 : 0;
     if (translation_enabled)
       hipLaunchKernelGGL(track_loop_kernel<true>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
     else
@@ -728,7 +748,7 @@ int vk_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm,
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, vk_s(stream), workspace, partials,
       translation_enabled, hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr,
-      Mirror{nullptr, 0});
+      Mirror{nullptr, 0, nullptr});
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -755,7 +775,7 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
 
   if (!reduce)
     return launch_loop(P, Twc_dev, iterations, translation_enabled, partials, workspace, hessian, gradient,
-        state_dev, update_dev, mirror, /*fresh_state*/ false, s);
+        state_dev, update_dev, mirror, /*fresh_state*/ false, /*ends_track*/ true, s);
 
   for (int it = 0; it < iterations; ++it)
   {
@@ -763,7 +783,7 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
 
     // multi-GPU rig: sum the packed system over ranks before every rank solves it
     hipLaunchKernelGGL(system_final_kernel, dim3(1), dim3(256), 0, s, workspace, partials, translation_enabled,
-        hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr, Mirror{nullptr, 0});
+        hessian, gradient, (vk_transform*)nullptr, (int32_t*)nullptr, (float*)nullptr, Mirror{nullptr, 0, nullptr});
     VK_LAUNCH_CHECK();
     const int rr = reduce(system, 48, reduce_user, stream);
     if (rr != 0) return rr;
@@ -776,6 +796,11 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
     // at the mirror every `chunk` steps and stops enqueuing when the loop has converged.
     if (chunked && (it + 1) % poll->chunk == 0 && it + 1 >= 2 * poll->chunk && it + 1 < iterations &&
         wait_for_steps(mirror, it + 1 - poll->chunk, s)) break;
+  }
+  if (mirror.host_pose)
+  {
+    hipLaunchKernelGGL(publish_pose_kernel, dim3(1), dim3(64), 0, s, mirror, Twc_dev);
+    VK_LAUNCH_CHECK();
   }
   return VK_OK;
 }
@@ -862,7 +887,7 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
       const int rc = fill_icp(P, views[level][0], Twm, views[level][1], &identity);
       if (rc != VK_OK) return rc;
       const int rl = launch_loop(P, Twc_dev, steps[level], 1, group_count_for(views[level][1]->width * views[level][1]->height, P.group_pixels),
-          workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ true, s);
+          workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ true, /*ends_track*/ level == 1, s);
       if (rl != VK_OK) return rl;
     }
     return VK_OK;
@@ -876,12 +901,27 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
       reduce, reduce_user, poll, stream);
 }
 
+int vk_track_wait(const vk_track_poll* poll, void* stream)
+{
+  VK_REQUIRE(poll && poll->host_state && poll->host_pose);
+  const volatile int32_t* host = poll->host_state;
+  const int32_t tag = host[2];
+  if (tag == 0) return VK_ERR_UNSUPPORTED;      // no Track has been issued with this block (tags are never 0)
+  hipStream_t s = vk_s(stream);
+  for (unsigned spin = 0;; ++spin)
+  {
+    if (host[3] == tag) return VK_OK;
+    if ((spin & 1023u) == 1023u && hipStreamQuery(s) != hipErrorNotReady)
+      return host[3] == tag ? VK_OK : VK_ERR_UNSUPPORTED;      // drained: whatever is there is final
+  }
+}
+
 int vk_icp_solve_update(const float* hessian, const float* gradient, int translation_enabled,
     vk_transform* Twc_dev, int32_t* state_dev, float* update_dev, void* stream)
 {
   VK_REQUIRE(hessian && gradient && Twc_dev);
   hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
-      translation_enabled, Twc_dev, state_dev, update_dev, Mirror{nullptr, 0});
+      translation_enabled, Twc_dev, state_dev, update_dev, Mirror{nullptr, 0, nullptr});
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

@@ -43,9 +43,16 @@ Tracker::Tracker() :
   VK_ASSERT(vk_malloc_host(&pinned, 4 * sizeof(int32_t)));
   poll_.host_state = static_cast<int32_t*>(pinned);
   for (int i = 0; i < 4; ++i) poll_.host_state[i] = 0;
+  poll_.host_pose = nullptr;
+  VK_ASSERT(vk_malloc_host(&pinned, sizeof(vk_transform)));
+  poll_.host_pose = static_cast<vk_transform*>(pinned);
 }
 
-Tracker::~Tracker() { vk_free_host(poll_.host_state); }
+Tracker::~Tracker()
+{
+  vk_free_host(poll_.host_pose);
+  vk_free_host(poll_.host_state);
+}
 
 std::shared_ptr<const Frame> Tracker::GetKeyframe() const { return keyframe_; }
 
@@ -103,14 +110,18 @@ void Tracker::BeginSolve(const Frame& frame)
   ResizeBuffers(frame);
   iteration_ = 0;
   const vk_transform pose = frame.depth_to_world_transform.ToVk();
+  poll_.host_state[3] = 0;   // no pose of this solve has arrived yet (tags are never 0)
   VK_ASSERT(vk_transform_upload(DevicePose(), &pose, Device::GetStream()));
   VK_ASSERT(vk_memset(state_.GetData(), 0, 2 * sizeof(int), Device::GetStream()));
 }
 
 void Tracker::EndSolve(Frame& frame)
 {
+  // the device loops leave the pose in pinned memory (vk_track_wait); a loop that does not
+  // (the step-by-step default of this class) is read back with a copy
   vk_transform pose;
-  VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));  // the only readback of the solve
+  if (vk_track_wait(&poll_, Device::GetStream()) == VK_OK) pose = *poll_.host_pose;
+  else VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));
   frame.depth_to_world_transform = Transform::FromVk(pose);
 }
 
@@ -209,6 +220,7 @@ void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& fr
   if (floats > pyramid_.GetSize()) pyramid_.Resize(floats);
   const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
   const vk_transform pose = frame.depth_to_world_transform.ToVk();
+  poll_.host_state[3] = 0;
   VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_icp_pyramid_track(&key, &Twm, &frm, pose_.GetData(), pyramid_.GetData(), workspace_.GetData(),

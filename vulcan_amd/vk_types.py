@@ -161,7 +161,7 @@ class LightTerms(C.Structure):
 
 
 class TrackPoll(C.Structure):
-    _fields_ = [("host_state", C.c_void_p), ("chunk", C.c_int32)]
+    _fields_ = [("host_state", C.c_void_p), ("chunk", C.c_int32), ("host_pose", C.c_void_p)]
 
 
 class ColorPose(C.Structure):
