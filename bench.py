@@ -191,6 +191,15 @@ class FrameLoop:
         self.m_ptr = None if self.mask is None else C.c_void_p(self.mask.data_ptr())
         self.r_ptr = None if self.records is None else C.c_void_p(self.records.data_ptr())
         self.depth_threshold = 0.2                                  # light_integrator.cu:256
+        # Volume::SetView prepares the light integrator's mask and records in its own request pass
+        # (vk_light_prep), as the class layer does; one record for all replica volumes
+        self.prep = None
+        if workload != "depth":
+            self.prep = T.LightPrep()
+            self.prep.depth_threshold = self.depth_threshold
+            self.prep.mask, self.prep.records = self.mask.data_ptr(), self.records.data_ptr()
+            self.prep.capacity = W * H
+        self.pprep = None if self.prep is None else C.byref(self.prep)
         self.tracker = None
         if workload == "rgbd-icp":
             # PyramidTracker<DepthTracker>::Track through its one C entry point, descriptors built once
@@ -225,9 +234,12 @@ class FrameLoop:
         self.fdesc.depth_to_world = pose
         self.kdesc.depth_to_world = pose
         vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
-        rc = lib.vk_volume_set_view(vv["vref"], self.fref, s)                       # volume.cu:430-437
+        rc = lib.vk_volume_set_view_prepare(vv["vref"], self.fref, self.pprep, s)   # volume.cu:430-437 (+ light_integrator.cu:277-293)
         if self.mode == 2:
-            rc |= lib.vk_light_prepare(self.fref, self.depth_threshold, self.m_ptr, self.r_ptr, s)   # light_integrator.cu:277-293
+            if lib.vk_light_prepared(self.pprep, self.fref, C.c_float(self.depth_threshold)):
+                self.prep.valid = 0
+            else:
+                rc |= lib.vk_light_prepare(self.fref, self.depth_threshold, self.m_ptr, self.r_ptr, s)
         if ev:
             lib.vk_event_record(ev[0], s)
         rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr, self.r_ptr,

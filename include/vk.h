@@ -352,6 +352,45 @@ VK_API int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth,
     float max_depth, float* bounds, int bounds_width, int bounds_height,
     float* out_depth, float* out_color, float* out_normals, void* stream);
 
+/* ------------------------------------------- light preparation, with SetView -- */
+
+/* LightIntegrator's per-pixel preparation (vk_light_prepare: the frame mask and one
+ * {Tcd * normal, mask} record per depth pixel) walks the depth image one lane per pixel,
+ * exactly as the request pass of vk_volume_set_view does, and as a launch of its own most
+ * of its ~6 us is the launch. An application that integrates the frame it has just set
+ * the view from (the reference's frame loop, apps/vulcan/vulcan.cu:316-325) can have it
+ * computed by that pass: vk_volume_set_view_prepare fills prep->mask / prep->records and
+ * notes which frame they are for; the integrator asks (vk_light_prepared) and skips its
+ * own pass on a match. The images must not be modified between the two calls.
+ * No reference counterpart; results are identical with or without it. */
+typedef struct vk_light_prep {
+  /* set by the caller */
+  float  depth_threshold;      /* LightIntegrator::depth_threshold_ (light_integrator.cu:256) */
+  float* mask;                 /* device float[capacity]                                       */
+  float* records;              /* device float[4 * capacity], 16-byte aligned                  */
+  int32_t capacity;            /* pixels the two buffers hold: a larger frame is not prepared  */
+  /* set by vk_volume_set_view_prepare, compared by vk_light_prepared */
+  int32_t      valid;
+  int32_t      width, height;
+  const float* depth;
+  const float* color;
+  const float* normals;
+  float        prepared_threshold;
+  vk_transform depth_to_color;
+} vk_light_prep;
+
+/* ref: src/volume.cu:430-437 Volume::SetView (as vk_volume_set_view) + src/light_integrator.cu:
+ * 277-293 — with a `prep` whose buffers are set and a frame that has colour and normals of
+ * the depth image's size, the same three launches also do vk_light_prepare. prep->valid
+ * tells whether they did. */
+VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
+    void* stream);
+
+/* ref: src/light_integrator.cu:270-275 LightIntegrator::Integrate decides here whether
+ * ComputeFrameMask still has to run: 1 if *prep holds the preparation of exactly `frame` (same
+ * image pointers and size, same depth->colour transform) at `depth_threshold`, else 0. */
+VK_API int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float depth_threshold);
+
 /* ---------------------------------------------------- raycast bounds, ahead -- */
 
 /* The first stage of a raycast (per-cell depth bounds of the visible blocks,

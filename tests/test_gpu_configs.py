@@ -375,3 +375,57 @@ def test_track_wait_hands_over_the_device_pose(api, orc):
     got = ct.track(moved)
     sync()
     assert bytes(got) == ct.pose.cpu().numpy().tobytes()[:128]
+
+
+def test_set_view_prepares_the_light_integrator(api, orc):
+    """vk_volume_set_view_prepare: the request pass of SetView also leaves LightIntegrator's frame
+    mask and per-pixel records — the same bits as vk_light_prepare — and the volume ends up exactly
+    as with the separate pass; a frame without normals, a second integrate of the same frame and a
+    larger frame fall back to the pass of their own."""
+    import torch
+    w, h = 200, 150                       # not a multiple of the request pass's 64x4 patches
+    k = T.Projection.make(170.0, 170.0, 100.3, 74.6)
+    rng = np.random.default_rng(5)
+    depth = (1.2 + 0.1 * np.sin(np.arange(w)[None, :] / 9.0) * np.cos(np.arange(h)[:, None] / 7.0)).astype(np.float32)
+    depth[rng.random((h, w)) < 0.02] = 0.0                       # holes: the 7x7 window sees them
+    depth[40:60, 80:100] += 0.5                                  # a step edge: mask 0 around it
+    color = rng.random((h, w, 3), dtype=np.float32)              # some pixels outside [0.02, 0.98]
+    pose = T.Transform.translate(0.01, -0.02, 0.03)
+
+    def run(fused):
+        vol = api.Volume(4096, 1024, voxel_length=0.008, truncation_length=0.04)
+        integ = api.LightIntegrator(vol)
+        integ.light = T.Light.make(1.3, (0.02, -0.01, 0.0))
+        frame = api.Frame(depth, k, pose, color=color)
+        frame.compute_normals()
+        for i in range(3):
+            frame.depth_to_world = T.Transform.translate(0.01 * i, -0.02, 0.03)
+            if not fused:
+                vol.light_prep = None                            # plain vk_volume_set_view every time
+            vol.set_view(frame)
+            if fused and i > 0:
+                assert integ._prep.valid == 1                    # prepared by set_view
+            integ.integrate(frame)
+            if fused:
+                assert integ._prep.valid == 0                    # used once
+        sync()
+        return (vol.voxels.cpu().numpy().tobytes(), vol.hash_entries.cpu().numpy().tobytes(),
+                integ.frame_mask.cpu().numpy().tobytes(), integ.pixel_records.cpu().numpy().tobytes())
+
+    assert run(True) == run(False)
+
+    # fallbacks: no normals -> no ride; a frame larger than the registered buffers -> no ride
+    vol = api.Volume(4096, 1024, voxel_length=0.008, truncation_length=0.04)
+    integ = api.LightIntegrator(vol)
+    frame = api.Frame(depth, k, pose, color=color)
+    frame.compute_normals()
+    vol.set_view(frame)
+    integ.integrate(frame)                                       # registers w x h buffers
+    bare = api.Frame(depth, k, pose, color=color)                # no normal image
+    vol.set_view(bare)
+    assert integ._prep.valid == 0
+    big = api.Frame(np.full((h + 8, w), 1.5, dtype=np.float32), k, pose, color=np.full((h + 8, w, 3), 0.5, dtype=np.float32))
+    big.compute_normals()
+    vol.set_view(big)
+    assert integ._prep.valid == 0
+    sync()

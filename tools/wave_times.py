@@ -53,5 +53,11 @@ for use_touched in (False, True):
     print(f"  wave end: median {np.median(end):.1f} p90 {np.percentile(end, 90):.1f} p99 {np.percentile(end, 99):.1f}")
     lt = life.reshape(30, 40, 4).max(axis=2)
     print("  life by tile row (max over the row):", np.round(lt.max(axis=1), 1))
+    if os.environ.get("VK_WAVE_MAP"):
+        np.set_printoptions(linewidth=250)
+        print("  life per 16x16 tile (max of its 4 waves), rows top to bottom:")
+        print(np.round(lt).astype(int))
+        print("  wave START per tile (us):")
+        print(np.round(start.reshape(30, 40, 4).max(axis=2)).astype(int))
     assert torch.equal(d2, out.depth)
 print("blocks touched by rays (Nhit):", int(touched.sum()), "visible:", vol.visible_count)

@@ -78,6 +78,8 @@ _SIGNATURES = {
     "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_track_wait": ([_P, _P], _I),
+    "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
+    "vk_light_prepared": ([_P, _P, C.c_float], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
     "vk_color_tracker_compute_residuals": ([_P, _P, _P, _P, _P], _I),
@@ -287,9 +289,20 @@ class Volume:
         return d
 
     # -- Volume::SetView and its four protected stages (volume.cu:430-535)
+    light_prep = None      # T.LightPrep of an attached LightIntegrator (attach_light_preparation)
+
+    def attach_light_preparation(self, prep):
+        """A LightIntegrator's mask / record buffers: set_view fills them in its own request pass
+        (vk_volume_set_view_prepare) for the integrate that follows."""
+        self.light_prep = prep
+
     def set_view(self, frame):
         self._view_changed()
-        check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
+        if self.light_prep is not None:
+            check(lib().vk_volume_set_view_prepare(_ref(self.desc()), _ref(frame.desc()), _ref(self.light_prep),
+                                                   stream()), "vk_volume_set_view_prepare")
+        else:
+            check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
 
     def reset_block_visibility(self):
         check(lib().vk_volume_reset_block_visibility(_ref(self.desc()), stream()), "reset_block_visibility")
@@ -414,6 +427,18 @@ class LightIntegrator(Integrator):
             self.frame_mask = torch.empty(shape, dtype=torch.float32, device=frame.device)
         if self.pixel_records is None or tuple(self.pixel_records.shape[:2]) != shape:
             self.pixel_records = torch.empty(shape + (4,), dtype=torch.float32, device=frame.device)
+        prep = getattr(self, "_prep", None)
+        if prep is None or prep.mask != self.frame_mask.data_ptr() or prep.records != self.pixel_records.data_ptr():
+            # (re)attach: the volume's next set_view prepares these buffers in its request pass
+            prep = T.LightPrep()
+            prep.mask, prep.records = self.frame_mask.data_ptr(), self.pixel_records.data_ptr()
+            prep.capacity = frame.width * frame.height
+            self._prep = prep
+            self.volume.attach_light_preparation(prep)
+        prep.depth_threshold = self.depth_threshold
+        if lib().vk_light_prepared(_ref(prep), _ref(frame.desc()), self.depth_threshold):
+            prep.valid = 0                           # used once: a second integrate of the frame prepares again
+            return
         check(lib().vk_light_prepare(_ref(frame.desc()), self.depth_threshold, _ptr(self.frame_mask),
                                      _ptr(self.pixel_records), stream()), "vk_light_prepare")
 

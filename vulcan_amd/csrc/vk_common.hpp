@@ -203,4 +203,31 @@ __device__ __forceinline__ void wave_lds_fence()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// ---- LightIntegrator's per-pixel preparation (ref: light_integrator.cu:16-94 frame mask,
+// :215-225 the per-pixel half of the colour kernel) — shared by frame_mask_kernel and by the
+// request pass of vk_volume_set_view_prepare. `window`: a depth tile in LDS, zero outside the
+// image, `stride` floats per row, in which pixel (x, y) sits at window[(cy - 2) * stride + cx - 2]
+// — upstream stages its tile with a -1 halo offset and reads it with a +3 centre, so the
+// 7x7 window of pixel (x, y) is [x-1, x+5] x [y-1, y+5] (kept as is) and (cx, cy)
+// is the window's CENTRE (x + 2, y + 2) in tile coordinates.
+__device__ __forceinline__ float light_window_mask(const float* window, int stride, int cx, int cy, float depth_threshold)
+{
+  float dmin = +FLT_MAX;
+  float dmax = -FLT_MAX;
+  for (int i = -3; i <= 3; ++i)
+    for (int j = -3; j <= 3; ++j)
+    {
+      const float depth = window[(cy + i) * stride + (cx + j)];
+      dmin = fminf(depth, dmin);
+      dmax = fmaxf(depth, dmax);
+    }
+  return (dmax - dmin <= depth_threshold) ? 1.0f : 0.0f;
+}
+
+__device__ __forceinline__ bool light_color_usable(float c0, float c1, float c2)
+{
+  return !(c0 < 0.02f || c0 > 0.98f || c1 < 0.02f || c1 > 0.98f || c2 < 0.02f || c2 > 0.98f);
+}
+
 }  // namespace vk

@@ -601,27 +601,14 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(int width, int height,
       Xcn = xform_dir(Tcd, make3(n.x, n.y, n.z));                     // light_integrator.cu:223
     }
 
-    if (c0 < 0.02f || c0 > 0.98f || c1 < 0.02f || c1 > 0.98f || c2 < 0.02f || c2 > 0.98f)
+    if (!light_color_usable(c0, c1, c2))
     {
       mask[index] = 0.0f;
       if (records) records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, 0.0f);
       return;
     }
 
-    float dmin = +FLT_MAX;
-    float dmax = -FLT_MAX;
-    const int cx = tx + KS;
-    const int cy = ty + KS;
-
-    for (int i = -KS; i <= KS; ++i)
-      for (int j = -KS; j <= KS; ++j)
-      {
-        const float depth = buffer[(cy + i) * DIM + (cx + j)];
-        dmin = fminf(depth, dmin);
-        dmax = fmaxf(depth, dmax);
-      }
-
-    const float m = (dmax - dmin <= depth_threshold) ? 1.0f : 0.0f;
+    const float m = light_window_mask(buffer, DIM, tx + KS, ty + KS, depth_threshold);
     mask[index] = m;
     if (records) records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
   }

@@ -6,6 +6,8 @@
 // v.counters[VK_CTR_VISIBLE]; every consumer reads it on the device.
 #include "vk_common.hpp"
 
+#include <string.h>
+
 using namespace vk;
 
 namespace
@@ -172,15 +174,55 @@ struct RequestParams
   int width, height;
   vk_projection k;
   Rt Twd;
+  // PREP only: LightIntegrator's per-pixel preparation rides along (vk_volume_set_view_prepare)
+  const float* colors;
+  const float* normals;
+  Rt Tcd;
+  float depth_threshold;
+  float* mask;
+  float4* records;
 };
 
 // ref: volume.cu:87-301. One lane per depth pixel; the lanes of a wave cover a
 // 64x1 run of a row so the depth read is one coalesced 256-byte load.
-template <bool DEFER>
+//
+// PREP: the same pass also leaves LightIntegrator's frame mask and per-pixel records
+// (light_integrator.cu:16-94,215-225; frame_mask_kernel in vk_integrate.hip is the launch of
+// its own) — both walk the depth image one lane per pixel, and as a launch of its own the
+// mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
+// depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
+template <bool DEFER, bool PREP>
 __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+
+  if (PREP)
+  {
+    constexpr int TW = 70, TH = 10, TS = 72;
+    __shared__ float tile[TH * TS];
+    const int x0 = (int)blockIdx.x * 64 - 1, y0 = (int)blockIdx.y * 4 - 1;
+    for (int i = threadIdx.x; i < TW * TH; i += 256)
+    {
+      const int r = i / TW, c = i - r * TW;
+      const int vx = x0 + c, vy = y0 + r;
+      tile[r * TS + c] = (vx >= 0 && vx < P.width && vy >= 0 && vy < P.height) ? P.depth[vy * P.width + vx] : 0.0f;
+    }
+    __syncthreads();
+    if (x < P.width && y < P.height)
+    {
+      const int index = y * P.width + x;
+      const vf3 rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
+      const vf3 n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
+      const f3 Xcn = xform_dir(P.Tcd, make3(n.x, n.y, n.z));                     // light_integrator.cu:223
+      float m = 0.0f;
+      if (light_color_usable(rgb.x, rgb.y, rgb.z))
+        m = light_window_mask(tile, TS, (int)(threadIdx.x & 63) + 3, (int)(threadIdx.x >> 6) + 3, P.depth_threshold);
+      P.mask[index] = m;
+      P.records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
+    }
+  }
+
   if (y >= P.height) return;                       // whole wave
 
   const vk_volume& v = P.v;
@@ -666,7 +708,8 @@ int check_volume(const vk_volume* v)
 }
 
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
-    const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s)
+    const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s,
+    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr)
 {
   RequestParams P;
   P.v = *v;
@@ -675,9 +718,24 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
   P.height = height;
   P.k = *projection;
   P.Twd = make_rt(Twd->m);
+  P.colors = P.normals = nullptr;
+  P.Tcd = P.Twd;
+  P.depth_threshold = 0.0f;
+  P.mask = nullptr;
+  P.records = nullptr;
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
-  if (deferred_reset) hipLaunchKernelGGL(create_requests_kernel<true>, grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(create_requests_kernel<false>, grid, dim3(256), 0, s, P);
+  if (prep && prep_frame)
+  {
+    P.colors = prep_frame->color;
+    P.normals = prep_frame->normals;
+    P.Tcd = make_rt(prep_frame->depth_to_color.m);
+    P.depth_threshold = prep->depth_threshold;
+    P.mask = prep->mask;
+    P.records = reinterpret_cast<float4*>(prep->records);
+    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P);
+  }
+  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -768,21 +826,63 @@ int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
   return launch_update_visibility(v, width, height, projection, Tdw->m, false, false, vk_s(stream));
 }
 
-int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
+// does `prep` hold the preparation of exactly this frame (same images, size, threshold, Tcd)?
+static bool prep_is_for(const vk_light_prep* prep, const vk_frame* frame)
+{
+  return prep && prep->valid && prep->depth == frame->depth && prep->color == frame->color &&
+      prep->normals == frame->normals && prep->width == frame->width && prep->height == frame->height &&
+      memcmp(&prep->depth_to_color, &frame->depth_to_color, sizeof(vk_transform)) == 0;
+}
+
+int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float depth_threshold)
+{
+  return (frame && prep_is_for(prep, frame) && prep->prepared_threshold == depth_threshold) ? 1 : 0;
+}
+
+static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, void* stream)
 {
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0);
   hipStream_t s = vk_s(stream);
+  // the preparation rides along when the frame has what LightIntegrator needs, in the
+  // depth image's size (light_integrator.cu:277-293 walks the colour image with it)
+  const bool ride = prep && prep->mask && prep->records && frame->color && frame->normals &&
+      (long long)frame->width * frame->height <= (long long)prep->capacity &&
+      (reinterpret_cast<uintptr_t>(prep->records) & 15) == 0 &&
+      (frame->color_width <= 0 || frame->color_width == frame->width) &&
+      (frame->color_height <= 0 || frame->color_height == frame->height);
+  if (prep) prep->valid = 0;
   // three launches: the reset pass is folded into the other three (see kTouched)
   int r;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
-           &frame->depth_projection, &frame->depth_to_world, true, s)) != VK_OK) return r;
+           &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr)) != VK_OK) return r;
+  if (ride)
+  {
+    prep->depth = frame->depth;
+    prep->color = frame->color;
+    prep->normals = frame->normals;
+    prep->width = frame->width;
+    prep->height = frame->height;
+    prep->depth_to_color = frame->depth_to_color;
+    prep->prepared_threshold = prep->depth_threshold;
+    prep->valid = 1;
+  }
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
       dim3(kHandleThreads), 0, s, *v, 1, 1);
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
   return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
       frame->depth_to_world.inv, true, true, s);
+}
+
+int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
+{
+  return set_view(v, frame, nullptr, stream);
+}
+
+int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, void* stream)
+{
+  return set_view(v, frame, prep, stream);
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)

@@ -81,6 +81,8 @@ class LightIntegrator : public Integrator
   public:
     explicit LightIntegrator(std::shared_ptr<Volume> volume);
 
+    ~LightIntegrator();   // takes its buffers off the volume's light preparation record
+
     const Light& GetLight() const;
     void SetLight(const Light& light);
 

@@ -80,6 +80,14 @@ class Volume
     void AttachViewBounds(float* scratch, int bounds_width, int bounds_height, const Vector2f& depth_range) const;
     void DetachViewBounds(const float* scratch) const;   // no-op unless `scratch` is the attached one
 
+    // LightIntegrator's per-pixel preparation, ahead of time (vk_light_prep, not upstream): a
+    // LightIntegrator registers its mask / record buffers here and SetView fills them in its own
+    // request pass, for the Integrate of the same frame that follows (the frame must not be
+    // modified in between). nullptr while nothing is attached.
+    vk_light_prep* GetLightPreparation() const;
+    void AttachLightPreparation(float* mask, float* records, int capacity_pixels, float depth_threshold) const;
+    void DetachLightPreparation(const float* mask) const;   // no-op unless `mask` is the attached one
+
   protected:
     // the four stages of SetView, in call order
     void ResetBlockVisibility();
@@ -108,6 +116,7 @@ class Volume
     bool empty_;
     mutable bool visible_count_stale_;
     mutable vk_view_bounds view_bounds_;
+    mutable vk_light_prep light_prep_;
 
   private:
     void Initialize();

@@ -105,6 +105,8 @@ LightIntegrator::LightIntegrator(std::shared_ptr<Volume> volume) :
 {
 }
 
+LightIntegrator::~LightIntegrator() { volume_->DetachLightPreparation(frame_mask_.GetData()); }
+
 const Light& LightIntegrator::GetLight() const { return light_; }
 
 void LightIntegrator::SetLight(const Light& light) { light_ = light; }
@@ -121,7 +123,17 @@ void LightIntegrator::Integrate(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_light l = light_.ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_light_prepare(&f, depth_threshold_, frame_mask_.GetData(), pixel_records_.GetData(), Device::GetStream()));
+  // Volume::SetView prepares these buffers in its own request pass once they are registered
+  // (vk_light_prep); whenever it has not done so for this very frame the pass runs here
+  vk_light_prep* prep = volume_->GetLightPreparation();
+  if (!prep || prep->mask != frame_mask_.GetData() || prep->records != pixel_records_.GetData() ||
+      prep->capacity != w * h || prep->depth_threshold != depth_threshold_)
+  {
+    volume_->AttachLightPreparation(frame_mask_.GetData(), pixel_records_.GetData(), w * h, depth_threshold_);
+    prep = volume_->GetLightPreparation();
+  }
+  if (vk_light_prepared(prep, &f, depth_threshold_)) prep->valid = 0;   // used once
+  else VK_ASSERT(vk_light_prepare(&f, depth_threshold_, frame_mask_.GetData(), pixel_records_.GetData(), Device::GetStream()));
   VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 2, &l, frame_mask_.GetData(), pixel_records_.GetData(),
       volume_->GetViewBounds(), Device::GetStream()));
 }

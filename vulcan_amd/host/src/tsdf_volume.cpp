@@ -21,6 +21,7 @@ Volume::Volume(int main_block_count, int excess_block_count) :
   visible_count_stale_(false)
 {
   std::memset(&view_bounds_, 0, sizeof(view_bounds_));
+  std::memset(&light_prep_, 0, sizeof(light_prep_));
   Initialize();
 }
 
@@ -95,13 +96,29 @@ void Volume::DetachViewBounds(const float* scratch) const
   if (view_bounds_.scratch == scratch) std::memset(&view_bounds_, 0, sizeof(view_bounds_));
 }
 
+vk_light_prep* Volume::GetLightPreparation() const { return light_prep_.mask ? &light_prep_ : nullptr; }
+
+void Volume::AttachLightPreparation(float* mask, float* records, int capacity_pixels, float depth_threshold) const
+{
+  std::memset(&light_prep_, 0, sizeof(light_prep_));
+  light_prep_.mask = mask;
+  light_prep_.records = records;
+  light_prep_.capacity = capacity_pixels;
+  light_prep_.depth_threshold = depth_threshold;
+}
+
+void Volume::DetachLightPreparation(const float* mask) const
+{
+  if (light_prep_.mask == mask) std::memset(&light_prep_, 0, sizeof(light_prep_));
+}
+
 void Volume::SetView(const Frame& frame)
 {
   view_bounds_.valid = 0;   // the visible list is about to change
   VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
   const vk_volume v = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_volume_set_view(&v, &f, Device::GetStream()));
+  VK_ASSERT(vk_volume_set_view_prepare(&v, &f, GetLightPreparation(), Device::GetStream()));
   visible_count_stale_ = true;
   empty_ = false;
 }

@@ -164,6 +164,13 @@ class TrackPoll(C.Structure):
     _fields_ = [("host_state", C.c_void_p), ("chunk", C.c_int32), ("host_pose", C.c_void_p)]
 
 
+class LightPrep(C.Structure):
+    _fields_ = [("depth_threshold", C.c_float), ("mask", C.c_void_p), ("records", C.c_void_p), ("capacity", C.c_int32),
+                ("valid", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_void_p),
+                ("color", C.c_void_p), ("normals", C.c_void_p), ("prepared_threshold", C.c_float),
+                ("depth_to_color", Transform)]
+
+
 class ColorPose(C.Structure):
     _fields_ = [("depth_to_world", Transform), ("Tcm", Transform)]
 
