@@ -428,7 +428,8 @@ class LightIntegrator(Integrator):
         if self.pixel_records is None or tuple(self.pixel_records.shape[:2]) != shape:
             self.pixel_records = torch.empty(shape + (4,), dtype=torch.float32, device=frame.device)
         prep = getattr(self, "_prep", None)
-        if prep is None or prep.mask != self.frame_mask.data_ptr() or prep.records != self.pixel_records.data_ptr():
+        if prep is None or self.volume.light_prep is not prep or prep.mask != self.frame_mask.data_ptr() \
+                or prep.records != self.pixel_records.data_ptr():
             # (re)attach: the volume's next set_view prepares these buffers in its request pass
             prep = T.LightPrep()
             prep.mask, prep.records = self.frame_mask.data_ptr(), self.pixel_records.data_ptr()
