@@ -445,6 +445,13 @@ VK_API int vk_image_downsample(int src_w, int src_h, const float* src,
 VK_API int vk_color_image_downsample(int src_w, int src_h, const float* src,
     float* dst, int nearest, void* stream);
 
+/* ref: src/frame.cpp:38-51 Frame::Downsample's three image passes in one launch: depth and
+ * normals nearest, colour 2x2 box (exactly vk_image_downsample / vk_color_image_downsample).
+ * An output that is NULL is skipped; depth and normals have the size frame->width x height,
+ * the colour image its own (color_width x color_height, 0 = the same); all sizes even. */
+VK_API int vk_frame_downsample(const vk_frame* frame, float* depth_out, float* color_out,
+    float* normals_out, void* stream);
+
 /* --------------------------------------------------------------------- ICP -- */
 
 /* One side of the ICP problem (keyframe or frame). */
@@ -627,6 +634,19 @@ typedef struct vk_color_pose {
 VK_API int vk_color_tracker_solve_update(const float* hessian, const float* gradient,
     int translation_enabled, const vk_transform* frame_Tcd, const vk_transform* keyframe_Twc,
     vk_color_pose* pose_dev, int32_t* state_dev, float* update_dev, void* stream);
+
+/* ref: src/tracker.cpp:65-76 Tracker::BeginSolve + src/color_tracker.cpp:19-25 ColorTracker::
+ * BeginSolve (+ src/light_tracker.cpp:34-41 with `frame_mask`) in ONE launch: the keyframe's and
+ * the frame's intensity images (vk_color_image_convert), the frame's gradients
+ * (vk_image_gradients), the light tracker's frame mask (vk_light_compute_frame_mask at
+ * `depth_threshold`; NULL for the colour tracker), the pose upload into
+ * pose_dev->depth_to_world (vk_transform_upload; both NULL to skip) and the reset of
+ * state_dev (may be NULL). Same bits as the staged calls: the jobs are independent once the
+ * gradients take their taps from the colour image, and run side by side. */
+VK_API int vk_color_tracker_begin(const vk_frame* keyframe, const vk_frame* frame,
+    float* keyframe_intensities, float* frame_intensities, float* gradient_x, float* gradient_y,
+    float depth_threshold, float* frame_mask, const vk_transform* pose_host,
+    vk_color_pose* pose_dev, int32_t* state_dev, void* stream);
 
 /* ref: src/tracker.cpp:53-63 Tracker::Track for ColorTracker: derive Tcm from
  * pose_dev->depth_to_world, then up to `iterations` Gauss-Newton steps without a host

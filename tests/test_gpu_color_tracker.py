@@ -171,3 +171,59 @@ def test_track_follows_the_oracle_loop(api, orc):
         assert np.all(np.isfinite(got.matrix()))
         np.testing.assert_allclose(got.matrix(), pose.depth_to_world.matrix(), atol=2e-4)
         np.testing.assert_allclose(got.inverse_matrix(), pose.depth_to_world.inverse_matrix(), atol=2e-4)
+
+
+def test_fused_begin_and_frame_downsample_match_the_staged_calls(api, orc):
+    """vk_color_tracker_begin (BeginSolve of the colour / light trackers as one launch) and
+    vk_frame_downsample (Frame::Downsample as one launch) leave the same bits as the staged
+    entry points they fuse, also for sizes that are no multiples of their tiles."""
+    import torch
+    rng = np.random.default_rng(9)
+    for (w, h) in ((640, 480), (202, 150), (64, 2)):
+        k = T.Projection.make(0.85 * w, 0.85 * w, w / 2, h / 2)
+        depth = (1.0 + 0.3 * rng.random((h, w), dtype=np.float32)).astype(np.float32)
+        depth[rng.random((h, w)) < 0.05] = 0.0
+        kcol = rng.random((h, w, 3), dtype=np.float32)
+        fcol = rng.random((h, w, 3), dtype=np.float32)
+        key = api.Frame(depth, k, T.Transform.identity(), color=kcol)
+        frm = api.Frame(depth, k, T.Transform.translate(0.01, 0.02, -0.01), color=fcol)
+        key.compute_normals()
+        frm.compute_normals()
+        lib, s = api.lib(), api.stream()
+        new = lambda *shape: torch.full(shape, -7.0, dtype=torch.float32, device="cuda")
+
+        # staged
+        ki, fi, gx, gy, mask = new(h, w), new(h, w), new(h, w), new(h, w), new(h, w)
+        api.check(lib.vk_color_image_convert(h * w, api._ptr(key.color), api._ptr(ki), s), "convert")
+        api.check(lib.vk_color_image_convert(h * w, api._ptr(frm.color), api._ptr(fi), s), "convert")
+        api.check(lib.vk_image_gradients(w, h, api._ptr(fi), api._ptr(gx), api._ptr(gy), s), "gradients")
+        api.check(lib.vk_light_compute_frame_mask(C.byref(frm.desc()), 0.2, api._ptr(mask), s), "mask")
+        # fused
+        ki2, fi2, gx2, gy2, mask2 = new(h, w), new(h, w), new(h, w), new(h, w), new(h, w)
+        pose_dev = torch.zeros(64, dtype=torch.float32, device="cuda")
+        state = torch.full((2,), 5, dtype=torch.int32, device="cuda")
+        start = T.Transform.translate(0.3, -0.2, 0.1) * T.Transform.rotate(0.9998719, 0.0085884, -0.0104268, 0.0085884)
+        api.check(lib.vk_color_tracker_begin(C.byref(key.desc()), C.byref(frm.desc()), api._ptr(ki2), api._ptr(fi2),
+                                             api._ptr(gx2), api._ptr(gy2), 0.2, api._ptr(mask2), C.byref(start),
+                                             api._ptr(pose_dev), api._ptr(state), s), "vk_color_tracker_begin")
+        sync()
+        for a, b in ((ki, ki2), (fi, fi2), (gx, gx2), (gy, gy2), (mask, mask2)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (w, h)
+        assert pose_dev[:32].cpu().numpy().tobytes() == bytes(start) and state.cpu().tolist() == [0, 0]
+        # colour tracker: no mask, no pose
+        gx3 = new(h, w)
+        api.check(lib.vk_color_tracker_begin(C.byref(key.desc()), C.byref(frm.desc()), api._ptr(ki2), api._ptr(fi2),
+                                             api._ptr(gx3), api._ptr(gy2), 0.0, None, None, None, None, s), "begin")
+        sync()
+        assert torch.equal(gx.view(torch.int32), gx3.view(torch.int32))
+
+        # Frame::Downsample
+        d1, c1, n1 = new(h // 2, w // 2), new(h // 2, w // 2, 3), new(h // 2, w // 2, 3)
+        api.check(lib.vk_image_downsample(w, h, api._ptr(frm.depth), api._ptr(d1), 1, s), "down")
+        api.check(lib.vk_color_image_downsample(w, h, api._ptr(frm.color), api._ptr(c1), 0, s), "down3")
+        api.check(lib.vk_color_image_downsample(w, h, api._ptr(frm.normals), api._ptr(n1), 1, s), "down3")
+        d2, c2, n2 = new(h // 2, w // 2), new(h // 2, w // 2, 3), new(h // 2, w // 2, 3)
+        api.check(lib.vk_frame_downsample(C.byref(frm.desc()), api._ptr(d2), api._ptr(c2), api._ptr(n2), s), "frame down")
+        sync()
+        for a, b in ((d1, d2), (c1, c2), (n1, n2)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (w, h)

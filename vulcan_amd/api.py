@@ -78,6 +78,8 @@ _SIGNATURES = {
     "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_track_wait": ([_P, _P], _I),
+    "vk_color_tracker_begin": ([_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
+    "vk_frame_downsample": ([_P, _P, _P, _P, _P], _I),
     "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
     "vk_light_prepared": ([_P, _P, C.c_float], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),

@@ -16,17 +16,30 @@ namespace
 
 // ---------------------------------------------------------------- images ----
 
+// image.cu:10-19, one pixel
+__device__ __forceinline__ float intensity_of(const float* rgb, int index)
+{
+  return (rgb[3 * index + 0] + rgb[3 * index + 1] + rgb[3 * index + 2]) / 3.0f;
+}
+
 // ref: image.cu:10-19
 __global__ __launch_bounds__(256) void convert_kernel(int total, const float* __restrict__ src,
     float* __restrict__ dst)
 {
   const int index = blockIdx.x * 256 + threadIdx.x;
-  if (index < total) dst[index] = (src[3 * index + 0] + src[3 * index + 1] + src[3 * index + 2]) / 3.0f;
+  if (index < total) dst[index] = intensity_of(src, index);
 }
 
 __device__ __forceinline__ float padded(const float* v, int w, int h, int x, int y)
 {
   return (x >= 0 && x < w && y >= 0 && y < h) ? v[y * w + x] : 0.0f;
+}
+
+// the same tap taken from the colour image: the intensity is recomputed (same expression,
+// same bits as the converted image holds)
+__device__ __forceinline__ float padded_intensity(const float* rgb, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? intensity_of(rgb, y * w + x) : 0.0f;
 }
 
 // ref: image.cu:21-99. The eight taps come through L1/L2 (each pixel is read by
@@ -49,6 +62,92 @@ __global__ __launch_bounds__(256) void gradients_kernel(int width, int height, c
 
   gx_out[y * width + x] = (i02 + i12 + i22) - (i00 + i10 + i20);
   gy_out[y * width + x] = (i20 + i21 + i22) - (i00 + i01 + i02);
+}
+
+
+// ---- everything a Track needs before its first step, in one launch ----------------
+//
+// Tracker::BeginSolve + ColorTracker / LightTracker::BeginSolve (tracker.cpp:65-76,
+// color_tracker.cpp:19-25, light_tracker.cpp:34-41) are, upstream and in the staged entry
+// points here, a pose upload, a state reset and four image passes: keyframe intensities, frame
+// intensities, frame gradients, frame mask — six launches of ~4.5 us of which a fraction is
+// work. None depends on another once the gradients take their taps from the colour image
+// (recomputing the intensity of a tap gives the bits the converted image holds), so they run
+// side by side in one launch: blockIdx.z picks the job.
+struct BeginParams
+{
+  const float* key_color;  float* key_intensities;  int key_total;
+  const float* frm_color;  float* frm_intensities;  float* gradient_x;  float* gradient_y;
+  int width, height;                      // of the frame's colour image
+  // light tracker only (mask == nullptr otherwise)
+  const float* frm_depth;  float depth_threshold;  float* mask;
+  // Tracker::BeginSolve
+  vk_transform pose;  vk_color_pose* pose_dev;  int32_t* state_dev;
+};
+
+__global__ __launch_bounds__(256) void color_begin_kernel(BeginParams B)
+{
+  __shared__ float buffer[22 * 22];
+  const int job = blockIdx.z;
+  const int linear = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+  if (job == 0)
+  {
+    if (linear < B.key_total) B.key_intensities[linear] = intensity_of(B.key_color, linear);
+    if (linear < 32 && B.pose_dev)
+    {
+      const float v = linear < 16 ? B.pose.m[linear] : B.pose.inv[linear - 16];
+      if (linear < 16) B.pose_dev->depth_to_world.m[linear] = v; else B.pose_dev->depth_to_world.inv[linear - 16] = v;
+    }
+    if (linear < 2 && B.state_dev) B.state_dev[linear] = 0;
+  }
+  else if (job == 1)
+  {
+    if (linear < B.width * B.height) B.frm_intensities[linear] = intensity_of(B.frm_color, linear);
+  }
+  else if (job == 2)
+  {
+    // gradients_kernel with the taps converted on the fly
+    const int x = linear % B.width, y = linear / B.width;
+    if (y >= B.height) return;
+    const float* c = B.frm_color;
+    const int w = B.width, h = B.height;
+    const float i00 = 0.125f * padded_intensity(c, w, h, x - 1, y - 1);
+    const float i01 = 0.250f * padded_intensity(c, w, h, x + 0, y - 1);
+    const float i02 = 0.125f * padded_intensity(c, w, h, x + 1, y - 1);
+    const float i10 = 0.250f * padded_intensity(c, w, h, x - 1, y + 0);
+    const float i12 = 0.250f * padded_intensity(c, w, h, x + 1, y + 0);
+    const float i20 = 0.125f * padded_intensity(c, w, h, x - 1, y + 1);
+    const float i21 = 0.250f * padded_intensity(c, w, h, x + 0, y + 1);
+    const float i22 = 0.125f * padded_intensity(c, w, h, x + 1, y + 1);
+    B.gradient_x[linear] = (i02 + i12 + i22) - (i00 + i10 + i20);
+    B.gradient_y[linear] = (i20 + i21 + i22) - (i00 + i01 + i02);
+  }
+  else
+  {
+    // frame_mask_kernel (vk_integrate.hip): 16x16 pixels per workgroup, 22x22 depth tile
+    if (!B.mask) return;
+    const int tiles_x = (B.width + 15) / 16, tiles_y = (B.height + 15) / 16;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tile >= tiles_x * tiles_y) return;             // whole workgroup
+    const int bx = tile % tiles_x, by = tile / tiles_x;
+    for (int sindex = threadIdx.x; sindex < 22 * 22; sindex += 256)
+    {
+      float depth = 0;
+      const int vx = (bx * 16 - 1) + (sindex % 22);
+      const int vy = (by * 16 - 1) + (sindex / 22);
+      if (vx >= 0 && vx < B.width && vy >= 0 && vy < B.height) depth = B.frm_depth[vy * B.width + vx];
+      buffer[sindex] = depth;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = bx * 16 + tx, y = by * 16 + ty;
+    if (x < B.width && y < B.height)
+    {
+      const int index = y * B.width + x;
+      const float c0 = B.frm_color[3 * index + 0], c1 = B.frm_color[3 * index + 1], c2 = B.frm_color[3 * index + 2];
+      B.mask[index] = light_color_usable(c0, c1, c2) ? light_window_mask(buffer, 22, tx + 3, ty + 3, B.depth_threshold) : 0.0f;
+    }
+  }
 }
 
 // -------------------------------------------------------------- evaluate ----
@@ -751,6 +850,44 @@ VK_API int vk_color_image_convert(int total, const float* src, float* dst, void*
   VK_REQUIRE(total >= 0 && (total == 0 || (src && dst)));
   if (total == 0) return VK_OK;
   hipLaunchKernelGGL(convert_kernel, dim3((total + 255) / 256), dim3(256), 0, vk_s(stream), total, src, dst);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+VK_API int vk_color_tracker_begin(const vk_frame* keyframe, const vk_frame* frame, float* keyframe_intensities,
+    float* frame_intensities, float* gradient_x, float* gradient_y, float depth_threshold, float* frame_mask,
+    const vk_transform* pose_host, vk_color_pose* pose_dev, int32_t* state_dev, void* stream)
+{
+  VK_REQUIRE(keyframe && frame && keyframe->color && frame->color && keyframe_intensities && frame_intensities);
+  VK_REQUIRE(gradient_x && gradient_y && keyframe->width > 0 && keyframe->height > 0 && frame->width > 0 && frame->height > 0);
+  VK_REQUIRE(!frame_mask || frame->depth);
+  VK_REQUIRE((pose_host != nullptr) == (pose_dev != nullptr));
+  // the trackers read the colour image with the depth image's size (color_tracker.cu:296-343)
+  VK_REQUIRE((frame->color_width <= 0 || frame->color_width == frame->width) &&
+             (frame->color_height <= 0 || frame->color_height == frame->height));
+  VK_REQUIRE((keyframe->color_width <= 0 || keyframe->color_width == keyframe->width) &&
+             (keyframe->color_height <= 0 || keyframe->color_height == keyframe->height));
+  BeginParams B;
+  B.key_color = keyframe->color;
+  B.key_intensities = keyframe_intensities;
+  B.key_total = keyframe->width * keyframe->height;
+  B.frm_color = frame->color;
+  B.frm_intensities = frame_intensities;
+  B.gradient_x = gradient_x;
+  B.gradient_y = gradient_y;
+  B.width = frame->width;
+  B.height = frame->height;
+  B.frm_depth = frame->depth;
+  B.depth_threshold = depth_threshold;
+  B.mask = frame_mask;
+  if (pose_host) B.pose = *pose_host; else B.pose = identity_transform();
+  B.pose_dev = pose_dev;
+  B.state_dev = state_dev;
+  const int total = B.key_total > B.width * B.height ? B.key_total : B.width * B.height;
+  const int tiles = ((B.width + 15) / 16) * ((B.height + 15) / 16);      // the mask job: one workgroup per 16x16 tile
+  const int groups = (total + 255) / 256 > tiles ? (total + 255) / 256 : tiles;
+  const int gx = groups < 1024 ? groups : 1024;
+  hipLaunchKernelGGL(color_begin_kernel, dim3(gx, (groups + gx - 1) / gx, frame_mask ? 4 : 3), dim3(256), 0, vk_s(stream), B);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

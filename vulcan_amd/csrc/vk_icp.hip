@@ -581,6 +581,50 @@ __global__ __launch_bounds__(256) void downsample3_kernel(int src_w, int dst_w, 
   }
 }
 
+// Frame::Downsample (frame.cpp:38-51) as one launch: blockIdx.z = 0 depth (nearest), 1 colour
+// (2x2 box), 2 normals (nearest); the same expressions as downsample_kernel / downsample3_kernel
+struct FrameLevel
+{
+  const float* src[3];
+  float* dst[3];
+  int src_w[3], dst_w[3], dst_h[3];
+};
+
+__global__ __launch_bounds__(256) void frame_downsample_kernel(FrameLevel L)
+{
+  const int job = blockIdx.z;
+  if (!L.dst[job]) return;
+  const int dst_x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int dst_y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dst_x >= L.dst_w[job] || dst_y >= L.dst_h[job]) return;
+  const int src_w = L.src_w[job], src_x = 2 * dst_x, src_y = 2 * dst_y;
+  const float* src = L.src[job];
+  float* dst = L.dst[job];
+  if (job == 0)
+  {
+    dst[dst_y * L.dst_w[job] + dst_x] = src[src_y * src_w + src_x];
+  }
+  else if (job == 2)
+  {
+    const vf3 n = *reinterpret_cast<const vf3*>(src + 3 * (src_y * src_w + src_x));
+    *reinterpret_cast<vf3*>(dst + 3 * (dst_y * L.dst_w[job] + dst_x)) = n;
+  }
+  else
+  {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+    {
+      float sample = 0;
+      sample += src[3 * ((src_y + 0) * src_w + (src_x + 1)) + c];
+      sample += src[3 * ((src_y + 0) * src_w + (src_x + 0)) + c];
+      sample += src[3 * ((src_y + 1) * src_w + (src_x + 1)) + c];
+      sample += src[3 * ((src_y + 1) * src_w + (src_x + 0)) + c];
+      sample *= 0.25f;
+      dst[3 * (dst_y * L.dst_w[job] + dst_x) + c] = sample;
+    }
+  }
+}
+
 // One pyramid level of BOTH sides of a depth-tracking problem in one launch (blockIdx.z:
 // keyframe / frame): nearest depth and nearest normals, exactly Image::Downsample(nearest)
 // and ColorImage::Downsample(nearest) of Frame::Downsample (frame.cpp:49-51). The colour
@@ -922,6 +966,33 @@ int vk_icp_solve_update(const float* hessian, const float* gradient, int transla
   VK_REQUIRE(hessian && gradient && Twc_dev);
   hipLaunchKernelGGL(solve_update_kernel, dim3(1), dim3(64), 0, vk_s(stream), hessian, gradient,
       translation_enabled, Twc_dev, state_dev, update_dev, Mirror{nullptr, 0, nullptr});
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_frame_downsample(const vk_frame* frame, float* depth_out, float* color_out, float* normals_out, void* stream)
+{
+  VK_REQUIRE(frame && frame->width > 0 && frame->height > 0 && (frame->width % 2) == 0 && (frame->height % 2) == 0);
+  VK_REQUIRE((!depth_out || frame->depth) && (!color_out || frame->color) && (!normals_out || frame->normals));
+  const int cw = frame->color_width > 0 ? frame->color_width : frame->width;
+  const int ch = frame->color_height > 0 ? frame->color_height : frame->height;
+  VK_REQUIRE(!color_out || ((cw % 2) == 0 && (ch % 2) == 0));
+  FrameLevel L;
+  const float* src[3] = {frame->depth, frame->color, frame->normals};
+  float* dst[3] = {depth_out, color_out, normals_out};
+  int gw = 0, gh = 0;
+  for (int job = 0; job < 3; ++job)
+  {
+    const int w = job == 1 ? cw : frame->width, h = job == 1 ? ch : frame->height;
+    L.src[job] = src[job];
+    L.dst[job] = dst[job];
+    L.src_w[job] = w;
+    L.dst_w[job] = w / 2;
+    L.dst_h[job] = h / 2;
+    if (dst[job]) { gw = gw > w / 2 ? gw : w / 2; gh = gh > h / 2 ? gh : h / 2; }
+  }
+  if (gw == 0) return VK_OK;
+  hipLaunchKernelGGL(frame_downsample_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 3), dim3(256), 0, vk_s(stream), L);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

@@ -142,6 +142,10 @@ class ColorTracker : public Tracker
     void ComputeFrameIntensities(const Frame& frame);
     void ComputeFrameGradients(const Frame& frame);
 
+    // BeginSolve of this class and of LightTracker as one launch (vk_color_tracker_begin); not upstream
+    void BeginOnDevice(const Frame& frame, Image* mask);
+    virtual float MaskThreshold() const { return 0.0f; }
+
     vk_color_view KeyframeView() const;
     vk_color_view FrameView(const Frame& frame) const;
     vk_transform GetTcm(const Frame& frame) const;        // color_tracker.cu:312-320
@@ -181,6 +185,8 @@ class LightTracker : public ColorTracker
     vk_light_terms GetTerms(const Frame& frame) const;
 
     Light light_;
+    float MaskThreshold() const override;
+
     Image frame_mask_;
     float depth_threshold_;
 };

@@ -287,10 +287,29 @@ void ColorTracker::ComputeFrameGradients(const Frame& frame)
 // ref: color_tracker.cpp:19-25
 void ColorTracker::BeginSolve(const Frame& frame)
 {
-  Tracker::BeginSolve(frame);
-  ComputeKeyframeIntensities();
-  ComputeFrameIntensities(frame);
-  ComputeFrameGradients(frame);
+  BeginOnDevice(frame, nullptr);
+}
+
+// Tracker::BeginSolve + the image passes of ColorTracker / LightTracker::BeginSolve as one launch
+// (vk_color_tracker_begin); `mask`: the light tracker's frame mask, or null
+void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask)
+{
+  ValidateKeyframe();
+  ValidateFrame(frame);
+  ResizeBuffers(frame);
+  iteration_ = 0;
+  poll_.host_state[3] = 0;   // no pose of this solve has arrived yet
+  VULCAN_ASSERT_MSG(keyframe_->color_image && frame.color_image, "missing color image");
+  keyframe_intensities_.Resize(keyframe_->color_image->GetSize());
+  frame_intensities_.Resize(frame.color_image->GetSize());
+  frame_gradient_x_.Resize(frame.color_image->GetSize());
+  frame_gradient_y_.Resize(frame.color_image->GetSize());
+  if (mask) mask->Resize(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+  const vk_frame key = keyframe_->ToVk(), frm = frame.ToVk();
+  const vk_transform pose = frame.depth_to_world_transform.ToVk();
+  VK_ASSERT(vk_color_tracker_begin(&key, &frm, keyframe_intensities_.GetData(), frame_intensities_.GetData(),
+      frame_gradient_x_.GetData(), frame_gradient_y_.GetData(), MaskThreshold(), mask ? mask->GetData() : nullptr,
+      &pose, color_pose_.GetData(), state_.GetData(), Device::GetStream()));
   // the residuals are per KEYFRAME pixel (color_tracker.cpp:27-32)
   const size_t floats = vk_icp_workspace_floats(keyframe_->depth_image->GetWidth(), keyframe_->depth_image->GetHeight());
   if (floats > workspace_.GetSize()) workspace_.Resize(floats);
@@ -443,9 +462,10 @@ vk_light_terms LightTracker::GetTerms(const Frame& frame) const
 // ref: light_tracker.cpp:34-41
 void LightTracker::BeginSolve(const Frame& frame)
 {
-  ColorTracker::BeginSolve(frame);
-  ComputeFrameMask(frame);
+  BeginOnDevice(frame, &frame_mask_);
 }
+
+float LightTracker::MaskThreshold() const { return depth_threshold_; }
 
 // Upstream's ComputeResiduals / ComputeJacobian read frame_mask_ without computing
 // it (light_tracker.cu:569-577,613-623); here they compute it first.
