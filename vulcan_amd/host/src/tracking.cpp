@@ -121,7 +121,14 @@ void Tracker::EndSolve(Frame& frame)
   // (the step-by-step default of this class) is read back with a copy
   vk_transform pose;
   if (vk_track_wait(&poll_, Device::GetStream()) == VK_OK) pose = *poll_.host_pose;
-  else VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));
+  else
+  {
+    VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));
+    int32_t state[2] = {0, 0};
+    VK_ASSERT(vk_memcpy_d2h(state, state_.GetData(), sizeof(state), Device::GetStream()));
+    VULCAN_ASSERT_MSG(state[1] != VK_TRACK_ABORTED,
+        "the tracking kernel could not get all of its workgroups onto the device (is another process using it?)");
+  }
   frame.depth_to_world_transform = Transform::FromVk(pose);
 }
 
