@@ -653,8 +653,8 @@ class DepthTracker(_PollMixin):
         import torch
         check(lib().vk_transform_upload(_ptr(self.pose), _ref(frame.depth_to_world), stream()), "vk_transform_upload")
         self.state.zero_()
-        # one C call enqueues the iterations (2 launches each, 3 with a reduce hook) and
-        # stops enqueuing once the loop has converged
+        # one C call: the whole loop is one launch (with a reduce hook: 3 launches per step,
+        # enqueuing stops once the loop has converged)
         check(lib().vk_icp_track(_ref(self._view(self.keyframe)), _ref(self.keyframe.depth_to_world),
                                  _ref(self._view(frame)), _ptr(self.pose), self.max_iterations,
                                  int(self.translation_enabled), _ptr(self._workspace(frame)), _ptr(self.system),

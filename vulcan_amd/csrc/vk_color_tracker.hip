@@ -1,10 +1,11 @@
 // vk_color_tracker.hip — photometric frame-to-keyframe tracking for gfx950
 // (ref: src/color_tracker.cu, src/color_tracker.cpp:34-96, src/image.cu:10-99).
 //
-// Same shape as the depth tracker (vk_icp.hip): one keyframe pixel per lane, the
-// 27 sums reduced by DPP row operations and a fixed-order second stage, the 6x6
-// solve and the pose update done by one lane out of registers, so that a
-// Gauss-Newton iteration is two launches and Track() never reads anything back.
+// Same shape as the depth tracker (vk_icp.hip): keyframe pixels in groups defined by the
+// image, the 27 sums reduced by DPP row operations and a fixed-order second stage, the 6x6
+// solve and the pose update done by one lane out of registers. Track() is ONE launch for
+// the whole Gauss-Newton loop (color_loop_kernel; three launches per step only with the
+// rig's reduce hook) after one launch that prepares the images (color_begin_kernel).
 // The reference zero-fills, accumulates with 27 float atomics per thread block and
 // copies 42 floats to the host for Eigen every iteration.
 #include "vk_gauss_newton.hpp"

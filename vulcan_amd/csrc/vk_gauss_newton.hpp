@@ -16,8 +16,6 @@
 namespace vk
 {
 
-constexpr int kSysThreads = 1024;  // 16 waves, one pixel per lane
-constexpr int kSysWaves = kSysThreads / 64;
 constexpr int kSysStride = 32;     // floats per workgroup partial: 6 gradient + 21 hessian + pad
 
 // Wave64 sum without LDS: four DPP steps fold each row of 16 lanes (two quad
@@ -56,7 +54,7 @@ __device__ __forceinline__ void outer_products(const float (&J)[6], float r, flo
 
 // First stage: the workgroup's 27 sums -> workspace[blockIdx.x]. Called by every
 // thread of a WAVES * 64 wide workgroup.
-template <int WAVES = kSysWaves>
+template <int WAVES>
 __device__ __forceinline__ void store_partial(const float (&acc)[27], float (*lds)[kSysStride], float* workspace)
 {
   const int lane = lane_id();

@@ -5,9 +5,9 @@
 // The reference reduces 27 sums with 9 rounds of three 256-wide LDS trees per
 // workgroup and 27 float atomicAdds per workgroup (order-nondeterministic), then
 // copies 42 floats to the host every Gauss-Newton iteration for an Eigen LDLT.
-// Here: registers -> wave64 butterfly -> one LDS hop -> per-workgroup partials,
-// summed by a second kernel in a fixed order (bit-reproducible), and the 6x6
-// solve + SE(3) update can run on the device so an iteration needs no readback.
+// Here: registers -> wave64 butterfly -> one LDS hop -> per-group partials, summed in a
+// fixed order (bit-reproducible, independent of the device), and the 6x6 solve + SE(3)
+// update run on the device: Track() is one launch for the whole loop (track_loop_kernel).
 #include "vk_gauss_newton.hpp"
 
 using namespace vk;
