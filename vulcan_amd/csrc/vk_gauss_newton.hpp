@@ -218,6 +218,9 @@ inline unsigned long long* loop_timing_attach(hipStream_t s)
 // give up after kExchangeTimeout and the launch ends with state[1] = VK_TRACK_ABORTED
 // instead of spinning for ever.
 constexpr unsigned long long kExchangeTimeout = 200000000ull;   // wall_clock64 ticks (100 MHz): 2 s
+#ifndef VK_POLL_GAP
+#define VK_POLL_GAP 2        // s_sleep units of 64 clocks between two rounds of questions
+#endif
 constexpr int kExchangeSteps = 1023;                              // ten tag bits name the step
 
 __device__ __forceinline__ uint32_t exchange_tag(uint32_t epoch, int step) { return (epoch << 10) | (uint32_t)(step + 1); }
@@ -330,7 +333,10 @@ __device__ __forceinline__ bool gather_partials(const Exchange& E, int step, int
       }
       // (Measured and rejected: letting only the lane of a slot's first word poll while the
       // slot is missing, the others asking again once it has arrived — a quarter of the polling
-      // requests, but one more round trip for most words: 256 -> 278 us per depth Track.)
+      // requests, but one more round trip for most words: 256 -> 278 us per depth Track. Two
+      // rounds of questions in flight, so that a word is seen at most one gap + one trip after
+      // it has landed: 256 -> 324 us. A longer pause between rounds: 0-8 x 64 clocks make no
+      // difference, 24 and 64 cost 5 % and 14 %.)
       for (;;)
       {
 #pragma unroll
@@ -345,7 +351,7 @@ __device__ __forceinline__ bool gather_partials(const Exchange& E, int step, int
           if ((missing & (1u << q)) && (uint32_t)(w[q] >> 32) == tag) missing &= ~(1u << q);
         if (!missing) break;
         if ((unsigned long long)wall_clock64() > deadline) { ok = false; break; }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(VK_POLL_GAP);
       }
       if (ok)
       {
