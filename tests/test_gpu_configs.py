@@ -429,3 +429,42 @@ def test_set_view_prepares_the_light_integrator(api, orc):
     vol.set_view(big)
     assert integ._prep.valid == 0
     sync()
+
+
+def test_fewer_workgroups_than_pixel_groups_gives_the_same_bits(api, orc, monkeypatch):
+    """The one-launch loops publish one slot per pixel GROUP: when the device holds fewer workgroups
+    than the image has groups (fewer CUs, lower occupancy — forced here with VK_LOOP_GRID_CAP), a
+    workgroup takes several groups and the poses come out bit for bit the same."""
+    import color_scenes as cs
+    w, h = 640, 480
+    k = T.Projection.make(547.0, 547.0, 320, 240)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    hf, df = frames(api, orc, key_depth, k, start)
+    df.compute_normals()
+    kc = cs.keyframe_images()[1]
+    key = api.Frame(key_depth, k, T.Transform.identity(), color=kc, normals=dk.normals)
+    moved = api.Frame(key_depth, k, start, color=kc, normals=dk.normals)
+
+    def run():
+        out = []
+        tracker = api.PyramidTracker()
+        tracker.keyframe = dk
+        df.depth_to_world = start
+        out.append(bytes(tracker.track(df)))
+        ct = api.ColorTracker()
+        ct.keyframe = key
+        ct.max_iterations = 4
+        moved.depth_to_world = start
+        out.append(bytes(ct.track(moved)))
+        sync()
+        assert int(tracker.tracker.state.cpu()[1]) in (0, 1) and int(ct.state.cpu()[1]) in (0, 1)
+        return out
+
+    full = run()
+    for cap in ("100", "7", "1"):
+        monkeypatch.setenv("VK_LOOP_GRID_CAP", cap)
+        assert run() == full, cap
+    monkeypatch.delenv("VK_LOOP_GRID_CAP")

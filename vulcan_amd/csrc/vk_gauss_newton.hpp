@@ -7,6 +7,8 @@
 
 #include "vk_common.hpp"
 
+#include <cstdlib>
+
 #ifdef VK_LOOP_TIMING
 #include <cstdio>
 #include <cstdlib>
@@ -253,23 +255,28 @@ inline int resident_workgroups(Kernel kernel, int threads)
   static int used = 0;
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return 0;
+  int capacity = -1;
   for (int i = 0; i < used; ++i)
-    if (cache[i].kernel == reinterpret_cast<const void*>(kernel) && cache[i].device == device) return cache[i].capacity;
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
-    return 0;
-  const int capacity = per_cu * cus > 0 ? per_cu * cus : 0;
-  if (used < 32) cache[used++] = Entry{reinterpret_cast<const void*>(kernel), device, capacity};   // benign if two threads race: same values
+    if (cache[i].kernel == reinterpret_cast<const void*>(kernel) && cache[i].device == device) capacity = cache[i].capacity;
+  if (capacity < 0)
+  {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+      return 0;
+    capacity = per_cu * cus > 0 ? per_cu * cus : 0;
+    if (used < 32) cache[used++] = Entry{reinterpret_cast<const void*>(kernel), device, capacity};   // benign if two threads race: same values
+  }
+  // test aid: a smaller grid than the device could hold (workgroups then take several pixel
+  // groups each — the path a device with fewer CUs, or larger images, would take)
+  if (const char* cap = getenv("VK_LOOP_GRID_CAP"))
+  {
+    const int n = atoi(cap);
+    if (n > 0 && n < capacity) capacity = n;
+  }
   return capacity;
 }
 
-// One slot per pixel GROUP, not per workgroup: a workgroup that is given several groups (more
-// groups than the device holds workgroups) publishes each group's sums separately, so what is
-// added up — and therefore every bit of the result — does not depend on the size of the grid,
-// i.e. on the device's CU count or the kernel's occupancy, and equals the launch-per-stage
-// path's partials.
-// A caller that publishes several groups puts a barrier between two calls (lds is reused).
 template <int WAVES>
 __device__ __forceinline__ void publish_partial(const float (&acc)[27], float (*lds)[kSysStride],
     const Exchange& E, int step, int group)
