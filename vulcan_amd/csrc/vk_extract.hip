@@ -78,44 +78,69 @@ __device__ __forceinline__ uint32_t info_voff(uint32_t i) { return i >> 13; }
 // extractor.cu:455-457 takes the visible blocks ("TODO: replace with all allocated blocks");
 // all_allocated walks the table instead. One workgroup, ordered: the list (and with it the
 // vertex and face order) does not depend on timing.
+// exclusive scan of one int per thread over a 1024-thread workgroup; *total = the sum.
+// Every thread calls it; ends with a barrier; `wave_sums` is 16 ints of LDS.
+__device__ __forceinline__ int group_exclusive_scan(int value, int* wave_sums, int& total)
+{
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int incl = value;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  int before = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w)
+  {
+    const int s = wave_sums[w];
+    if (w < wave) before += s;
+    total += s;
+  }
+  __syncthreads();
+  return before + incl - value;
+}
+
+constexpr int kPerThread = 8;   // consecutive entries per thread and trip of the two ordered passes
+
 __global__ __launch_bounds__(1024) void build_list_kernel(ExtractParams P)
 {
-  __shared__ int wave_count[16];
-  __shared__ int running;
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
+  __shared__ int wave_sums[16];
   const int n = P.all_allocated ? P.total : min(P.v.counters[VK_CTR_VISIBLE], P.total);
+  int running = 0;
 
-  for (int base = 0; base < n; base += 1024)
+  for (int base = 0; base < n; base += 1024 * kPerThread)
   {
-    const int i = base + (int)threadIdx.x;
-    int entry = -1, slot = -1;
-    if (i < n)
+    const int first = base + (int)threadIdx.x * kPerThread;
+    int entry[kPerThread], slot[kPerThread], kept = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
     {
-      entry = P.all_allocated ? i : P.v.visible_blocks[i];
-      slot = P.v.hash_entries[entry].data;      // the unallocated origin block can sit in the visible list
+      const int i = first + k;
+      entry[k] = -1;
+      slot[k] = -1;
+      if (i < n)
+      {
+        entry[k] = P.all_allocated ? i : P.v.visible_blocks[i];
+        slot[k] = P.v.hash_entries[entry[k]].data;      // the unallocated origin block can sit in the visible list
+      }
+      kept += slot[k] >= 0 ? 1 : 0;
     }
-    const bool keep = slot >= 0;
-    const unsigned long long mask = __ballot(keep);
-    const int before = __popcll(mask & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_count[wave] = __popcll(mask);
-    __syncthreads();
-    int offset = running;
-    for (int w = 0; w < wave; ++w) offset += wave_count[w];
-    if (keep)
-    {
-      P.list[offset + before] = entry;
-      P.listed[slot] = offset + before;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      int sum = 0;
-      for (int w = 0; w < 16; ++w) sum += wave_count[w];
-      running += sum;
-    }
-    __syncthreads();
+    int total;
+    int at = running + group_exclusive_scan(kept, wave_sums, total);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+      if (slot[k] >= 0)
+      {
+        P.list[at] = entry[k];
+        P.listed[slot[k]] = at;
+        ++at;
+      }
+    running += total;
   }
   if (threadIdx.x == 0) { *P.list_count = running; P.counts[3] = running; }
 }
@@ -298,44 +323,41 @@ __global__ __launch_bounds__(kExtractThreads) void classify_kernel(ExtractParams
 // ordered exclusive scan of the per-block counts (one workgroup)
 __global__ __launch_bounds__(1024) void scan_blocks_kernel(ExtractParams P)
 {
-  __shared__ int wave_sum[16][2];
-  __shared__ int running[2];
-  const int lane = lane_id(), wave = threadIdx.x >> 6;
-  if (threadIdx.x < 2) running[threadIdx.x] = 0;
-  __syncthreads();
+  __shared__ int wave_sums[16];
   const int n = *P.list_count;
-  for (int base = 0; base < n; base += 1024)
+  int running_a = 0, running_b = 0;
+  for (int base = 0; base < n; base += 1024 * kPerThread)
   {
-    const int i = base + (int)threadIdx.x;
-    const int a = i < n ? P.block_counts[2 * i + 0] : 0;
-    const int b = i < n ? P.block_counts[2 * i + 1] : 0;
-    int va = a, vb = b;
+    const int first = base + (int)threadIdx.x * kPerThread;
+    int a[kPerThread], b[kPerThread], sum_a = 0, sum_b = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
+    for (int k = 0; k < kPerThread; ++k)
     {
-      const int ta = __shfl_up(va, d), tb = __shfl_up(vb, d);
-      if (lane >= d) { va += ta; vb += tb; }
+      const int i = first + k;
+      a[k] = i < n ? P.block_counts[2 * i + 0] : 0;
+      b[k] = i < n ? P.block_counts[2 * i + 1] : 0;
+      sum_a += a[k];
+      sum_b += b[k];
     }
-    if (lane == 63) { wave_sum[wave][0] = va; wave_sum[wave][1] = vb; }
-    __syncthreads();
-    int before_a = running[0], before_b = running[1];
-    for (int w = 0; w < wave; ++w) { before_a += wave_sum[w][0]; before_b += wave_sum[w][1]; }
-    if (i < n)
+    int total_a, total_b;
+    int at_a = running_a + group_exclusive_scan(sum_a, wave_sums, total_a);
+    int at_b = running_b + group_exclusive_scan(sum_b, wave_sums, total_b);
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
     {
-      P.block_offsets[2 * i + 0] = before_a + va - a;
-      P.block_offsets[2 * i + 1] = before_b + vb - b;
+      const int i = first + k;
+      if (i < n)
+      {
+        P.block_offsets[2 * i + 0] = at_a;
+        P.block_offsets[2 * i + 1] = at_b;
+      }
+      at_a += a[k];
+      at_b += b[k];
     }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-      int sa = 0, sb = 0;
-      for (int w = 0; w < 16; ++w) { sa += wave_sum[w][0]; sb += wave_sum[w][1]; }
-      running[0] += sa;
-      running[1] += sb;
-    }
-    __syncthreads();
+    running_a += total_a;
+    running_b += total_b;
   }
-  if (threadIdx.x == 0) { P.counts[0] = running[0]; P.counts[1] = running[1]; }
+  if (threadIdx.x == 0) { P.counts[0] = running_a; P.counts[1] = running_b; }
 }
 
 // global index of the vertex on the axis-th owned edge of a cube, from its record
