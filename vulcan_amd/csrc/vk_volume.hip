@@ -197,33 +197,33 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
 
+  // PREP: the loads of the depth tile and of the pixel's colour and normal are issued first and
+  // consumed after the request walk, which hides their latency
+  constexpr int TW = 70, TH = 10, TS = 72;
+  __shared__ float tile[PREP ? TH * TS : 1];
+  float staged[3] = {0.0f, 0.0f, 0.0f};
+  vf3 prep_rgb = {0.0f, 0.0f, 0.0f}, prep_n = {0.0f, 0.0f, 0.0f};
   if (PREP)
   {
-    constexpr int TW = 70, TH = 10, TS = 72;
-    __shared__ float tile[TH * TS];
     const int x0 = (int)blockIdx.x * 64 - 1, y0 = (int)blockIdx.y * 4 - 1;
-    for (int i = threadIdx.x; i < TW * TH; i += 256)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
     {
+      const int i = (int)threadIdx.x + 256 * t;
       const int r = i / TW, c = i - r * TW;
       const int vx = x0 + c, vy = y0 + r;
-      tile[r * TS + c] = (vx >= 0 && vx < P.width && vy >= 0 && vy < P.height) ? P.depth[vy * P.width + vx] : 0.0f;
+      if (i < TW * TH && vx >= 0 && vx < P.width && vy >= 0 && vy < P.height) staged[t] = P.depth[vy * P.width + vx];
     }
-    __syncthreads();
     if (x < P.width && y < P.height)
     {
       const int index = y * P.width + x;
-      const vf3 rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
-      const vf3 n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
-      const f3 Xcn = xform_dir(P.Tcd, make3(n.x, n.y, n.z));                     // light_integrator.cu:223
-      float m = 0.0f;
-      if (light_color_usable(rgb.x, rgb.y, rgb.z))
-        m = light_window_mask(tile, TS, (int)(threadIdx.x & 63) + 3, (int)(threadIdx.x >> 6) + 3, P.depth_threshold);
-      P.mask[index] = m;
-      P.records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
+      prep_rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
+      prep_n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
     }
   }
 
-  if (y >= P.height) return;                       // whole wave
+  do {
+  if (y >= P.height) break;                        // whole wave
 
   const vk_volume& v = P.v;
   const uint32_t K = (uint32_t)v.main_block_count;
@@ -375,6 +375,28 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
         if (bz == ez + step_z) break;
         tmax_z += tdelta_z;
       }
+    }
+  }
+  } while (false);
+
+  if (PREP)
+  {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+    {
+      const int i = (int)threadIdx.x + 256 * t;
+      if (i < TW * TH) tile[(i / TW) * TS + (i % TW)] = staged[t];
+    }
+    __syncthreads();
+    if (x < P.width && y < P.height)
+    {
+      const int index = y * P.width + x;
+      const f3 Xcn = xform_dir(P.Tcd, make3(prep_n.x, prep_n.y, prep_n.z));      // light_integrator.cu:223
+      float m = 0.0f;
+      if (light_color_usable(prep_rgb.x, prep_rgb.y, prep_rgb.z))
+        m = light_window_mask(tile, TS, (int)(threadIdx.x & 63) + 3, (int)(threadIdx.x >> 6) + 3, P.depth_threshold);
+      P.mask[index] = m;
+      P.records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
     }
   }
 }
