@@ -132,6 +132,12 @@ class ColorTracker : public Tracker
     // host form of the pose update (ref: color_tracker.cpp:34-96)
     void ApplyUpdate(Frame& frame, const Vector6f& x) const override;
 
+    // PyramidTracker<ColorTracker / LightTracker>::Track (pyramid_tracker.cpp:79-89) with both
+    // levels enqueued back to back: the full-resolution loop starts from the pose the half-
+    // resolution loop left ON THE DEVICE, the host waits once, for the final pose (not upstream)
+    void TrackCoarseToFine(std::shared_ptr<const Frame> half_keyframe, Frame& half_frame,
+        std::shared_ptr<const Frame> keyframe, Frame& frame);
+
   protected:
     void BeginSolve(const Frame& frame) override;
     int GetResidualCount(const Frame& frame) const override;
@@ -143,8 +149,9 @@ class ColorTracker : public Tracker
     void ComputeFrameGradients(const Frame& frame);
 
     // BeginSolve of this class and of LightTracker as one launch (vk_color_tracker_begin); not upstream
-    void BeginOnDevice(const Frame& frame, Image* mask);
+    void BeginOnDevice(const Frame& frame, Image* mask, bool upload_pose = true);
     virtual float MaskThreshold() const { return 0.0f; }
+    virtual Image* MaskImage() { return nullptr; }      // the light tracker's frame mask
 
     vk_color_view KeyframeView() const;
     vk_color_view FrameView(const Frame& frame) const;
@@ -186,6 +193,7 @@ class LightTracker : public ColorTracker
 
     Light light_;
     float MaskThreshold() const override;
+    Image* MaskImage() override { return &frame_mask_; }
 
     Image frame_mask_;
     float depth_threshold_;

@@ -299,7 +299,7 @@ void ColorTracker::BeginSolve(const Frame& frame)
 
 // Tracker::BeginSolve + the image passes of ColorTracker / LightTracker::BeginSolve as one launch
 // (vk_color_tracker_begin); `mask`: the light tracker's frame mask, or null
-void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask)
+void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask, bool upload_pose)
 {
   ValidateKeyframe();
   ValidateFrame(frame);
@@ -316,10 +316,30 @@ void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask)
   const vk_transform pose = frame.depth_to_world_transform.ToVk();
   VK_ASSERT(vk_color_tracker_begin(&key, &frm, keyframe_intensities_.GetData(), frame_intensities_.GetData(),
       frame_gradient_x_.GetData(), frame_gradient_y_.GetData(), MaskThreshold(), mask ? mask->GetData() : nullptr,
-      &pose, color_pose_.GetData(), state_.GetData(), Device::GetStream()));
+      upload_pose ? &pose : nullptr, upload_pose ? color_pose_.GetData() : nullptr, state_.GetData(), Device::GetStream()));
   // the residuals are per KEYFRAME pixel (color_tracker.cpp:27-32)
   const size_t floats = vk_icp_workspace_floats(keyframe_->depth_image->GetWidth(), keyframe_->depth_image->GetHeight());
   if (floats > workspace_.GetSize()) workspace_.Resize(floats);
+}
+
+void ColorTracker::TrackCoarseToFine(std::shared_ptr<const Frame> half_keyframe, Frame& half_frame,
+    std::shared_ptr<const Frame> keyframe, Frame& frame)
+{
+  // :79-83 half level, 15 steps, from the frame's pose
+  SetMaxIterations(15);
+  SetTranslationEnabled(true);
+  SetKeyframe(half_keyframe);
+  BeginOnDevice(half_frame, MaskImage(), true);
+  TrackOnDevice(half_frame);
+  // :85-89 full level, 20 steps, from the pose the half level left in color_pose_ (upstream
+  // carries it through half_frame.depth_to_world_transform: the same bits)
+  SetMaxIterations(20);
+  SetKeyframe(keyframe);
+  BeginOnDevice(frame, MaskImage(), false);
+  TrackOnDevice(frame);
+  iteration_ = max_iterations_;
+  EndSolve(frame);
+  half_frame.depth_to_world_transform = frame.depth_to_world_transform;   // not the half level's own result: see above
 }
 
 int ColorTracker::GetResidualCount(const Frame&) const
@@ -571,6 +591,32 @@ void PyramidTracker<DepthTracker>::Track(Frame& frame)
 {
   VULCAN_DEBUG(keyframe_);
   tracker_->TrackPyramid(keyframe_, frame);
+  ++iter_;
+}
+
+// the photometric trackers run both levels without a host round trip in between
+template <typename Tracker>
+static void TrackPhotometricLevels(Tracker& tracker, std::shared_ptr<const Frame> keyframe,
+    std::shared_ptr<Frame> half_keyframe, Frame& half_frame, Frame& frame)
+{
+  frame.Downsample(half_frame);
+  keyframe->Downsample(*half_keyframe);
+  tracker.TrackCoarseToFine(half_keyframe, half_frame, keyframe, frame);
+}
+
+template <>
+void PyramidTracker<ColorTracker>::Track(Frame& frame)
+{
+  VULCAN_DEBUG(keyframe_);
+  TrackPhotometricLevels(*tracker_, keyframe_, half_keyframe_, *half_frame_, frame);
+  ++iter_;
+}
+
+template <>
+void PyramidTracker<LightTracker>::Track(Frame& frame)
+{
+  VULCAN_DEBUG(keyframe_);
+  TrackPhotometricLevels(*tracker_, keyframe_, half_keyframe_, *half_frame_, frame);
   ++iter_;
 }
 
