@@ -518,7 +518,10 @@ VK_API int vk_transform_upload(vk_transform* dst_dev, const vk_transform* src_ho
  * memory, vk_malloc_host), and the enqueuing function looks at it after every
  * `chunk` steps and stops once the loop has converged: the pose is the same, the
  * call blocks for at most one chunk, and no launch follows convergence by more
- * than chunk-1 steps. NULL (or chunk <= 0): enqueue every step, never block. */
+ * than 2 * chunk - 1 steps. The number of steps enqueued depends only on the step at
+ * which the loop converged — not on timing — so all ranks of a multi-GPU rig (whose
+ * steps carry an all-reduce each) enqueue the same number. NULL (or chunk <= 0):
+ * enqueue every step, never block. */
 typedef struct vk_track_poll {
   int32_t* host_state;   /* pinned int32[4], 8-byte aligned, zeroed once by the caller: [0..1] the
                             device's word {steps, converged | call tag}, [2] the library's call counter,

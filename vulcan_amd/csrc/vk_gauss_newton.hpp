@@ -563,10 +563,14 @@ __device__ __forceinline__ void finish_step(const float (&update)[6], int32_t* s
 
 // ---- host side of the chunked loop ------------------------------------------------
 
-// After the steps up to `target` have been enqueued on `s`: wait until the mirror shows
-// that many steps or a converged loop. Returns true when the loop has converged (stop
-// enqueuing). The spin is bounded by the stream itself: once the stream has drained
-// nothing more will be written.
+// After the steps up to `target` have been enqueued on `s`: wait until the mirror shows that
+// many steps or a converged loop, and say whether the loop had converged BY step `target`
+// (stop enqueuing). The answer must not depend on how far ahead this GPU happens to be: in a
+// multi-GPU rig every rank has to enqueue the same number of steps, because each step carries
+// an all-reduce. A loop that converges stops writing the mirror, so a converged word holds the
+// step at which it converged — the same number on every rank — and only that is compared.
+// The spin is bounded by the stream itself: once the stream has drained nothing more will be
+// written.
 inline bool wait_for_steps(const Mirror& mirror, int target, hipStream_t s)
 {
   const volatile unsigned long long* word = reinterpret_cast<const volatile unsigned long long*>(mirror.word);
@@ -576,13 +580,14 @@ inline bool wait_for_steps(const Mirror& mirror, int target, hipStream_t s)
     const unsigned long long v = *word;
     if ((v >> 48) == tag)                          // a word of THIS call (earlier calls' launches may still write theirs)
     {
-      if ((v >> 32) & 1u) return true;
-      if ((int)(uint32_t)v >= target) return false;
+      const int steps = (int)(uint32_t)v;
+      if ((v >> 32) & 1u) return steps <= target;  // converged at step `steps`
+      if (steps >= target) return false;
     }
     if ((spin & 1023u) == 1023u && hipStreamQuery(s) != hipErrorNotReady)
     {
       const unsigned long long last = *word;      // drained: the mirror is final
-      return (last >> 48) == tag && ((last >> 32) & 1u);
+      return (last >> 48) == tag && ((last >> 32) & 1u) && (int)(uint32_t)last <= target;
     }
   }
 }
