@@ -552,7 +552,9 @@ VK_API int vk_track_wait(const vk_track_poll* poll, void* stream);
  * needed for an early exit on this path (its mirror still receives the final state).
  * Should the device be unable to hold the launch's workgroups at the same time — not
  * expected: the grid is sized from the occupancy query — the launch gives up after two
- * seconds and leaves state_dev[1] = VK_TRACK_ABORTED.
+ * seconds and leaves state_dev[1] = VK_TRACK_ABORTED. Tracks issued on different streams of
+ * one device are run one after the other by the library (a loop launch fills the device); two
+ * processes that share a device are not protected from starving each other.
  *
  * With a `reduce` hook (multi-GPU rig) a step is three launches — partial sums, sum,
  * [the hook's all-reduce], solve — and `poll` stops the enqueuing after convergence. */

@@ -468,3 +468,53 @@ def test_fewer_workgroups_than_pixel_groups_gives_the_same_bits(api, orc, monkey
         monkeypatch.setenv("VK_LOOP_GRID_CAP", cap)
         assert run() == full, cap
     monkeypatch.delenv("VK_LOOP_GRID_CAP")
+
+
+def test_two_streams_track_concurrently(api, orc):
+    """Two host threads, each with a stream and a tracker of its own, track at the same time on
+    one device. A loop kernel needs all of its workgroups resident and one fills the device, so
+    two that start together could starve each other; the library chains loop kernels of different
+    streams (vk_loop_launch_begin). Every Track must finish un-aborted with the single-stream bits."""
+    import threading
+    import torch
+    w, h = 640, 480
+    k = T.Projection.make(547.0, 547.0, 320, 240)
+    key_depth = curved_depth(w, h)
+    hk, dk = frames(api, orc, key_depth, k, T.Transform.identity())
+    dk.compute_normals()
+    start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+    _, df0 = frames(api, orc, key_depth, k, start)
+    df0.compute_normals()
+    tracker = api.PyramidTracker()
+    tracker.keyframe = dk
+    want = bytes(tracker.track(df0))
+    sync()
+
+    results, errors = {}, []
+
+    def work(name):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                _, df = frames(api, orc, key_depth, k, start)
+                df.normals = df0.normals.clone()
+                t = api.PyramidTracker()
+                t.keyframe = dk
+                out = []
+                for _ in range(40):
+                    df.depth_to_world = start
+                    out.append(bytes(t.track(df)))
+                    assert int(t.tracker.state.cpu()[1]) in (0, 1)
+                stream.synchronize()
+                results[name] = out
+        except Exception as e:            # noqa: BLE001 — reported by the main thread
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(n,)) for n in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name in ("a", "b"):
+        assert all(p == want for p in results[name]), name

@@ -779,7 +779,9 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.last_launch = done + kExchangeSteps >= iterations ? 1 : 0;
+    vk_loop_launch_begin(s);
     hipLaunchKernelGGL((color_loop_kernel<LIGHT, TRANSLATION>), dim3(grid), dim3(kColorThreads), 0, s, P, L);
+    vk_loop_launch_end(s);
     VK_LAUNCH_CHECK();
     L.fresh_state = 0;
   }

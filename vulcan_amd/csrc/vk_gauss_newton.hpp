@@ -242,6 +242,10 @@ struct Exchange
 // process-wide source of launch tags (vk_runtime.hip): 22 bits, never 0
 uint32_t vk_next_loop_epoch();
 
+// bracket every loop-kernel launch: loop kernels of different streams of one device never overlap
+void vk_loop_launch_begin(hipStream_t stream);
+void vk_loop_launch_end(hipStream_t stream);
+
 namespace vk
 {
 

@@ -720,10 +720,12 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.fresh_state = (fresh_state && done == 0) ? 1 : 0;
     L.last_launch = (ends_track && done + kExchangeSteps >= iterations) ? 1 : 0;
+    vk_loop_launch_begin(s);
     if (translation_enabled)
       hipLaunchKernelGGL(track_loop_kernel<true>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
     else
       hipLaunchKernelGGL(track_loop_kernel<false>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
+    vk_loop_launch_end(s);
     VK_LAUNCH_CHECK();
   }
   return VK_OK;

@@ -8,6 +8,7 @@
 #include <time.h>
 
 #include <atomic>
+#include <mutex>
 
 // Launch tags of the loop kernels (vk_gauss_newton.hpp, "partials exchanged inside a
 // launch"): one counter for the whole library, so that two trackers that are handed the
@@ -26,6 +27,56 @@ uint32_t vk_next_loop_epoch()
   uint32_t e;
   do { e = (counter.fetch_add(1) + 1u) & 0x3fffffu; } while (e == 0);
   return e;
+}
+
+
+// Loop kernels (one launch per Gauss-Newton loop) need all their workgroups on the device at
+// the same time, and one of them fills it. Two of them started at the same moment on two
+// streams could each get a part of the device and wait for the rest — for two seconds, until
+// both give up (VK_TRACK_ABORTED). Loop kernels of one process are therefore chained across
+// streams: once a second stream is seen on a device, every loop launch waits for the
+// previous one's event. A process that tracks on one stream per device never creates an
+// event. (Two PROCESSES sharing a device are not covered: give each its own GPU.)
+namespace
+{
+struct LoopChain
+{
+  std::mutex lock;
+  hipStream_t last_stream = nullptr;
+  bool seen = false, chained = false;
+  hipEvent_t event = nullptr;
+};
+LoopChain g_loop_chain[16];
+}
+
+void vk_loop_launch_begin(hipStream_t s)
+{
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return;
+  LoopChain& c = g_loop_chain[device];
+  c.lock.lock();
+  if (c.seen && !c.chained && c.last_stream != s)
+  {
+    // a second stream: from now on launches are chained; the launches so far had no event
+    c.chained = true;
+    (void)hipStreamSynchronize(c.last_stream);
+    (void)hipEventCreateWithFlags(&c.event, hipEventDisableTiming | hipEventDisableSystemFence);
+  }
+  else if (c.chained && c.event && c.last_stream != s)
+  {
+    (void)hipStreamWaitEvent(s, c.event, 0);
+  }
+}
+
+void vk_loop_launch_end(hipStream_t s)
+{
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return;
+  LoopChain& c = g_loop_chain[device];
+  if (c.chained && c.event) (void)hipEventRecord(c.event, s);
+  c.last_stream = s;
+  c.seen = true;
+  c.lock.unlock();
 }
 
 extern "C" {
