@@ -3,15 +3,21 @@
 
 Headline workload (`--workload rgbd`, the default): BASELINE.json's metric is "RGB-D
 frames/sec (integrate+raycast), 640x480 @ 5 mm voxels", so one step = one 640x480 RGB-D
-frame = Volume::SetView -> LightIntegrator::Integrate (frame mask, depth, shaded colour:
-configs[2]'s integrators) -> Tracer::Trace, through the C ABI (include/vk.h), into
-Volume(65024, 8192) (apps/vulcan/vulcan.cu:12-13). The camera sits at the centre of a 2 m
-sphere and yaws 0.5 deg per frame: the depth image (resident in HBM) is the same closed
-form every frame while new blocks are allocated every frame.
+frame = Frame::ComputeNormals -> Volume::SetView x3 -> LightIntegrator::Integrate (frame
+mask, depth, shaded colour: configs[2]'s integrators) -> Tracer::Trace — the calls of the
+reference's frame loop (apps/vulcan/vulcan.cu:297,316-325) — through the C ABI
+(include/vk.h), into Volume(65024, 8192) (vulcan.cu:12-13). The three SetView calls are ONE
+vk_volume_set_view_rounds(.., 3): same state, the later rounds run on the device and only
+when the round before lost a request. The camera sits at the centre of a 2 m sphere and yaws
+0.5 deg per frame: the depth image (resident in HBM) is the same closed form every frame
+while new blocks are allocated every frame.
 
   --workload depth      BASELINE configs[1]: depth-only sequence, DepthIntegrator + Tracer
-  --workload rgbd-icp   configs[2] in full: PyramidTracker<DepthTracker> against the previous
-                        raycast, then SetView + LightIntegrator + Tracer
+  --workload rgbd-icp   configs[2] in full, closed loop: a camera moving through a box room
+                        with spheres (tests/scenes.py: every pose parameter observable), each
+                        frame tracked by PyramidTracker<DepthTracker> against the previous
+                        raycast from the previous TRACKED pose, then fused and raycast at the
+                        tracked pose; the ground truth only scores the result
 
 The default run prints ONE JSON line for `rgbd` that also carries the other two workloads
 under "other_workloads" (same loop, same sizes, fewer steps).
@@ -58,6 +64,7 @@ IMAGE_BYTES = {"depth": W * H * 4,                          # depth
                "rgbd": W * H * (4 + 12 + 12 + 4)}           # + colour + normals + mask (light integrator)
 METRIC = "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels"
 LIGHT = (2.0, (0.025, 0.08, 0.0))                           # apps/vulcan/vulcan.cu:87-88
+SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan.cu:316-318
 
 
 def sphere_room_depth(k):
@@ -146,29 +153,57 @@ def launch_selftest(args):
 
 # ------------------------------------------------------------------- frame loops ----
 
+class RoomSequence:
+    """The tracking workload's input, resident in HBM before the timed region: depth + colour of
+    every frame of the room sequence (tests/scenes.py) and the true poses, which only score."""
+
+    def __init__(self, count, k):
+        import torch
+        import scenes
+        from concurrent.futures import ThreadPoolExecutor
+        self.truth = [scenes.room_pose(i) for i in range(count)]
+        with ThreadPoolExecutor(max_workers=8) as pool:
+            frames = list(pool.map(lambda p: scenes.room_frame(k, p, W, H, light=LIGHT), self.truth))
+        self.depth = [torch.from_numpy(d).cuda() for d, _ in frames]
+        self.color = [torch.from_numpy(c).cuda() for _, c in frames]
+
+
+def pose_error(got, truth):
+    """(translation error in metres, rotation error in degrees) of a tracked pose."""
+    d = got.matrix().astype(np.float64) @ truth.inverse_matrix().astype(np.float64)
+    angle = np.degrees(np.arccos(np.clip((np.trace(d[:3, :3]) - 1.0) / 2.0, -1.0, 1.0)))
+    return float(np.linalg.norm(got.matrix()[:3, 3].astype(np.float64) - truth.matrix()[:3, 3])), float(angle)
+
+
 class FrameLoop:
     """One rank's replica volume and frame loop, calling the C ABI with descriptors built
     once, the way a C++ caller would (the api.* wrappers rebuild ctypes structs per call)."""
 
-    def __init__(self, workload, poses, volumes=1):
+    def __init__(self, workload, poses, volumes=1, sequence=None):
         import torch
         from vulcan_amd import api, vk_types as T
         import scenes
         self.api, self.T, self.torch = api, T, torch
-        self.workload, self.poses = workload, poses
+        self.workload, self.poses, self.sequence = workload, poses, sequence
         self.lib, self.stream = api.lib(), api.stream()
         k = T.Projection.make(*scenes.APP_INTRINSICS)
         self.k = k
-        self.depth_np = sphere_room_depth(k)
-        self.color_np = scenes.checker_color(W, H, 0.1, 0.9) if workload != "depth" else None
-        self.frame = api.Frame(self.depth_np, k, poses[0], color=self.color_np)
+        if sequence is None:
+            self.depth_np = sphere_room_depth(k)
+            self.color_np = scenes.checker_color(W, H, 0.1, 0.9) if workload != "depth" else None
+            self.frame = api.Frame(self.depth_np, k, poses[0], color=self.color_np)
+        else:
+            self.frame = api.Frame(sequence.depth[0], k, sequence.truth[0], color=sequence.color[0])
         if workload != "depth":
-            self.frame.compute_normals()
+            # Frame::ComputeNormals runs every frame, inside the timed step (vulcan.cu:297)
+            self.frame.normals = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
         self.key = api.Frame(torch.zeros((H, W), dtype=torch.float32, device="cuda"), k, poses[0],
                              color=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"),
                              normals=torch.zeros((H, W, 3), dtype=torch.float32, device="cuda"))
         self.fdesc, self.kdesc = self.frame.desc(), self.key.desc()
         self.fref, self.kref = C.byref(self.fdesc), C.byref(self.kdesc)
+        self.kproj = C.byref(self.k)
+        self.n_ptr = None if workload == "depth" else C.c_void_p(self.frame.normals.data_ptr())
         self.out_ptrs = tuple(C.c_void_p(t.data_ptr()) for t in (self.key.depth, self.key.color, self.key.normals))
         self.mode = 0 if workload == "depth" else 2
         # `volumes` > 1: the same sequence applied to several replica volumes in lock step, so
@@ -201,6 +236,7 @@ class FrameLoop:
             self.prep.capacity = W * H
         self.pprep = None if self.prep is None else C.byref(self.prep)
         self.tracker = None
+        self.tracked_poses, self.gn_steps = [], []
         if workload == "rgbd-icp":
             # PyramidTracker<DepthTracker>::Track through its one C entry point, descriptors built once
             self.tracker = api.PyramidTracker()
@@ -213,28 +249,44 @@ class FrameLoop:
                                C.c_void_p(t.system.data_ptr()), C.c_void_p(t.state.data_ptr()),
                                C.c_void_p(t.update.data_ptr()), None, None, t._poll())
             self.pose_dev = C.c_void_p(t.pose.data_ptr())
-            self.tracked = T.Transform()
+            self.poll_words = (C.c_int32 * 4).from_address(t._poll_host.value)
+            self.current = T.Transform.from_buffer_copy(bytes(sequence.truth[0]))   # the first frame defines the map
 
     def step(self, i, ev=None, v=0):
         lib, s, vv = self.lib, self.stream, self.vols[v]
-        if self.tracker is not None and i > 0:
-            # tracker -> SetView -> Integrate -> Trace (apps/vulcan/vulcan.cu:300-325): the frame
-            # starts from the previous pose and is tracked against the previous raycast (whose
-            # pose is poses[i - 1]); the tracked pose is read back, as Tracker::EndSolve does
-            a, t = self.track_args, self.tracker.tracker
-            rc = lib.vk_transform_upload(self.pose_dev, C.byref(self.poses[i - 1]), s)
-            rc |= lib.vk_icp_pyramid_track(a[0], C.byref(self.poses[i - 1]), *a[2:], s)
-            rc |= lib.vk_track_wait(a[-1], s)                       # Tracker::EndSolve: the pose, from pinned memory
-            C.memmove(C.byref(self.tracked), t._pose_host, 128)
-            if rc:
-                raise self.api.VkError(f"frame {i}: tracking returned {rc}")
-        pose = self.poses[i]                       # ground truth keeps the map consistent
-        self.frame.depth_to_world = pose
-        self.key.depth_to_world = pose
+        seq = self.sequence
+        if seq is not None:
+            # the next camera frame: images that are already resident in HBM
+            self.fdesc.depth = seq.depth[i].data_ptr()
+            self.fdesc.color = seq.color[i].data_ptr()
+        rc = 0
+        if self.mode == 2:
+            rc = lib.vk_frame_compute_normals(C.c_void_p(self.fdesc.depth), self.kproj, self.n_ptr, W, H, s)   # vulcan.cu:297
+        if self.tracker is not None:
+            pose = self.current
+            if i > 0:
+                # tracker -> SetView -> Integrate -> Trace (apps/vulcan/vulcan.cu:300-325): the frame starts
+                # from the previous tracked pose and is tracked against the previous raycast, which was
+                # made from that pose; the tracked pose is read back, as Tracker::EndSolve does
+                a = self.track_args
+                self.frame_view.depths = self.fdesc.depth
+                rc |= lib.vk_transform_upload(self.pose_dev, C.byref(pose), s)
+                rc |= lib.vk_icp_pyramid_track(a[0], C.byref(pose), *a[2:], s)
+                rc |= lib.vk_track_wait(a[-1], s)                   # Tracker::EndSolve: the pose, from pinned memory
+                if rc:
+                    raise self.api.VkError(f"frame {i}: tracking returned {rc}")
+                pose = self.T.Transform.from_buffer_copy(C.string_at(self.tracker.tracker._pose_host, 128))
+                self.current = pose
+                self.gn_steps.append(int(self.poll_words[0]))
+            self.tracked_poses.append(pose)
+        else:
+            pose = self.poses[i]
         self.fdesc.depth_to_world = pose
         self.kdesc.depth_to_world = pose
+        self.fdesc.content_id += 2                 # this step's normals (and images): new content, odd ids
         vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
-        rc = lib.vk_volume_set_view_prepare(vv["vref"], self.fref, self.pprep, s)   # volume.cu:430-437 (+ light_integrator.cu:277-293)
+        # volume.cu:430-437, three times (vulcan.cu:316-318), + light_integrator.cu:277-293
+        rc |= lib.vk_volume_set_view_rounds(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, s)
         if self.mode == 2:
             if lib.vk_light_prepared(self.pprep, self.fref, C.c_float(self.depth_threshold)):
                 self.prep.valid = 0
@@ -265,27 +317,37 @@ class FrameLoop:
         return ms.value
 
 
-def visible_counts(poses):
+def visible_counts(poses, depths=None):
     """Allocation depends only on the depth image and the pose and is deterministic, so an
     untimed replay of SetView over the same poses gives the visible-block count every
-    integrate launch of the timed run saw."""
+    integrate launch of the timed run saw. Also returns how many SetView rounds ran in all."""
     from vulcan_amd import api, vk_types as T
     import scenes
     k = T.Projection.make(*scenes.APP_INTRINSICS)
     vol = api.Volume(MAIN, EXCESS, voxel_length=VOXEL, truncation_length=TRUNC)
-    frame = api.Frame(sphere_room_depth(k), k, poses[0])
-    out = []
-    for p in poses:
+    frame = api.Frame(sphere_room_depth(k) if depths is None else depths[0], k, poses[0])
+    out, rounds = [], []
+    for i, p in enumerate(poses):
+        if depths is not None:
+            frame.depth = depths[i]
         frame.depth_to_world = p
-        vol.set_view(frame)
-        out.append(vol.visible_count)
-    return np.array(out, dtype=np.float64), vol
+        vol.set_view(frame, rounds=SET_VIEW_ROUNDS)
+        ctr = vol.read_counters()
+        out.append(int(ctr[T.VK_CTR_VISIBLE]))
+        rounds.append(int(ctr[T.VK_CTR_ROUNDS]))
+    per_frame = np.diff(np.array([0] + rounds))
+    return np.array(out, dtype=np.float64), per_frame
 
 
 def run_workload(workload, poses, warmup, steps, vd, with_roofline):
     """W untimed + K timed frames; returns the JSON fields of that workload."""
     import torch
-    loop = FrameLoop(workload, poses)
+    from vulcan_amd import vk_types as T
+    import scenes
+    sequence = None
+    if workload == "rgbd-icp":
+        sequence = RoomSequence(warmup + steps, T.Projection.make(*scenes.APP_INTRINSICS))
+    loop = FrameLoop(workload, poses, sequence=sequence)
     # HIP events (created without the system-scope fence, vk_event_create) around the integrate
     # launch: a pair of records costs the stream ~1.7 us, so long runs sample every 4th frame
     stride = 1 if steps <= 64 else 4
@@ -311,8 +373,22 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline):
         out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, sampled
     ctr = loop.vols[0]["vol"].read_counters()
     out["_counters"] = ctr
+    out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps)
     if loop.tracker is not None:
-        out["gauss_newton_steps_last_frame"] = int(loop.tracker.tracker.state.cpu()[0])
+        # the closed loop, scored against the ground truth it never saw
+        errors = [pose_error(p, sequence.truth[i]) for i, p in enumerate(loop.tracked_poses)]
+        timed = errors[warmup:]
+        steps_timed = np.array(loop.gn_steps[max(0, warmup - 1):], dtype=np.int64)
+        hist = np.bincount(steps_timed, minlength=21)
+        out["tracked_pose_drives_fusion"] = True
+        out["pose_error_max"] = {"translation_m": max(e[0] for e in timed), "rotation_deg": max(e[1] for e in timed)}
+        out["pose_error_last_frame"] = {"translation_m": errors[-1][0], "rotation_deg": errors[-1][1]}
+        motion = pose_error(sequence.truth[-1], sequence.truth[0])
+        out["camera_motion_over_run"] = {"translation_m": motion[0], "rotation_deg": motion[1]}
+        out["gn_steps_median"] = float(np.median(steps_timed))
+        out["gn_steps_histogram_full_resolution_level"] = {str(n): int(c) for n, c in enumerate(hist) if c}
+        out["_tracked"] = loop.tracked_poses
+        out["_depths"] = sequence.depth
     return out, loop
 
 
@@ -542,7 +618,8 @@ def main():
     wl = args.workload
     res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True)
 
-    nvis, _ = visible_counts(poses)
+    tracked, depths = res.pop("_tracked", None), res.pop("_depths", None)
+    nvis, rounds_per_frame = visible_counts(tracked or poses, depths)
     nvis_timed = nvis[args.warmup:]
     image_bytes = IMAGE_BYTES["depth" if wl == "depth" else "rgbd"]
     alg = nvis_timed * BYTES_PER_BLOCK + image_bytes
@@ -553,18 +630,31 @@ def main():
     frame_bytes = float(alg.mean())
     voxel_ws = float(nvis_timed.mean()) * 10240
 
-    names = {"rgbd": "BASELINE configs[2] fusion+raycast: 640x480 RGB-D, SetView + LightIntegrator (frame mask, depth, "
-                     "shaded colour in one pass) + Tracer",
-             "depth": "BASELINE configs[1]: 640x480 depth-only sequence, SetView + DepthIntegrator + Tracer",
-             "rgbd-icp": "BASELINE configs[2]: 640x480 RGB-D, PyramidTracker<DepthTracker> vs the previous raycast + SetView + "
-                         "LightIntegrator + Tracer"}
+    sphere = ", camera at the centre of a 2 m sphere yawing 0.5 deg/frame"
+    names = {"rgbd": "BASELINE configs[2] fusion+raycast: 640x480 RGB-D, Frame::ComputeNormals + SetView x3 + LightIntegrator "
+                     "(frame mask, depth, shaded colour in one pass) + Tracer" + sphere,
+             "depth": "BASELINE configs[1]: 640x480 depth-only sequence, SetView x3 + DepthIntegrator + Tracer" + sphere,
+             "rgbd-icp": "BASELINE configs[2], closed loop: 640x480 RGB-D, Frame::ComputeNormals + PyramidTracker<DepthTracker> "
+                         "vs the previous raycast (from the previous tracked pose) + SetView x3 + LightIntegrator + Tracer at "
+                         "the TRACKED pose; camera swinging +-40 deg and translating through a 4.4 x 3 x 5.2 m box room with "
+                         "9 spheres (closed form, all six pose parameters observable)"}
+    set_view_policy = {
+        "calls_per_frame_upstream": 3, "max_rounds": SET_VIEW_ROUNDS,
+        "policy": "one vk_volume_set_view_rounds(.., 3) per frame = the state of upstream's three SetView calls "
+                  "(apps/vulcan/vulcan.cu:316-318), bit for bit; rounds 2 and 3 run inside the last launch of round 1, "
+                  "and only when the round before lost a request to a bucket contest or dropped one",
+        "rounds_run_per_frame": res.pop("set_view_rounds_run_per_frame"),
+        "frames_that_needed_more_than_one_round": int((rounds_per_frame > 1).sum()),
+    }
     result = {
         "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192), camera at the centre of a 2 m sphere yawing "
-                                    "0.5 deg/frame, one SetView per frame (allocation is iterated on the device)",
+            "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
+            "set_view": set_view_policy,
+            "input_normals": "Frame::ComputeNormals of the input frame runs inside every timed step (vulcan.cu:297)"
+                             if wl != "depth" else "not needed by DepthIntegrator (configs[1])",
             "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
             "visible_blocks_mean": float(nvis_timed.mean()),
             "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
@@ -586,7 +676,8 @@ def main():
                         "avg_us": float(trace_ms.mean() * 1e3)},
         },
     }
-    for key_ in ("gauss_newton_steps_last_frame",):
+    for key_ in ("tracked_pose_drives_fusion", "pose_error_max", "pose_error_last_frame", "camera_motion_over_run",
+                 "gn_steps_median", "gn_steps_histogram_full_resolution_level"):
         if key_ in res:
             result["config"][key_] = res[key_]
 
@@ -610,11 +701,14 @@ def main():
 
     if extras:
         # the same kernel with the working set pushed out of the Infinity Cache
-        pl3 = past_l3(wl, poses, min(args.warmup, 10), 6, nvis)
-        pl3["frac"] = pl3["achieved"] / HBM_PEAK_GBS
-        pl3["frac_of_measured_copy_peak"] = pl3["achieved"] / HBM_COPY_GBS
-        result["roofline"]["past_l3"] = pl3
-        torch.cuda.empty_cache()
+        if wl != "rgbd-icp":
+            pl3 = past_l3(wl, poses, min(args.warmup, 10), 6, nvis)
+            pl3["frac"] = pl3["achieved"] / HBM_PEAK_GBS
+            pl3["frac_of_measured_copy_peak"] = pl3["achieved"] / HBM_COPY_GBS
+            result["roofline"]["past_l3"] = pl3
+            # next to `frac`: the same kernel when its voxels come from HBM, not from the Infinity Cache
+            result["roofline"]["frac_past_l3"] = pl3["frac"]
+            torch.cuda.empty_cache()
 
         others = {}
         for other in ("depth", "rgbd", "rgbd-icp"):
@@ -624,7 +718,14 @@ def main():
             o, oloop = run_workload(other, poses[:k_warm + k_steps], k_warm, k_steps, vd, with_roofline=True)
             ims, tms, smp = np.array(o.pop("_integrate_ms")), np.array(o.pop("_trace_ms")), o.pop("_sampled")
             o.pop("_counters")
-            oalg = nvis[k_warm:k_warm + k_steps] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if other == "depth" else "rgbd"]
+            onvis = nvis
+            if "_tracked" in o:
+                del oloop
+                oloop = None
+                torch.cuda.empty_cache()
+                onvis, _ = visible_counts(o.pop("_tracked"), o.pop("_depths"))
+                o["visible_blocks_mean"] = float(onvis[k_warm:].mean())
+            oalg = onvis[k_warm:k_warm + k_steps] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if other == "depth" else "rgbd"]
             o["workload"] = names[other]
             o["unit"] = "frames/s"
             o["integrate_avg_us"] = float(ims.mean() * 1e3)
@@ -683,12 +784,12 @@ def cpu_baseline(workload, poses, seconds):
     color = scenes.checker_color(W, H, 0.1, 0.9) if workload != "depth" else None
     hf = orc.HostFrame(depth_np, k, poses[0], color=color)
     light = T.Light.make(*LIGHT)
-    if workload != "depth":
-        hf.compute_normals()
-
     def frame(i):
         hf.depth_to_world = poses[i]
-        hv.set_view(hf, orc.POLICY_SERIAL)
+        if workload != "depth":
+            hf.compute_normals()                  # Frame::ComputeNormals, every frame (vulcan.cu:297)
+        for _ in range(SET_VIEW_ROUNDS):          # vulcan.cu:316-318
+            hv.set_view(hf, orc.POLICY_SERIAL)
         orc.integrate_depth(hv, hf)
         if workload != "depth":
             mask = orc.light_frame_mask(hf, 0.2)
@@ -704,7 +805,8 @@ def cpu_baseline(workload, poses, seconds):
     dt = time.perf_counter() - t0
 
     out = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"frames 2..{1 + n} of the same sequence ({dt:.1f} s: SetView + "
+           "sample": f"frames 2..{1 + n} of the same sequence ({dt:.1f} s: "
+                     + ("" if workload == "depth" else "input normals + ") + "SetView x3 + "
                      + ("depth integrate" if workload == "depth" else "frame mask + depth + shaded-colour integrate")
                      + f" + raycast + normals each), allocation serial, the rest OpenMP x{cores}"}
     out["configs0_dense_128"] = dense_128(orc, T, depth_np, k, cores, 0.3 * seconds)

@@ -105,7 +105,14 @@ enum {
   VK_CTR_DROPPED    = 5,  /* requests dropped so far: pool or excess list exhausted */
   VK_CTR_PENDING_ALL    = 6,  /* internal: pointer updates of a handle pass, not yet folded in */
   VK_CTR_PENDING_EXCESS = 7,
-  VK_CTR_COUNT      = 8
+  VK_CTR_ROUNDS     = 8,  /* SetView rounds run so far by vk_volume_set_view* (cumulative) */
+  VK_CTR_UNSETTLED  = 9,  /* the last vk_volume_set_view* ended with a request lost to a bucket
+                             contest or dropped: another SetView would have work (1), or its
+                             rounds were cut short by a barrier timeout (-1, never seen) */
+  VK_CTR_CONTENDED  = 10, /* internal: a request pass lost a request to a bucket contest */
+  VK_CTR_GATE       = 11, /* internal [2]: "another round is needed", by round parity */
+  VK_CTR_BARRIER    = 13, /* internal: arrivals at the grid barriers of the later rounds */
+  VK_CTR_COUNT      = 16
 };
 
 enum {
@@ -155,6 +162,12 @@ typedef struct vk_frame {
   vk_projection color_projection;
   vk_transform  depth_to_world;   /* Twd */
   vk_transform  depth_to_color;   /* Tcd */
+  /* Identity of the images' CONTENT, maintained by the caller: a value that changes whenever
+   * a pixel of the depth, colour or normal image changes (the class layer stamps its images on
+   * every write it can see, image.h). 0 = unknown. Only vk_volume_set_view_prepare /
+   * vk_light_prepared look at it: work done ahead for a frame is reused for the same
+   * content only, never for "the same pointers". No reference counterpart. */
+  uint64_t      content_id;
 } vk_frame;
 
 /* ------------------------------------------------------ library / device -- */
@@ -361,7 +374,10 @@ VK_API int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth,
  * the view from (the reference's frame loop, apps/vulcan/vulcan.cu:316-325) can have it
  * computed by that pass: vk_volume_set_view_prepare fills prep->mask / prep->records and
  * notes which frame they are for; the integrator asks (vk_light_prepared) and skips its
- * own pass on a match. The images must not be modified between the two calls.
+ * own pass on a match. "Which frame" means which CONTENT (vk_frame.content_id): upstream's
+ * SetView reads the depth image only, so SetView(frame); frame.ComputeNormals();
+ * Integrate(frame) is a legal sequence, and a preparation made before the normals changed
+ * must not be used after. A frame whose content_id is 0 is never prepared ahead.
  * No reference counterpart; results are identical with or without it. */
 typedef struct vk_light_prep {
   /* set by the caller */
@@ -377,6 +393,7 @@ typedef struct vk_light_prep {
   const float* normals;
   float        prepared_threshold;
   vk_transform depth_to_color;
+  uint64_t     content_id;     /* frame->content_id at the time; a frame with id 0 is never prepared */
 } vk_light_prep;
 
 /* ref: src/volume.cu:430-437 Volume::SetView (as vk_volume_set_view) + src/light_integrator.cu:
@@ -386,9 +403,23 @@ typedef struct vk_light_prep {
 VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
     void* stream);
 
+/* ref: apps/vulcan/vulcan.cu:316-318 — the frame loop calls SetView(frame) three times per frame,
+ * because a bucket takes one request per call and a block that loses the contest for its bucket
+ * (or finds its bucket's main entry taken by the winner) must ask again. This entry point leaves
+ * exactly the state of `max_rounds` consecutive vk_volume_set_view(_prepare) calls with the same
+ * frame — every buffer, the visible set, VK_CTR_VOXEL_PTR / EXCESS_PTR / REQUESTS / DROPPED — in the
+ * three launches of ONE call: the rounds after the first run inside the last launch, and only
+ * when the round before lost or dropped a request (otherwise another SetView changes nothing,
+ * and none is run). `prep` as in vk_volume_set_view_prepare (may be NULL). max_rounds >= 1.
+ * VK_CTR_ROUNDS counts the rounds that ran; VK_CTR_UNSETTLED tells whether one more would still
+ * have had work. */
+VK_API int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
+    int max_rounds, void* stream);
+
 /* ref: src/light_integrator.cu:270-275 LightIntegrator::Integrate decides here whether
  * ComputeFrameMask still has to run: 1 if *prep holds the preparation of exactly `frame` (same
- * image pointers and size, same depth->colour transform) at `depth_threshold`, else 0. */
+ * non-zero content_id, same image pointers and size, same depth->colour transform) at
+ * `depth_threshold`, else 0. */
 VK_API int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float depth_threshold);
 
 /* ---------------------------------------------------- raycast bounds, ahead -- */

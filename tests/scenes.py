@@ -107,3 +107,92 @@ def tracer_patch_kat():
         entries["block"]["origin"][i] = [np.int16(int(F(c) / block_length)) for c in xwp[:3]]
         entries["data"][i], entries["next"][i] = 0, -1
     return entries, tcw, k
+
+
+# ---------------------------------------------------------------- the room ----
+# A closed-form scene in which a depth camera observes all six degrees of freedom: a box room
+# (three pairs of orthogonal walls) with spheres standing on the floor, hanging from the ceiling
+# and attached to the walls. Every ray hits something, so the depth image has no holes; the
+# intersections are analytic (a slab test and a quadratic per sphere, float64, rounded once).
+# Used by the tracking workloads of bench.py / fuse_sequence and by the closed-loop parity test:
+# the sphere-centred scene of the fusion benchmark is invariant under rotation, hence useless
+# for tracking.
+ROOM_HALF = (2.2, 1.5, 2.6)                                   # box half extents (x, y, z), metres; +y is down
+ROOM_SPHERES = ((1.2, 0.9, 1.6, 0.6), (-1.4, 1.0, 1.2, 0.5), (-1.0, 0.95, -1.7, 0.55), (1.5, 1.05, -1.3, 0.45),
+                (0.2, -0.9, 2.1, 0.5), (-1.9, -0.2, -0.3, 0.5), (1.9, 0.1, 0.2, 0.45), (0.1, 1.1, 2.2, 0.4),
+                (-0.3, 1.15, -2.2, 0.35))                     # (cx, cy, cz, radius)
+
+
+def room_pose(i, frames_per_cycle=320, yaw_amplitude_deg=40.0, pitch_deg=12.0):
+    """Camera pose i of the room sequence (depth-to-world): the yaw swings +-40 deg (at most
+    0.8 deg per frame), the camera is pitched 12 deg towards the floor and its centre moves on a
+    small closed curve (a few millimetres per frame), so depth changes in every pixel, every frame."""
+    phase = 2.0 * np.pi * i / frames_per_cycle
+    a = np.deg2rad(yaw_amplitude_deg) * np.sin(phase)
+    p = np.deg2rad(pitch_deg)
+    position = (0.25 * np.sin(phase), 0.04 * np.sin(2.0 * phase), 0.25 * (np.cos(phase) - 1.0))
+    yaw_q = T.Transform.rotate(np.cos(a / 2), 0.0, np.sin(a / 2), 0.0)
+    pitch_q = T.Transform.rotate(np.cos(p / 2), np.sin(p / 2), 0.0, 0.0)
+    return T.Transform.translate(*position) * yaw_q * pitch_q
+
+
+def _room_hit(k, pose, w, h, with_normal=True):
+    """Per pixel: depth z (the ray is unproject(u, v) with z = 1, so its parameter IS the depth),
+    the world point and the inward surface normal (world) as three planes each, float64."""
+    m = pose.matrix().astype(np.float64)
+    rot, pos = m[:3, :3], m[:3, 3]
+    rx = ((np.arange(w) + 0.5 - k.cx) / k.fx)[None, :]
+    ry = ((np.arange(h) + 0.5 - k.cy) / k.fy)[:, None]
+    d = [rot[j, 0] * rx + rot[j, 1] * ry + rot[j, 2] for j in range(3)]      # world direction, |d| != 1
+    s = np.full((h, w), np.inf)
+    axis = np.zeros((h, w), dtype=np.int8)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for j in range(3):
+            sj = np.where(d[j] == 0, np.inf, (np.sign(d[j]) * ROOM_HALF[j] - pos[j]) / d[j])   # exit parameter
+            closer = sj < s
+            s = np.where(closer, sj, s)
+            axis[closer] = j
+    normal = [np.where(axis == j, -np.sign(d[j]), 0.0) for j in range(3)] if with_normal else None
+    aa = d[0] * d[0] + d[1] * d[1] + d[2] * d[2]
+    for cx, cy, cz, r in ROOM_SPHERES:
+        oc = pos - np.array([cx, cy, cz])
+        b = d[0] * oc[0] + d[1] * oc[1] + d[2] * oc[2]
+        disc = b * b - aa * (oc @ oc - r * r)
+        t = (-b - np.sqrt(np.maximum(disc, 0.0))) / aa
+        hit = (disc > 0) & (t > 0) & (t < s)
+        if not hit.any():
+            continue
+        s = np.where(hit, t, s)
+        if with_normal:                                        # outward from the ball = into the room
+            normal = [np.where(hit, (oc[j] + t * d[j]) / r, normal[j]) for j in range(3)]
+    point = [pos[j] + s * d[j] for j in range(3)]
+    return s, point, normal, (np.broadcast_to(rx, (h, w)), np.broadcast_to(ry, (h, w))), rot
+
+
+def room_depth(k, pose, w, h):
+    return _room_hit(k, pose, w, h, with_normal=False)[0].astype(np.float32)
+
+
+def room_albedo(point):
+    return 0.5 + 0.15 * np.cos(5.0 * point[0] + 1.0) * np.cos(4.0 * point[2]) + 0.15 * np.cos(6.0 * point[1])
+
+
+def room_frame(k, pose, w, h, light=None):
+    """(depth, colour) of the room from `pose`. With a light (intensity, position in the camera
+    frame: the app's lamp sits next to the camera, apps/vulcan/vulcan.cu:87-88) the colour is
+    albedo x Light::GetShading (light.h:53-60: intensity * cos / distance^2), grey; without, the
+    bare albedo. Values stay inside (.02, .98), the range LightIntegrator accepts."""
+    s, point, normal, (rx, ry), rot = _room_hit(k, pose, w, h, with_normal=light is not None)
+    value = room_albedo(point)
+    if light is not None:
+        intensity, lp = light
+        pc = (s * rx, s * ry, s)                               # the point in the camera frame
+        nc = [rot[0, j] * normal[0] + rot[1, j] * normal[1] + rot[2, j] * normal[2] for j in range(3)]   # R^T n
+        to_light = [lp[j] - pc[j] for j in range(3)]
+        dist2 = to_light[0] ** 2 + to_light[1] ** 2 + to_light[2] ** 2
+        cos = (nc[0] * to_light[0] + nc[1] * to_light[1] + nc[2] * to_light[2]) / np.sqrt(dist2)
+        value = value * np.clip(intensity * cos / dist2, 0.0, None)
+    value = np.clip(value, 0.03, 0.97).astype(np.float32)
+    color = np.empty((h, w, 3), dtype=np.float32)
+    color[...] = value[..., None]
+    return s.astype(np.float32), color

@@ -518,3 +518,66 @@ def test_two_streams_track_concurrently(api, orc):
     assert not errors, errors
     for name in ("a", "b"):
         assert all(p == want for p in results[name]), name
+
+
+def test_stale_light_preparation_is_never_used(api, orc):
+    """Upstream's SetView reads the depth image only, so SetView(frame); <change normals or colours>;
+    Integrate(frame) is legal. The preparation SetView made ahead is tied to the frame's content
+    (vk_frame.content_id), not to its pointers: after an in-place change Integrate prepares again."""
+    import torch
+    w, h = 160, 120
+    k = T.Projection.make(136, 136, 80, 60)
+    depth = scenes.sphere(4 * w, 4 * h)[::4, ::4].copy()
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    hf = orc.HostFrame(depth, k, T.Transform.identity(), color=color)
+    df = api.Frame(depth, k, T.Transform.identity(), color=color)
+    hf.compute_normals()
+    df.compute_normals()
+    hv, dv = make_pair(api, orc, 8192, 2048, 0.008, 0.04)
+    integ = api.LightIntegrator(dv)
+    integ.light = light
+
+    def oracle_step():
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        orc.integrate_light_color(hv, hf, light, orc.light_frame_mask(hf, 0.2))
+
+    oracle_step()
+    dv.set_view(df)
+    integ.integrate(df)
+    assert_volume_equal(dv, hv)
+
+    # (1) an in-place torch write between SetView and Integrate (torch's version counter sees it)
+    dv.set_view(df)
+    assert integ._prep.valid == 1
+    df.normals.mul_(-1.0)
+    df.color.mul_(0.5).add_(0.2)
+    hf.normals, hf.color = -hf.normals, (hf.color * np.float32(0.5) + np.float32(0.2)).astype(np.float32)
+    assert not api.lib().vk_light_prepared(api._ref(integ._prep), api._ref(df.desc()), integ.depth_threshold)
+    oracle_step()
+    integ.integrate(df)
+    assert_volume_equal(dv, hv)
+
+    # (2) a write through the raw pointer (a kernel of the caller's own), announced with touch()
+    dv.set_view(df)
+    raw = torch.full_like(df.normals, 0.0)
+    raw[..., 2] = -1.0
+    api.check(api.lib().vk_memcpy_d2d(api._ptr(df.normals), api._ptr(raw), raw.numel() * 4, api.stream()), "copy")
+    df.touch()
+    hf.normals = raw.cpu().numpy()
+    oracle_step()
+    integ.integrate(df)
+    assert_volume_equal(dv, hv)
+
+    # (3) nothing changed: the preparation made by SetView is used
+    hv.set_view(hf, orc.POLICY_MAXKEY)
+    dv.set_view(df)
+    assert api.lib().vk_light_prepared(api._ref(integ._prep), api._ref(df.desc()), integ.depth_threshold)
+
+    # a frame that does not say what it holds (content_id 0) is never prepared ahead
+    desc = df.desc()
+    desc.content_id = 0
+    api.check(api.lib().vk_volume_set_view_prepare(api._ref(dv.desc()), api._ref(desc), api._ref(integ._prep), api.stream()),
+              "vk_volume_set_view_prepare")
+    assert integ._prep.valid == 0

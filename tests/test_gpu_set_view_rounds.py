@@ -1,0 +1,160 @@
+"""vk_volume_set_view_rounds: the reference's frame loop calls SetView three times per frame
+(apps/vulcan/vulcan.cu:316-318) because a bucket takes one request per call. One call with
+`rounds` must leave exactly the state of that many consecutive SetView calls — every buffer,
+the visible set, the pool pointers and the request / drop counters — although the later rounds
+run inside the last launch of the first one, and only when the round before lost a request.
+
+The checker is the oracle's set_view called `rounds` times.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import api, assert_volume_equal, frames, make_pair, sync  # noqa: F401
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+
+K_SMALL = T.Projection.make(272.0, 272.0, 155.6, 117.4)
+
+
+def oracle_rounds(orc, hv, hf, rounds):
+    for _ in range(rounds):
+        hv.set_view(hf, orc.POLICY_MAXKEY)
+
+
+def assert_same_requests(dv, hv):
+    ctr = dv.read_counters()
+    assert ctr[T.VK_CTR_REQUESTS] == hv.counters[T.VK_CTR_REQUESTS], (ctr, hv.counters)
+    return ctr
+
+
+@pytest.mark.parametrize("scene", ["sphere", "ramp"])
+@pytest.mark.parametrize("rounds", [2, 3, 6])
+def test_rounds_equal_consecutive_set_views(api, orc, scene, rounds):
+    """A table far too small for the scene (1024 buckets for ~2 000 blocks): every round loses
+    requests to bucket contests and grows chains, so each round changes the state."""
+    w, h = 320, 240
+    depth = {"sphere": scenes.sphere(2 * w, 2 * h)[::2, ::2].copy(), "ramp": scenes.ramp(w, h)}[scene]
+    hv, dv = make_pair(api, orc, 1024, 16384, 0.01, 0.04)
+    for step, pose in enumerate((scenes.tracer_test_pose(), scenes.yaw(4.0) * scenes.tracer_test_pose())):
+        hf, df = frames(api, orc, depth, K_SMALL, pose)
+        before = int(dv.read_counters()[T.VK_CTR_ROUNDS])
+        oracle_rounds(orc, hv, hf, rounds)
+        dv.set_view(df, rounds=rounds)
+        assert_volume_equal(dv, hv, voxels=False)
+        ctr = assert_same_requests(dv, hv)
+        ran = int(ctr[T.VK_CTR_ROUNDS]) - before
+        assert 1 <= ran <= rounds
+        if step == 0 and rounds <= 3:
+            assert ran == rounds                              # contested: no round could be skipped
+        assert ctr[T.VK_CTR_UNSETTLED] in (0, 1)
+    assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 500   # chains exercised
+    assert hv.counters[T.VK_CTR_DROPPED] == 0
+
+
+def test_later_rounds_are_skipped_when_nothing_is_pending(api, orc):
+    """A table with room: the first frame needs a second round for its few collisions, the same
+    view again needs none — and the state still equals three SetView calls."""
+    w, h = 320, 240
+    hf, df = frames(api, orc, scenes.plane(w, h, 1.5), K_SMALL, scenes.tracer_test_pose())
+    hv, dv = make_pair(api, orc, 65024, 8192, 0.01, 0.04)
+    ran = []
+    for _ in range(3):
+        before = int(dv.read_counters()[T.VK_CTR_ROUNDS])
+        oracle_rounds(orc, hv, hf, 3)
+        dv.set_view(df, rounds=3)
+        assert_volume_equal(dv, hv, voxels=False)
+        ctr = assert_same_requests(dv, hv)
+        ran.append(int(ctr[T.VK_CTR_ROUNDS]) - before)
+        assert ctr[T.VK_CTR_UNSETTLED] == 0
+    assert ran[0] in (1, 2, 3) and ran[1:] == [1, 1], ran
+
+
+def test_pool_exhaustion_is_repeated_like_upstream(api, orc):
+    """A pool of 600 blocks for a scene that needs more: upstream asks again on every call and
+    drops again (volume.cu:356), moving the pointers each time; so do the rounds."""
+    w, h = 320, 240
+    hf, df = frames(api, orc, scenes.sphere(2 * w, 2 * h)[::2, ::2].copy(), K_SMALL, scenes.tracer_test_pose())
+    hv, dv = make_pair(api, orc, 512, 88, 0.01, 0.04)
+    oracle_rounds(orc, hv, hf, 3)
+    dv.set_view(df, rounds=3)
+    assert_volume_equal(dv, hv, voxels=False)
+    ctr = assert_same_requests(dv, hv)
+    assert hv.counters[T.VK_CTR_DROPPED] > 100 and ctr[T.VK_CTR_UNSETTLED] == 1
+
+
+def test_few_workgroups_walk_the_same_rounds(api, orc):
+    """The rounds inside the launch with 3 workgroups instead of ~290 (test aid
+    VK_SETTLE_GRID_CAP): every workgroup takes many chunks, runs and bucket groups."""
+    w, h = 320, 240
+    depth = scenes.ramp(w, h)
+    hf, df = frames(api, orc, depth, K_SMALL, scenes.tracer_test_pose())
+    hv, dv = make_pair(api, orc, 2048, 8192, 0.01, 0.04)
+    os.environ["VK_SETTLE_GRID_CAP"] = "6"          # halved by the launcher: 3 workgroups
+    try:
+        oracle_rounds(orc, hv, hf, 4)
+        dv.set_view(df, rounds=4)
+        assert_volume_equal(dv, hv, voxels=False)
+        assert_same_requests(dv, hv)
+    finally:
+        del os.environ["VK_SETTLE_GRID_CAP"]
+    assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 200
+
+
+def test_rounds_with_the_light_preparation_riding_along(api, orc):
+    """The mask / record pass of LightIntegrator rides in the first round's request launch only."""
+    w, h = 320, 240
+    depth = scenes.sphere(2 * w, 2 * h)[::2, ::2].copy()
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+    hf, df = frames(api, orc, depth, K_SMALL, scenes.tracer_test_pose(), color=color)
+    hf.compute_normals()
+    df.compute_normals()
+    hv, dv = make_pair(api, orc, 1024, 8192, 0.01, 0.04)
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    integ = api.LightIntegrator(dv)
+    integ.light = light
+    for _ in range(2):
+        oracle_rounds(orc, hv, hf, 3)
+        dv.set_view(df, rounds=3)
+        assert integ._prep.valid == 1
+        orc.integrate_depth(hv, hf)
+        orc.integrate_light_color(hv, hf, light, orc.light_frame_mask(hf, 0.2))
+        integ.integrate(df)
+        assert_volume_equal(dv, hv)
+
+
+def test_bench_frame_zero(api, orc):
+    """The first frame of bench.py's sequence (640x480, 5 mm, Volume(65024, 8192)) allocates ~7 k
+    blocks at once: hundreds of bucket contests. rounds=3 equals the app's three SetView calls;
+    with enough rounds nothing is left pending, and that state is the oracle's fixed point."""
+    import bench
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    pose = scenes.orbit_pose(0, bench.YAW_STEP)
+    hf, df = frames(api, orc, depth, k, pose)
+
+    hv, dv = make_pair(api, orc, bench.MAIN, bench.EXCESS, bench.VOXEL, bench.TRUNC)
+    oracle_rounds(orc, hv, hf, 3)
+    dv.set_view(df, rounds=3)
+    assert_volume_equal(dv, hv, voxels=False)
+    ctr = assert_same_requests(dv, hv)
+    assert ctr[T.VK_CTR_ROUNDS] >= 2 and hv.visible_count > 5000
+    pending_after_three = int(ctr[T.VK_CTR_UNSETTLED])
+
+    hv2, dv2 = make_pair(api, orc, bench.MAIN, bench.EXCESS, bench.VOXEL, bench.TRUNC)
+    dv2.set_view(df, rounds=16)
+    ctr2 = dv2.read_counters()
+    assert ctr2[T.VK_CTR_UNSETTLED] == 0 and ctr2[T.VK_CTR_ROUNDS] < 16
+    calls = 0
+    while True:                                   # the oracle's fixed point: a call that sees no request
+        hv2.set_view(hf, orc.POLICY_MAXKEY)
+        calls += 1
+        if hv2.counters[T.VK_CTR_REQUESTS] == 0:
+            break
+    # the device stops after the first round that loses nothing; one more oracle call only confirms it
+    assert calls in (ctr2[T.VK_CTR_ROUNDS], ctr2[T.VK_CTR_ROUNDS] + 1)
+    assert_volume_equal(dv2, hv2, voxels=False)
+    assert (pending_after_three == 0) == (int(ctr2[T.VK_CTR_ROUNDS]) <= 3)

@@ -142,6 +142,13 @@ __global__ __launch_bounds__(256) void count_points_kernel(PointParams P, unsign
   }
 }
 
+// launch-floor probe: a kernel whose every wave reads one counter and leaves
+__global__ __launch_bounds__(256) void early_exit_kernel(const int32_t* __restrict__ counters, float* __restrict__ sink)
+{
+  if (counters[0] == 0) return;
+  sink[blockIdx.x * 256 + threadIdx.x] = 1.0f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,6 +229,17 @@ int vk_probe_block_rmw(const vk_volume* v, int mode, void* stream)
     case 2: hipLaunchKernelGGL(block_rmw_kernel<2>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
     default: hipLaunchKernelGGL(block_rmw_kernel<0>, dim3(grid), dim3(256), 0, vk_s(stream), vox, v->hash_entries, v->visible_blocks, v->counters); break;
   }
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
+
+int vk_probe_launch_floor(const int32_t* counters, float* sink, int workgroups, int launches, int replays, void* stream)
+{
+  VK_REQUIRE(counters && sink && workgroups > 0 && launches > 0 && replays > 0);
+  hipStream_t s = vk_s(stream);
+  for (int r = 0; r < replays; ++r)
+    for (int i = 0; i < launches; ++i)
+      hipLaunchKernelGGL(early_exit_kernel, dim3(workgroups), dim3(256), 0, s, counters, sink);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "vk_color_tracker_begin": ([_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "vk_frame_downsample": ([_P, _P, _P, _P, _P], _I),
     "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
+    "vk_volume_set_view_rounds": ([_P, _P, _P, _I, _P], _I),
     "vk_light_prepared": ([_P, _P, C.c_float], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
@@ -159,8 +160,35 @@ def to_numpy(t, dtype):
     return np.frombuffer(t.cpu().numpy().tobytes(), dtype=dtype).copy()
 
 
+_STAMP = [0]
+
+
+def _next_stamp():
+    _STAMP[0] += 1
+    return _STAMP[0]
+
+
 class Frame:
-    """vulcan::Frame (frame.h:11-32) with images in device memory."""
+    """vulcan::Frame (frame.h:11-32) with images in device memory.
+
+    vk_frame.content_id (which content the images hold) = the stamp of the last change this class
+    saw — a tensor assigned to .depth / .color / .normals, compute_normals, filter_depths, a raycast
+    into the frame — mixed with the tensors' own torch version counters (in-place torch ops).
+    A kernel of your own that writes through data_ptr() is invisible: call touch() after it."""
+
+    def __setattr__(self, name, value):
+        if name in ("depth", "color", "normals"):
+            object.__setattr__(self, "_stamp", _next_stamp())
+        object.__setattr__(self, name, value)
+
+    def touch(self):
+        self._stamp = _next_stamp()
+
+    def content_id(self):
+        h = self._stamp
+        for t in (self.depth, self.color, self.normals):
+            h = (h * 0x9E3779B97F4A7C15 + (0 if t is None else (t._version + 1) * 0xC2B2AE3D27D4EB4F + t.data_ptr())) & (2 ** 64 - 1)
+        return h | 1
 
     def __init__(self, depth, depth_projection, depth_to_world=None, color=None, normals=None,
                  color_projection=None, depth_to_color=None, device="cuda"):
@@ -192,6 +220,7 @@ class Frame:
             d.color_height, d.color_width = self.color.shape[0], self.color.shape[1]
         d.depth_projection, d.color_projection = self.depth_projection, self.color_projection
         d.depth_to_world, d.depth_to_color = self.depth_to_world, self.depth_to_color
+        d.content_id = self.content_id()
         return d
 
     def compute_normals(self):
@@ -202,6 +231,7 @@ class Frame:
         k = self.depth_projection
         check(lib().vk_frame_compute_normals(_ptr(self.depth), _ref(k), _ptr(self.normals),
                                              self.width, self.height, stream()), "vk_frame_compute_normals")
+        self.touch()
         return self.normals
 
     def filter_depths(self):
@@ -211,6 +241,7 @@ class Frame:
         check(lib().vk_frame_filter_depths(self.width, self.height, _ptr(self.depth), _ptr(tmp), stream()),
               "vk_frame_filter_depths")
         self.depth.copy_(tmp)
+        self.touch()
 
     def downsample(self):
         """Frame::Downsample (frame.cpp:38-58): nearest depth/normals, box colour,
@@ -298,11 +329,17 @@ class Volume:
         (vk_volume_set_view_prepare) for the integrate that follows."""
         self.light_prep = prep
 
-    def set_view(self, frame):
+    def set_view(self, frame, rounds=1):
+        """Volume::SetView. `rounds` > 1: the state of that many consecutive SetView calls with this
+        frame (the reference's frame loop makes three, apps/vulcan/vulcan.cu:316-318), in one call."""
         self._view_changed()
-        if self.light_prep is not None:
-            check(lib().vk_volume_set_view_prepare(_ref(self.desc()), _ref(frame.desc()), _ref(self.light_prep),
-                                                   stream()), "vk_volume_set_view_prepare")
+        prep = _ref(self.light_prep) if self.light_prep is not None else None
+        if rounds != 1:
+            check(lib().vk_volume_set_view_rounds(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds), stream()),
+                  "vk_volume_set_view_rounds")
+        elif prep is not None:
+            check(lib().vk_volume_set_view_prepare(_ref(self.desc()), _ref(frame.desc()), prep, stream()),
+                  "vk_volume_set_view_prepare")
         else:
             check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
 
@@ -492,6 +529,7 @@ class Tracer:
             vb.valid = 0
         check(lib().vk_trace_ahead(_ref(self.volume.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth),
                                    _ptr(frame.color), _ptr(frame.normals), stream()), "vk_trace_ahead")
+        frame.touch()
 
     # the tracer.cuh free functions, for the stage-by-stage tests
     def compute_patches(self, frame, block_count=None):

@@ -6,6 +6,7 @@
 // v.counters[VK_CTR_VISIBLE]; every consumer reads it on the device.
 #include "vk_common.hpp"
 
+#include <stdlib.h>
 #include <string.h>
 
 using namespace vk;
@@ -108,13 +109,22 @@ __device__ __forceinline__ void mark_visible(uint8_t* vis, uint32_t index)
   else if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
 }
 
-__device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz)
+// `contended` (optional): set when two DIFFERENT blocks ask for the same bucket in one round —
+// the loser has to ask again in another round (SetView is called three times per frame upstream,
+// apps/vulcan/vulcan.cu:316-318, for exactly this). Every key ever posted to a slot either
+// finds a different key there or is later replaced by one whose poster finds it, so the flag
+// is exact: it is set if and only if some request of this round is lost.
+__device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz,
+    int* contended)
 {
   unsigned long long* slot = reinterpret_cast<unsigned long long*>(v.allocation_blocks) + h;
   const unsigned long long key = request_key(type, bx, by, bz);
   // monotonic max: skip the atomic when the slot already holds a key >= ours
-  if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key)
-    atomicMax(slot, key);
+  unsigned long long seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (seen < key) seen = atomicMax(slot, key);
+  if (contended && seen != 0ull && seen != key &&
+      __hip_atomic_load(contended, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    __hip_atomic_store(contended, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
 }
 
@@ -122,7 +132,7 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 // main entry is known
 template <bool DEFER>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
-    int bx, int by, int bz)
+    int bx, int by, int bz, int* contended)
 {
   if (entry_is(entry, bx, by, bz))
   {
@@ -131,7 +141,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   else if (entry.data == -1)
   {
     mark_visible<DEFER>(v.block_visibility, hash_code);
-    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz);
+    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, contended);
   }
   else
   {
@@ -152,7 +162,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
       }
     }
 
-    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz);
+    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz, contended);
   }
 }
 
@@ -183,48 +193,12 @@ struct RequestParams
   float4* records;
 };
 
-// ref: volume.cu:87-301. One lane per depth pixel; the lanes of a wave cover a
-// 64x1 run of a row so the depth read is one coalesced 256-byte load.
-//
-// PREP: the same pass also leaves LightIntegrator's frame mask and per-pixel records
-// (light_integrator.cu:16-94,215-225; frame_mask_kernel in vk_integrate.hip is the launch of
-// its own) — both walk the depth image one lane per pixel, and as a launch of its own the
-// mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
-// depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
-template <bool DEFER, bool PREP>
-__global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
+// ref: volume.cu:87-301, the walk of one depth pixel (x, y). Called by WHOLE waves whose 64
+// lanes hold 64 consecutive pixels of one row (lanes past the image stay in: their neighbours
+// read their registers), so that the depth read is one coalesced 256-byte load.
+template <bool DEFER>
+__device__ __forceinline__ void request_walk(const RequestParams& P, int x, int y, int* contended)
 {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-
-  // PREP: the loads of the depth tile and of the pixel's colour and normal are issued first and
-  // consumed after the request walk, which hides their latency
-  constexpr int TW = 70, TH = 10, TS = 72;
-  __shared__ float tile[PREP ? TH * TS : 1];
-  float staged[3] = {0.0f, 0.0f, 0.0f};
-  vf3 prep_rgb = {0.0f, 0.0f, 0.0f}, prep_n = {0.0f, 0.0f, 0.0f};
-  if (PREP)
-  {
-    const int x0 = (int)blockIdx.x * 64 - 1, y0 = (int)blockIdx.y * 4 - 1;
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-    {
-      const int i = (int)threadIdx.x + 256 * t;
-      const int r = i / TW, c = i - r * TW;
-      const int vx = x0 + c, vy = y0 + r;
-      if (i < TW * TH && vx >= 0 && vx < P.width && vy >= 0 && vy < P.height) staged[t] = P.depth[vy * P.width + vx];
-    }
-    if (x < P.width && y < P.height)
-    {
-      const int index = y * P.width + x;
-      prep_rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
-      prep_n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
-    }
-  }
-
-  do {
-  if (y >= P.height) break;                        // whole wave
-
   const vk_volume& v = P.v;
   const uint32_t K = (uint32_t)v.main_block_count;
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
@@ -336,7 +310,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx]);
+    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], contended);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
@@ -344,7 +318,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
   for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz);
+    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, contended);
 
     if (tmax_x < tmax_y)
     {
@@ -377,7 +351,57 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P)
       }
     }
   }
-  } while (false);
+}
+
+// ref: volume.cu:87-301. One lane per depth pixel; the lanes of a wave cover a
+// 64x1 run of a row so the depth read is one coalesced 256-byte load.
+//
+// PREP: the same pass also leaves LightIntegrator's frame mask and per-pixel records
+// (light_integrator.cu:16-94,215-225; frame_mask_kernel in vk_integrate.hip is the launch of
+// its own) — both walk the depth image one lane per pixel, and as a launch of its own the
+// mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
+// depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
+template <bool DEFER, bool PREP>
+__global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, int* contended)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+
+  // PREP: the loads of the depth tile and of the pixel's colour and normal are issued first and
+  // consumed after the request walk, which hides their latency
+  constexpr int TW = 70, TH = 10, TS = 72;
+  __shared__ float tile[PREP ? TH * TS : 1];
+  float staged[3] = {0.0f, 0.0f, 0.0f};
+  vf3 prep_rgb = {0.0f, 0.0f, 0.0f}, prep_n = {0.0f, 0.0f, 0.0f};
+  if (PREP)
+  {
+    const int x0 = (int)blockIdx.x * 64 - 1, y0 = (int)blockIdx.y * 4 - 1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+    {
+      const int i = (int)threadIdx.x + 256 * t;
+      const int r = i / TW, c = i - r * TW;
+      const int vx = x0 + c, vy = y0 + r;
+      if (i < TW * TH && vx >= 0 && vx < P.width && vy >= 0 && vy < P.height) staged[t] = P.depth[vy * P.width + vx];
+    }
+    if (x < P.width && y < P.height)
+    {
+      const int index = y * P.width + x;
+      prep_rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
+      prep_n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
+    }
+  }
+
+  // the fused SetView: later rounds (settle_visibility_kernel) are gated and counted through
+  // these words, which nothing else touches while this kernel runs
+  if (contended && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+  {
+    P.v.counters[VK_CTR_GATE + 0] = 0;
+    P.v.counters[VK_CTR_GATE + 1] = 0;
+    P.v.counters[VK_CTR_BARRIER] = 0;
+  }
+
+  if (y < P.height) request_walk<DEFER>(P, x, y, contended);   // whole wave
 
   if (PREP)
   {
@@ -443,7 +467,13 @@ __device__ __forceinline__ void count_flags(uint32_t w, int& n_all, int& n_exces
 // workgroup publishes the totals in VK_CTR_PENDING_*, and finish_handle() —
 // run by the kernel that follows — folds them in and clears the flags
 // (volume.cu:365).
-__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible, int deferred_reset)
+//
+// `gate` (-1: none): the counter that tells the fused SetView whether another round is needed —
+// set when this round lost a request to a bucket contest (VK_CTR_CONTENDED, left by the request
+// pass and cleared here) or dropped one (upstream asks again, and drops again, on every call).
+// One call handles the 1024 buckets of `group` with a 256-lane workgroup (uniform call).
+__device__ __forceinline__ void handle_group(const vk_volume& v, int group, int groups, int zero_visible,
+    int deferred_reset, int gate)
 {
   __shared__ int red[2 * (kHandleThreads / 64)];
   __shared__ int wave_a[kHandleThreads / 64], wave_b[kHandleThreads / 64];
@@ -452,7 +482,7 @@ __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volu
   const int max_count = v.main_block_count + v.excess_block_count;
   const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
   const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
-  const int first = blockIdx.x * kHandlePerGroup;
+  const int first = group * kHandlePerGroup;
 
   // (1) requests in buckets [0, first): 16 bytes per load, first is a multiple of 1024
   int base_all = 0, base_excess = 0;
@@ -572,16 +602,35 @@ __global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volu
     }
   }
 
-  if (dropped) atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
+  if (dropped)
+  {
+    atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
+    if (gate >= 0) __hip_atomic_store(&v.counters[gate], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+  if (group == groups - 1 && threadIdx.x == 0)
   {
     v.counters[VK_CTR_PENDING_ALL] = base_all + group_all;
     v.counters[VK_CTR_PENDING_EXCESS] = base_excess + group_excess;
     v.counters[VK_CTR_REQUESTS] = base_all + group_all;
     // volume.cu:488 ResetBufferSize for the visibility pass that follows in SetView
     if (zero_visible) v.counters[VK_CTR_VISIBLE] = 0;
+    if (gate >= 0)
+    {
+      if (__hip_atomic_load(&v.counters[VK_CTR_CONTENDED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+      {
+        __hip_atomic_store(&v.counters[gate], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&v.counters[VK_CTR_CONTENDED], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
+  __syncthreads();   // the LDS words above are reused by the next call of this workgroup
+}
+
+__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible, int deferred_reset,
+    int gate)
+{
+  handle_group(v, (int)blockIdx.x, (int)gridDim.x, zero_visible, deferred_reset, gate);
 }
 
 // Second half of the handle pass, one lane per main bucket: clear the request
@@ -630,26 +679,28 @@ constexpr int kVisThreads = 1024;
 
 // ref: volume.cu:25-84. Frustum test of UNKNOWN entries + compaction of the
 // visible ones. Compaction: wave ballot -> per-wave count in LDS -> ONE atomic
-// per 1024-entry workgroup (72 atomics for 73 216 entries, instead of the
-// reference's 10-step LDS scan + atomic per 512).
-__global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(VisibilityParams P)
+// per workgroup-sized chunk (72 atomics for 73 216 entries with 1024 lanes, instead of the
+// reference's 10-step LDS scan + atomic per 512). One call takes the THREADS entries
+// that start at `first` (uniform call).
+template <int THREADS>
+__device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int first, int finish, int deferred_reset)
 {
-  __shared__ int wave_count[kVisThreads / 64];
+  __shared__ int wave_count[THREADS / 64];
   __shared__ int block_base;
 
   const vk_volume& v = P.v;
   const int count = v.main_block_count + v.excess_block_count;
-  const int index = blockIdx.x * kVisThreads + threadIdx.x;
+  const int index = first + (int)threadIdx.x;
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
   bool visible = false;
 
-  if (P.finish_handle) finish_handle(v, index);
+  if (finish) finish_handle(v, index);
 
   if (index < count)
   {
     const int stored = v.block_visibility[index];
     int visibility = stored;
-    if (P.deferred_reset)
+    if (deferred_reset)
     {
       // touched this frame -> TRUE; otherwise what the reset pass would have left
       const int before = stored & 3;
@@ -697,7 +748,7 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
   if (threadIdx.x == 0)
   {
     int total = 0;
-    for (int w = 0; w < kVisThreads / 64; ++w)
+    for (int w = 0; w < THREADS / 64; ++w)
     {
       const int c = wave_count[w];
       wave_count[w] = total;
@@ -712,6 +763,177 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
     const int offset = block_base + wave_count[wave] + __popcll(mask & ((1ull << lane) - 1ull));
     v.visible_blocks[offset] = index;
   }
+  __syncthreads();   // the LDS words are reused by the next call of this workgroup
+}
+
+__global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(VisibilityParams P)
+{
+  visibility_chunk<kVisThreads>(P, (int)blockIdx.x * kVisThreads, P.finish_handle, P.deferred_reset);
+}
+
+// ------------------------------------------------ SetView, several rounds in one call ----
+
+// The reference's frame loop calls SetView three times per frame (apps/vulcan/vulcan.cu:316-318)
+// because a bucket takes one request per call: a block that loses the contest for its bucket
+// has to ask again. That is rare — a handful of new blocks per frame into 65 024 buckets — so
+// the later calls almost always find nothing to do, and as launches of their own they would
+// cost three launch floors each (~3 us per launch that does nothing on this part).
+//
+// vk_volume_set_view_rounds(.., max_rounds) gives the state of `max_rounds` consecutive SetView
+// calls with the same frame, exactly (every buffer and counter), in three launches: the last
+// kernel of the first round — this one: finish the handle pass, visibility test, compaction —
+// looks at the round's gate word (handle_group) and ends unless a request was lost or dropped.
+// Only then does it run whole further SetViews inside the launch (reset, requests, handle,
+// visibility), its workgroups separated by grid-wide barriers. The grid is sized so that all
+// of its workgroups are resident (settle_grid); a barrier nevertheless gives up after 2 s.
+struct SettleParams
+{
+  VisibilityParams vis;
+  RequestParams req;     // PREP fields unused
+  int max_rounds;
+};
+
+constexpr int kSettleThreads = 256;
+constexpr unsigned long long kBarrierTimeout = 200000000ull;   // wall_clock64 ticks (100 MHz): 2 s
+
+// All workgroups of the launch meet here for the `nth` time (1, 2, ...; VK_CTR_BARRIER was
+// zeroed by the request kernel of the same SetView). Agent-scope fences on both sides: what
+// other workgroups — on other XCDs, behind other L2s — wrote before is visible after.
+__device__ __forceinline__ bool grid_barrier(int* counter, int nth)
+{
+  __shared__ int ok;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    const int target = nth * (int)gridDim.x;
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long deadline = (unsigned long long)wall_clock64() + kBarrierTimeout;
+    int good = 1;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+    {
+      if ((unsigned long long)wall_clock64() > deadline) { good = 0; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    ok = good;
+  }
+  __syncthreads();
+  const bool result = ok != 0;
+  __threadfence();
+  __syncthreads();
+  return result;
+}
+
+__global__ __launch_bounds__(kSettleThreads) void settle_visibility_kernel(SettleParams P)
+{
+  __shared__ int gate_lds;
+  const vk_volume& v = P.vis.v;
+  const int max_count = v.main_block_count + v.excess_block_count;
+  const int chunks = (max_count + kSettleThreads - 1) / kSettleThreads;
+  const int groups = (v.main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
+  const int lane = lane_id();
+  int barriers = 0;
+
+  for (int round = 1;; ++round)
+  {
+    // the last stage of SetView number `round`: the first one ran its other stages as launches
+    // of their own (with the reset pass folded in, kTouched), the later ones ran them below
+    for (int c = (int)blockIdx.x; c < chunks; c += (int)gridDim.x)
+      visibility_chunk<kSettleThreads>(P.vis, c * kSettleThreads, 1, round == 1 ? P.vis.deferred_reset : 0);
+
+    if (threadIdx.x == 0)
+      gate_lds = round < P.max_rounds
+          ? __hip_atomic_load(&v.counters[VK_CTR_GATE + (round & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    const int again = gate_lds;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !again)
+    {
+      v.counters[VK_CTR_ROUNDS] += round;
+      // a round that is not run would have seen no request (volume.cu:520-535 on an empty list)
+      if (round < P.max_rounds) v.counters[VK_CTR_REQUESTS] = 0;
+      // what the caller may want to know: did the last round leave a request unanswered?
+      v.counters[VK_CTR_UNSETTLED] =
+          __hip_atomic_load(&v.counters[VK_CTR_GATE + (round & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!again) return;
+
+    // ---- another whole SetView (volume.cu:430-437), inside this launch
+    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
+
+    // ResetBlockVisibility (volume.cu:465-471) + ResetBufferSize (:488)
+    {
+      const int words = max_count >> 2;
+      uint32_t* vis32 = reinterpret_cast<uint32_t*>(v.block_visibility);
+      for (int i = (int)(blockIdx.x * kSettleThreads + threadIdx.x); i < words; i += (int)(gridDim.x * kSettleThreads))
+      {
+        const uint32_t w = vis32[i];
+        const uint32_t is_true = (w >> 1) & 0x01010101u;
+        if (is_true) vis32[i] = w & ~(is_true * 0x3u);
+      }
+      if (blockIdx.x == 0 && (int)threadIdx.x < (max_count & 3))
+      {
+        const int j = (words << 2) + (int)threadIdx.x;
+        if (v.block_visibility[j] == VK_VISIBILITY_TRUE) v.block_visibility[j] = VK_VISIBILITY_UNKNOWN;
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+      {
+        v.counters[VK_CTR_VISIBLE] = 0;
+        __hip_atomic_store(&v.counters[VK_CTR_GATE + ((round + 1) & 1)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
+
+    // CreateAllocationRequests (volume.cu:497-518): a wave per 64-pixel run of a row
+    {
+      const int runs_x = (P.req.width + 63) / 64;
+      const int runs = runs_x * P.req.height;
+      const int waves = (int)gridDim.x * (kSettleThreads / 64);
+      for (int run = (int)blockIdx.x * (kSettleThreads / 64) + (int)(threadIdx.x >> 6); run < runs; run += waves)
+      {
+        const int y = run / runs_x;
+        const int x = (run - y * runs_x) * 64 + lane;
+        request_walk<false>(P.req, x, y, &v.counters[VK_CTR_CONTENDED]);
+      }
+    }
+    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
+
+    // HandleAllocationRequests (volume.cu:520-535)
+    for (int g = (int)blockIdx.x; g < groups; g += (int)gridDim.x)
+      handle_group(v, g, groups, 0, 0, VK_CTR_GATE + ((round + 1) & 1));
+    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
+  }
+
+  // only reached from a barrier that timed out (never seen): say so instead of spinning for ever
+  if (threadIdx.x == 0) v.counters[VK_CTR_UNSETTLED] = -1;
+}
+
+// workgroups of settle_visibility_kernel that are resident at the same time on this device
+int settle_grid(int chunks)
+{
+  static int capacity[16] = {0};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return 0;
+  int cap = __atomic_load_n(&capacity[device], __ATOMIC_ACQUIRE);
+  if (cap == 0)
+  {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, settle_visibility_kernel, kSettleThreads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+      return 0;
+    cap = per_cu * cus;
+    if (cap <= 0) return 0;
+    __atomic_store_n(&capacity[device], cap, __ATOMIC_RELEASE);
+  }
+  // test aid: a small grid walks the same code with many chunks / groups / runs per workgroup
+  if (const char* env = getenv("VK_SETTLE_GRID_CAP"))
+  {
+    const int n = atoi(env);
+    if (n > 0 && n < cap) cap = n;
+  }
+  // half of what fits: a barrier must not depend on the last free slot of a CU
+  if (cap > 2) cap /= 2;
+  return chunks < cap ? chunks : cap;
 }
 
 int check_volume(const vk_volume* v)
@@ -731,7 +953,8 @@ int check_volume(const vk_volume* v)
 
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
     const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s,
-    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr)
+    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr, bool fused = false,
+    RequestParams* params_out = nullptr)
 {
   RequestParams P;
   P.v = *v;
@@ -746,6 +969,9 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
   P.mask = nullptr;
   P.records = nullptr;
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
+  // the fused SetView records bucket contests (post_request) for its later rounds
+  int* contended = fused ? v->counters + VK_CTR_CONTENDED : nullptr;
+  if (params_out) *params_out = P;
   if (prep && prep_frame)
   {
     P.colors = prep_frame->color;
@@ -754,10 +980,10 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
     P.depth_threshold = prep->depth_threshold;
     P.mask = prep->mask;
     P.records = reinterpret_cast<float4*>(prep->records);
-    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P);
+    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P, contended);
   }
-  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P);
+  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P, contended);
+  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P, contended);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -830,7 +1056,7 @@ int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, vk_s(stream), *v, 0, 0);
+      dim3(kHandleThreads), 0, vk_s(stream), *v, 0, 0, -1);
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(finish_handle_kernel, dim3((v->main_block_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
   VK_LAUNCH_CHECK();
@@ -851,7 +1077,8 @@ int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
 // does `prep` hold the preparation of exactly this frame (same images, size, threshold, Tcd)?
 static bool prep_is_for(const vk_light_prep* prep, const vk_frame* frame)
 {
-  return prep && prep->valid && prep->depth == frame->depth && prep->color == frame->color &&
+  return prep && prep->valid && frame->content_id != 0 && prep->content_id == frame->content_id &&
+      prep->depth == frame->depth && prep->color == frame->color &&
       prep->normals == frame->normals && prep->width == frame->width && prep->height == frame->height &&
       memcmp(&prep->depth_to_color, &frame->depth_to_color, sizeof(vk_transform)) == 0;
 }
@@ -861,24 +1088,30 @@ int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float de
   return (frame && prep_is_for(prep, frame) && prep->prepared_threshold == depth_threshold) ? 1 : 0;
 }
 
-static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, void* stream)
+static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds, void* stream)
 {
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
-  VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0);
+  VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0 && max_rounds >= 1);
   hipStream_t s = vk_s(stream);
   // the preparation rides along when the frame has what LightIntegrator needs, in the
   // depth image's size (light_integrator.cu:277-293 walks the colour image with it)
-  const bool ride = prep && prep->mask && prep->records && frame->color && frame->normals &&
+  const bool ride = prep && prep->mask && prep->records && frame->color && frame->normals && frame->content_id != 0 &&
       (long long)frame->width * frame->height <= (long long)prep->capacity &&
       (reinterpret_cast<uintptr_t>(prep->records) & 15) == 0 &&
       (frame->color_width <= 0 || frame->color_width == frame->width) &&
       (frame->color_height <= 0 || frame->color_height == frame->height);
   if (prep) prep->valid = 0;
-  // three launches: the reset pass is folded into the other three (see kTouched)
+  const int max_count = v->main_block_count + v->excess_block_count;
+  const int grid = settle_grid((max_count + kSettleThreads - 1) / kSettleThreads);
+  VK_REQUIRE(grid > 0);
+  // three launches: the reset pass is folded into the other three (see kTouched), and so are
+  // all rounds after the first (settle_visibility_kernel)
   int r;
+  SettleParams S;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
-           &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr)) != VK_OK) return r;
+           &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr,
+           true, &S.req)) != VK_OK) return r;
   if (ride)
   {
     prep->depth = frame->depth;
@@ -887,24 +1120,40 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     prep->width = frame->width;
     prep->height = frame->height;
     prep->depth_to_color = frame->depth_to_color;
+    prep->content_id = frame->content_id;
     prep->prepared_threshold = prep->depth_threshold;
     prep->valid = 1;
   }
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, s, *v, 1, 1);
+      dim3(kHandleThreads), 0, s, *v, 1, 1, VK_CTR_GATE + 1);
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
-  return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
-      frame->depth_to_world.inv, true, true, s);
+  S.vis.v = *v;
+  S.vis.finish_handle = 1;
+  S.vis.deferred_reset = 1;
+  S.vis.width = frame->width;
+  S.vis.height = frame->height;
+  S.vis.k = frame->depth_projection;
+  S.vis.Tdw = make_rt(frame->depth_to_world.inv);
+  S.max_rounds = max_rounds;
+  hipLaunchKernelGGL(settle_visibility_kernel, dim3(grid), dim3(kSettleThreads), 0, s, S);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
 }
 
 int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
 {
-  return set_view(v, frame, nullptr, stream);
+  return set_view(v, frame, nullptr, 1, stream);
 }
 
 int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, void* stream)
 {
-  return set_view(v, frame, prep, stream);
+  return set_view(v, frame, prep, 1, stream);
+}
+
+int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
+    void* stream)
+{
+  return set_view(v, frame, prep, max_rounds, stream);
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)

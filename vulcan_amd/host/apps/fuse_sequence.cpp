@@ -1,14 +1,23 @@
 // fuse_sequence.cpp — the frame loop of the reference's demo app
 // (ref: apps/vulcan/vulcan.cu:181-367) on synthetic input: the HAL camera,
-// OpenCV conversion and PNG dumps are replaced by a closed-form depth image
-// (camera at the centre of a sphere, yawing), everything else is the same
-// sequence of class calls:  [Track] -> SetView -> Integrate -> Trace.
+// OpenCV conversion and PNG dumps are replaced by closed-form images that are
+// resident on the device before the clock starts; everything else is the same
+// sequence of class calls per frame:
+//   frame.ComputeNormals() -> [tracker.Track(frame)] -> volume.SetView(frame) x3 ->
+//   integrator.Integrate(frame) -> tracer.Trace(keyframe)       (vulcan.cu:297-325)
+// The three SetView calls are one SetView(frame, 3) (same state, tsdf_volume.h).
 //
 //   fuse_sequence [frames=200] [mode=0|1|2]
-//     0  SetView + DepthIntegrator + Tracer                       (BASELINE configs[1])
+//     0  DepthIntegrator + Tracer, no tracking                    (BASELINE configs[1]):
+//        camera at the centre of a 2 m sphere, yawing 0.5 degree per frame
 //     1  PyramidTracker<DepthTracker> in front of mode 0          (configs[2] tracking)
 //     2  PyramidTracker<LightTracker> + LightIntegrator + Tracer: what the shipped
-//        app is configured to run (vulcan.cu:87-111), on a textured, lit sphere
+//        app is configured to run (vulcan.cu:87-111)
+//   Modes 1 and 2 run CLOSED LOOP in the room scene (room_scene.h): every frame is tracked
+//   from the previous tracked pose against the previous raycast, then fused and raycast at
+//   the tracked pose; the true poses only score the result.
+// Prints one human-readable line and one JSON line.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -17,7 +26,25 @@
 
 #include <vulcan/vulcan.h>
 
+#include "room_scene.h"
+
 using namespace vulcan;
+
+namespace
+{
+
+// translation error (m) and rotation error (degrees) of `got` against `truth`
+void PoseError(const Transform& got, const Transform& truth, double& translation, double& rotation)
+{
+  const Matrix4f D = got.GetMatrix() * truth.GetInverseMatrix();
+  const double trace = double(D(0, 0)) + D(1, 1) + D(2, 2);
+  rotation = std::acos(std::min(1.0, std::max(-1.0, (trace - 1.0) / 2.0))) * 180.0 / M_PI;
+  const Vector3f a = got.GetTranslation(), b = truth.GetTranslation();
+  translation = std::sqrt(double(a[0] - b[0]) * (a[0] - b[0]) + double(a[1] - b[1]) * (a[1] - b[1]) +
+      double(a[2] - b[2]) * (a[2] - b[2]));
+}
+
+}  // namespace
 
 int main(int argc, char** argv)
 {
@@ -50,33 +77,44 @@ int main(int argc, char** argv)
   frame.depth_projection.SetFocalLength(544.162f, 544.3847f);
   frame.depth_projection.SetCenterPoint(311.2701f, 234.7798f);
   frame.color_projection = frame.depth_projection;
-  std::vector<float> depth(size_t(w) * h);
-  for (int y = 0; y < h; ++y)
-    for (int x = 0; x < w; ++x)
-    {
-      const Vector3f ray = frame.depth_projection.Unproject(x + 0.5f, y + 0.5f);
-      depth[size_t(y) * w + x] = radius / ray.Norm();
-    }
-  frame.depth_image = std::make_shared<Image>(w, h);
-  frame.depth_image->CopyFromHost(depth.data());
-  frame.color_image = std::make_shared<ColorImage>(w, h);
-  if (mode == 2)
+
+  // ---- the camera's frames, resident on the device before the clock starts ----
+  std::vector<std::shared_ptr<Image>> depth_images;
+  std::vector<std::shared_ptr<ColorImage>> color_images;
+  std::vector<Transform> truth(frames);
+  std::vector<float> depth;
+  std::vector<Vector3f> colors;
+  if (!track)
   {
-    // a smooth texture on the sphere, shaded by the light next to the camera
-    std::vector<Vector3f> colors(size_t(w) * h);
+    depth.resize(size_t(w) * h);
     for (int y = 0; y < h; ++y)
       for (int x = 0; x < w; ++x)
-      {
-        const Vector3f ray = frame.depth_projection.Unproject(x + 0.5f, y + 0.5f);
-        const Vector3f point = depth[size_t(y) * w + x] * ray;
-        const Vector3f normal = Vector3f(-point[0], -point[1], -point[2]) / radius;   // inward
-        const float albedo = 0.5f + 0.2f * std::cos(9.0f * point[0]) + 0.2f * std::cos(7.0f * point[1]);
-        const float c = albedo * light.GetShading(point, normal);
-        colors[size_t(y) * w + x] = Vector3f(c, c, c);
-      }
-    frame.color_image->CopyFromHost(colors.data());
+        depth[size_t(y) * w + x] = radius / frame.depth_projection.Unproject(x + 0.5f, y + 0.5f).Norm();
+    depth_images.push_back(std::make_shared<Image>(w, h));
+    depth_images[0]->CopyFromHost(depth.data());
+    color_images.push_back(std::make_shared<ColorImage>(w, h));
+    for (int i = 0; i < frames; ++i)
+    {
+      const float half = 0.5f * (0.5f * i) * float(M_PI) / 180.0f;   // 0.5 degree of yaw per frame
+      truth[i] = Transform::Rotate(std::cos(half), 0.0f, std::sin(half), 0.0f);
+    }
   }
-  frame.ComputeNormals();
+  else
+  {
+    const double lamp[3] = {0.025, 0.08, 0.0};
+    for (int i = 0; i < frames; ++i)
+    {
+      truth[i] = room::Pose(i);
+      room::Render(frame.depth_projection, truth[i], w, h, 2.0, lamp, depth, colors);
+      depth_images.push_back(std::make_shared<Image>(w, h));
+      depth_images[i]->CopyFromHost(depth.data());
+      color_images.push_back(std::make_shared<ColorImage>(w, h));
+      color_images[i]->CopyFromHost(colors.data());
+    }
+  }
+  frame.depth_image = depth_images[0];
+  frame.color_image = color_images[0];
+  frame.normal_image = std::make_shared<ColorImage>(w, h);
 
   auto keyframe = std::make_shared<Frame>();
   keyframe->depth_projection = keyframe->color_projection = frame.depth_projection;
@@ -84,26 +122,41 @@ int main(int argc, char** argv)
   keyframe->color_image = std::make_shared<ColorImage>(w, h);
   keyframe->normal_image = std::make_shared<ColorImage>(w, h);
 
+  std::vector<int> steps_histogram(64, 0);
+  std::vector<int> steps_run;
+  double worst_translation = 0, worst_rotation = 0, last_translation = 0, last_rotation = 0;
+  frame.depth_to_world_transform = truth[0];      // the first frame defines the map
+
   Device::Synchronize();
   const auto t0 = std::chrono::steady_clock::now();
 
   for (int i = 0; i < frames; ++i)
   {
-    const float half = 0.5f * (0.5f * i) * float(M_PI) / 180.0f;   // 0.5 degree of yaw per frame
-    const Transform truth = Transform::Rotate(std::cos(half), 0.0f, std::sin(half), 0.0f);
+    if (track)
+    {
+      frame.depth_image = depth_images[i];
+      frame.color_image = color_images[i];
+    }
+    if (mode != 0) frame.ComputeNormals();        // vulcan.cu:297 (DepthIntegrator alone needs none)
 
     if (track && i > 0)
     {
       // start from the previous pose, refine against the raycast keyframe (vulcan.cu:300-311)
       if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); }
       else { depth_tracker.SetKeyframe(keyframe); depth_tracker.Track(frame); }
+      const int run = mode == 2 ? light_tracker.GetTracker()->GetIterationsRun() : depth_tracker.GetTracker()->GetIterationsRun();
+      steps_run.push_back(run);
+      if (run >= 0 && run < 64) ++steps_histogram[run];
+      PoseError(frame.depth_to_world_transform, truth[i], last_translation, last_rotation);
+      worst_translation = std::max(worst_translation, last_translation);
+      worst_rotation = std::max(worst_rotation, last_rotation);
     }
-    else
+    else if (!track)
     {
-      frame.depth_to_world_transform = truth;
+      frame.depth_to_world_transform = truth[i];
     }
 
-    volume->SetView(frame);            // vulcan.cu:316-318
+    volume->SetView(frame, 3);         // vulcan.cu:316-318: three SetView calls
     if (mode == 2) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
     keyframe->depth_to_world_transform = frame.depth_to_world_transform;
     tracer.Trace(*keyframe);           // :325
@@ -118,5 +171,30 @@ int main(int argc, char** argv)
       counters[VK_CTR_DROPPED], mode == 0 ? "off" : (mode == 1 ? "depth" : "light"));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
+
+  double motion_translation = 0, motion_rotation = 0;
+  PoseError(truth[frames - 1], truth[0], motion_translation, motion_rotation);
+  int median = 0;
+  if (!steps_run.empty())
+  {
+    std::sort(steps_run.begin(), steps_run.end());
+    median = steps_run[steps_run.size() / 2];
+  }
+  std::printf("{\"app\": \"fuse_sequence\", \"mode\": %d, \"tracker\": \"%s\", \"integrator\": \"%s\", \"frames\": %d, "
+      "\"frames_per_s\": %.1f, \"us_per_frame\": %.1f, \"set_view_rounds_run_per_frame\": %.4f, \"visible_blocks_last\": %d, "
+      "\"allocated_blocks\": %d, \"dropped_requests\": %d, \"tracked_pose_drives_fusion\": %s, "
+      "\"pose_error_max\": {\"translation_m\": %.6f, \"rotation_deg\": %.5f}, "
+      "\"pose_error_last_frame\": {\"translation_m\": %.6f, \"rotation_deg\": %.5f}, "
+      "\"camera_motion_over_run\": {\"translation_m\": %.4f, \"rotation_deg\": %.3f}, \"gn_steps_median\": %d, "
+      "\"gn_steps_histogram_full_resolution_level\": {",
+      mode, mode == 0 ? "none" : (mode == 1 ? "PyramidTracker<DepthTracker>" : "PyramidTracker<LightTracker>"),
+      mode == 2 ? "LightIntegrator" : "DepthIntegrator", frames, frames / seconds, 1e6 * seconds / frames,
+      double(counters[VK_CTR_ROUNDS]) / frames, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
+      counters[VK_CTR_DROPPED], track ? "true" : "false", worst_translation, worst_rotation, last_translation,
+      last_rotation, motion_translation, motion_rotation, median);
+  bool first = true;
+  for (int n = 0; n < 64; ++n)
+    if (steps_histogram[n]) { std::printf("%s\"%d\": %d", first ? "" : ", ", n, steps_histogram[n]); first = false; }
+  std::printf("}}\n");
   return 0;
 }

@@ -6,6 +6,8 @@
 // even(v * alpha + beta)).
 #pragma once
 
+#include <atomic>
+#include <stdint.h>
 #include <string>
 #include <vulcan/device.h>
 #include <vulcan/matrix.h>
@@ -16,15 +18,23 @@ namespace vulcan
 namespace detail
 {
 
+// A process-wide sequence of stamps: an image takes a new one whenever its pixels may have
+// changed, so two equal stamps mean "the same image, untouched in between" (vk_frame.content_id).
+inline uint64_t NextContentStamp()
+{
+  static std::atomic<uint64_t> next(1);
+  return next.fetch_add(1, std::memory_order_relaxed);
+}
+
 // shared storage logic of Image (1 float / pixel) and ColorImage (3 floats / pixel)
 template <typename Pixel>
 class ImageStorage
 {
   public:
 
-    ImageStorage() : size_(0, 0), data_(nullptr), capacity_(0) {}
+    ImageStorage() : size_(0, 0), data_(nullptr), capacity_(0), stamp_(NextContentStamp()) {}
 
-    ImageStorage(int w, int h) : size_(0, 0), data_(nullptr), capacity_(0) { Resize(w, h); }
+    ImageStorage(int w, int h) : size_(0, 0), data_(nullptr), capacity_(0), stamp_(NextContentStamp()) { Resize(w, h); }
 
     ~ImageStorage() { vk_free(data_); }
 
@@ -40,13 +50,21 @@ class ImageStorage
 
     const Pixel* GetData() const { return data_; }
 
-    Pixel* GetData() { return data_; }
+    // a pointer that can be written through: the content counts as changed from here on (a
+    // caller that keeps the pointer and writes later must call Touch() after writing)
+    Pixel* GetData() { Touch(); return data_; }
+
+    // not upstream: identity of the content, see NextContentStamp
+    uint64_t GetContentStamp() const { return stamp_; }
+
+    void Touch() { stamp_ = NextContentStamp(); }
 
     void Resize(int w, int h) { Resize(Vector2i(w, h)); }
 
     void Resize(const Vector2i& size)
     {
       VULCAN_DEBUG(size[0] >= 0 && size[1] >= 0);
+      if (size[0] != size_[0] || size[1] != size_[1]) Touch();
       size_ = size;
       // upstream frees and allocates whenever the pixel count changes (image.h:85-97); a
       // pyramid tracker alternates between two sizes every frame, and on this runtime a free
@@ -64,6 +82,7 @@ class ImageStorage
     void CopyFromHost(const Pixel* pixels)
     {
       VK_ASSERT(vk_memcpy_h2d(data_, pixels, GetBytes(), Device::GetStream()));
+      Touch();
     }
 
     void CopyToHost(Pixel* pixels) const
@@ -84,6 +103,8 @@ class ImageStorage
     Pixel* data_;
 
     size_t capacity_;   // pixels allocated (>= GetTotal())
+
+    uint64_t stamp_;    // GetContentStamp()
 };
 
 } // namespace detail

@@ -87,6 +87,9 @@ class Tracker
     vk_track_poll poll_;
 
   public:
+    // Gauss-Newton steps the last Track ran at its last level (from the pinned mirror the
+    // device loop writes; not upstream — its loop counter iteration_ has no getter)
+    int GetIterationsRun() const { return poll_.host_state ? poll_.host_state[0] : 0; }
     int GetPollChunk() const { return poll_.chunk; }
     void SetPollChunk(int steps) { poll_.chunk = steps; }
 };

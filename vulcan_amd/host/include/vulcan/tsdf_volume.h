@@ -60,6 +60,9 @@ class Volume
 
     // ---- per frame: allocate what the depth image touches, list what is visible ----
     void SetView(const Frame& frame);
+    // `rounds` consecutive SetView(frame) calls (the app makes three per frame, vulcan.cu:316-318)
+    // in one: the later rounds run on the device, and only when the round before lost a request
+    void SetView(const Frame& frame, int rounds);
 
     // ---- storage ----
     const Buffer<HashEntry>& GetHashEntries() const;

@@ -101,18 +101,26 @@ void Frame::Downsample(Frame& frame) const
 
 vk_frame Frame::ToVk() const
 {
+  // read-only views: a non-const GetData() would stamp the images as modified
+  const Image* depth = depth_image.get();
+  const ColorImage* color = color_image.get();
+  const ColorImage* normals = normal_image.get();
   vk_frame f;
-  f.depth = depth_image ? depth_image->GetData() : nullptr;
-  f.color = color_image ? reinterpret_cast<const float*>(color_image->GetData()) : nullptr;
-  f.normals = normal_image ? reinterpret_cast<const float*>(normal_image->GetData()) : nullptr;
-  f.width = depth_image ? depth_image->GetWidth() : (color_image ? color_image->GetWidth() : 0);
-  f.height = depth_image ? depth_image->GetHeight() : (color_image ? color_image->GetHeight() : 0);
-  f.color_width = color_image ? color_image->GetWidth() : 0;     // color_integrator.cu:183-184
-  f.color_height = color_image ? color_image->GetHeight() : 0;
+  f.depth = depth ? depth->GetData() : nullptr;
+  f.color = color ? reinterpret_cast<const float*>(color->GetData()) : nullptr;
+  f.normals = normals ? reinterpret_cast<const float*>(normals->GetData()) : nullptr;
+  f.width = depth ? depth->GetWidth() : (color ? color->GetWidth() : 0);
+  f.height = depth ? depth->GetHeight() : (color ? color->GetHeight() : 0);
+  f.color_width = color ? color->GetWidth() : 0;     // color_integrator.cu:183-184
+  f.color_height = color ? color->GetHeight() : 0;
   f.depth_projection = depth_projection.ToVk();
   f.color_projection = color_projection.ToVk();
   f.depth_to_world = depth_to_world_transform.ToVk();
   f.depth_to_color = depth_to_color_transform.ToVk();
+  // which content this is: the three images' stamps, mixed (0 = unknown is never produced here)
+  const uint64_t a = depth ? depth->GetContentStamp() : 0, b = color ? color->GetContentStamp() : 0,
+      c = normals ? normals->GetContentStamp() : 0;
+  f.content_id = ((a * 0x9E3779B97F4A7C15ull) ^ (b * 0xC2B2AE3D27D4EB4Full) ^ (c * 0x165667B19E3779F9ull)) | 1ull;
   return f;
 }
 

@@ -112,13 +112,16 @@ void Volume::DetachLightPreparation(const float* mask) const
   if (light_prep_.mask == mask) std::memset(&light_prep_, 0, sizeof(light_prep_));
 }
 
-void Volume::SetView(const Frame& frame)
+void Volume::SetView(const Frame& frame) { SetView(frame, 1); }
+
+void Volume::SetView(const Frame& frame, int rounds)
 {
   view_bounds_.valid = 0;   // the visible list is about to change
   VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+  VULCAN_ASSERT_MSG(rounds >= 1, "SetView needs at least one round");
   const vk_volume v = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_volume_set_view_prepare(&v, &f, GetLightPreparation(), Device::GetStream()));
+  VK_ASSERT(vk_volume_set_view_rounds(&v, &f, GetLightPreparation(), rounds, Device::GetStream()));
   visible_count_stale_ = true;
   empty_ = false;
 }

@@ -1259,6 +1259,57 @@ static std::shared_ptr<Volume> FusedPlane(Frame& frame)
   return volume;
 }
 
+// Upstream's SetView reads the depth image only (volume.cu:430-437), so the normals or colours of a
+// frame may legally change between SetView and Integrate. The light preparation that rides in
+// SetView's request pass (vk_light_prep) must then not be used: it is tied to the images' content
+// stamps (image.h), not to their addresses.
+TEST(LightIntegrator, PreparationFollowsContentNotPointers)
+{
+  const int w = 160, h = 120;
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.025f, 0.08f, 0.0f);
+  std::vector<Voxel> results[2];
+  for (int variant = 0; variant < 2; ++variant)
+  {
+    Frame frame;
+    frame.depth_projection.SetFocalLength(136, 136);
+    frame.depth_projection.SetCenterPoint(80, 60);
+    frame.color_projection = frame.depth_projection;
+    frame.depth_image = MakeDepth(w, h, [](int x, int) { return 1.5f + 0.001f * x; });
+    frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+    frame.ComputeNormals();
+    auto volume = std::make_shared<Volume>(8192, 2048);
+    volume->SetVoxelLength(0.008f);
+    LightIntegrator integrator(volume);
+    integrator.SetLight(light);
+    for (int i = 0; i < 4; ++i) volume->SetView(frame);
+    integrator.Integrate(frame);                       // registers the integrator's buffers with the volume
+    // what the second integration has to see: other normals and other colours in the SAME buffers
+    const std::vector<Vector3f> flipped(size_t(w) * h, Vector3f(0.0f, 0.6f, -0.8f));
+    const std::vector<Vector3f> recolored(size_t(w) * h, Vector3f(0.5f, 0.25f, 0.75f));
+    if (variant == 0)
+    {
+      volume->SetView(frame);                          // prepares mask + records from the OLD normals and colours
+      frame.normal_image->CopyFromHost(flipped.data());
+      frame.color_image->CopyFromHost(recolored.data());
+    }
+    else
+    {
+      frame.normal_image->CopyFromHost(flipped.data());
+      frame.color_image->CopyFromHost(recolored.data());
+      volume->SetView(frame);
+    }
+    integrator.Integrate(frame);
+    results[variant] = Download(volume->GetVoxels());
+  }
+  ASSERT_EQ(results[0].size(), results[1].size());
+  ASSERT_TRUE(std::memcmp(results[0].data(), results[1].data(), results[0].size() * sizeof(Voxel)) == 0);
+  size_t coloured = 0;
+  for (const Voxel& voxel : results[0]) coloured += voxel.color_weight > 1;
+  ASSERT_TRUE(coloured > 1000);
+}
+
 TEST(Extractor, Extract)   // extractor.h:116-134; faces are what upstream leaves unwritten (extractor.cu:392-430)
 {
   Frame frame;

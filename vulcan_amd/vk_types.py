@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 VK_CTR_VISIBLE, VK_CTR_VOXEL_PTR, VK_CTR_EXCESS_PTR, VK_CTR_PATCHES = 0, 1, 2, 3
-VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS, VK_CTR_COUNT = 4, 5, 6, 7, 8
+VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 5, 6, 7
+VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_GATE, VK_CTR_BARRIER, VK_CTR_COUNT = 8, 9, 10, 11, 13, 16
 VISIBILITY_UNKNOWN, VISIBILITY_FALSE, VISIBILITY_TRUE = 0, 1, 2
 ALLOC_NONE, ALLOC_MAIN, ALLOC_EXCESS = 0, 1, 2
 BLOCK_RESOLUTION, BLOCK_VOXELS, PATCH_MAX_SIZE = 8, 512, 16
@@ -130,7 +131,7 @@ class Frame(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32),
                 ("color_width", C.c_int32), ("color_height", C.c_int32),
                 ("depth_projection", Projection), ("color_projection", Projection),
-                ("depth_to_world", Transform), ("depth_to_color", Transform)]
+                ("depth_to_world", Transform), ("depth_to_color", Transform), ("content_id", C.c_uint64)]
 
 
 class Integrator(C.Structure):
@@ -168,7 +169,7 @@ class LightPrep(C.Structure):
     _fields_ = [("depth_threshold", C.c_float), ("mask", C.c_void_p), ("records", C.c_void_p), ("capacity", C.c_int32),
                 ("valid", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_void_p),
                 ("color", C.c_void_p), ("normals", C.c_void_p), ("prepared_threshold", C.c_float),
-                ("depth_to_color", Transform)]
+                ("depth_to_color", Transform), ("content_id", C.c_uint64)]
 
 
 class ColorPose(C.Structure):
