@@ -536,6 +536,11 @@ VK_API int vk_icp_solve_update(const float* hessian, const float* gradient,
  * it over ranks here (ncclAllReduce on `stream`). Returns 0 on success. */
 typedef int (*vk_icp_reduce_fn)(float* system_dev, int count, void* user, void* stream);
 
+/* A reduce hook that changes nothing. Passing it selects the launch-per-stage loop of a tracker
+ * on one GPU (ref: src/tracker.cpp:53-63, one ComputeSystem + ComputeUpdate per iteration): what a
+ * host falls back to when a one-launch loop ends with VK_TRACK_ABORTED. */
+VK_API int vk_reduce_nothing(float* system_dev, int count, void* user, void* stream);
+
 /* *dst_dev = *src_host, stream-ordered and without a host synchronisation (the 128
  * bytes travel as kernel arguments): how a tracker's device-side pose is seeded
  * from frame.depth_to_world_transform (ref: src/tracker.cpp:70-76 BeginSolve). */
@@ -583,7 +588,13 @@ VK_API int vk_track_wait(const vk_track_poll* poll, void* stream);
  * needed for an early exit on this path (its mirror still receives the final state).
  * Should the device be unable to hold the launch's workgroups at the same time — not
  * expected: the grid is sized from the occupancy query — the launch gives up after two
- * seconds and leaves state_dev[1] = VK_TRACK_ABORTED. Tracks issued on different streams of
+ * seconds and leaves state_dev[1] = VK_TRACK_ABORTED; no pose is published then (vk_track_wait
+ * returns VK_ERR_UNSUPPORTED), a later level of the same coarse-to-fine Track does not run,
+ * and the host's way out is the same call again from the start pose with `reduce` =
+ * vk_reduce_nothing, i.e. the launch-per-stage loop, which waits for nobody (the class layer and
+ * vulcan_amd/api.py do exactly that). With VK_LOOP_COOPERATIVE=1 in the environment the loop
+ * kernels are launched with hipLaunchCooperativeKernel, which refuses a grid that cannot be
+ * resident instead of letting the kernel find out. Tracks issued on different streams of
  * one device are run one after the other by the library (a loop launch fills the device); two
  * processes that share a device are not protected from starving each other.
  *
@@ -677,7 +688,8 @@ VK_API int vk_color_tracker_solve_update(const float* hessian, const float* grad
  * (vk_image_gradients), the light tracker's frame mask (vk_light_compute_frame_mask at
  * `depth_threshold`; NULL for the colour tracker), the pose upload into
  * pose_dev->depth_to_world (vk_transform_upload; both NULL to skip) and the reset of
- * state_dev (may be NULL). Same bits as the staged calls: the jobs are independent once the
+ * state_dev (may be NULL; without a pose upload — a later level of a coarse-to-fine Track — a
+ * state that says VK_TRACK_ABORTED is kept, so that the Track fails as a whole). Same bits as the staged calls: the jobs are independent once the
  * gradients take their taps from the colour image, and run side by side. */
 VK_API int vk_color_tracker_begin(const vk_frame* keyframe, const vk_frame* frame,
     float* keyframe_intensities, float* frame_intensities, float* gradient_x, float* gradient_y,

@@ -91,6 +91,10 @@ void orc_icp_compute_system(const vk_icp_view* keyframe, const vk_transform* Twm
     const vk_icp_view* frame, const vk_transform* Twc, int translation_enabled,
     double* hessian, double* gradient);
 /* tracker.cpp:124-163 + depth_tracker.cpp:22-86; returns ||x||. */
+/* the 6x6 (or 3x3) solve of tracker.cpp:127,153-159 twice: LDL^T without pivoting (what the device
+ * runs) and with Eigen's diagonal pivoting (its published algorithm); A: n*n row-major symmetric */
+void orc_ldlt_solve(int n, const float* A, const float* b, float* x);
+void orc_ldlt_solve_pivoted(int n, const float* A, const float* b, float* x);
 float orc_icp_solve_update(const float* hessian_packed, const float* gradient,
     int translation_enabled, vk_transform* Twc, float* update);
 

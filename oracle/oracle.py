@@ -299,6 +299,16 @@ def icp_system(key, frame, translation_enabled=True):
     return hessian, gradient
 
 
+def ldlt_solve(A, b, pivoted=False):
+    """x with A x = b: the unpivoted LDL^T the device runs, or Eigen's pivoted one (orc_ldlt_solve_pivoted)."""
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    n = len(b)
+    x = np.zeros(n, dtype=np.float32)
+    (lib().orc_ldlt_solve_pivoted if pivoted else lib().orc_ldlt_solve)(n, _p(A), _p(b), _p(x))
+    return x
+
+
 def icp_solve_update(hessian_packed, gradient, Twc, translation_enabled=True):
     h = np.ascontiguousarray(hessian_packed, dtype=np.float32)
     g = np.ascontiguousarray(gradient, dtype=np.float32)

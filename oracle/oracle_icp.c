@@ -171,6 +171,77 @@ void orc_ldlt_solve(int n, const float* A /* n*n row-major, symmetric */,
   }
 }
 
+/* The same solve the way Eigen does it — a second statement of tracker.cpp:127,153-159, kept
+ * beside the unpivoted one to bound what pivoting can change (tests/test_oracle_icp.py).
+ * Eigen::LDLT is a PIVOTED factorisation P A P^T = L D L^T: at step k the largest remaining
+ * |diagonal| entry is brought to position k by a symmetric row / column exchange before the
+ * column is eliminated (published algorithm: Eigen 3.3 Cholesky/LDLT.h, ldlt_inplace<Lower>::
+ * unblocked; solve: LDLT::_solve_impl — x = P^T L^-T D^-1 L^-1 P b with components under a
+ * pivot of magnitude <= 1 / FLT_MAX set to 0). Eigen is not vendored and its version is not
+ * pinned (CMakeLists.txt:18), and its vectorised inner products do not promise an order of
+ * additions: this is the algorithm in plain loops, float32 — PARITY UNPINNED to Eigen's bits,
+ * like orc_ldlt_solve. Test infrastructure only. */
+void orc_ldlt_solve_pivoted(int n, const float* A /* n*n row-major, symmetric */,
+    const float* b, float* x)
+{
+  float M[36], temp[6], y[6];
+  int transpositions[6];
+  memcpy(M, A, sizeof(float) * (size_t)(n * n));   /* only the lower triangle M[i*n+j], i >= j, is used */
+
+  for (int k = 0; k < n; ++k)
+  {
+    int biggest = k;
+    float big = fabsf(M[k * n + k]);
+    for (int i = k + 1; i < n; ++i)
+      if (fabsf(M[i * n + i]) > big) { big = fabsf(M[i * n + i]); biggest = i; }
+    transpositions[k] = biggest;
+
+    if (biggest != k)
+    {
+      float t;
+      for (int j = 0; j < k; ++j) { t = M[k * n + j]; M[k * n + j] = M[biggest * n + j]; M[biggest * n + j] = t; }
+      for (int i = biggest + 1; i < n; ++i) { t = M[i * n + k]; M[i * n + k] = M[i * n + biggest]; M[i * n + biggest] = t; }
+      t = M[k * n + k]; M[k * n + k] = M[biggest * n + biggest]; M[biggest * n + biggest] = t;
+      for (int i = k + 1; i < biggest; ++i) { t = M[i * n + k]; M[i * n + k] = M[biggest * n + i]; M[biggest * n + i] = t; }
+    }
+
+    if (k > 0)
+    {
+      float acc = 0.0f;
+      for (int j = 0; j < k; ++j) temp[j] = M[j * n + j] * M[k * n + j];
+      for (int j = 0; j < k; ++j) acc += M[k * n + j] * temp[j];
+      M[k * n + k] -= acc;
+      for (int i = k + 1; i < n; ++i)
+      {
+        acc = 0.0f;
+        for (int j = 0; j < k; ++j) acc += M[i * n + j] * temp[j];
+        M[i * n + k] -= acc;
+      }
+    }
+
+    const float akk = M[k * n + k];
+    const int valid = fabsf(akk) > 0.0f;
+    if (k == 0 && !valid)
+    {
+      /* the matrix is zero: every transposition is the identity, D = 0 */
+      for (int j = 0; j < n; ++j) transpositions[j] = j;
+      break;
+    }
+    if (valid)
+      for (int i = k + 1; i < n; ++i) M[i * n + k] /= akk;
+  }
+
+  for (int i = 0; i < n; ++i) y[i] = b[i];
+  for (int k = 0; k < n; ++k) { const float t = y[k]; y[k] = y[transpositions[k]]; y[transpositions[k]] = t; }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j) y[i] -= M[i * n + j] * y[j];
+  for (int i = 0; i < n; ++i) y[i] = (fabsf(M[i * n + i]) > 1.0f / FLT_MAX) ? y[i] / M[i * n + i] : 0.0f;
+  for (int i = n - 1; i >= 0; --i)
+    for (int j = i + 1; j < n; ++j) y[i] -= M[j * n + i] * y[j];
+  for (int k = n - 1; k >= 0; --k) { const float t = y[k]; y[k] = y[transpositions[k]]; y[transpositions[k]] = t; }
+  for (int i = 0; i < n; ++i) x[i] = y[i];
+}
+
 /* ref: tracker.cpp:142-159: unpack the packed lower triangle (mirrored), solve,
  * update = -x; entries beyond the parameter count stay 0 */
 void orc_solve_step(const float* hessian_packed, const float* gradient, int translation_enabled,

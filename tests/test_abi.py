@@ -57,7 +57,7 @@ def test_version_and_errors_without_gpu():
 def test_pod_layouts_match_header():
     from vulcan_amd import vk_types as T
     assert C.sizeof(T.Volume) == 8 * 8 + 2 * 4 + 4 * 4
-    assert C.sizeof(T.Frame) == 3 * 8 + 4 * 4 + 2 * 16 + 2 * 128
+    assert C.sizeof(T.Frame) == 3 * 8 + 4 * 4 + 2 * 16 + 2 * 128 + 8 and T.Frame.content_id.offset == 328
     assert T.Frame.color_width.offset == 32 and T.Frame.depth_projection.offset == 40
     assert C.sizeof(T.Integrator) == 16 and C.sizeof(T.IcpView) == 2 * 8 + 2 * 4 + 16
 

@@ -581,3 +581,34 @@ def test_stale_light_preparation_is_never_used(api, orc):
     api.check(api.lib().vk_volume_set_view_prepare(api._ref(dv.desc()), api._ref(desc), api._ref(integ._prep), api.stream()),
               "vk_volume_set_view_prepare")
     assert integ._prep.valid == 0
+
+
+def test_configs0_dense_128_on_the_device(api, orc):
+    """BASELINE configs[0] (SURVEY 8d Config 1): one 640x480 depth frame into a dense 128^3 voxel
+    region = 16^3 = 4096 hand-placed blocks of 8^3 straddling the surface (the layout bench.py's
+    cpu_baseline times on the host; tests/integrator_test.cu:141-199 is the arithmetic). The device
+    integrates the same hand-placed volume: every voxel byte equals the oracle's."""
+    import bench
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    hv = orc.HostVolume(8192, 1024, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    origin = np.array([[x, y, z] for z in range(42, 58) for y in range(-8, 8) for x in range(-8, 8)], dtype=np.int16)
+    n = len(origin)
+    assert n == 4096
+    hv.hash_entries["block"]["origin"][:n] = origin
+    hv.hash_entries["data"][:n] = np.arange(n)
+    hv.hash_entries["next"][:n] = -1
+    hv.visible_blocks[:n] = np.arange(n)
+    hv.counters[T.VK_CTR_VISIBLE] = n
+    dv = api.Volume(8192, 1024, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    dv.upload(hv)
+    hf = orc.HostFrame(depth, k, T.Transform.identity())
+    df = api.Frame(depth, k, T.Transform.identity())
+    integ = api.DepthIntegrator(dv)
+    for _ in range(2):
+        orc.integrate_depth(hv, hf)
+        integ.integrate(df)
+        sync()
+        assert dv.host_voxels().tobytes() == hv.voxels.tobytes()
+    updated = int((hv.voxels["distance_weight"][:n * 512] > 0).sum())
+    assert updated > 500000 and hv.voxels["distance_weight"].max() == 2      # the band through 2 097 152 voxels

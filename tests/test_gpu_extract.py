@@ -111,6 +111,27 @@ def test_full_size_mesh_properties(api, orc):
     big = np.linalg.norm(normals, axis=1) > 1e-12
     inward = -(tri.mean(axis=1))
     assert ((normals * inward).sum(axis=1)[big] > 0).mean() > 0.999       # towards the camera: the positive side
+    # a 2-manifold with boundary: no edge belongs to more than two faces, an edge of two faces is
+    # walked once in each direction (consistent orientation), and the edges of ONE face — where the
+    # observed surface ends — are few and form closed loops (every boundary vertex has an even degree)
+    f64 = f.astype(np.int64)
+    directed = np.concatenate([f64[:, [0, 1]], f64[:, [1, 2]], f64[:, [2, 0]]])
+    assert (directed[:, 0] != directed[:, 1]).all()
+    n = len(p)
+    dkey = directed[:, 0] * n + directed[:, 1]
+    assert len(np.unique(dkey)) == len(dkey)                      # no directed edge twice
+    lo, hi = directed.min(axis=1), directed.max(axis=1)
+    ukey, counts = np.unique(lo * n + hi, return_counts=True)
+    assert counts.max() == 2
+    interior = ukey[counts == 2]
+    reverse = directed[:, 1] * n + directed[:, 0]
+    both_ways = np.isin(dkey, reverse)
+    assert both_ways.sum() == 2 * len(interior)                   # each shared edge: once (a, b), once (b, a)
+    boundary = ukey[counts == 1]
+    assert len(boundary) < 0.02 * len(ukey)
+    ends = np.concatenate([boundary // n, boundary % n])
+    _, degree = np.unique(ends, return_counts=True)
+    assert (degree % 2 == 0).all()
     # reproducible
     again = ex.extract()
     sync()

@@ -43,7 +43,7 @@ def device_backend(api):
         sync()
         points, faces = mesh.host()
         return dict(frame_normals=df.normals.cpu().numpy(), depth=out.depth.cpu().numpy(), color=out.color.cpu().numpy(),
-                    normals=out.normals.cpu().numpy(), bounds=tracer.bounds.cpu().numpy(), counters=dv.read_counters(),
+                    normals=out.normals.cpu().numpy(), bounds=tracer.bounds.cpu().numpy(), counters=dv.read_counters()[:8],
                     visible=np.sort(dv.visible()), voxels_sha256=mf.digest(dv.host_voxels()),
                     entries_sha256=mf.digest(dv.host_entries()), visibility_sha256=mf.digest(dv.host_visibility()),
                     mesh_points_sha256=mf.digest(points), mesh_faces_sha256=mf.digest(faces),

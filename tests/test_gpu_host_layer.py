@@ -32,13 +32,24 @@ def test_cpp_frame_loop_runs_and_tracks():
     assert m, out
     assert int(m.group(2)) > 3000 and int(m.group(4)) == 0
     # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: the shipped app's
-    # set-up (PyramidTracker<LightTracker> + LightIntegrator). The depth image is the same from
-    # every pose, so tracking must hold the pose it starts from.
+    # set-up (PyramidTracker<LightTracker> + LightIntegrator). Closed loop in the room scene
+    # (room_scene.h): the camera turns ~37 degrees and moves ~0.28 m over 60 frames, every frame
+    # is fused and raycast at its TRACKED pose, and the true poses only score the result.
+    import json
     for mode, label in (("1", "depth"), ("2", "light")):
         out = subprocess.run([exe, "60", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
         assert re.search(r"dropped 0 +tracking " + label, out), out
-        row = re.search(r"final pose row0: ([-\d.]+) ([-\d.]+) ([-\d.]+) ([-\d.]+)", out)
-        assert row and abs(float(row.group(1)) - 1.0) < 1e-3 and abs(float(row.group(4))) < 0.01, out
+        line = [text for text in out.splitlines() if text.startswith("{")]
+        assert line, out
+        rec = json.loads(line[-1])
+        assert rec["tracked_pose_drives_fusion"] is True and rec["frames"] == 60
+        assert rec["camera_motion_over_run"]["rotation_deg"] > 30 and rec["camera_motion_over_run"]["translation_m"] > 0.2
+        print(mode, rec["pose_error_max"], rec["gn_steps_median"], rec["frames_per_s"])
+        # the geometric tracker holds the truth to ~1 mm; the photometric one (shading model on a
+        # lamp-lit, mostly dark room) drifts by centimetres — still a small fraction of the motion
+        limit_m, limit_deg = (0.01, 0.2) if mode == "1" else (0.06, 2.0)
+        assert rec["pose_error_max"]["translation_m"] < limit_m and rec["pose_error_max"]["rotation_deg"] < limit_deg, rec
+        assert 1 <= rec["gn_steps_median"] <= 20 and 1.0 <= rec["set_view_rounds_run_per_frame"] <= 3.0
 
 
 def test_host_layer_builds_and_links_only_the_c_abi():

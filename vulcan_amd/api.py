@@ -78,6 +78,7 @@ _SIGNATURES = {
     "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_track_wait": ([_P, _P], _I),
+    "vk_reduce_nothing": ([_P, _I, _P, _P], _I),
     "vk_color_tracker_begin": ([_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "vk_frame_downsample": ([_P, _P, _P, _P, _P], _I),
     "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
@@ -104,6 +105,10 @@ _SIGNATURES = {
 }
 EXPORTS = tuple(_SIGNATURES)
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn
+
+
+class TrackAborted(RuntimeError):
+    """A Gauss-Newton loop kernel gave up waiting for the other workgroups (vk.h VK_TRACK_ABORTED)."""
 
 
 class VkError(RuntimeError):
@@ -593,8 +598,28 @@ class _PollMixin:
     def _wait_pose(self):
         """Tracker::EndSolve (tracker.cpp:78-82): the pose of the Track just issued, picked up from
         pinned memory (vk_track_wait) instead of a copy + stream synchronisation."""
-        check(lib().vk_track_wait(_ref(self._poll_desc), stream()), "vk_track_wait")
+        rc = lib().vk_track_wait(_ref(self._poll_desc), stream())
+        if rc != 0 and int(self.state.cpu()[1]) == T.VK_TRACK_ABORTED:
+            raise TrackAborted("the one-launch loop ended with VK_TRACK_ABORTED")
+        check(rc, "vk_track_wait")
         return T.Transform.from_buffer_copy(C.string_at(self._pose_host, C.sizeof(T.Transform)))
+
+    _staged = False                          # falling back from an aborted one-launch loop
+
+    def _with_fallback(self, frame, run):
+        """A one-launch loop that could not get its workgroups onto the device together ends with
+        VK_TRACK_ABORTED and no pose: run the Track again from the start pose with a reduce hook
+        that changes nothing, i.e. one launch per stage (vk_reduce_nothing, vk.h)."""
+        start = frame.depth_to_world
+        try:
+            return run(frame)
+        except TrackAborted:
+            frame.depth_to_world = start
+            self._staged = True
+            try:
+                return run(frame)
+            finally:
+                self._staged = False
 
     comm = None                              # vulcan_amd.comm.Communicator: the rig's all-reduce, from C
 
@@ -608,6 +633,8 @@ class _PollMixin:
         if self.comm is not None:
             return self.comm.hook_fn
         if self.reduce_hook is None:
+            if self._staged:
+                return C.cast(lib().vk_reduce_nothing, C.c_void_p)
             return None
         system, py_hook = self.system, self.reduce_hook
 
@@ -618,10 +645,17 @@ class _PollMixin:
         return C.cast(self._hook_keepalive, C.c_void_p)
 
     def __del__(self):
-        host = getattr(self, "_poll_host", None)
-        if host is not None and _LIB is not None:
-            _LIB.vk_free_host(host)
-            self._poll_host = None
+        # a loop kernel that is still running writes both pinned blocks: drain the stream first
+        host, pose = getattr(self, "_poll_host", None), getattr(self, "_pose_host", None)
+        if (host is not None or pose is not None) and _LIB is not None:
+            try:
+                _LIB.vk_stream_synchronize(stream())
+            except Exception:      # noqa: BLE001  (interpreter shutdown: torch may be gone; the process ends anyway)
+                return
+            for block in (host, pose):
+                if block is not None:
+                    _LIB.vk_free_host(block)
+            self._poll_host = self._pose_host = None
 
 
 class DepthTracker(_PollMixin):
@@ -686,6 +720,9 @@ class DepthTracker(_PollMixin):
             "vk_icp_compute_system")
 
     def track(self, frame):
+        return self._with_fallback(frame, self._track)
+
+    def _track(self, frame):
         """Tracker::Track (tracker.cpp:53-63): <= max_iterations Gauss-Newton steps,
         all enqueued without a host sync; one 128-byte readback of the pose at the end."""
         import torch
@@ -797,6 +834,9 @@ class ColorTracker(_PollMixin):
               "vk_color_tracker_compute_system")
 
     def track(self, frame):
+        return self._with_fallback(frame, self._track)
+
+    def _track(self, frame):
         """Tracker::Track (tracker.cpp:53-63) with ColorTracker::BeginSolve
         (color_tracker.cpp:19-25): intensities and gradients once, then
         max_iterations steps enqueued without a host sync."""
@@ -877,6 +917,9 @@ class LightTracker(ColorTracker):
               "vk_light_tracker_compute_system")
 
     def track(self, frame):
+        return self._with_fallback(frame, self._track)
+
+    def _track(self, frame):
         """Tracker::Track with LightTracker::BeginSolve (light_tracker.cpp:34-41)."""
         import torch
         kv, keep_k = self._key()
@@ -921,6 +964,9 @@ class PyramidTracker:
 
 
     def _track_depth(self, frame):
+        return self.tracker._with_fallback(frame, self._track_depth_once)
+
+    def _track_depth_once(self, frame):
         """PyramidTracker<DepthTracker>::Track as ONE call (vk_icp_pyramid_track): both levels
         are enqueued from C, the pose stays on the device in between, one readback at the end."""
         import torch

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void color_begin_kernel(BeginParams B)
       const float v = linear < 16 ? B.pose.m[linear] : B.pose.inv[linear - 16];
       if (linear < 16) B.pose_dev->depth_to_world.m[linear] = v; else B.pose_dev->depth_to_world.inv[linear - 16] = v;
     }
-    if (linear < 2 && B.state_dev) B.state_dev[linear] = 0;
+    // a Track's first level (it uploads the pose) starts from a clean state; a later level keeps
+    // an abort of the level before it, so that the Track fails as a whole
+    if (linear < 2 && B.state_dev && (B.pose_dev || B.state_dev[1] != VK_TRACK_ABORTED)) B.state_dev[linear] = 0;
   }
   else if (job == 1)
   {
@@ -614,6 +616,7 @@ struct ColorLoopParams
   int groups;
   int iterations;
   int fresh_state;
+  int force_abort;         // test aid, vk_forced_loop_abort()
   int last_launch;         // 1: this launch ends the Track (it leaves the pose for vk_track_wait)
   float* hessian;
   float* gradient;
@@ -639,7 +642,14 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
   const int steps_before = L.fresh_state ? 0 : L.state[0];
   if (!L.fresh_state && L.state[1])           // uniform over the grid
   {
-    if (blockIdx.x == 0 && L.last_launch) publish_host_pose(L.mirror, &L.pose->depth_to_world);
+    // converged earlier: the pose stands. Aborted earlier (a level of a coarse-to-fine Track):
+    // no pose is published, the host sees the Track fail and runs it again, launch per stage
+    if (blockIdx.x == 0 && L.last_launch && L.state[1] != VK_TRACK_ABORTED) publish_host_pose(L.mirror, &L.pose->depth_to_world);
+    return;
+  }
+  if (L.force_abort)
+  {
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.state[1] = VK_TRACK_ABORTED;
     return;
   }
 
@@ -779,9 +789,12 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.last_launch = done + kExchangeSteps >= iterations ? 1 : 0;
+    L.force_abort = vk_forced_loop_abort();
+    ColorParams Pk = P;
     vk_loop_launch_begin(s);
-    hipLaunchKernelGGL((color_loop_kernel<LIGHT, TRANSLATION>), dim3(grid), dim3(kColorThreads), 0, s, P, L);
+    const hipError_t le = launch_loop_kernel(color_loop_kernel<LIGHT, TRANSLATION>, grid, kColorThreads, s, Pk, L);
     vk_loop_launch_end(s);
+    VK_CHECK(le);
     VK_LAUNCH_CHECK();
     L.fresh_state = 0;
   }

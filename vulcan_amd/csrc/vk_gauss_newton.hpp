@@ -8,6 +8,7 @@
 #include "vk_common.hpp"
 
 #include <cstdlib>
+#include <mutex>
 
 #ifdef VK_LOOP_TIMING
 #include <cstdio>
@@ -242,6 +243,35 @@ struct Exchange
 // process-wide source of launch tags (vk_runtime.hip): 22 bits, never 0
 uint32_t vk_next_loop_epoch();
 
+// test aid (VK_TEST_FORCE_LOOP_ABORT=1): the next loop launches behave as if a workgroup's sums had
+// never arrived — they end with VK_TRACK_ABORTED at once — so that the hosts' way out of an
+// aborted Track (the launch-per-stage loop) can be tested without starving a real launch
+inline int vk_forced_loop_abort()
+{
+  const char* e = getenv("VK_TEST_FORCE_LOOP_ABORT");
+  return (e && e[0] == '1') ? 1 : 0;
+}
+
+// VK_LOOP_COOPERATIVE=1: loop kernels go through hipLaunchCooperativeKernel, which refuses a grid
+// that cannot be resident at once instead of letting the kernel find out (measured: see DESIGN.md)
+inline bool vk_loop_cooperative()
+{
+  static const int on = [] { const char* e = getenv("VK_LOOP_COOPERATIVE"); return (e && e[0] == '1') ? 1 : 0; }();
+  return on != 0;
+}
+
+template <typename Kernel, typename A, typename B>
+inline hipError_t launch_loop_kernel(Kernel kernel, int grid, int threads, hipStream_t s, A& a, B& b)
+{
+  if (vk_loop_cooperative())
+  {
+    void* args[2] = {&a, &b};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kernel), dim3(grid), dim3(threads), args, 0, s);
+  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, s, a, b);
+  return hipGetLastError();
+}
+
 // bracket every loop-kernel launch: loop kernels of different streams of one device never overlap
 void vk_loop_launch_begin(hipStream_t stream);
 void vk_loop_launch_end(hipStream_t stream);
@@ -257,6 +287,8 @@ inline int resident_workgroups(Kernel kernel, int threads)
   struct Entry { const void* kernel; int device; int capacity; };
   static Entry cache[32];
   static int used = 0;
+  static std::mutex guard;       // Tracks may be issued from several host threads (one per stream)
+  std::lock_guard<std::mutex> hold(guard);
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return 0;
   int capacity = -1;
@@ -269,7 +301,7 @@ inline int resident_workgroups(Kernel kernel, int threads)
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
       return 0;
     capacity = per_cu * cus > 0 ? per_cu * cus : 0;
-    if (used < 32) cache[used++] = Entry{reinterpret_cast<const void*>(kernel), device, capacity};   // benign if two threads race: same values
+    if (used < 32) cache[used++] = Entry{reinterpret_cast<const void*>(kernel), device, capacity};
   }
   // test aid: a smaller grid than the device could hold (workgroups then take several pixel
   // groups each — the path a device with fewer CUs, or larger images, would take)

@@ -394,7 +394,9 @@ struct LoopParams
   vk_transform* pose;            // in: the pose to start from; out: the pose after the loop
   int groups;                    // 1024-pixel groups of the frame (gridDim.x <= groups)
   int iterations;
-  int fresh_state;               // 1: the loop starts at {0 steps, not converged} whatever `state` holds
+  int fresh_state;               // 1: the loop starts at {0 steps, not converged} whatever `state` holds;
+                                 // 2: the same, unless an earlier level of this Track was aborted
+  int force_abort;               // test aid, vk_forced_loop_abort()
   int last_launch;               // 1: this launch ends the Track (it leaves the pose for vk_track_wait)
   float* hessian;
   float* gradient;
@@ -418,7 +420,15 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   const int steps_before = L.fresh_state ? 0 : L.state[0];
   if (!L.fresh_state && L.state[1])           // uniform over the grid: nobody waits for anybody
   {
-    if (blockIdx.x == 0 && L.last_launch) publish_host_pose(L.mirror, L.pose);
+    if (blockIdx.x == 0 && L.last_launch && L.state[1] != VK_TRACK_ABORTED) publish_host_pose(L.mirror, L.pose);
+    return;
+  }
+  // an aborted level ends the whole Track: the next level must not start from the pose it left
+  // behind and report success (the host then runs the Track again, launch per stage)
+  if (L.fresh_state == 2 && L.state[1] == VK_TRACK_ABORTED) return;
+  if (L.force_abort)
+  {
+    if (blockIdx.x == 0 && threadIdx.x == 0) L.state[1] = VK_TRACK_ABORTED;
     return;
   }
 
@@ -694,7 +704,7 @@ __global__ void publish_pose_kernel(Mirror mirror, const vk_transform* pose)
 // the non-rig loop: one launch (track_loop_kernel)
 int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int translation_enabled, int groups,
     float* workspace, float* hessian, float* gradient, int32_t* state_dev, float* update_dev, Mirror mirror,
-    bool fresh_state, bool ends_track, hipStream_t s)
+    int fresh_state, bool ends_track, hipStream_t s)
 {
   VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
   const int capacity = translation_enabled ? resident_workgroups(track_loop_kernel<true>, kIcpThreads)
@@ -718,14 +728,15 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     L.exchange.epoch = vk_next_loop_epoch();
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
-    L.fresh_state = (fresh_state && done == 0) ? 1 : 0;
+    L.fresh_state = (fresh_state && done == 0) ? fresh_state : 0;
+    L.force_abort = vk_forced_loop_abort();
     L.last_launch = (ends_track && done + kExchangeSteps >= iterations) ? 1 : 0;
+    IcpParams Pk = P;
     vk_loop_launch_begin(s);
-    if (translation_enabled)
-      hipLaunchKernelGGL(track_loop_kernel<true>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
-    else
-      hipLaunchKernelGGL(track_loop_kernel<false>, dim3(grid), dim3(kIcpThreads), 0, s, P, L);
+    const hipError_t le = translation_enabled ? launch_loop_kernel(track_loop_kernel<true>, grid, kIcpThreads, s, Pk, L)
+                                              : launch_loop_kernel(track_loop_kernel<false>, grid, kIcpThreads, s, Pk, L);
     vk_loop_launch_end(s);
+    VK_CHECK(le);
     VK_LAUNCH_CHECK();
   }
   return VK_OK;
@@ -821,7 +832,7 @@ int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_
 
   if (!reduce)
     return launch_loop(P, Twc_dev, iterations, translation_enabled, partials, workspace, hessian, gradient,
-        state_dev, update_dev, mirror, /*fresh_state*/ false, /*ends_track*/ true, s);
+        state_dev, update_dev, mirror, /*fresh_state*/ 0, /*ends_track*/ true, s);
 
   for (int it = 0; it < iterations; ++it)
   {
@@ -933,7 +944,7 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
       const int rc = fill_icp(P, views[level][0], Twm, views[level][1], &identity);
       if (rc != VK_OK) return rc;
       const int rl = launch_loop(P, Twc_dev, steps[level], 1, group_count_for(views[level][1]->width * views[level][1]->height, P.group_pixels),
-          workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ true, /*ends_track*/ level == 1, s);
+          workspace, system, system + 36, state_dev, update_dev, mirror, /*fresh_state*/ level == 0 ? 1 : 2, /*ends_track*/ level == 1, s);
       if (rl != VK_OK) return rl;
     }
     return VK_OK;
@@ -946,6 +957,8 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
   return vk_icp_track(keyframe, Twm, frame, Twc_dev, 20, 1, workspace, system, state_dev, update_dev,
       reduce, reduce_user, poll, stream);
 }
+
+int vk_reduce_nothing(float*, int, void*, void*) { return 0; }
 
 int vk_track_wait(const vk_track_poll* poll, void* stream)
 {

@@ -54,11 +54,26 @@ struct IntegrateParams
   Rt Tdw, Tcw, Tcd;
   vk_light light;
   float voxel_length, block_length, truncation_length;
+  double inv_truncation_length;   // RN64(1 / truncation_length), see exact_quotient
   float min_depth, max_depth;
   float max_distance_weight, max_color_weight;
 };
 
 constexpr int kTileF4 = 640;  // float4 per voxel block
+
+// a / b for binary32 a, b, correctly rounded, from inv_b = RN64(1 / b): the double product is
+// within 2^-52 (relative) of a / b and a binary32 quotient is never within 2^-49 of the midpoint
+// of two binary32 neighbours, so rounding it gives exactly RN32(a / b) — the value the
+// reference's `a / b` has (vk_raycast.hpp div_uniform has the argument in full). Three
+// instructions instead of the ten of the division expansion. The same argument makes
+// (float)RN64(1 / b) equal to RN32(1 / b), the reference's `1.0f / b`.
+__device__ __forceinline__ float exact_quotient(float a, double inv_b) { return (float)((double)a * inv_b); }
+
+// The running averages divide by a weight: a small integer (the weights are capped at 16 by
+// default, integrator.cu:7-13). RN64(1 / n) for n < kReciprocals sits in LDS, filled once per
+// workgroup with the correctly rounded double division; a wave that meets a larger weight takes
+// the plain division.
+constexpr int kReciprocals = 33;    // weights 0 .. 31 divide by 1 .. 32
 
 // light.h:53-60
 __device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 normal)
@@ -153,7 +168,7 @@ __device__ __forceinline__ void unit_issue(const IntegrateParams& P, int4 my_ent
 
 template <bool DEPTH, int COLOR, bool SAME_CAM, bool RECORDS>
 __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, float4* tile4, uint8_t* changed,
-    UNIT_PARAMS)
+    const double* reciprocal, UNIT_PARAMS)
 {
   float* tile = reinterpret_cast<float*>(tile4);
   const int vx = lane & 7, vy = lane >> 3;
@@ -179,6 +194,10 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
     old_w[k] = __float_as_uint(vox[4]);
   }
 
+  // every weight of the wave's voxels below kReciprocals (bits 5..14 of both 16-bit halves clear;
+  // a negative weight has bit 15 set): the divisions by weight + 1 use the reciprocal table
+  const bool small_weights = !__any(((old_w[0] | old_w[1] | old_w[2] | old_w[3]) & 0xffe0ffe0u) != 0u);
+
   bool dirty = false;
   float dist[4];   // the voxel's current distance after the depth pass (or as stored)
 
@@ -200,10 +219,12 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
       const uint32_t weights = old_w[k];
       const int16_t dw = (int16_t)(weights & 0xffff);
       const float prev_dist = dw * old_d[k];
-      const float curr_dist = vmin(1.0f, distance / P.truncation_length);
+      const float curr_dist = vmin(1.0f, exact_quotient(distance, P.inv_truncation_length));
       const float dist_weight = dw + 1;
       const int16_t new_dw = (int16_t)vmin(P.max_distance_weight, dist_weight);
-      const float new_distance = (prev_dist + curr_dist) / dist_weight;
+      float new_distance;
+      if (small_weights) new_distance = exact_quotient(prev_dist + curr_dist, reciprocal[dw + 1]);
+      else new_distance = (prev_dist + curr_dist) / dist_weight;
       dist[k] = update ? new_distance : old_d[k];
       old_w[k] = update ? ((weights & 0xffff0000u) | (uint16_t)new_dw) : weights;
       if (update)
@@ -331,7 +352,9 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
         const f3 prev_color = scale3(stored, cwf);
         const float color_weight = cw + 1;
         const int16_t new_cw = (int16_t)vmin(P.max_color_weight, color_weight);
-        const f3 c = div3(add3(prev_color, curr_color), color_weight);
+        // matrix.h:279-295: operator/ multiplies by 1.0f / s
+        const float inv_weight = small_weights ? (float)reciprocal[cw + 1] : 1.0f / color_weight;
+        const f3 c = scale3(add3(prev_color, curr_color), inv_weight);
         const uint32_t new_weights = (weights & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw << 16);
         vox[1] = c.x;
         vox[2] = c.y;
@@ -393,6 +416,7 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
   constexpr int kPoolInts = AHEAD ? (2 * kAheadMaxCells > kTileInts ? 2 * kAheadMaxCells : kTileInts) : kTileInts;
   __shared__ __attribute__((aligned(16))) int pool[kPoolInts];
   __shared__ __attribute__((aligned(8))) uint8_t changed_bytes[kPipeWavesPerGroup][512];
+  __shared__ double reciprocal[kReciprocals];
 
   int group = (int)blockIdx.x, groups = (int)gridDim.x;
   if (AHEAD)
@@ -405,6 +429,8 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
     group -= kBoundsGroups;
     groups -= kBoundsGroups;
   }
+  if (threadIdx.x < kReciprocals) reciprocal[threadIdx.x] = threadIdx.x ? 1.0 / (double)(int)threadIdx.x : 0.0;
+  __syncthreads();
 
   const int lane = lane_id();
   const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -431,14 +457,14 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
     for (; s + 2 < units; s += 2)   // steady state: two units per trip, next one always in flight
     {
       unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
-      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(A));
+      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, reciprocal, UNIT_ARGS(A));
       unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 2, lane, UNIT_ARGS(A));
-      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(B));
+      unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, reciprocal, UNIT_ARGS(B));
     }
     // units is even and >= 2: exactly two remain (s, s + 1)
     unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, s + 1, lane, UNIT_ARGS(B));
-    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(A));
-    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, UNIT_ARGS(B));
+    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, reciprocal, UNIT_ARGS(A));
+    unit_update<DEPTH, COLOR, SAME_CAM, RECORDS>(P, lane, tile4, changed, reciprocal, UNIT_ARGS(B));
   }
 }
 
@@ -497,6 +523,7 @@ int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, 
   P.voxel_length = v->voxel_length;
   P.block_length = VK_BLOCK_RESOLUTION * v->voxel_length;
   P.truncation_length = v->truncation_length;
+  P.inv_truncation_length = 1.0 / (double)v->truncation_length;
   P.min_depth = p->min_depth;
   P.max_depth = p->max_depth;
   P.max_distance_weight = p->max_distance_weight;

@@ -54,6 +54,8 @@ class Tracker
     virtual void ComputeSystem(const Frame& frame) = 0;
     virtual void ApplyUpdate(Frame& frame, const Vector6f& x) const = 0;
     void EndSolve(Frame& frame);
+    bool FinishSolve(Frame& frame, bool must_succeed);   // EndSolve that reports VK_TRACK_ABORTED as false
+    vk_icp_reduce_fn DeviceHook() const;                  // the user's hook, or the no-op one while falling back
 
     // whole loop on the device; subclasses with a fused ABI entry override it
     virtual void TrackOnDevice(Frame& frame);
@@ -81,6 +83,7 @@ class Tracker
 
     ReduceHook reduce_hook_;
     void* reduce_user_;
+    bool staged_only_ = false;    // falling back from an aborted one-launch loop: one launch per stage
 
     // early exit of the device loop (vk_track_poll): pinned {iterations, converged} mirror
     // and the number of steps enqueued between two looks at it (0 = enqueue all steps)

@@ -26,6 +26,20 @@ vk_icp_view ViewOf(const Frame& frame)
 
 // ---- Tracker -------------------------------------------------------------------
 
+namespace
+{
+
+struct HookAdapter { Tracker::ReduceHook hook; void* user; };
+
+int CallReduceHook(float* system_dev, int count, void* user, void*)
+{
+  const HookAdapter* a = static_cast<const HookAdapter*>(user);
+  a->hook(system_dev, count, a->user);
+  return 0;
+}
+
+} // namespace
+
 Tracker::Tracker() :
   translation_enabled_(true),
   iteration_(0),
@@ -50,6 +64,8 @@ Tracker::Tracker() :
 
 Tracker::~Tracker()
 {
+  // a loop kernel that is still running writes both pinned blocks: drain the stream first
+  vk_stream_synchronize(Device::GetStream());
   vk_free_host(poll_.host_pose);
   vk_free_host(poll_.host_state);
 }
@@ -82,10 +98,19 @@ void Tracker::SetReduceHook(ReduceHook hook, void* user)
 // the solve converged and the remaining updates are no-ops.
 void Tracker::Track(Frame& frame)
 {
-  BeginSolve(frame);
-  TrackOnDevice(frame);
-  iteration_ = max_iterations_;
-  EndSolve(frame);
+  const Transform start = frame.depth_to_world_transform;
+  for (int attempt = 0; attempt < 2; ++attempt)
+  {
+    BeginSolve(frame);
+    TrackOnDevice(frame);
+    iteration_ = max_iterations_;
+    if (FinishSolve(frame, attempt == 1)) break;
+    // the one-launch loop could not get its workgroups onto the device together
+    // (VK_TRACK_ABORTED): once more from the start pose, one launch per stage
+    frame.depth_to_world_transform = start;
+    staged_only_ = true;
+  }
+  staged_only_ = false;
 }
 
 // default: iterate ComputeSystem + solve; DepthTracker enqueues the whole loop with one C call
@@ -115,7 +140,12 @@ void Tracker::BeginSolve(const Frame& frame)
   VK_ASSERT(vk_memset(state_.GetData(), 0, 2 * sizeof(int), Device::GetStream()));
 }
 
-void Tracker::EndSolve(Frame& frame)
+void Tracker::EndSolve(Frame& frame) { FinishSolve(frame, true); }
+
+// Tracker::EndSolve (tracker.cpp:78-82) that can say "aborted" instead of throwing: false when
+// the device loop ended with VK_TRACK_ABORTED and `must_succeed` is not set (the frame's pose is
+// then left alone)
+bool Tracker::FinishSolve(Frame& frame, bool must_succeed)
 {
   // the device loops leave the pose in pinned memory (vk_track_wait); a loop that does not
   // (the step-by-step default of this class) is read back with a copy
@@ -126,10 +156,22 @@ void Tracker::EndSolve(Frame& frame)
     VK_ASSERT(vk_memcpy_d2h(&pose, DevicePose(), sizeof(pose), Device::GetStream()));
     int32_t state[2] = {0, 0};
     VK_ASSERT(vk_memcpy_d2h(state, state_.GetData(), sizeof(state), Device::GetStream()));
-    VULCAN_ASSERT_MSG(state[1] != VK_TRACK_ABORTED,
-        "the tracking kernel could not get all of its workgroups onto the device (is another process using it?)");
+    if (state[1] == VK_TRACK_ABORTED)
+    {
+      VULCAN_ASSERT_MSG(!must_succeed,
+          "the tracking kernel could not get all of its workgroups onto the device (is another process using it?)");
+      return false;
+    }
   }
   frame.depth_to_world_transform = Transform::FromVk(pose);
+  return true;
+}
+
+// the hook handed to the C ABI: the user's, or — while falling back from an aborted one-launch
+// loop — one that changes nothing and thereby selects the launch-per-stage loop
+vk_icp_reduce_fn Tracker::DeviceHook() const
+{
+  return reduce_hook_ ? CallReduceHook : (staged_only_ ? vk_reduce_nothing : nullptr);
 }
 
 void Tracker::ValidateKeyframe() const
@@ -189,19 +231,6 @@ void DepthTracker::ComputeJacobian(const Frame& frame, Buffer<Vector6f>& jacobia
       reinterpret_cast<float*>(jacobian.GetData()), Device::GetStream()));
 }
 
-namespace
-{
-
-struct HookAdapter { Tracker::ReduceHook hook; void* user; };
-
-int CallReduceHook(float* system_dev, int count, void* user, void*)
-{
-  const HookAdapter* a = static_cast<const HookAdapter*>(user);
-  a->hook(system_dev, count, a->user);
-  return 0;
-}
-
-} // namespace
 
 void DepthTracker::TrackOnDevice(Frame& frame)
 {
@@ -210,7 +239,7 @@ void DepthTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_icp_track(&key, &Twm, &frm, pose_.GetData(), max_iterations_, translation_enabled_ ? 1 : 0,
       workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
+      DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
 void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame)
@@ -226,15 +255,21 @@ void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& fr
   VULCAN_ASSERT_MSG(floats > 0, "pyramid tracking needs even image sizes");
   if (floats > pyramid_.GetSize()) pyramid_.Resize(floats);
   const vk_transform Twm = keyframe_->depth_to_world_transform.ToVk();
-  const vk_transform pose = frame.depth_to_world_transform.ToVk();
-  poll_.host_state[3] = 0;
-  VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
-  HookAdapter adapter = { reduce_hook_, reduce_user_ };
-  VK_ASSERT(vk_icp_pyramid_track(&key, &Twm, &frm, pose_.GetData(), pyramid_.GetData(), workspace_.GetData(),
-      system_.GetData(), state_.GetData(), update_.GetData(), reduce_hook_ ? CallReduceHook : nullptr, &adapter,
-      &poll_, Device::GetStream()));
-  iteration_ = max_iterations_;
-  EndSolve(frame);
+  const Transform start = frame.depth_to_world_transform;
+  for (int attempt = 0; attempt < 2; ++attempt)
+  {
+    const vk_transform pose = frame.depth_to_world_transform.ToVk();
+    poll_.host_state[3] = 0;
+    VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
+    HookAdapter adapter = { reduce_hook_, reduce_user_ };
+    VK_ASSERT(vk_icp_pyramid_track(&key, &Twm, &frm, pose_.GetData(), pyramid_.GetData(), workspace_.GetData(),
+        system_.GetData(), state_.GetData(), update_.GetData(), DeviceHook(), &adapter, &poll_, Device::GetStream()));
+    iteration_ = max_iterations_;
+    if (FinishSolve(frame, attempt == 1)) break;
+    frame.depth_to_world_transform = start;      // aborted: again, one launch per stage (Tracker::Track)
+    staged_only_ = true;
+  }
+  staged_only_ = false;
 }
 
 void DepthTracker::ComputeSystem(const Frame& frame)
@@ -325,20 +360,27 @@ void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask, bool upload_po
 void ColorTracker::TrackCoarseToFine(std::shared_ptr<const Frame> half_keyframe, Frame& half_frame,
     std::shared_ptr<const Frame> keyframe, Frame& frame)
 {
-  // :79-83 half level, 15 steps, from the frame's pose
-  SetMaxIterations(15);
-  SetTranslationEnabled(true);
-  SetKeyframe(half_keyframe);
-  BeginOnDevice(half_frame, MaskImage(), true);
-  TrackOnDevice(half_frame);
-  // :85-89 full level, 20 steps, from the pose the half level left in color_pose_ (upstream
-  // carries it through half_frame.depth_to_world_transform: the same bits)
-  SetMaxIterations(20);
-  SetKeyframe(keyframe);
-  BeginOnDevice(frame, MaskImage(), false);
-  TrackOnDevice(frame);
-  iteration_ = max_iterations_;
-  EndSolve(frame);
+  const Transform start = half_frame.depth_to_world_transform;
+  for (int attempt = 0; attempt < 2; ++attempt)
+  {
+    // :79-83 half level, 15 steps, from the frame's pose
+    SetMaxIterations(15);
+    SetTranslationEnabled(true);
+    SetKeyframe(half_keyframe);
+    BeginOnDevice(half_frame, MaskImage(), true);
+    TrackOnDevice(half_frame);
+    // :85-89 full level, 20 steps, from the pose the half level left in color_pose_ (upstream
+    // carries it through half_frame.depth_to_world_transform: the same bits)
+    SetMaxIterations(20);
+    SetKeyframe(keyframe);
+    BeginOnDevice(frame, MaskImage(), false);
+    TrackOnDevice(frame);
+    iteration_ = max_iterations_;
+    if (FinishSolve(frame, attempt == 1)) break;
+    half_frame.depth_to_world_transform = start;   // aborted: again, one launch per stage (Tracker::Track)
+    staged_only_ = true;
+  }
+  staged_only_ = false;
   half_frame.depth_to_world_transform = frame.depth_to_world_transform;   // not the half level's own result: see above
 }
 
@@ -427,7 +469,7 @@ void ColorTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_color_tracker_track(&key, &frm, &frame_Tcd, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
+      DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
 // ref: color_tracker.cpp:34-96 (host form; Track() uses the device form)
@@ -539,7 +581,7 @@ void LightTracker::TrackOnDevice(Frame& frame)
   HookAdapter adapter = { reduce_hook_, reduce_user_ };
   VK_ASSERT(vk_light_tracker_track(&key, &frm, &terms, &key_Twc, color_pose_.GetData(), max_iterations_,
       translation_enabled_ ? 1 : 0, workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(),
-      reduce_hook_ ? CallReduceHook : nullptr, &adapter, &poll_, Device::GetStream()));
+      DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
 // ---- PyramidTracker ---------------------------------------------------------------
