@@ -636,7 +636,7 @@ def main():
              "depth": "BASELINE configs[1]: 640x480 depth-only sequence, SetView x3 + DepthIntegrator + Tracer" + sphere,
              "rgbd-icp": "BASELINE configs[2], closed loop: 640x480 RGB-D, Frame::ComputeNormals + PyramidTracker<DepthTracker> "
                          "vs the previous raycast (from the previous tracked pose) + SetView x3 + LightIntegrator + Tracer at "
-                         "the TRACKED pose; camera swinging +-40 deg and translating through a 4.4 x 3 x 5.2 m box room with "
+                         "the TRACKED pose; camera swinging +-24 deg and translating through a 4.4 x 3 x 5.2 m box room with "
                          "9 spheres (closed form, all six pose parameters observable)"}
     set_view_policy = {
         "calls_per_frame_upstream": 3, "max_rounds": SET_VIEW_ROUNDS,

@@ -95,7 +95,7 @@ enum {
 
 /* Per-volume device counters. The reference keeps these as file-scope
  * __device__ symbols shared by every Volume (volume.cu:17-21); here each
- * volume owns an int[VK_CTR_COUNT] in device memory. */
+ * volume owns an int[VK_CTR_COUNT] in device memory, 8-byte aligned. */
 enum {
   VK_CTR_VISIBLE    = 0,  /* buffer_size: number of entries in visible_blocks */
   VK_CTR_VOXEL_PTR  = 1,  /* voxel_pointer: top of the free-slot stack */
@@ -106,13 +106,24 @@ enum {
   VK_CTR_PENDING_ALL    = 6,  /* internal: pointer updates of a handle pass, not yet folded in */
   VK_CTR_PENDING_EXCESS = 7,
   VK_CTR_ROUNDS     = 8,  /* SetView rounds run so far by vk_volume_set_view* (cumulative) */
-  VK_CTR_UNSETTLED  = 9,  /* the last vk_volume_set_view* ended with a request lost to a bucket
-                             contest or dropped: another SetView would have work (1), or its
-                             rounds were cut short by a barrier timeout (-1, never seen) */
-  VK_CTR_CONTENDED  = 10, /* internal: a request pass lost a request to a bucket contest */
-  VK_CTR_GATE       = 11, /* internal [2]: "another round is needed", by round parity */
-  VK_CTR_BARRIER    = 13, /* internal: arrivals at the grid barriers of the later rounds */
-  VK_CTR_COUNT      = 16
+  VK_CTR_UNSETTLED  = 9,  /* the last vk_volume_set_view* left a request unanswered: lost to a bucket
+                             contest in its last round, or dropped (pool / excess list exhausted), or
+                             more losers than the retry list holds — another SetView call has work */
+  VK_CTR_CONTENDED  = 10, /* internal: the request pass lost a request to a bucket contest */
+  VK_CTR_TICKET     = 11, /* internal: handle workgroups that have finished the first round */
+  VK_CTR_RETRY_COUNT = 12, /* internal [2]: keys filed in the two retry lists */
+  VK_CTR_RETRY_OVERFLOW = 14, /* internal: a retry list (or the ordering buffer of a later round) was too small */
+  VK_CTR_DROPPED_NOW = 15, /* internal: the current call dropped a request */
+  VK_CTR_ORIGIN_SEEN = 16, /* internal: a ray met block (0,0,0) while the main entry of its bucket was
+                              unallocated — such an entry compares equal to that block (volume.cu:186-191),
+                              so the block counts as present until the entry is taken by another block */
+  VK_CTR_PUBLIC     = 24, /* what vk_volume_read_counters_sync copies */
+  /* behind the counters, for vk_volume_set_view_rounds: the blocks whose request lost its bucket in
+   * the round before — two open-addressing sets of VK_RETRY_SLOTS 64-bit request keys (current
+   * round / next round) and, for each, the list of the slots in use (VK_RETRY_KEYS ints) */
+  VK_RETRY_SLOTS    = 65536,
+  VK_RETRY_KEYS     = 8192,
+  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192
 };
 
 enum {
@@ -242,8 +253,8 @@ VK_API int vk_volume_update_block_visibility(const vk_volume* v, int width,
 /* ref: src/volume.cu:430-437 Volume::SetView = the four calls above. */
 VK_API int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream);
 
-/* ref: src/volume.cu:537-543 Volume::GetBufferSize — blocking readback of all
- * VK_CTR_COUNT counters into host memory. */
+/* ref: src/volume.cu:537-543 Volume::GetBufferSize — blocking readback of the first
+ * VK_CTR_PUBLIC counters into host memory (int32[VK_CTR_PUBLIC] or larger). */
 VK_API int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream);
 
 /* ------------------------------------------------------------- integrators -- */
@@ -408,11 +419,16 @@ VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame,
  * (or finds its bucket's main entry taken by the winner) must ask again. This entry point leaves
  * exactly the state of `max_rounds` consecutive vk_volume_set_view(_prepare) calls with the same
  * frame — every buffer, the visible set, VK_CTR_VOXEL_PTR / EXCESS_PTR / REQUESTS / DROPPED — in the
- * three launches of ONE call: the rounds after the first run inside the last launch, and only
- * when the round before lost or dropped a request (otherwise another SetView changes nothing,
- * and none is run). `prep` as in vk_volume_set_view_prepare (may be NULL). max_rounds >= 1.
- * VK_CTR_ROUNDS counts the rounds that ran; VK_CTR_UNSETTLED tells whether one more would still
- * have had work. */
+ * three launches of ONE call. What a further call changes is only this: the blocks that lost ask
+ * again, the winners among them are committed, their entries become visible. The request pass
+ * therefore files the losers in a list, and — only when there are any — the handle pass replays
+ * the later rounds from that list before the visibility pass runs; the rays are walked once.
+ * `prep` as in vk_volume_set_view_prepare (may be NULL). max_rounds >= 1. VK_CTR_ROUNDS counts the
+ * rounds that ran; VK_CTR_UNSETTLED tells whether one more call would still have work.
+ * Two cases end the rounds early, with VK_CTR_UNSETTLED = 1 and the state of as many calls as
+ * rounds ran (VK_CTR_ROUNDS): a round that drops a request (pool or excess list exhausted —
+ * upstream's calls after that link entries they never write, its state is inconsistent from
+ * there on), and more than VK_RETRY_KEYS different blocks losing in one round. */
 VK_API int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
     int max_rounds, void* stream);
 

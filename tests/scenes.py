@@ -123,10 +123,11 @@ ROOM_SPHERES = ((1.2, 0.9, 1.6, 0.6), (-1.4, 1.0, 1.2, 0.5), (-1.0, 0.95, -1.7, 
                 (-0.3, 1.15, -2.2, 0.35))                     # (cx, cy, cz, radius)
 
 
-def room_pose(i, frames_per_cycle=320, yaw_amplitude_deg=40.0, pitch_deg=12.0):
-    """Camera pose i of the room sequence (depth-to-world): the yaw swings +-40 deg (at most
-    0.8 deg per frame), the camera is pitched 12 deg towards the floor and its centre moves on a
-    small closed curve (a few millimetres per frame), so depth changes in every pixel, every frame."""
+def room_pose(i, frames_per_cycle=240, yaw_amplitude_deg=24.0, pitch_deg=12.0):
+    """Camera pose i of the room sequence (depth-to-world): the yaw swings +-24 deg (at most
+    0.63 deg per frame), the camera is pitched 12 deg towards the floor and its centre moves on a
+    small closed curve (up to 6.5 mm per frame), so depth changes in every pixel, every frame. A
+    whole cycle shows the camera ~56 k blocks of 4 cm: it fits the app's Volume(65024, 8192)."""
     phase = 2.0 * np.pi * i / frames_per_cycle
     a = np.deg2rad(yaw_amplitude_deg) * np.sin(phase)
     p = np.deg2rad(pitch_deg)

@@ -33,7 +33,7 @@ def test_cpp_frame_loop_runs_and_tracks():
     assert int(m.group(2)) > 3000 and int(m.group(4)) == 0
     # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: the shipped app's
     # set-up (PyramidTracker<LightTracker> + LightIntegrator). Closed loop in the room scene
-    # (room_scene.h): the camera turns ~37 degrees and moves ~0.28 m over 60 frames, every frame
+    # (room_scene.h): the camera turns ~24 degrees and moves ~0.35 m over 60 frames, every frame
     # is fused and raycast at its TRACKED pose, and the true poses only score the result.
     import json
     for mode, label in (("1", "depth"), ("2", "light")):
@@ -43,7 +43,7 @@ def test_cpp_frame_loop_runs_and_tracks():
         assert line, out
         rec = json.loads(line[-1])
         assert rec["tracked_pose_drives_fusion"] is True and rec["frames"] == 60
-        assert rec["camera_motion_over_run"]["rotation_deg"] > 30 and rec["camera_motion_over_run"]["translation_m"] > 0.2
+        assert rec["camera_motion_over_run"]["rotation_deg"] > 15 and rec["camera_motion_over_run"]["translation_m"] > 0.2
         print(mode, rec["pose_error_max"], rec["gn_steps_median"], rec["frames_per_s"])
         # the geometric tracker holds the truth to ~1 mm; the photometric one (shading model on a
         # lamp-lit, mostly dark room) drifts by centimetres — still a small fraction of the motion

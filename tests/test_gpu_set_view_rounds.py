@@ -1,8 +1,9 @@
 """vk_volume_set_view_rounds: the reference's frame loop calls SetView three times per frame
 (apps/vulcan/vulcan.cu:316-318) because a bucket takes one request per call. One call with
 `rounds` must leave exactly the state of that many consecutive SetView calls — every buffer,
-the visible set, the pool pointers and the request / drop counters — although the later rounds
-run inside the last launch of the first one, and only when the round before lost a request.
+the visible set, the pool pointers and the request / drop counters — although the rays are
+walked once: the later rounds are replayed from the list of requests that lost their bucket,
+inside the handle launch, and only when there are any.
 
 The checker is the oracle's set_view called `rounds` times.
 """
@@ -73,34 +74,54 @@ def test_later_rounds_are_skipped_when_nothing_is_pending(api, orc):
     assert ran[0] in (1, 2, 3) and ran[1:] == [1, 1], ran
 
 
-def test_pool_exhaustion_is_repeated_like_upstream(api, orc):
-    """A pool of 600 blocks for a scene that needs more: upstream asks again on every call and
-    drops again (volume.cu:356), moving the pointers each time; so do the rounds."""
+def test_rounds_end_with_the_first_round_that_drops_a_request(api, orc):
+    """A pool of 600 blocks for a scene that needs more. Upstream asks again on every call, drops
+    again and links excess entries it never writes (volume.cu:337-356); from there on its state is
+    inconsistent. The rounds therefore end with the first round that drops a request (vk.h): the
+    state is that of so many SetView calls — here the first call fills the 512 main entries, the
+    second exhausts the pool — and VK_CTR_UNSETTLED says that requests are unanswered."""
     w, h = 320, 240
     hf, df = frames(api, orc, scenes.sphere(2 * w, 2 * h)[::2, ::2].copy(), K_SMALL, scenes.tracer_test_pose())
     hv, dv = make_pair(api, orc, 512, 88, 0.01, 0.04)
-    oracle_rounds(orc, hv, hf, 3)
+    dv.set_view(df, rounds=5)
+    ctr = dv.read_counters()
+    assert ctr[T.VK_CTR_ROUNDS] == 2 and ctr[T.VK_CTR_UNSETTLED] == 1
+    oracle_rounds(orc, hv, hf, 2)
+    assert_volume_equal(dv, hv, voxels=False)
+    assert_same_requests(dv, hv)
+    assert hv.counters[T.VK_CTR_DROPPED] > 100 and hv.counters[T.VK_CTR_VOXEL_PTR] < 0
+    # a pool that is exhausted in the FIRST round: one round, whatever was asked for
+    hv, dv = make_pair(api, orc, 2048, 512, 0.01, 0.04)
+    hv.counters[T.VK_CTR_VOXEL_PTR] = 99
+    dv.upload(hv)
+    oracle_rounds(orc, hv, hf, 1)
     dv.set_view(df, rounds=3)
     assert_volume_equal(dv, hv, voxels=False)
     ctr = assert_same_requests(dv, hv)
-    assert hv.counters[T.VK_CTR_DROPPED] > 100 and ctr[T.VK_CTR_UNSETTLED] == 1
+    assert hv.counters[T.VK_CTR_DROPPED] > 100 and ctr[T.VK_CTR_UNSETTLED] == 1 and ctr[T.VK_CTR_ROUNDS] == 1
 
 
-def test_few_workgroups_walk_the_same_rounds(api, orc):
-    """The rounds inside the launch with 3 workgroups instead of ~290 (test aid
-    VK_SETTLE_GRID_CAP): every workgroup takes many chunks, runs and bucket groups."""
+def test_a_retry_list_that_is_too_small_ends_the_rounds(api, orc):
+    """More lost requests than the retry list holds (forced: VK_RETRY_CAPACITY=64): the rounds
+    stop, the state is ONE SetView call's with VK_CTR_UNSETTLED = 1, and later calls settle it."""
     w, h = 320, 240
-    depth = scenes.ramp(w, h)
-    hf, df = frames(api, orc, depth, K_SMALL, scenes.tracer_test_pose())
+    hf, df = frames(api, orc, scenes.ramp(w, h), K_SMALL, scenes.tracer_test_pose())
     hv, dv = make_pair(api, orc, 2048, 8192, 0.01, 0.04)
-    os.environ["VK_SETTLE_GRID_CAP"] = "6"          # halved by the launcher: 3 workgroups
+    os.environ["VK_RETRY_CAPACITY"] = "64"
     try:
+        oracle_rounds(orc, hv, hf, 1)
+        dv.set_view(df, rounds=4)
+        assert_volume_equal(dv, hv, voxels=False)
+        ctr = dv.read_counters()
+        assert ctr[T.VK_CTR_UNSETTLED] == 1 and ctr[T.VK_CTR_ROUNDS] == 1
+    finally:
+        del os.environ["VK_RETRY_CAPACITY"]
+    for _ in range(6):
         oracle_rounds(orc, hv, hf, 4)
         dv.set_view(df, rounds=4)
         assert_volume_equal(dv, hv, voxels=False)
         assert_same_requests(dv, hv)
-    finally:
-        del os.environ["VK_SETTLE_GRID_CAP"]
+    assert dv.read_counters()[T.VK_CTR_UNSETTLED] == 0
     assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 200
 
 

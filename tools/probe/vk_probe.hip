@@ -186,6 +186,15 @@ int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels,
     const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
     int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, void* stream)
 {
+  return vk_probe_trace_steps(entries, voxels, bounds, block_count, block_length, voxel_length, trunc_length, Twc, projection,
+      depths, colors, image_width, image_height, bounds_width, bounds_height, touched, wave_clocks, nullptr, stream);
+}
+
+int vk_probe_trace_steps(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
+    const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
+    int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, int* march_steps, void* stream)
+{
   VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors && (touched || wave_clocks));
   VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
   PointParams P;
@@ -210,6 +219,7 @@ int vk_probe_trace_touched(const vk_hash_entry* entries, const vk_voxel* voxels,
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
   P.touched = touched;
+  P.march_steps = march_steps;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
   hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P, wave_clocks);
   VK_LAUNCH_CHECK();

@@ -15,6 +15,7 @@ import bench
 import scenes
 from vulcan_amd import api, vk_types as T
 
+ROOM = "--room" in sys.argv          # the tracking workload's scene (true poses) instead of the sphere
 k = T.Projection.make(*scenes.APP_INTRINSICS)
 depth = bench.sphere_room_depth(k)
 vol = api.Volume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
@@ -22,8 +23,14 @@ frame = api.Frame(depth, k, T.Transform.identity(), color=scenes.checker_color(b
 out = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, T.Transform.identity())
 integ, tracer = api.ColorIntegrator(vol), api.Tracer(vol)
 for i in range(30):
-    frame.depth_to_world = out.depth_to_world = scenes.orbit_pose(i, bench.YAW_STEP)
-    vol.set_view(frame)
+    if ROOM:
+        pose = scenes.room_pose(i)
+        d, c = scenes.room_frame(k, pose, bench.W, bench.H)
+        frame = api.Frame(d, k, pose, color=c)
+        out.depth_to_world = pose
+    else:
+        frame.depth_to_world = out.depth_to_world = scenes.orbit_pose(i, bench.YAW_STEP)
+    vol.set_view(frame, rounds=3)
     integ.integrate(frame)
     tracer.trace(out)
 torch.cuda.synchronize()
@@ -61,3 +68,24 @@ for use_touched in (False, True):
         print(np.round(start.reshape(30, 40, 4).max(axis=2)).astype(int))
     assert torch.equal(d2, out.depth)
 print("blocks touched by rays (Nhit):", int(touched.sum()), "visible:", vol.visible_count)
+# trips through the march loop per pixel (the counting kernel again, with its step image)
+steps = torch.zeros((bench.H, bench.W), dtype=torch.int32, device="cuda")
+pl.vk_probe_trace_steps(C.c_void_p(vol.hash_entries.data_ptr()), C.c_void_p(vol.voxels.data_ptr()),
+                        C.c_void_p(tracer.bounds.data_ptr()), vol.main, F(8 * bench.VOXEL), F(bench.VOXEL), F(bench.TRUNC),
+                        C.byref(out.depth_to_world), C.byref(k), C.c_void_p(d2.data_ptr()), C.c_void_p(c2.data_ptr()),
+                        bench.W, bench.H, 80, 60, C.c_void_p(touched.data_ptr()), C.c_void_p(clocks.data_ptr()),
+                        C.c_void_p(steps.data_ptr()), api.stream())
+torch.cuda.synchronize()
+st = steps.cpu().numpy()
+print(f"march trips per ray: mean {st.mean():.1f} median {np.median(st):.0f} p90 {np.percentile(st, 90):.0f} p99 {np.percentile(st, 99):.0f} max {st.max()}")
+tile_max = st.reshape(bench.H // 8, 8, bench.W // 8, 8).max(axis=(1, 3))
+print(f"per 8x8 tile, the slowest ray: mean {tile_max.mean():.1f} median {np.median(tile_max):.0f} p90 {np.percentile(tile_max, 90):.0f} p99 {np.percentile(tile_max, 99):.0f} max {tile_max.max()}")
+b = tracer.bounds.cpu().numpy()
+span = (b[..., 1] - b[..., 0])
+print(f"bounds span per cell (m): mean {span[span > 0].mean():.2f} p90 {np.percentile(span[span > 0], 90):.2f} max {span.max():.2f}")
+if os.environ.get("VK_WAVE_MAP"):
+    np.set_printoptions(linewidth=250)
+    print("slowest ray per 16x16 tile:")
+    print(st.reshape(30, 16, 40, 16).max(axis=(1, 3)))
+    print("bounds span (cm) per 2x2 cells:")
+    print(np.round(100 * span.reshape(30, 2, 40, 2).max(axis=(1, 3))).astype(int))

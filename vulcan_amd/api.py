@@ -368,7 +368,7 @@ class Volume:
 
     # -- host views (blocking)
     def read_counters(self):
-        out = (C.c_int32 * T.VK_CTR_COUNT)()
+        out = (C.c_int32 * T.VK_CTR_PUBLIC)()
         check(lib().vk_volume_read_counters_sync(_ref(self.desc()), out, stream()), "read_counters")
         return np.array(out[:], dtype=np.int32)
 

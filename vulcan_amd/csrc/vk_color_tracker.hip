@@ -637,6 +637,8 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
   __shared__ float tcm[32];      // Tcm: matrix, inverse
   __shared__ float last_update[6];
   __shared__ float last_M[16];   // workgroup 0: Tinc * Twd^-1 of the last step
+  __shared__ float solve_scratch[64];   // wave_solve_step / wave_rigid_from
+  __shared__ float fixed_m[32];         // frame_Tcd.m, key_Twc.m: indexed per lane by the wave-wide products
   __shared__ int stop, failed;
 
   const int steps_before = L.fresh_state ? 0 : L.state[0];
@@ -654,7 +656,10 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
   }
 
   if (threadIdx.x < 32)
+  {
     twd[threadIdx.x] = threadIdx.x < 16 ? L.pose->depth_to_world.m[threadIdx.x] : L.pose->depth_to_world.inv[threadIdx.x - 16];
+    fixed_m[threadIdx.x] = threadIdx.x < 16 ? L.frame_Tcd.m[threadIdx.x] : L.key_Twc.m[threadIdx.x - 16];
+  }
   if (threadIdx.x == 0) { stop = 0; failed = 0; }
   __syncthreads();
   if (threadIdx.x == 0)
@@ -693,6 +698,7 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
     steps = it + 1;
     VK_STAMP(4);
 
+#ifdef VK_SCALAR_SOLVE
     if (threadIdx.x == 0)
     {
       // A step needs depth_to_world^-1 (the next update multiplies it) and Tcm's matrix (the
@@ -718,6 +724,52 @@ __global__ __launch_bounds__(kColorThreads, 1024 / kColorThreads) void color_loo
         for (int k = 0; k < 6; ++k) last_update[k] = update[k];
       }
     }
+#else
+    if (threadIdx.x < 64)
+    {
+      // The same step across the lanes of the first wave (vk_gauss_newton.hpp wave_solve_step: the
+      // bits of the one-lane code). A step needs depth_to_world^-1 (the next update multiplies it)
+      // and Tcm's matrix (the pixels); depth_to_world itself and Tcm^-1 are made once, after the
+      // loop, from the last step's M.
+      float update[6];
+      wave_solve_step<N>(sums, solve_scratch, update);
+      // color_tracker.cpp:45-65: a proper skew matrix (DepthTracker's has Tinc(1,2) = +u0); element l = c * 4 + r
+      const int l = (int)threadIdx.x & 15;
+      float tinc = (l % 5 == 0) ? 1.0f : 0.0f;
+      tinc = (l == 4) ? -update[2] : tinc;  tinc = (l == 8) ? +update[1] : tinc;  tinc = (l == 12) ? +update[3] : tinc;
+      tinc = (l == 1) ? +update[2] : tinc;  tinc = (l == 9) ? -update[0] : tinc;  tinc = (l == 13) ? +update[4] : tinc;
+      tinc = (l == 2) ? -update[1] : tinc;  tinc = (l == 6) ? +update[0] : tinc;  tinc = (l == 14) ? +update[5] : tinc;
+      if (threadIdx.x < 16) solve_scratch[threadIdx.x] = tinc;
+      wave_lds_fence();
+      const float M_lane = matmul4_lane(solve_scratch, twd + 16, (int)threadIdx.x);       // :67  M = Tinc * Twd^-1
+      wave_lds_fence();
+      const float inv_lane = wave_rigid_from(M_lane, solve_scratch);                       // :69-95: the new Twd^-1
+      if (threadIdx.x < 16) twd[16 + threadIdx.x] = inv_lane;
+      wave_lds_fence();
+      const float tcw_lane = matmul4_lane(fixed_m, twd + 16, (int)threadIdx.x);            // frame_Tcw.m = Tcd.m * (Twd^-1).m
+      if (threadIdx.x < 16) solve_scratch[32 + threadIdx.x] = tcw_lane;
+      wave_lds_fence();
+      const float tcm_lane = matmul4_lane(solve_scratch + 32, fixed_m + 16, (int)threadIdx.x);   // Tcm.m = frame_Tcw.m * key_Twc.m
+      wave_lds_fence();
+      float sq = 0.0f;
+#pragma unroll
+      for (int k = 0; k < N; ++k) sq += update[k] * update[k];
+      if (threadIdx.x < 16)
+      {
+        tcm[threadIdx.x] = tcm_lane;
+        if (publisher) last_M[threadIdx.x] = M_lane;
+      }
+      if (threadIdx.x == 0)
+      {
+        stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
+        if (publisher)
+        {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) last_update[k] = update[k];
+        }
+      }
+    }
+#endif
     __syncthreads();
     VK_STAMP(5);
     if (stop) break;             // tracker.cpp:162

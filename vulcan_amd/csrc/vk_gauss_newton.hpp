@@ -542,6 +542,124 @@ __device__ __forceinline__ void rigid_from(const float (&M)[16], float (&out_m)[
   matmul4(Ri, Ti, out_i);
 }
 
+// ---- the solve + pose update of one Gauss-Newton step, spread over the lanes of ONE wave ----
+//
+// solve_step / matmul4 / rigid_from above run on one lane: ~1000 dependent instructions of four
+// cycles each, 1.7 us of every step of the loop kernels, on the critical path of every workgroup.
+// Here the same operations — each element computed by exactly the same expression in the same
+// order, so the bits are those of the one-lane code — are laid across lanes: row i of the LDL^T
+// factorisation in lane i (the k-loop of an element stays sequential, the elements of a column
+// are independent), a 4x4 product with one output element per lane. Values cross lanes through
+// v_readlane (to scalar registers) and, for the transposed accesses, a few LDS words.
+__device__ __forceinline__ float lane_value(float v, int from)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
+}
+
+// element (lane & 15) of A * B for column-major 4x4 matrices in LDS (matmul4: r = 0, r += A[n*4+m] * B[p*4+n])
+__device__ __forceinline__ float matmul4_lane(const float* A, const float* B, int lane)
+{
+  const int p = (lane >> 2) & 3, m = lane & 3;
+  float r = 0.0f;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) r += A[n * 4 + m] * B[p * 4 + n];
+  return r;
+}
+
+// x with H x = g for the packed system in `sums` (LDS: hessian [0, 21), gradient [36, 42)); returns
+// update = -x in every lane (entries beyond N are 0). `scratch`: LDS, 64 floats. One whole wave.
+template <int N>
+__device__ __forceinline__ void wave_solve_step(const float* sums, float* scratch, float (&update)[6])
+{
+  const int lane = lane_id();
+  const int row = lane < N ? lane : 0;          // lanes >= N repeat row 0; nothing of theirs is used
+  float A[N], L[N], D[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    const int r = row > j ? row : j, c = row > j ? j : row;
+    A[j] = sums[r * (r + 1) / 2 + c];
+  }
+  const float b = sums[36 + row];
+  float Dv = 0.0f;
+
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    float s = A[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[k] * lane_value(L[k], j) * D[k];
+    const float d = lane_value(s, j);
+    D[j] = d;
+    const float q = s / d;
+    L[j] = (lane > j) ? ((fabsf(d) > 0.0f) ? q : 0.0f) : ((lane == j) ? 1.0f : 0.0f);
+    Dv = (lane == j) ? d : Dv;
+  }
+
+  float y = b;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+  {
+    const float yk = lane_value(y, k);
+    if (lane > k) y -= L[k] * yk;
+  }
+  y = (fabsf(Dv) > FLT_MIN) ? y / Dv : 0.0f;
+
+  // column `lane` of L for the back substitution
+  if (lane < N)
+  {
+#pragma unroll
+    for (int j = 0; j < N; ++j) scratch[lane * 8 + j] = L[j];
+  }
+  wave_lds_fence();
+  float Lt[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) Lt[k] = scratch[k * 8 + row];
+  wave_lds_fence();
+
+  float x[N];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i)
+  {
+    float s = y;
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= Lt[k] * x[k];
+    x[i] = lane_value(s, i);
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) update[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) update[i] = -x[i];
+}
+
+// rigid_from() with one element of the result per lane: `M_lane` = element (lane & 15) of M in the
+// lanes 0..15; returns element (lane & 15) of Translate(t) * Rotate(R) (out_m of rigid_from).
+// `scratch`: LDS, 64 floats.
+__device__ __forceinline__ float wave_rigid_from(float M_lane, float* scratch)
+{
+  const int lane = lane_id();
+  const int l = lane & 15;
+  f3 x_axis = normalized3(make3(lane_value(M_lane, 0), lane_value(M_lane, 1), lane_value(M_lane, 2)));
+  f3 y_axis = normalized3(make3(lane_value(M_lane, 4), lane_value(M_lane, 5), lane_value(M_lane, 6)));
+  const f3 z_axis = cross3(x_axis, y_axis);
+  y_axis = cross3(z_axis, x_axis);
+  const float tx = lane_value(M_lane, 12), ty = lane_value(M_lane, 13), tz = lane_value(M_lane, 14);
+
+  float Tm = (l % 5 == 0) ? 1.0f : 0.0f;
+  Tm = (l == 12) ? tx : Tm;
+  Tm = (l == 13) ? ty : Tm;
+  Tm = (l == 14) ? tz : Tm;
+  float Rm = (l == 15) ? 1.0f : 0.0f;
+  Rm = (l == 0) ? x_axis.x : Rm;  Rm = (l == 1) ? x_axis.y : Rm;  Rm = (l == 2) ? x_axis.z : Rm;
+  Rm = (l == 4) ? y_axis.x : Rm;  Rm = (l == 5) ? y_axis.y : Rm;  Rm = (l == 6) ? y_axis.z : Rm;
+  Rm = (l == 8) ? z_axis.x : Rm;  Rm = (l == 9) ? z_axis.y : Rm;  Rm = (l == 10) ? z_axis.z : Rm;
+  if (lane < 16) { scratch[lane] = Tm; scratch[16 + lane] = Rm; }
+  wave_lds_fence();
+  const float out = matmul4_lane(scratch, scratch + 16, lane);
+  wave_lds_fence();
+  return out;
+}
+
 // tracker.cpp:160-162: record the step and stop once it is shorter than 1e-6.
 // `mirror` (optional): pinned host memory that receives {iterations, converged, epoch} as
 // ONE 64-bit system-scope store after every step, so a host that enqueues the loop

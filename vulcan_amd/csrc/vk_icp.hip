@@ -414,6 +414,7 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
   __shared__ float sums[48];
   __shared__ float pose_m[16];
   __shared__ float result[16 + 6];        // workgroup 0: M (see below) and update of the last step
+  __shared__ float solve_scratch[64];     // wave_solve_step / wave_rigid_from
   __shared__ int stop, failed;
 
   // tracker.cpp:162 / Tracker::CreateState: a state that already says "converged" ends the call
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
     steps = it + 1;
     VK_STAMP(4);
 
+#ifdef VK_SCALAR_SOLVE
     if (threadIdx.x == 0)
     {
       // the pixels only ever need the pose's matrix; its inverse (a second 4x4 product per
@@ -490,6 +492,44 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
         for (int i = 0; i < 6; ++i) result[16 + i] = update[i];
       }
     }
+#else
+    if (threadIdx.x < 64)
+    {
+      // solve + pose update across the lanes of the first wave (wave_solve_step): the bits of
+      // pose_matrix<N> + rigid_from on one lane. The pixels only ever need the pose's matrix; its
+      // inverse (a second 4x4 product per step) is made once, after the loop, from the last M.
+      float update[6];
+      wave_solve_step<N>(sums, solve_scratch, update);
+      // depth_tracker.cpp:33-53, including Tinc(1,2) = +update[0]; element l = c * 4 + r
+      const int l = (int)threadIdx.x & 15;
+      float tinc = (l % 5 == 0) ? 1.0f : 0.0f;
+      tinc = (l == 4) ? -update[2] : tinc;  tinc = (l == 8) ? +update[1] : tinc;  tinc = (l == 12) ? +update[3] : tinc;
+      tinc = (l == 1) ? +update[2] : tinc;  tinc = (l == 9) ? +update[0] : tinc;  tinc = (l == 13) ? +update[4] : tinc;
+      tinc = (l == 2) ? -update[1] : tinc;  tinc = (l == 6) ? +update[0] : tinc;  tinc = (l == 14) ? +update[5] : tinc;
+      if (threadIdx.x < 16) solve_scratch[threadIdx.x] = tinc;
+      wave_lds_fence();
+      const float M_lane = matmul4_lane(solve_scratch, pose_m, (int)threadIdx.x);     // Tinc * old pose
+      wave_lds_fence();
+      const float out = wave_rigid_from(M_lane, solve_scratch);
+      float sq = 0.0f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sq += update[i] * update[i];
+      if (threadIdx.x < 16)
+      {
+        pose_m[threadIdx.x] = out;
+        if (publisher) result[threadIdx.x] = M_lane;
+      }
+      if (threadIdx.x == 0)
+      {
+        stop = (sqrtf(sq) < 1E-6f) ? 1 : 0;
+        if (publisher)
+        {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) result[16 + i] = update[i];
+        }
+      }
+    }
+#endif
     __syncthreads();
     VK_STAMP(5);
     if (stop) break;             // tracker.cpp:162

@@ -40,6 +40,7 @@ struct PointParams
   float* colors;
   int image_width, image_height, bounds_width, bounds_height;
   uint8_t* touched;           // COUNT only: one byte per pool slot
+  int* march_steps;           // COUNT only (optional): trips through the march loop, per pixel
 };
 
 // a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).
@@ -359,6 +360,7 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
   int sbx = 0, sby = 0, sbz = 0, sdata = -1;
   float swx = 0, swy = 0, swz = 0;
   bool capped = false;
+  int trips = 0;              // COUNT only
   if (bound.x < bound.y)
   {
     const f3 Xcp = unproject_d(P.k, x + 0.5f, y + 0.5f, bound.x);
@@ -385,6 +387,7 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
       const int by = f2i(floorf(div_uniform(p.y, P.inv_block_length)));
       const int bz = f2i(floorf(div_uniform(p.z, P.inv_block_length)));
       const int data = find_block(P, cache, bdir, bx, by, bz);
+      if (COUNT) ++trips;
       bool done = false;
 
       if (data >= 0)
@@ -415,6 +418,16 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
         }
         // (Measured and rejected, r02: resolving the block one block-length further along the
         // ray while the nearest-voxel load is in flight — 31.8 us against 31.0.)
+        // (Measured and rejected, r03, for rays that cross dozens of absent blocks behind an object's
+        // silhouette — the room scene of the tracking workload, where 1 % of the waves live 75-105 us
+        // and the launch with them, profiles/r03_e_wave_times_room.txt: reading the table entries of
+        // the next four positions together and taking the trips through the absent ones in one go.
+        // Inside this loop: room 104 -> 91 us, but the fusion benchmark's raycast 31.9 -> 34.0 us;
+        // as a phase before the loop (leading absent blocks only): no loss, no gain — the long empty
+        // runs come AFTER the ray has grazed the object's band. The same blocks prefetched into the
+        // directory instead: room 100 -> 112 us. The slow waves are slow because their lanes are out
+        // of phase — some sample while others still march — not because of the table reads: a ray
+        // waits for at most 10 of them on 48 trips.)
         // (Measured and rejected, r02: resolving the corners and issuing their loads together
         // with the nearest-voxel read on every trip, to save the second round trip of a
         // sampling step — 34.7 us against 30.9: the lanes that do not sample add lookups and
@@ -490,6 +503,7 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
   if (capped) color = make3(1, 0, 0);
 
   const int pixel = y * P.image_width + x;
+  if (COUNT) { if (P.march_steps) P.march_steps[pixel] = trips; }
   P.depths[pixel] = final_depth;
   P.colors[3 * pixel + 0] = color.x;
   P.colors[3 * pixel + 1] = color.y;

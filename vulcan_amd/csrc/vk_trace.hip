@@ -423,6 +423,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.inv_block_length = 1.0 / (double)block_length;   // correctly rounded: vk_raycast.hpp div_uniform
   P.inv_voxel_length = 1.0 / (double)voxel_length;
   P.touched = nullptr;
+  P.march_steps = nullptr;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
   P.k = *projection;

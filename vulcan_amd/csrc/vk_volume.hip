@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void init_tables_kernel(vk_volume v)
     reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
   }
 
-  if (i < VK_CTR_COUNT)
+  if (i < VK_CTR_PUBLIC)
   {
     int value = 0;
     if (i == VK_CTR_EXCESS_PTR) value = v.main_block_count;  // volume.cu:581-586
@@ -109,22 +109,82 @@ __device__ __forceinline__ void mark_visible(uint8_t* vis, uint32_t index)
   else if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
 }
 
-// `contended` (optional): set when two DIFFERENT blocks ask for the same bucket in one round —
-// the loser has to ask again in another round (SetView is called three times per frame upstream,
-// apps/vulcan/vulcan.cu:316-318, for exactly this). Every key ever posted to a slot either
-// finds a different key there or is later replaced by one whose poster finds it, so the flag
-// is exact: it is set if and only if some request of this round is lost.
+// What the fused SetView (vk_volume_set_view_rounds) keeps of a request pass so that its later
+// rounds need not walk the rays again. A bucket takes one request per round; when two DIFFERENT
+// blocks ask for the same bucket, one of them loses and has to ask again in another round
+// (SetView is called three times per frame upstream, apps/vulcan/vulcan.cu:316-318, for exactly
+// this). Every key ever posted to a slot either finds a different key there or is later
+// replaced by one whose poster finds it, and whoever sees the two keys files the SMALLER one —
+// the loser: after the pass the list holds every block that lost, once, and `contended` is set
+// if and only if there is one. `posted` (LDS, optional): the
+// buckets that received their first request of this pass.
+// behind the VK_CTR_PUBLIC counters: two key sets, then their two slot lists (vk.h)
+__host__ __device__ inline unsigned long long* retry_table(int32_t* counters, int which)
+{
+  return reinterpret_cast<unsigned long long*>(counters + VK_CTR_PUBLIC) + (size_t)which * VK_RETRY_SLOTS;
+}
+__host__ __device__ inline int* retry_slots(int32_t* counters, int which)
+{
+  return counters + VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + which * VK_RETRY_KEYS;
+}
+
+struct Retry
+{
+  int* contended;               // nullptr: nothing is recorded (the staged entry points)
+  int* origin_seen;             // set when block (0,0,0) is "found" in an unallocated main entry (see probe_block)
+  int* count;                   // distinct keys filed so far (may exceed capacity: then *overflow is set)
+  int* overflow;
+  unsigned long long* table;    // open-addressing set of the keys (VK_RETRY_SLOTS slots, 0 = free)
+  int* slots;                   // where in the table each distinct key sits, in order of arrival
+  int capacity;                 // entries `slots` holds
+  int* posted;
+  int* posted_count;
+  int posted_capacity;
+};
+
+// files a lost key once: hundreds of rays cross the same block and each of them finds out that
+// it lost, so the list is fronted by a set (linear probing from a multiplicative hash)
+__device__ __forceinline__ void file_loser(const Retry& retry, unsigned long long key)
+{
+  uint32_t at = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(VK_RETRY_SLOTS - 1);
+  for (int tries = 0; tries < 64; ++tries)
+  {
+    const unsigned long long old = atomicCAS(retry.table + at, 0ull, key);
+    if (old == key) return;
+    if (old == 0ull)
+    {
+      const int n = atomicAdd(retry.count, 1);
+      if (n < retry.capacity) retry.slots[n] = (int)at;
+      else __hip_atomic_store(retry.overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    at = (at + 1) & (uint32_t)(VK_RETRY_SLOTS - 1);
+  }
+  __hip_atomic_store(retry.overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz,
-    int* contended)
+    const Retry& retry)
 {
   unsigned long long* slot = reinterpret_cast<unsigned long long*>(v.allocation_blocks) + h;
   const unsigned long long key = request_key(type, bx, by, bz);
   // monotonic max: skip the atomic when the slot already holds a key >= ours
   unsigned long long seen = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (seen < key) seen = atomicMax(slot, key);
-  if (contended && seen != 0ull && seen != key &&
-      __hip_atomic_load(contended, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-    __hip_atomic_store(contended, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (retry.contended)
+  {
+    if (seen != 0ull && seen != key)
+    {
+      file_loser(retry, seen < key ? seen : key);
+      if (__hip_atomic_load(retry.contended, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(retry.contended, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (seen == 0ull && retry.posted)
+    {
+      const int at = atomicAdd(retry.posted_count, 1);
+      if (at < retry.posted_capacity) retry.posted[at] = (int)h;
+    }
+  }
   if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
 }
 
@@ -132,16 +192,23 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 // main entry is known
 template <bool DEFER>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
-    int bx, int by, int bz, int* contended)
+    int bx, int by, int bz, const Retry& retry)
 {
   if (entry_is(entry, bx, by, bz))
   {
     mark_visible<DEFER>(v.block_visibility, hash_code);
+    // An unallocated main entry holds block (0,0,0) and compares equal to it (volume.cu:186-191):
+    // the origin block counts as present without ever having been requested — until another
+    // block takes that entry, from when on its rays do request it. It is the one block a later
+    // SetView round can request that did not lose in the round before; the rounds need to know.
+    if (entry.data == -1 && retry.contended &&
+        __hip_atomic_load(retry.origin_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      __hip_atomic_store(retry.origin_seen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   else if (entry.data == -1)
   {
     mark_visible<DEFER>(v.block_visibility, hash_code);
-    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, contended);
+    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry);
   }
   else
   {
@@ -162,7 +229,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
       }
     }
 
-    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz, contended);
+    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz, retry);
   }
 }
 
@@ -197,7 +264,7 @@ struct RequestParams
 // lanes hold 64 consecutive pixels of one row (lanes past the image stay in: their neighbours
 // read their registers), so that the depth read is one coalesced 256-byte load.
 template <bool DEFER>
-__device__ __forceinline__ void request_walk(const RequestParams& P, int x, int y, int* contended)
+__device__ __forceinline__ void request_walk(const RequestParams& P, int x, int y, const Retry& retry)
 {
   const vk_volume& v = P.v;
   const uint32_t K = (uint32_t)v.main_block_count;
@@ -310,7 +377,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], contended);
+    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
@@ -318,7 +385,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, contended);
+    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, retry);
 
     if (tmax_x < tmax_y)
     {
@@ -361,8 +428,10 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
 // its own) — both walk the depth image one lane per pixel, and as a launch of its own the
 // mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
 // depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
+// (7 waves per SIMD = at most 72 VGPRs, what the kernel had before it recorded contests: at 6
+// waves it ran 1 us longer, profiles/r03_*)
 template <bool DEFER, bool PREP>
-__global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, int* contended)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREP ? 5 : 7))) void create_requests_kernel(RequestParams P, Retry retry)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -392,16 +461,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, i
     }
   }
 
-  // the fused SetView: later rounds (settle_visibility_kernel) are gated and counted through
-  // these words, which nothing else touches while this kernel runs
-  if (contended && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-  {
-    P.v.counters[VK_CTR_GATE + 0] = 0;
-    P.v.counters[VK_CTR_GATE + 1] = 0;
-    P.v.counters[VK_CTR_BARRIER] = 0;
-  }
-
-  if (y < P.height) request_walk<DEFER>(P, x, y, contended);   // whole wave
+  if (y < P.height) request_walk<DEFER>(P, x, y, retry);   // whole wave
 
   if (PREP)
   {
@@ -468,12 +528,10 @@ __device__ __forceinline__ void count_flags(uint32_t w, int& n_all, int& n_exces
 // run by the kernel that follows — folds them in and clears the flags
 // (volume.cu:365).
 //
-// `gate` (-1: none): the counter that tells the fused SetView whether another round is needed —
-// set when this round lost a request to a bucket contest (VK_CTR_CONTENDED, left by the request
-// pass and cleared here) or dropped one (upstream asks again, and drops again, on every call).
-// One call handles the 1024 buckets of `group` with a 256-lane workgroup (uniform call).
+// `dropped_now` (optional): set when a request of this pass is dropped (pool or excess list
+// exhausted). One call handles the 1024 buckets of `group` with a 256-lane workgroup (uniform call).
 __device__ __forceinline__ void handle_group(const vk_volume& v, int group, int groups, int zero_visible,
-    int deferred_reset, int gate)
+    int deferred_reset, int* dropped_now)
 {
   __shared__ int red[2 * (kHandleThreads / 64)];
   __shared__ int wave_a[kHandleThreads / 64], wave_b[kHandleThreads / 64];
@@ -605,7 +663,7 @@ __device__ __forceinline__ void handle_group(const vk_volume& v, int group, int 
   if (dropped)
   {
     atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
-    if (gate >= 0) __hip_atomic_store(&v.counters[gate], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dropped_now) __hip_atomic_store(dropped_now, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
   if (group == groups - 1 && threadIdx.x == 0)
@@ -615,28 +673,32 @@ __device__ __forceinline__ void handle_group(const vk_volume& v, int group, int 
     v.counters[VK_CTR_REQUESTS] = base_all + group_all;
     // volume.cu:488 ResetBufferSize for the visibility pass that follows in SetView
     if (zero_visible) v.counters[VK_CTR_VISIBLE] = 0;
-    if (gate >= 0)
-    {
-      if (__hip_atomic_load(&v.counters[VK_CTR_CONTENDED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-      {
-        __hip_atomic_store(&v.counters[gate], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&v.counters[VK_CTR_CONTENDED], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
   __syncthreads();   // the LDS words above are reused by the next call of this workgroup
 }
 
-__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible, int deferred_reset,
-    int gate)
+__global__ __launch_bounds__(kHandleThreads) void handle_requests_kernel(vk_volume v, int zero_visible, int deferred_reset)
 {
-  handle_group(v, (int)blockIdx.x, (int)gridDim.x, zero_visible, deferred_reset, gate);
+  handle_group(v, (int)blockIdx.x, (int)gridDim.x, zero_visible, deferred_reset, nullptr);
+}
+
+// the origin block would be requested by another SetView round: its rays met it in an unallocated
+// main entry (probe_block) and that entry has been given to another block since
+__device__ __forceinline__ int origin_block_pending(const vk_volume& v)
+{
+  if (__hip_atomic_load(&v.counters[VK_CTR_ORIGIN_SEEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return 0;
+  const int data = __hip_atomic_load(&v.hash_entries[block_hash(0, 0, 0, (uint32_t)v.main_block_count)].data,
+      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return data != -1 ? 1 : 0;
 }
 
 // Second half of the handle pass, one lane per main bucket: clear the request
 // (volume.cu:365) and, once, apply the pointer updates the reference does with
 // atomics (volume.cu:337,352).
-__device__ __forceinline__ void finish_handle(const vk_volume& v, int index)
+// `max_rounds` > 0 (the fused SetView only): also the end-of-call bookkeeping of
+// vk_volume_set_view_rounds — VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_REQUESTS of rounds that were
+// not needed — and the reset of the words the next call's request pass records into.
+__device__ __forceinline__ void finish_handle(const vk_volume& v, int index, int max_rounds = 0)
 {
   if (index < v.main_block_count && v.allocation_types[index] != VK_ALLOC_NONE)
   {
@@ -655,6 +717,22 @@ __device__ __forceinline__ void finish_handle(const vk_volume& v, int index)
       v.counters[VK_CTR_PENDING_ALL] = 0;
       v.counters[VK_CTR_PENDING_EXCESS] = 0;
     }
+    if (max_rounds > 0)
+    {
+      // what is still unanswered: a request lost to a bucket contest (after the last round that
+      // ran) or dropped, or more losers than the retry list holds
+      const int unsettled = (v.counters[VK_CTR_CONTENDED] | v.counters[VK_CTR_DROPPED_NOW] | v.counters[VK_CTR_RETRY_OVERFLOW] |
+          origin_block_pending(v)) != 0;
+      v.counters[VK_CTR_UNSETTLED] = unsettled;
+      v.counters[VK_CTR_ROUNDS] += 1;            // the first round; later_rounds() has added the others
+      // a round that is not run because nothing was pending would have seen no request
+      if (max_rounds > 1 && !unsettled && v.counters[VK_CTR_TICKET] == 0) v.counters[VK_CTR_REQUESTS] = 0;
+      v.counters[VK_CTR_CONTENDED] = 0;
+      v.counters[VK_CTR_DROPPED_NOW] = 0;
+      v.counters[VK_CTR_RETRY_OVERFLOW] = 0;
+      v.counters[VK_CTR_ORIGIN_SEEN] = 0;
+      v.counters[VK_CTR_TICKET] = 0;
+    }
   }
 }
 
@@ -668,7 +746,8 @@ __global__ __launch_bounds__(256) void finish_handle_kernel(vk_volume v)
 struct VisibilityParams
 {
   vk_volume v;
-  int finish_handle;   // SetView: this kernel also completes the handle pass before it
+  int finish_handle;   // SetView: this kernel also completes the handle pass before it; the fused
+                       // SetView passes its max_rounds here (>= 1)
   int deferred_reset;  // SetView: the reset pass was skipped, bytes may carry kTouched
   int width, height;
   vk_projection k;
@@ -694,7 +773,7 @@ __device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int 
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
   bool visible = false;
 
-  if (finish) finish_handle(v, index);
+  if (finish) finish_handle(v, index, finish);
 
   if (index < count)
   {
@@ -769,171 +848,261 @@ __device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int 
 __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(VisibilityParams P)
 {
   visibility_chunk<kVisThreads>(P, (int)blockIdx.x * kVisThreads, P.finish_handle, P.deferred_reset);
+  if (P.finish_handle && blockIdx.x == 0)
+  {
+    // the fused SetView: losers that no later round consumed (max_rounds reached, or the rounds
+    // were cut short) leave the sets, so that the next call's request pass starts from empty ones
+    for (int which = 0; which < 2; ++which)
+    {
+      int n = P.v.counters[VK_CTR_RETRY_COUNT + which];
+      if (n > VK_RETRY_KEYS) n = VK_RETRY_KEYS;
+      unsigned long long* table = retry_table(P.v.counters, which);
+      const int* slots = retry_slots(P.v.counters, which);
+      for (int i = (int)threadIdx.x; i < n; i += kVisThreads) table[slots[i]] = 0ull;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) P.v.counters[VK_CTR_RETRY_COUNT + threadIdx.x] = 0;
+  }
 }
 
 // ------------------------------------------------ SetView, several rounds in one call ----
 
 // The reference's frame loop calls SetView three times per frame (apps/vulcan/vulcan.cu:316-318)
 // because a bucket takes one request per call: a block that loses the contest for its bucket
-// has to ask again. That is rare — a handful of new blocks per frame into 65 024 buckets — so
-// the later calls almost always find nothing to do, and as launches of their own they would
-// cost three launch floors each (~3 us per launch that does nothing on this part).
+// has to ask again. As launches of their own the later calls would cost three launch floors
+// each (~3 us per launch that does nothing on this part) and walk all the rays again although
+// only the losers have anything to ask.
 //
-// vk_volume_set_view_rounds(.., max_rounds) gives the state of `max_rounds` consecutive SetView
-// calls with the same frame, exactly (every buffer and counter), in three launches: the last
-// kernel of the first round — this one: finish the handle pass, visibility test, compaction —
-// looks at the round's gate word (handle_group) and ends unless a request was lost or dropped.
-// Only then does it run whole further SetViews inside the launch (reset, requests, handle,
-// visibility), its workgroups separated by grid-wide barriers. The grid is sized so that all
-// of its workgroups are resident (settle_grid); a barrier nevertheless gives up after 2 s.
-struct SettleParams
-{
-  VisibilityParams vis;
-  RequestParams req;     // PREP fields unused
-  int max_rounds;
-};
+// vk_volume_set_view_rounds(.., max_rounds) leaves the state of `max_rounds` consecutive SetView
+// calls with the same frame in the three launches of one. What another SetView call with the same
+// frame changes is exactly this: every block that lost asks again (its rays walk the same blocks
+// as before, find everything else in the table, and mark visible what is already marked), the
+// winners are committed, and the entries so created become visible. So the request pass files the
+// losers in a list (Retry), and when there are any the workgroup of the handle pass that finishes
+// LAST plays the later rounds from that list by itself, before the visibility pass runs: probe
+// (volume.cu:183-239), commit in bucket order (:304-368), until a round loses nothing or
+// max_rounds is reached. Without losers — almost every frame — none of this runs, and no
+// workgroup pays for the arrival count either.
+//
+// The rounds end early (VK_CTR_UNSETTLED says so) with a round that drops a request (pool or
+// excess list exhausted: upstream's own state is inconsistent from there on, its later calls
+// link entries it never writes) and when more blocks lose in one round than the list holds.
+constexpr int kMaxPosted = 4096;   // buckets that can receive a request in one later round
 
-constexpr int kSettleThreads = 256;
-constexpr unsigned long long kBarrierTimeout = 200000000ull;   // wall_clock64 ticks (100 MHz): 2 s
 
-// All workgroups of the launch meet here for the `nth` time (1, 2, ...; VK_CTR_BARRIER was
-// zeroed by the request kernel of the same SetView). Agent-scope fences on both sides: what
-// other workgroups — on other XCDs, behind other L2s — wrote before is visible after.
-__device__ __forceinline__ bool grid_barrier(int* counter, int nth)
+__device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds, int retry_capacity)
 {
-  __shared__ int ok;
+  __shared__ int posted[kMaxPosted];
+  __shared__ uint8_t posted_type[kMaxPosted];
+  __shared__ int posted_count, dropped_total, stop, origin;
+
+  const int count = v.main_block_count;
+  const int max_count = v.main_block_count + v.excess_block_count;
+
+  // the first round's second half (finish_handle): requests cleared, pointers moved. Sixteen
+  // flags per load (the array is 16-byte aligned, check_volume), the tail byte by byte.
+  {
+    const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
+    const int chunks = count / 16;
+    for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
+    {
+      const uint4 q = flags16[c];
+      if ((q.x | q.y | q.z | q.w) == 0u) continue;
+      for (int b = 0; b < 16; ++b)
+      {
+        const int i = c * 16 + b;
+        if (v.allocation_types[i] != VK_ALLOC_NONE)
+        {
+          v.allocation_types[i] = VK_ALLOC_NONE;
+          reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+        }
+      }
+    }
+    for (int i = chunks * 16 + (int)threadIdx.x; i < count; i += kHandleThreads)
+      if (v.allocation_types[i] != VK_ALLOC_NONE)
+      {
+        v.allocation_types[i] = VK_ALLOC_NONE;
+        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+      }
+  }
+  if (threadIdx.x == 0)
+  {
+    v.counters[VK_CTR_VOXEL_PTR] -= v.counters[VK_CTR_PENDING_ALL];
+    v.counters[VK_CTR_EXCESS_PTR] += v.counters[VK_CTR_PENDING_EXCESS];
+    v.counters[VK_CTR_PENDING_ALL] = 0;
+    v.counters[VK_CTR_PENDING_EXCESS] = 0;
+    stop = (v.counters[VK_CTR_DROPPED_NOW] | v.counters[VK_CTR_RETRY_OVERFLOW]) != 0;
+  }
+  __syncthreads();
+
+  int current = 0, rounds_run = 1, last_posted = 0;
+  while (rounds_run < max_rounds && !stop)
+  {
+    __threadfence();     // rare path: what the other lanes wrote in the phase before is read from L2
+    __syncthreads();
+    int listed = __hip_atomic_load(&v.counters[VK_CTR_RETRY_COUNT + current], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (listed > retry_capacity) listed = retry_capacity;   // the surplus raised VK_CTR_RETRY_OVERFLOW
+    // the origin block (probe_block): its rays request it in this round if they met it in the
+    // round before and its bucket's main entry has been taken since
+    if (threadIdx.x == 0) origin = origin_block_pending(v);
+    __syncthreads();
+    const bool origin_asks = origin != 0;
+    if (listed == 0 && !origin_asks) break;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      posted_count = 0;
+      dropped_total = 0;
+      if (origin_asks) __hip_atomic_store(&v.counters[VK_CTR_ORIGIN_SEEN], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // atomic stores + fence: the lanes' atomic increments that follow must not be overtaken
+      __hip_atomic_store(&v.counters[VK_CTR_RETRY_COUNT + (current ^ 1)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&v.counters[VK_CTR_CONTENDED], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+
+    // CreateAllocationRequests for the blocks that lost (volume.cu:183-239)
+    Retry next;
+    next.contended = v.counters + VK_CTR_CONTENDED;
+    next.origin_seen = v.counters + VK_CTR_ORIGIN_SEEN;
+    next.count = v.counters + VK_CTR_RETRY_COUNT + (current ^ 1);
+    next.overflow = v.counters + VK_CTR_RETRY_OVERFLOW;
+    next.table = retry_table(v.counters, current ^ 1);
+    next.slots = retry_slots(v.counters, current ^ 1);
+    next.capacity = retry_capacity;
+    next.posted = posted;
+    next.posted_count = &posted_count;
+    next.posted_capacity = kMaxPosted;
+    unsigned long long* table = retry_table(v.counters, current);
+    const int* slots = retry_slots(v.counters, current);
+    for (int i = (int)threadIdx.x; i < listed; i += kHandleThreads)
+    {
+      const unsigned long long key = table[slots[i]];
+      table[slots[i]] = 0ull;                       // the set is left empty for the call after this one
+      const int bx = (int16_t)(key & 0xffffull), by = (int16_t)((key >> 16) & 0xffffull), bz = (int16_t)((key >> 32) & 0xffffull);
+      const uint32_t h = block_hash(bx, by, bz, (uint32_t)count);
+      probe_block<true>(v, h, load_entry(v.hash_entries, h), bx, by, bz, next);
+    }
+    if (origin_asks && threadIdx.x == 0)
+    {
+      const uint32_t h = block_hash(0, 0, 0, (uint32_t)count);
+      probe_block<true>(v, h, load_entry(v.hash_entries, h), 0, 0, 0, next);
+    }
+    __threadfence();
+    __syncthreads();
+    const int m = posted_count;
+    if (m > kMaxPosted || __hip_atomic_load(&v.counters[VK_CTR_RETRY_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    {
+      // more than this workgroup can order: the requests stay posted for the next SetView call
+      if (threadIdx.x == 0) { v.counters[VK_CTR_RETRY_OVERFLOW] = 1; stop = 1; }
+      __syncthreads();
+      break;
+    }
+
+    // HandleAllocationRequests (volume.cu:304-368) in ascending bucket order
+    for (int i = (int)threadIdx.x; i < m; i += kHandleThreads) posted_type[i] = v.allocation_types[posted[i]];
+    __syncthreads();
+    const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
+    const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
+    int m_excess = 0;
+    for (int j = 0; j < m; ++j) m_excess += posted_type[j] == VK_ALLOC_EXCESS ? 1 : 0;
+    int dropped = 0;
+    for (int i = (int)threadIdx.x; i < m; i += kHandleThreads)
+    {
+      const int index = posted[i];
+      const int type = posted_type[i];
+      int rank_all = 0, rank_excess = 0;
+      for (int j = 0; j < m; ++j)
+      {
+        const bool before = posted[j] < index;
+        rank_all += before ? 1 : 0;
+        rank_excess += (before && posted_type[j] == VK_ALLOC_EXCESS) ? 1 : 0;
+      }
+      const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[index];
+      int entry_index = index;
+      if (type == VK_ALLOC_EXCESS)
+      {
+        int other_index = index;
+        int next_index = v.hash_entries[other_index].next;
+        for (int guard = 0; next_index != -1 && guard < max_count; ++guard)
+        {
+          other_index = next_index;
+          next_index = v.hash_entries[other_index].next;
+        }
+        entry_index = excess_ptr0 + rank_excess;
+        if (entry_index < max_count)
+        {
+          v.hash_entries[other_index].next = entry_index;
+          v.block_visibility[entry_index] = (uint8_t)(VK_VISIBILITY_TRUE | kTouched);   // decoded by the visibility pass
+        }
+      }
+      const int voxel_index = voxel_ptr0 - rank_all;
+      if (entry_index < max_count && voxel_index >= 0)
+      {
+        const int lo = (int)(packed & 0xffffffffull);
+        const int hi = (int)((packed >> 32) & 0xffffull);
+        reinterpret_cast<int4*>(v.hash_entries)[entry_index] = make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
+      }
+      else
+      {
+        ++dropped;
+      }
+      v.allocation_types[index] = VK_ALLOC_NONE;                                          // volume.cu:365
+      reinterpret_cast<unsigned long long*>(v.allocation_blocks)[index] = 0ull;
+    }
+    if (dropped) atomicAdd(&dropped_total, dropped);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+      v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - m;
+      v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + m_excess;
+      if (dropped_total)
+      {
+        v.counters[VK_CTR_DROPPED] += dropped_total;
+        v.counters[VK_CTR_DROPPED_NOW] = 1;
+        stop = 1;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)   // consumed
+      __hip_atomic_store(&v.counters[VK_CTR_RETRY_COUNT + current], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_posted = m;
+    ++rounds_run;
+    current ^= 1;
+  }
+
+  if (threadIdx.x == 0)
+  {
+    const bool pending = stop || origin_block_pending(v) ||
+        __hip_atomic_load(&v.counters[VK_CTR_RETRY_COUNT + current], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    v.counters[VK_CTR_ROUNDS] += rounds_run - 1;
+    v.counters[VK_CTR_CONTENDED] = pending ? 1 : 0;
+    // a round that did not run because nothing was pending would have seen no request
+    v.counters[VK_CTR_REQUESTS] = (rounds_run < max_rounds && !pending) ? 0 : (rounds_run > 1 ? last_posted : v.counters[VK_CTR_REQUESTS]);
+  }
+}
+
+// The handle pass of the fused SetView. With losers on file (VK_CTR_CONTENDED, left by the request
+// pass: the same answer in every workgroup) each workgroup announces its end — release, count,
+// acquire: the only fences of the whole SetView, paid in the rare case alone — and the one that
+// arrives last runs the later rounds.
+__global__ __launch_bounds__(kHandleThreads) void handle_rounds_kernel(vk_volume v, int max_rounds, int retry_capacity)
+{
+  __shared__ int last;
+  // (the origin block: met in an unallocated main entry that this round gives to another block)
+  const bool losers = max_rounds > 1 && (v.counters[VK_CTR_CONTENDED] != 0 ||
+      (v.counters[VK_CTR_ORIGIN_SEEN] != 0 && v.allocation_types[block_hash(0, 0, 0, (uint32_t)v.main_block_count)] != VK_ALLOC_NONE));
+  handle_group(v, (int)blockIdx.x, (int)gridDim.x, 1, 1, v.counters + VK_CTR_DROPPED_NOW);
+  if (!losers) return;
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0)
-  {
-    const int target = nth * (int)gridDim.x;
-    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long deadline = (unsigned long long)wall_clock64() + kBarrierTimeout;
-    int good = 1;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
-    {
-      if ((unsigned long long)wall_clock64() > deadline) { good = 0; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    ok = good;
-  }
+    last = __hip_atomic_fetch_add(&v.counters[VK_CTR_TICKET], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   __syncthreads();
-  const bool result = ok != 0;
+  if (!last) return;
   __threadfence();
-  __syncthreads();
-  return result;
-}
-
-__global__ __launch_bounds__(kSettleThreads) void settle_visibility_kernel(SettleParams P)
-{
-  __shared__ int gate_lds;
-  const vk_volume& v = P.vis.v;
-  const int max_count = v.main_block_count + v.excess_block_count;
-  const int chunks = (max_count + kSettleThreads - 1) / kSettleThreads;
-  const int groups = (v.main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
-  const int lane = lane_id();
-  int barriers = 0;
-
-  for (int round = 1;; ++round)
-  {
-    // the last stage of SetView number `round`: the first one ran its other stages as launches
-    // of their own (with the reset pass folded in, kTouched), the later ones ran them below
-    for (int c = (int)blockIdx.x; c < chunks; c += (int)gridDim.x)
-      visibility_chunk<kSettleThreads>(P.vis, c * kSettleThreads, 1, round == 1 ? P.vis.deferred_reset : 0);
-
-    if (threadIdx.x == 0)
-      gate_lds = round < P.max_rounds
-          ? __hip_atomic_load(&v.counters[VK_CTR_GATE + (round & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    __syncthreads();
-    const int again = gate_lds;
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !again)
-    {
-      v.counters[VK_CTR_ROUNDS] += round;
-      // a round that is not run would have seen no request (volume.cu:520-535 on an empty list)
-      if (round < P.max_rounds) v.counters[VK_CTR_REQUESTS] = 0;
-      // what the caller may want to know: did the last round leave a request unanswered?
-      v.counters[VK_CTR_UNSETTLED] =
-          __hip_atomic_load(&v.counters[VK_CTR_GATE + (round & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (!again) return;
-
-    // ---- another whole SetView (volume.cu:430-437), inside this launch
-    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
-
-    // ResetBlockVisibility (volume.cu:465-471) + ResetBufferSize (:488)
-    {
-      const int words = max_count >> 2;
-      uint32_t* vis32 = reinterpret_cast<uint32_t*>(v.block_visibility);
-      for (int i = (int)(blockIdx.x * kSettleThreads + threadIdx.x); i < words; i += (int)(gridDim.x * kSettleThreads))
-      {
-        const uint32_t w = vis32[i];
-        const uint32_t is_true = (w >> 1) & 0x01010101u;
-        if (is_true) vis32[i] = w & ~(is_true * 0x3u);
-      }
-      if (blockIdx.x == 0 && (int)threadIdx.x < (max_count & 3))
-      {
-        const int j = (words << 2) + (int)threadIdx.x;
-        if (v.block_visibility[j] == VK_VISIBILITY_TRUE) v.block_visibility[j] = VK_VISIBILITY_UNKNOWN;
-      }
-      if (blockIdx.x == 0 && threadIdx.x == 0)
-      {
-        v.counters[VK_CTR_VISIBLE] = 0;
-        __hip_atomic_store(&v.counters[VK_CTR_GATE + ((round + 1) & 1)], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
-
-    // CreateAllocationRequests (volume.cu:497-518): a wave per 64-pixel run of a row
-    {
-      const int runs_x = (P.req.width + 63) / 64;
-      const int runs = runs_x * P.req.height;
-      const int waves = (int)gridDim.x * (kSettleThreads / 64);
-      for (int run = (int)blockIdx.x * (kSettleThreads / 64) + (int)(threadIdx.x >> 6); run < runs; run += waves)
-      {
-        const int y = run / runs_x;
-        const int x = (run - y * runs_x) * 64 + lane;
-        request_walk<false>(P.req, x, y, &v.counters[VK_CTR_CONTENDED]);
-      }
-    }
-    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
-
-    // HandleAllocationRequests (volume.cu:520-535)
-    for (int g = (int)blockIdx.x; g < groups; g += (int)gridDim.x)
-      handle_group(v, g, groups, 0, 0, VK_CTR_GATE + ((round + 1) & 1));
-    if (!grid_barrier(&v.counters[VK_CTR_BARRIER], ++barriers)) break;
-  }
-
-  // only reached from a barrier that timed out (never seen): say so instead of spinning for ever
-  if (threadIdx.x == 0) v.counters[VK_CTR_UNSETTLED] = -1;
-}
-
-// workgroups of settle_visibility_kernel that are resident at the same time on this device
-int settle_grid(int chunks)
-{
-  static int capacity[16] = {0};
-  int device = 0;
-  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return 0;
-  int cap = __atomic_load_n(&capacity[device], __ATOMIC_ACQUIRE);
-  if (cap == 0)
-  {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, settle_visibility_kernel, kSettleThreads, 0) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
-      return 0;
-    cap = per_cu * cus;
-    if (cap <= 0) return 0;
-    __atomic_store_n(&capacity[device], cap, __ATOMIC_RELEASE);
-  }
-  // test aid: a small grid walks the same code with many chunks / groups / runs per workgroup
-  if (const char* env = getenv("VK_SETTLE_GRID_CAP"))
-  {
-    const int n = atoi(env);
-    if (n > 0 && n < cap) cap = n;
-  }
-  // half of what fits: a barrier must not depend on the last free slot of a CU
-  if (cap > 2) cap /= 2;
-  return chunks < cap ? chunks : cap;
+  later_rounds(v, max_rounds, retry_capacity);
 }
 
 int check_volume(const vk_volume* v)
@@ -944,17 +1113,27 @@ int check_volume(const vk_volume* v)
     return VK_ERR_ARGUMENT;
   if (v->main_block_count <= 0 || v->excess_block_count < 0) return VK_ERR_ARGUMENT;
   if (!(v->voxel_length > 0) || !(v->truncation_length > 0)) return VK_ERR_ARGUMENT;
-  if ((reinterpret_cast<uintptr_t>(v->allocation_blocks) & 7) || (reinterpret_cast<uintptr_t>(v->hash_entries) & 15) ||
+  if ((reinterpret_cast<uintptr_t>(v->counters) & 7) || (reinterpret_cast<uintptr_t>(v->allocation_blocks) & 7) || (reinterpret_cast<uintptr_t>(v->hash_entries) & 15) ||
       (reinterpret_cast<uintptr_t>(v->voxels) & 15) || (reinterpret_cast<uintptr_t>(v->block_visibility) & 3) ||
       (reinterpret_cast<uintptr_t>(v->allocation_types) & 15))
     return VK_ERR_ARGUMENT;
   return VK_OK;
 }
 
+// distinct keys per retry list (test aid VK_RETRY_CAPACITY: a small list overflows on purpose)
+int retry_capacity()
+{
+  if (const char* env = getenv("VK_RETRY_CAPACITY"))
+  {
+    const int n = atoi(env);
+    if (n > 0 && n < VK_RETRY_KEYS) return n;
+  }
+  return VK_RETRY_KEYS;
+}
+
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
     const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s,
-    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr, bool fused = false,
-    RequestParams* params_out = nullptr)
+    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr, bool fused = false)
 {
   RequestParams P;
   P.v = *v;
@@ -969,9 +1148,19 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
   P.mask = nullptr;
   P.records = nullptr;
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
-  // the fused SetView records bucket contests (post_request) for its later rounds
-  int* contended = fused ? v->counters + VK_CTR_CONTENDED : nullptr;
-  if (params_out) *params_out = P;
+  // the fused SetView files the requests that lose a bucket contest (post_request) for its later rounds
+  Retry retry;
+  memset(&retry, 0, sizeof(retry));
+  if (fused)
+  {
+    retry.contended = v->counters + VK_CTR_CONTENDED;
+    retry.origin_seen = v->counters + VK_CTR_ORIGIN_SEEN;
+    retry.count = v->counters + VK_CTR_RETRY_COUNT;
+    retry.overflow = v->counters + VK_CTR_RETRY_OVERFLOW;
+    retry.table = retry_table(v->counters, 0);
+    retry.slots = retry_slots(v->counters, 0);
+    retry.capacity = retry_capacity();
+  }
   if (prep && prep_frame)
   {
     P.colors = prep_frame->color;
@@ -980,20 +1169,20 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
     P.depth_threshold = prep->depth_threshold;
     P.mask = prep->mask;
     P.records = reinterpret_cast<float4*>(prep->records);
-    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P, contended);
+    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P, retry);
   }
-  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P, contended);
-  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P, contended);
+  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P, retry);
+  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P, retry);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
 
 int launch_update_visibility(const vk_volume* v, int width, int height,
-    const vk_projection* projection, const float* Tdw_m, bool finish, bool deferred_reset, hipStream_t s)
+    const vk_projection* projection, const float* Tdw_m, int finish, bool deferred_reset, hipStream_t s)
 {
   VisibilityParams P;
   P.v = *v;
-  P.finish_handle = finish ? 1 : 0;
+  P.finish_handle = finish;      // 0: the staged pass; n >= 1: the fused SetView of n rounds
   P.deferred_reset = deferred_reset ? 1 : 0;
   P.width = width;
   P.height = height;
@@ -1032,6 +1221,8 @@ int vk_volume_initialize(const vk_volume* v, void* stream)
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(init_tables_kernel, dim3((max_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
   VK_LAUNCH_CHECK();
+  // the retry sets and slot lists behind the counters start empty
+  VK_CHECK(hipMemsetAsync(v->counters + VK_CTR_PUBLIC, 0, sizeof(int32_t) * (VK_CTR_COUNT - VK_CTR_PUBLIC), vk_s(stream)));
   return VK_OK;
 }
 
@@ -1056,7 +1247,7 @@ int vk_volume_handle_allocation_requests(const vk_volume* v, void* stream)
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, vk_s(stream), *v, 0, 0, -1);
+      dim3(kHandleThreads), 0, vk_s(stream), *v, 0, 0);
   VK_LAUNCH_CHECK();
   hipLaunchKernelGGL(finish_handle_kernel, dim3((v->main_block_count + 255) / 256), dim3(256), 0, vk_s(stream), *v);
   VK_LAUNCH_CHECK();
@@ -1071,7 +1262,7 @@ int vk_volume_update_block_visibility(const vk_volume* v, int width, int height,
   VK_REQUIRE(projection && Tdw && width > 0 && height > 0);
   // volume.cu:488 ResetBufferSize
   VK_CHECK(hipMemsetAsync(v->counters + VK_CTR_VISIBLE, 0, sizeof(int32_t), vk_s(stream)));
-  return launch_update_visibility(v, width, height, projection, Tdw->m, false, false, vk_s(stream));
+  return launch_update_visibility(v, width, height, projection, Tdw->m, 0, false, vk_s(stream));
 }
 
 // does `prep` hold the preparation of exactly this frame (same images, size, threshold, Tcd)?
@@ -1102,16 +1293,12 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
       (frame->color_width <= 0 || frame->color_width == frame->width) &&
       (frame->color_height <= 0 || frame->color_height == frame->height);
   if (prep) prep->valid = 0;
-  const int max_count = v->main_block_count + v->excess_block_count;
-  const int grid = settle_grid((max_count + kSettleThreads - 1) / kSettleThreads);
-  VK_REQUIRE(grid > 0);
   // three launches: the reset pass is folded into the other three (see kTouched), and so are
-  // all rounds after the first (settle_visibility_kernel)
+  // all rounds after the first (later_rounds)
   int r;
-  SettleParams S;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
            &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr,
-           true, &S.req)) != VK_OK) return r;
+           true)) != VK_OK) return r;
   if (ride)
   {
     prep->depth = frame->depth;
@@ -1124,20 +1311,11 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     prep->prepared_threshold = prep->depth_threshold;
     prep->valid = 1;
   }
-  hipLaunchKernelGGL(handle_requests_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, s, *v, 1, 1, VK_CTR_GATE + 1);
+  hipLaunchKernelGGL(handle_rounds_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
+      dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
-  S.vis.v = *v;
-  S.vis.finish_handle = 1;
-  S.vis.deferred_reset = 1;
-  S.vis.width = frame->width;
-  S.vis.height = frame->height;
-  S.vis.k = frame->depth_projection;
-  S.vis.Tdw = make_rt(frame->depth_to_world.inv);
-  S.max_rounds = max_rounds;
-  hipLaunchKernelGGL(settle_visibility_kernel, dim3(grid), dim3(kSettleThreads), 0, s, S);
-  VK_LAUNCH_CHECK();
-  return VK_OK;
+  return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
+      frame->depth_to_world.inv, max_rounds, true, s);
 }
 
 int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
@@ -1159,7 +1337,7 @@ int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_ligh
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)
 {
   VK_REQUIRE(v && v->counters && host_out);
-  VK_CHECK(hipMemcpyAsync(host_out, v->counters, sizeof(int32_t) * VK_CTR_COUNT,
+  VK_CHECK(hipMemcpyAsync(host_out, v->counters, sizeof(int32_t) * VK_CTR_PUBLIC,
       hipMemcpyDeviceToHost, vk_s(stream)));
   VK_CHECK(hipStreamSynchronize(vk_s(stream)));
   return VK_OK;

@@ -164,7 +164,7 @@ int main(int argc, char** argv)
 
   Device::Synchronize();
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  int32_t counters[VK_CTR_COUNT];
+  int32_t counters[VK_CTR_PUBLIC];
   volume->GetCounters(counters);
   std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  tracking %s\n", frames,
       seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],

@@ -1,6 +1,6 @@
 // room_scene.h — the closed-form tracking scene of the demo loop (tests/scenes.py holds the same
 // definition for the Python side): a 4.4 x 3 x 5.2 m box room with nine spheres on its floor,
-// ceiling and walls, seen by a camera whose yaw swings +-40 degrees while its centre moves on a
+// ceiling and walls, seen by a camera whose yaw swings +-24 degrees while its centre moves on a
 // small closed curve. Three pairs of orthogonal planes plus curved objects make every one of the
 // six pose parameters observable to point-to-plane ICP (the sphere-centred scene of the fusion
 // benchmark is invariant under rotation and cannot be tracked). Ray-surface intersections are
@@ -22,7 +22,7 @@ const double kSpheres[9][4] = {{1.2, 0.9, 1.6, 0.6}, {-1.4, 1.0, 1.2, 0.5}, {-1.
     {0.1, 1.1, 2.2, 0.4}, {-0.3, 1.15, -2.2, 0.35}};
 
 // depth-to-world pose of frame i
-inline vulcan::Transform Pose(int i, int frames_per_cycle = 320, double yaw_amplitude_deg = 40.0, double pitch_deg = 12.0)
+inline vulcan::Transform Pose(int i, int frames_per_cycle = 240, double yaw_amplitude_deg = 24.0, double pitch_deg = 12.0)
 {
   const double phase = 2.0 * M_PI * i / frames_per_cycle;
   const double a = yaw_amplitude_deg * M_PI / 180.0 * std::sin(phase);

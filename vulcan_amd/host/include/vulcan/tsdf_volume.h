@@ -72,7 +72,7 @@ class Volume
     Buffer<Voxel>& GetVoxels();
 
     vk_volume ToVk() const;                        // device view for the C ABI
-    void GetCounters(int32_t* counters) const;     // blocking readback of VK_CTR_*
+    void GetCounters(int32_t* counters) const;     // blocking readback of the VK_CTR_PUBLIC counters
 
     // Raycast bounds prepared ahead of time (vk_view_bounds, not upstream): a Tracer
     // registers its scratch buffer and settings here, the integrators then compute

@@ -188,7 +188,7 @@ void Volume::HandleAllocationRequests()
 
 int Volume::GetBufferSize() const
 {
-  int32_t counters[VK_CTR_COUNT];
+  int32_t counters[VK_CTR_PUBLIC];
   GetCounters(counters);
   return counters[VK_CTR_VISIBLE];
 }
