@@ -623,6 +623,36 @@ VK_API int vk_icp_track(const vk_icp_view* keyframe, const vk_transform* Twm,
     float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll,
     void* stream);
 
+/* A rigid multi-camera rig, one camera per GPU (BASELINE configs[4]; no reference counterpart): the
+ * ranks' views contribute to ONE normal system, so after every rank has summed its own view the 27
+ * sums are added over ranks and every rank runs the same solve. With `reduce` that costs three
+ * launches and an all-reduce per Gauss-Newton step; with a vk_rig_exchange the one-launch loop is
+ * kept: one workgroup of every rank writes its 27 {tag, value} words straight into every peer's
+ * memory (areas mapped over xGMI by vk_comm_exchange_attach, include/vk_comm.h), all workgroups
+ * read their own GPU's area, add the ranks' words in rank order (the same bits everywhere) and
+ * solve. Protocol and its proof obligations: vulcan_amd/csrc/vk_rig_protocol.h. */
+#define VK_RIG_MAX_RANKS 8
+typedef struct vk_rig_exchange {
+  unsigned long long* areas[VK_RIG_MAX_RANKS]; /* areas[r]: rank r's area as mapped into THIS process (areas[rank]:
+                                                  its own); each of the size vk_rig_area_bytes returns, zeroed once, fine-grained */
+  int32_t  rank, world;
+  uint32_t sequence;      /* names the Track: the same on every rank, different from the Track before (the
+                             caller adds 1 per Track), 22 bits, never 0 */
+} vk_rig_exchange;
+
+/* bytes of one rank's area (ref: none — the reference has no multi-GPU code) */
+VK_API size_t vk_rig_area_bytes(void);
+
+/* ref: src/tracker.cpp:53-63 Tracker::Track for DepthTracker on a rig: vk_icp_track (no `reduce`: the whole
+ * loop is one launch per rank) with the ranks' sums added through `rig` after every step. Every rank
+ * calls it for the same Track with the same sequence number, iterations (<= 1000) and
+ * translation_enabled; world == 1 gives vk_icp_track's bits. A rank that waits two seconds for a peer
+ * ends with VK_TRACK_ABORTED. */
+VK_API int vk_icp_track_rig(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, vk_transform* Twc_dev, int iterations,
+    int translation_enabled, float* workspace, float* system, int32_t* state_dev,
+    float* update_dev, const vk_rig_exchange* rig, const vk_track_poll* poll, void* stream);
+
 /* ref: src/pyramid_tracker.cpp:52-90 PyramidTracker<DepthTracker>::Track — the half-
  * resolution level of both frames (Frame::Downsample, src/frame.cpp:38-58: nearest
  * depth and normals, intrinsics / 2; ONE launch for the four images), vk_icp_track

@@ -55,6 +55,21 @@ VK_API int vk_comm_allreduce_system(void* comm, float* system_dev, int count, vo
  * vk_light_tracker_track, or wrap it in Tracker::SetReduceHook. */
 VK_API int vk_comm_reduce_hook(float* system_dev, int count, void* comm, void* stream);
 
+/* The rig's exchange INSIDE the one-launch Gauss-Newton loop (vk.h vk_rig_exchange, vk_icp_track_rig;
+ * protocol: vulcan_amd/csrc/vk_rig_protocol.h). Collective over the communicator's ranks: every rank
+ * allocates its area (fine-grained device memory, zeroed), the ranks exchange the areas' IPC handles
+ * (hipIpcGetMemHandle, one ncclAllGather) and map each other's (hipIpcOpenMemHandle with lazy peer
+ * access, i.e. direct stores over xGMI). Fills *exchange (a vk_rig_exchange: areas[0 .. world), rank,
+ * world, sequence = 1); the caller adds 1 to `sequence` after every Track, on every rank. With a
+ * loopback communicator (world == 1) only the own area is made. The all-reduce hook above remains
+ * the fallback (a rank that cannot map a peer returns the HIP error, and the caller keeps the hook).
+ * HIP is resolved at run time like RCCL ($VK_HIP_RUNTIME_LIBRARY, else libamdhip64.so).
+ * NOT exercised with more than one rank on hardware: this pool hands out single-GPU boxes. */
+VK_API int vk_comm_exchange_attach(void* comm, void* exchange /* vk_rig_exchange* */);
+
+/* unmaps the peers' areas and frees the own one (call on every rank, before vk_comm_destroy) */
+VK_API int vk_comm_exchange_detach(void* comm, void* exchange /* vk_rig_exchange* */);
+
 VK_API int vk_comm_destroy(void* comm);
 
 VK_API const char* vk_comm_error_string(int code);

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_track_wait": ([_P, _P], _I),
     "vk_reduce_nothing": ([_P, _I, _P, _P], _I),
+    "vk_rig_area_bytes": ([], _SZ),
+    "vk_icp_track_rig": ([_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_color_tracker_begin": ([_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P], _I),
     "vk_frame_downsample": ([_P, _P, _P, _P, _P], _I),
     "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
@@ -738,6 +740,21 @@ class DepthTracker(_PollMixin):
         out = self._wait_pose()
         frame.depth_to_world = out
         return out
+
+
+def track_rig(tracker, frame, exchange):
+    """vk_icp_track_rig: DepthTracker::Track of one camera of a rigid rig, the ranks' normal systems
+    added inside the one-launch loop through `exchange` (a T.RigExchange, vulcan_amd.comm)."""
+    check(lib().vk_transform_upload(_ptr(tracker.pose), _ref(frame.depth_to_world), stream()), "vk_transform_upload")
+    tracker.state.zero_()
+    check(lib().vk_icp_track_rig(_ref(tracker._view(tracker.keyframe)), _ref(tracker.keyframe.depth_to_world),
+                                 _ref(tracker._view(frame)), _ptr(tracker.pose), tracker.max_iterations,
+                                 int(tracker.translation_enabled), _ptr(tracker._workspace(frame)), _ptr(tracker.system),
+                                 _ptr(tracker.state), _ptr(tracker.update), _ref(exchange), tracker._poll(), stream()),
+          "vk_icp_track_rig")
+    out = tracker._wait_pose()
+    frame.depth_to_world = out
+    return out
 
 
 class ColorTracker(_PollMixin):

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvk_comm.so")
 ID_BYTES = 128
 EXPORTS = ("vk_comm_unique_id", "vk_comm_init", "vk_comm_rank", "vk_comm_allreduce_system",
-           "vk_comm_reduce_hook", "vk_comm_destroy", "vk_comm_error_string")
+           "vk_comm_reduce_hook", "vk_comm_exchange_attach", "vk_comm_exchange_detach", "vk_comm_destroy",
+           "vk_comm_error_string")
 _LIB = None
 
 
@@ -44,6 +45,8 @@ def lib():
         h.vk_comm_rank.argtypes, h.vk_comm_rank.restype = [P, C.POINTER(I), C.POINTER(I)], I
         h.vk_comm_allreduce_system.argtypes, h.vk_comm_allreduce_system.restype = [P, P, I, P], I
         h.vk_comm_reduce_hook.argtypes, h.vk_comm_reduce_hook.restype = [P, I, P, P], I
+        h.vk_comm_exchange_attach.argtypes, h.vk_comm_exchange_attach.restype = [P, P], I
+        h.vk_comm_exchange_detach.argtypes, h.vk_comm_exchange_detach.restype = [P, P], I
         h.vk_comm_destroy.argtypes, h.vk_comm_destroy.restype = [P], I
         h.vk_comm_error_string.argtypes, h.vk_comm_error_string.restype = [I], C.c_char_p
         _LIB = h
@@ -97,6 +100,32 @@ class Communicator:
         tracker.comm = self
         return tracker.track(frame)
 
+    # -- the exchange inside the one-launch loop (vk_rig_exchange, vk_icp_track_rig)
+    exchange = None
+
+    def attach_exchange(self):
+        """Collective: every rank's area mapped into every rank (vk_comm_exchange_attach)."""
+        from . import vk_types as T
+        x = T.RigExchange()
+        check(lib().vk_comm_exchange_attach(self.handle, C.byref(x)), "vk_comm_exchange_attach")
+        self.exchange = x
+        return x
+
+    def track_rig(self, tracker, frame):
+        """DepthTracker::Track on the rig with the ranks' sums exchanged inside the launch; every
+        rank calls it for the same Track (the sequence number advances here, identically)."""
+        from . import api
+        if self.exchange is None:
+            self.attach_exchange()
+        out = api.track_rig(tracker, frame, self.exchange)
+        self.exchange.sequence = (self.exchange.sequence % ((1 << 22) - 1)) + 1
+        return out
+
+    def detach_exchange(self):
+        if self.exchange is not None:
+            check(lib().vk_comm_exchange_detach(self.handle, C.byref(self.exchange)), "vk_comm_exchange_detach")
+            self.exchange = None
+
     def time_allreduce(self, reps=200):
         """Microseconds per 48-float all-reduce, enqueued back to back."""
         import time
@@ -112,6 +141,7 @@ class Communicator:
         return (time.perf_counter() - t0) / reps * 1e6
 
     def close(self):
+        self.detach_exchange()
         if self.handle:
             check(lib().vk_comm_destroy(self.handle), "vk_comm_destroy")
             self.handle = C.c_void_p()

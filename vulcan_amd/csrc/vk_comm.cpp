@@ -4,6 +4,7 @@
 #include "../../include/vk_comm.h"
 
 #include <dlfcn.h>
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,6 +27,7 @@ struct Rccl
   Result (*GetUniqueId)(UniqueId*) = nullptr;
   Result (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
   Result (*AllReduce)(const void*, void*, size_t, int, int, Comm, void*) = nullptr;
+  Result (*AllGather)(const void*, void*, size_t, int, Comm, void*) = nullptr;
   Result (*CommDestroy)(Comm) = nullptr;
   const char* (*GetErrorString)(Result) = nullptr;
   bool ok = false;
@@ -47,6 +49,7 @@ void load_rccl()
   g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.handle, "ncclGetUniqueId"));
   g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.handle, "ncclCommInitRank"));
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.handle, "ncclAllReduce"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
   g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
@@ -62,6 +65,69 @@ struct Communicator
 {
   Comm comm;     // null for the single-rank loopback
   int rank, world;
+};
+
+// ---- the part of the HIP runtime the rig exchange needs (hip_runtime_api.h), bound like RCCL ----
+enum { kIpcHandleBytes = 64, kMallocFinegrained = 0x1, kIpcLazyPeerAccess = 0x1, kCopyDefault = 4, kInt8 = 0 /* ncclInt8 */ };
+struct IpcHandle { char reserved[kIpcHandleBytes]; };
+
+struct Hip
+{
+  void* handle = nullptr;
+  int (*ExtMallocWithFlags)(void**, size_t, unsigned) = nullptr;
+  int (*Malloc)(void**, size_t) = nullptr;
+  int (*Free)(void*) = nullptr;
+  int (*Memset)(void*, int, size_t) = nullptr;
+  int (*Memcpy)(void*, const void*, size_t, int) = nullptr;
+  int (*DeviceSynchronize)() = nullptr;
+  int (*IpcGetMemHandle)(IpcHandle*, void*) = nullptr;
+  int (*IpcOpenMemHandle)(void**, IpcHandle, unsigned) = nullptr;
+  int (*IpcCloseMemHandle)(void*) = nullptr;
+  bool ok = false;
+};
+
+Hip g_hip;
+std::once_flag g_hip_once;
+
+void load_hip()
+{
+  const char* names[] = { getenv("VK_HIP_RUNTIME_LIBRARY"), "libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so" };
+  for (const char* name : names)
+  {
+    if (!name || !*name) continue;
+    g_hip.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_hip.handle) break;
+  }
+  if (!g_hip.handle) return;
+#define VK_BIND(field, symbol) g_hip.field = reinterpret_cast<decltype(g_hip.field)>(dlsym(g_hip.handle, symbol))
+  VK_BIND(ExtMallocWithFlags, "hipExtMallocWithFlags");
+  VK_BIND(Malloc, "hipMalloc");
+  VK_BIND(Free, "hipFree");
+  VK_BIND(Memset, "hipMemset");
+  VK_BIND(Memcpy, "hipMemcpy");
+  VK_BIND(DeviceSynchronize, "hipDeviceSynchronize");
+  VK_BIND(IpcGetMemHandle, "hipIpcGetMemHandle");
+  VK_BIND(IpcOpenMemHandle, "hipIpcOpenMemHandle");
+  VK_BIND(IpcCloseMemHandle, "hipIpcCloseMemHandle");
+#undef VK_BIND
+  g_hip.ok = g_hip.ExtMallocWithFlags && g_hip.Malloc && g_hip.Free && g_hip.Memset && g_hip.Memcpy &&
+      g_hip.DeviceSynchronize && g_hip.IpcGetMemHandle && g_hip.IpcOpenMemHandle && g_hip.IpcCloseMemHandle;
+}
+
+const Hip* hip()
+{
+  std::call_once(g_hip_once, load_hip);
+  return g_hip.ok ? &g_hip : nullptr;
+}
+
+// include/vk.h vk_rig_exchange and vulcan_amd/csrc/vk_rig_protocol.h rig_area_words(), restated so that this
+// file needs neither header (static_asserts in vk_icp.hip would not see this file; tests/test_abi.py compares)
+enum { kRigMaxRanks = 8, kRigAreaBytes = 4 * 8 * 32 * 8 };
+struct RigExchange
+{
+  unsigned long long* areas[kRigMaxRanks];
+  int32_t rank, world;
+  uint32_t sequence;
 };
 
 inline int from_nccl(Result r) { return r == 0 ? VK_OK_ : 1000 + r; }
@@ -122,6 +188,73 @@ int vk_comm_allreduce_system(void* comm, float* system_dev, int count, void* str
 int vk_comm_reduce_hook(float* system_dev, int count, void* comm, void* stream)
 {
   return vk_comm_allreduce_system(comm, system_dev, count, stream);
+}
+
+int vk_comm_exchange_attach(void* comm, void* exchange)
+{
+  if (!comm || !exchange) return VK_ERR_ARGUMENT_;
+  Communicator* c = static_cast<Communicator*>(comm);
+  RigExchange* x = static_cast<RigExchange*>(exchange);
+  if (c->world > kRigMaxRanks) return VK_ERR_ARGUMENT_;
+  const Hip* h = hip();
+  if (!h) return VK_COMM_ERR_NO_RCCL;
+  memset(x, 0, sizeof(*x));
+  x->rank = c->rank;
+  x->world = c->world;
+  x->sequence = 1;
+  void* own = nullptr;
+  int rc = h->ExtMallocWithFlags(&own, kRigAreaBytes, kMallocFinegrained);
+  if (rc != 0) return rc;
+  rc = h->Memset(own, 0, kRigAreaBytes);
+  if (rc == 0) rc = h->DeviceSynchronize();
+  if (rc != 0) { h->Free(own); return rc; }
+  x->areas[c->rank] = static_cast<unsigned long long*>(own);
+  if (c->world == 1 || !c->comm) return VK_OK_;
+
+  // every rank's handle to every rank: one all-gather of 64 bytes per rank, through device memory
+  if (!g_rccl.AllGather) { h->Free(own); x->areas[c->rank] = nullptr; return VK_COMM_ERR_NO_RCCL; }
+  IpcHandle mine;
+  rc = h->IpcGetMemHandle(&mine, own);
+  void* staging = nullptr;
+  if (rc == 0) rc = h->Malloc(&staging, (size_t)kIpcHandleBytes * (size_t)(c->world + 1));
+  if (rc != 0) { h->Free(own); x->areas[c->rank] = nullptr; return rc; }
+  char* send = static_cast<char*>(staging);
+  char* recv = send + kIpcHandleBytes;
+  rc = h->Memcpy(send, &mine, kIpcHandleBytes, kCopyDefault);
+  if (rc == 0)
+  {
+    const Result nr = g_rccl.AllGather(send, recv, kIpcHandleBytes, kInt8, c->comm, nullptr);
+    rc = nr == 0 ? h->DeviceSynchronize() : 1000 + nr;
+  }
+  IpcHandle all[kRigMaxRanks];
+  if (rc == 0) rc = h->Memcpy(all, recv, (size_t)kIpcHandleBytes * (size_t)c->world, kCopyDefault);
+  h->Free(staging);
+  for (int r = 0; rc == 0 && r < c->world; ++r)
+  {
+    if (r == c->rank) continue;
+    void* peer = nullptr;
+    rc = h->IpcOpenMemHandle(&peer, all[r], kIpcLazyPeerAccess);
+    if (rc == 0) x->areas[r] = static_cast<unsigned long long*>(peer);
+  }
+  if (rc != 0) { vk_comm_exchange_detach(comm, exchange); return rc; }
+  return VK_OK_;
+}
+
+int vk_comm_exchange_detach(void* comm, void* exchange)
+{
+  if (!comm || !exchange) return VK_ERR_ARGUMENT_;
+  Communicator* c = static_cast<Communicator*>(comm);
+  RigExchange* x = static_cast<RigExchange*>(exchange);
+  const Hip* h = hip();
+  if (!h) return VK_COMM_ERR_NO_RCCL;
+  (void)h->DeviceSynchronize();          // no loop kernel may still be writing into a peer
+  for (int r = 0; r < kRigMaxRanks; ++r)
+  {
+    if (!x->areas[r]) continue;
+    if (r == c->rank) (void)h->Free(x->areas[r]); else (void)h->IpcCloseMemHandle(x->areas[r]);
+    x->areas[r] = nullptr;
+  }
+  return VK_OK_;
 }
 
 int vk_comm_destroy(void* comm)

@@ -9,6 +9,9 @@
 // fixed order (bit-reproducible, independent of the device), and the 6x6 solve + SE(3)
 // update run on the device: Track() is one launch for the whole loop (track_loop_kernel).
 #include "vk_gauss_newton.hpp"
+#include "vk_rig_protocol.h"
+
+#include <string.h>
 
 using namespace vk;
 
@@ -397,6 +400,7 @@ struct LoopParams
   int fresh_state;               // 1: the loop starts at {0 steps, not converged} whatever `state` holds;
                                  // 2: the same, unless an earlier level of this Track was aborted
   int force_abort;               // test aid, vk_forced_loop_abort()
+  vk_rig_exchange rig;           // world > 0: the sums are added over the ranks of a rig after every step
   int last_launch;               // 1: this launch ends the Track (it leaves the pose for vk_track_wait)
   float* hessian;
   float* gradient;
@@ -465,6 +469,35 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
     if (!gather_partials<kIcpThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
             publisher ? L.gradient : nullptr, slices, sums, &failed))
       break;
+    if (L.rig.world > 0)
+    {
+      // a rigid rig: this view's sums go to every rank, every rank's come back (vk_rig_protocol.h);
+      // `sums` holds the packed hessian at [0, 21) and the gradient at [36, 42)
+      if (publisher && threadIdx.x < VK_RIG_VALUES)
+        rig_publish(L.rig.areas, L.rig.rank, L.rig.world, L.rig.sequence, it, (int)threadIdx.x,
+            threadIdx.x < 6 ? sums[36 + threadIdx.x] : sums[threadIdx.x - 6],
+            [](unsigned long long* at, unsigned long long word) { __hip_atomic_store(at, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); });
+      if (threadIdx.x < VK_RIG_VALUES)
+      {
+        const unsigned long long deadline = (unsigned long long)wall_clock64() + kExchangeTimeout;
+        float total = 0.0f;
+        const bool arrived = rig_gather(L.rig.areas[L.rig.rank], L.rig.world, L.rig.sequence, it, (int)threadIdx.x, total,
+            [](const unsigned long long* at) { return __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); },
+            [deadline] { __builtin_amdgcn_s_sleep(VK_POLL_GAP); return (unsigned long long)wall_clock64() > deadline; });
+        if (!arrived) failed = 1;
+        else
+        {
+          sums[threadIdx.x < 6 ? 36 + threadIdx.x : threadIdx.x - 6] = total;
+          if (publisher)
+          {
+            if (threadIdx.x < 6) { if (L.gradient) L.gradient[threadIdx.x] = total; }
+            else if (L.hessian) L.hessian[threadIdx.x - 6] = total;
+          }
+        }
+      }
+      __syncthreads();
+      if (failed) break;
+    }
     steps = it + 1;
     VK_STAMP(4);
 
@@ -744,7 +777,7 @@ __global__ void publish_pose_kernel(Mirror mirror, const vk_transform* pose)
 // the non-rig loop: one launch (track_loop_kernel)
 int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int translation_enabled, int groups,
     float* workspace, float* hessian, float* gradient, int32_t* state_dev, float* update_dev, Mirror mirror,
-    int fresh_state, bool ends_track, hipStream_t s)
+    int fresh_state, bool ends_track, hipStream_t s, const vk_rig_exchange* rig = nullptr)
 {
   VK_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0);   // the exchange holds 64-bit words
   const int capacity = translation_enabled ? resident_workgroups(track_loop_kernel<true>, kIcpThreads)
@@ -759,6 +792,8 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
   L.state = state_dev;
   L.update_out = update_dev;
   L.mirror = mirror;
+  memset(&L.rig, 0, sizeof(L.rig));
+  if (rig) L.rig = *rig;
   // ten tag bits name the step: a longer loop continues in another launch (which returns at
   // once if the state says the loop has converged)
   for (int done = 0; done < iterations; done += kExchangeSteps)
@@ -999,6 +1034,28 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
 }
 
 int vk_reduce_nothing(float*, int, void*, void*) { return 0; }
+
+size_t vk_rig_area_bytes(void) { return rig_area_words() * sizeof(unsigned long long); }
+
+int vk_icp_track_rig(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, int iterations, int translation_enabled, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, const vk_rig_exchange* rig, const vk_track_poll* poll, void* stream)
+{
+  IcpParams P;
+  vk_transform identity;
+  for (int i = 0; i < 16; ++i) identity.m[i] = identity.inv[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  const int rc = fill_icp(P, keyframe, Twm, frame, &identity);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(Twc_dev && workspace && system && state_dev && iterations > 0 && iterations <= 1000);
+  VK_REQUIRE(rig && rig->world >= 1 && rig->world <= VK_RIG_MAX_RANKS && rig->rank >= 0 && rig->rank < rig->world);
+  VK_REQUIRE(rig->sequence != 0 && rig->sequence < (1u << 22));
+  for (int r = 0; r < rig->world; ++r) VK_REQUIRE(rig->areas[r] && (reinterpret_cast<uintptr_t>(rig->areas[r]) & 7u) == 0);
+  P.Twc_dev = Twc_dev;
+  P.state = state_dev;
+  const int partials = group_count_for(frame->width * frame->height, P.group_pixels);
+  return launch_loop(P, Twc_dev, iterations, translation_enabled, partials, workspace, system, system + 36,
+      state_dev, update_dev, begin_mirror(poll), /*fresh_state*/ 0, /*ends_track*/ true, vk_s(stream), rig);
+}
 
 int vk_track_wait(const vk_track_poll* poll, void* stream)
 {

@@ -3,7 +3,8 @@
 // No reference counterpart: the reference has no multi-GPU code.
 //
 // Every rank owns one AREA in its own memory, mapped into every peer (xGMI peer access): two
-// parities x VK_RIG_MAX_RANKS senders x VK_RIG_WORDS words of 64 bits {tag, value}. After a rank
+// Track parities x two step parities x VK_RIG_MAX_RANKS senders x VK_RIG_WORDS words of 64 bits
+// {tag, value}. After a rank
 // has summed its own view's 27 sums (the exchange among its workgroups, vk_gauss_newton.hpp),
 // ONE workgroup writes them into every rank's area — slot [step parity][its own rank] — with
 // system-scope stores that travel over the links by themselves; every workgroup of every rank
@@ -13,8 +14,13 @@
 //
 // Tag = sequence (22 bits, the same on all ranks for one Track, never 0) << 10 | step + 1; value
 // and tag are one atomic object, so a reader can never pair a value with the wrong step.
-// Double buffering by step parity is enough: a rank writes step i + 2 over step i only after it
-// has read every rank's step i + 1, which they wrote after reading all of step i.
+// Within a Track, double buffering by step parity is enough: a rank writes step i + 2 over step i
+// only after it has read every rank's step i + 1, which they wrote after reading all of step i.
+// Across Tracks the loops end at a step whose parity nobody knows in advance (tracker.cpp:162), so
+// the buffers are doubled once more by the parity of the sequence number: a rank writes into Track
+// T + 1's buffers only after it has read every rank's last step of Track T, which they wrote after
+// they had finished Track T - 1 — the last user of those buffers. (The rehearsal with one step per
+// Track deadlocked without this.)
 //
 // Plain C++ (host and device): tests/test_rig_protocol.py drives the same functions from host
 // threads standing in for the ranks' workgroups.
@@ -34,11 +40,11 @@
 #define VK_RIG_FN inline
 #endif
 
-VK_RIG_FN size_t rig_area_words() { return (size_t)2 * VK_RIG_MAX_RANKS * VK_RIG_WORDS; }
+VK_RIG_FN size_t rig_area_words() { return (size_t)4 * VK_RIG_MAX_RANKS * VK_RIG_WORDS; }
 
-VK_RIG_FN size_t rig_word_index(int step, int sender, int word)
+VK_RIG_FN size_t rig_word_index(uint32_t sequence, int step, int sender, int word)
 {
-  return ((size_t)(step & 1) * VK_RIG_MAX_RANKS + (size_t)sender) * VK_RIG_WORDS + (size_t)word;
+  return ((size_t)((sequence & 1u) * 2u + (uint32_t)(step & 1)) * VK_RIG_MAX_RANKS + (size_t)sender) * VK_RIG_WORDS + (size_t)word;
 }
 
 VK_RIG_FN uint32_t rig_tag(uint32_t sequence, int step) { return (sequence << 10) | (uint32_t)(step + 1); }
@@ -66,7 +72,7 @@ VK_RIG_FN void rig_publish(unsigned long long* const* areas, int rank, int world
     float value, Store store)
 {
   const unsigned long long packed = rig_pack(rig_tag(sequence, step), value);
-  for (int r = 0; r < world; ++r) store(areas[r] + rig_word_index(step, rank, word), packed);
+  for (int r = 0; r < world; ++r) store(areas[r] + rig_word_index(sequence, step, rank, word), packed);
 }
 
 // Gather: the sum over ranks of word `word`, in rank order (the first term is taken as it is, so
@@ -79,7 +85,7 @@ VK_RIG_FN bool rig_gather(const unsigned long long* own_area, int world, uint32_
   const uint32_t tag = rig_tag(sequence, step);
   for (int s = 0; s < world; ++s)
   {
-    const unsigned long long* at = own_area + rig_word_index(step, s, word);
+    const unsigned long long* at = own_area + rig_word_index(sequence, step, s, word);
     unsigned long long w = load(at);
     while (rig_word_tag(w) != tag)
     {

@@ -175,6 +175,11 @@ class LightPrep(C.Structure):
                 ("depth_to_color", Transform), ("content_id", C.c_uint64)]
 
 
+class RigExchange(C.Structure):
+    """vk_rig_exchange (vk.h): the peers' areas of the rig's in-launch exchange."""
+    _fields_ = [("areas", C.c_void_p * 8), ("rank", C.c_int32), ("world", C.c_int32), ("sequence", C.c_uint32)]
+
+
 class ColorPose(C.Structure):
     _fields_ = [("depth_to_world", Transform), ("Tcm", Transform)]
 
