@@ -99,7 +99,7 @@ def test_comm_library_exports_and_loopback():
     from vulcan_amd import comm
     text = open(os.path.join(ROOT, "include", "vk_comm.h")).read()
     names = sorted(set(re.findall(r"VK_API\s+[\w\s\*]+?\b(vk_comm_\w+)\s*\(", text)))
-    assert names == sorted(comm.EXPORTS) and len(names) == 7
+    assert names == sorted(comm.EXPORTS) and len(names) == 9
     out = subprocess.run(["nm", "-D", "--defined-only", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     assert sorted(l.split()[-1] for l in out.splitlines() if " T vk_" in l) == names
     assert "rccl" not in subprocess.run(["ldd", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout   # bound at run time
@@ -109,6 +109,7 @@ def test_comm_library_exports_and_loopback():
     assert lib.vk_comm_init(C.byref(h), None, 2, 2) == -1          # rank out of range
     assert lib.vk_comm_init(C.byref(h), None, 0, 2) == -1          # world > 1 needs an id
     assert lib.vk_comm_allreduce_system(None, None, 48, None) == -1
+    assert lib.vk_comm_exchange_attach(None, None) == -1 and lib.vk_comm_exchange_detach(None, None) == -1
     assert b"invalid argument" in lib.vk_comm_error_string(-1)
     c = comm.Communicator(None, 0, 1)
     r, w = C.c_int(-1), C.c_int(-1)
