@@ -555,6 +555,9 @@ def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
         import torch.distributed as dist
         from vulcan_amd import comm
         c = comm.Communicator.from_torch_group(rank, world)
+        seen = c.rccl_count()                       # what RCCL itself says, not the launcher's environment
+        if seen != world:
+            raise RuntimeError(f"ncclCommCount says {seen} ranks, WORLD_SIZE is {world}")
         tracker.reduce_hook = None
         frame.depth_to_world = start
         c.track(tracker, frame)
@@ -569,8 +572,32 @@ def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
         us = c.time_allreduce(200)
         us = vd.max_over_ranks(us, device="cuda")
         it = int(tracker.state.cpu()[0])
+        out = {"ok": True, "ranks_rccl": seen, "allreduce_us": us, "track_ms_per_frame": ms, "iterations_per_frame": it}
+        # the same Track with the ranks' sums exchanged INSIDE the one-launch loop (peer-mapped areas,
+        # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
+        # on a multi-GPU node the path is unmeasured on hardware
+        try:
+            tracker.comm = None
+            c.attach_exchange()
+            frame.depth_to_world = start
+            c.track_rig(tracker, frame)
+            torch.cuda.synchronize()
+            vd.barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                frame.depth_to_world = start
+                got = c.track_rig(tracker, frame)
+            torch.cuda.synchronize()
+            xms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
+            upd = tracker.update.clone()
+            gathered = [torch.empty_like(upd) for _ in range(world)]
+            dist.all_gather(gathered, upd)
+            out["in_launch_exchange"] = {"ok": True, "track_ms_per_frame": xms, "iterations_per_frame": int(tracker.state.cpu()[0]),
+                                         "update_identical_on_all_ranks": bool(all(torch.equal(g, gathered[0]) for g in gathered))}
+        except Exception as e:     # noqa: BLE001
+            out["in_launch_exchange"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
         c.close()
-        return {"ok": True, "allreduce_us": us, "track_ms_per_frame": ms, "iterations_per_frame": it}
+        return out
     except Exception as e:     # noqa: BLE001  (reported in the JSON line)
         return {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
 

@@ -46,6 +46,10 @@ VK_API int vk_comm_init(void** comm, const void* id, int rank, int world);
 
 VK_API int vk_comm_rank(const void* comm, int* rank, int* world);
 
+/* How many ranks RCCL itself says the communicator has (ncclCommCount; 1 for the loopback): a
+ * launcher's WORLD_SIZE is checked against this, not only against its own environment. */
+VK_API int vk_comm_count(const void* comm, int* ranks);
+
 /* In-place sum of `count` floats (the packed ICP system) over all ranks on
  * `stream`; asynchronous. ref: the slot is src/tracker.cpp:136-153. */
 VK_API int vk_comm_allreduce_system(void* comm, float* system_dev, int count, void* stream);

@@ -99,7 +99,7 @@ def test_comm_library_exports_and_loopback():
     from vulcan_amd import comm
     text = open(os.path.join(ROOT, "include", "vk_comm.h")).read()
     names = sorted(set(re.findall(r"VK_API\s+[\w\s\*]+?\b(vk_comm_\w+)\s*\(", text)))
-    assert names == sorted(comm.EXPORTS) and len(names) == 9
+    assert names == sorted(comm.EXPORTS) and len(names) == 10
     out = subprocess.run(["nm", "-D", "--defined-only", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     assert sorted(l.split()[-1] for l in out.splitlines() if " T vk_" in l) == names
     assert "rccl" not in subprocess.run(["ldd", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout   # bound at run time
@@ -114,6 +114,7 @@ def test_comm_library_exports_and_loopback():
     c = comm.Communicator(None, 0, 1)
     r, w = C.c_int(-1), C.c_int(-1)
     assert lib.vk_comm_rank(c.handle, C.byref(r), C.byref(w)) == 0 and (r.value, w.value) == (0, 1)
+    assert c.rccl_count() == 1
     buf = np.arange(48, dtype=np.float32)
     assert lib.vk_comm_reduce_hook(buf.ctypes.data_as(C.c_void_p), 48, c.handle, None) == 0
     assert np.array_equal(buf, np.arange(48, dtype=np.float32))

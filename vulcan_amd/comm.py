@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvk_comm.so")
 ID_BYTES = 128
 EXPORTS = ("vk_comm_unique_id", "vk_comm_init", "vk_comm_rank", "vk_comm_allreduce_system",
-           "vk_comm_reduce_hook", "vk_comm_exchange_attach", "vk_comm_exchange_detach", "vk_comm_destroy",
+           "vk_comm_reduce_hook", "vk_comm_count", "vk_comm_exchange_attach", "vk_comm_exchange_detach", "vk_comm_destroy",
            "vk_comm_error_string")
 _LIB = None
 
@@ -45,6 +45,7 @@ def lib():
         h.vk_comm_rank.argtypes, h.vk_comm_rank.restype = [P, C.POINTER(I), C.POINTER(I)], I
         h.vk_comm_allreduce_system.argtypes, h.vk_comm_allreduce_system.restype = [P, P, I, P], I
         h.vk_comm_reduce_hook.argtypes, h.vk_comm_reduce_hook.restype = [P, I, P, P], I
+        h.vk_comm_count.argtypes, h.vk_comm_count.restype = [P, C.POINTER(I)], I
         h.vk_comm_exchange_attach.argtypes, h.vk_comm_exchange_attach.restype = [P, P], I
         h.vk_comm_exchange_detach.argtypes, h.vk_comm_exchange_detach.restype = [P, P], I
         h.vk_comm_destroy.argtypes, h.vk_comm_destroy.restype = [P], I
@@ -86,6 +87,12 @@ class Communicator:
         t = torch.tensor(list(raw), dtype=torch.uint8, device=device)
         dist.broadcast(t, src=0)
         return cls(bytes(t.cpu().tolist()), rank, world)
+
+    def rccl_count(self):
+        """Ranks RCCL itself reports for this communicator (ncclCommCount)."""
+        n = C.c_int(-1)
+        check(lib().vk_comm_count(self.handle, C.byref(n)), "vk_comm_count")
+        return n.value
 
     def allreduce_system(self, system, stream=None):
         """In-place sum of a device float tensor over ranks on torch's current stream."""

@@ -29,6 +29,7 @@ struct Rccl
   Result (*AllReduce)(const void*, void*, size_t, int, int, Comm, void*) = nullptr;
   Result (*AllGather)(const void*, void*, size_t, int, Comm, void*) = nullptr;
   Result (*CommDestroy)(Comm) = nullptr;
+  Result (*CommCount)(Comm, int*) = nullptr;
   const char* (*GetErrorString)(Result) = nullptr;
   bool ok = false;
 };
@@ -51,6 +52,7 @@ void load_rccl()
   g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(g_rccl.handle, "ncclAllReduce"));
   g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.handle, "ncclAllGather"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(g_rccl.handle, "ncclCommCount"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
   g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
 }
@@ -175,6 +177,16 @@ int vk_comm_rank(const void* comm, int* rank, int* world)
   if (rank) *rank = c->rank;
   if (world) *world = c->world;
   return VK_OK_;
+}
+
+int vk_comm_count(const void* comm, int* ranks)
+{
+  if (!comm || !ranks) return VK_ERR_ARGUMENT_;
+  const Communicator* c = static_cast<const Communicator*>(comm);
+  *ranks = 1;
+  if (!c->comm) return VK_OK_;
+  if (!g_rccl.CommCount) return VK_COMM_ERR_NO_RCCL;
+  return from_nccl(g_rccl.CommCount(c->comm, ranks));
 }
 
 int vk_comm_allreduce_system(void* comm, float* system_dev, int count, void* stream)
