@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Microseconds per Gauss-Newton step of PyramidTracker<DepthTracker> in the bench's own
-rgbd-icp loop (tracking a frame against the previous raycast: 15 + 20 steps, the update
-never drops below 1e-6), from HIP events around the tracking calls. Development aid."""
-import ctypes as C
+"""The bench's own rgbd-icp loop (closed-loop tracking in the room scene) for 60 frames: Gauss-Newton
+steps per frame at the full-resolution level, and — with a -DVK_LOOP_TIMING build of the library
+(tools/icp_variants.sh) and VK_LOOP_TIMING_DUMP=1 — the phase times of every step on stderr.
+Development aid."""
 import os
 import sys
 
@@ -14,30 +14,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench
 import scenes
+from vulcan_amd import vk_types as T
 
 frames = 60
-poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(frames)]
-loop = bench.FrameLoop("rgbd-icp", poses)
-lib, s = loop.lib, loop.stream
+seq = bench.RoomSequence(frames, T.Projection.make(*scenes.APP_INTRINSICS))
+loop = bench.FrameLoop("rgbd-icp", seq.truth, sequence=seq)
 ev = [(loop.make_event(), loop.make_event()) for _ in range(frames)]
-steps = []
-t = loop.tracker.tracker
 for i in range(frames):
-    if i > 0:
-        a = loop.track_args
-        lib.vk_event_record(ev[i][0], s)
-        lib.vk_transform_upload(loop.pose_dev, C.byref(poses[i - 1]), s)
-        lib.vk_icp_pyramid_track(a[0], C.byref(poses[i - 1]), *a[2:], s)
-        lib.vk_event_record(ev[i][1], s)
-        lib.vk_memcpy_d2h(C.byref(loop.tracked), loop.pose_dev, 128, s)
-        steps.append(int(t.state.cpu()[0]))
-    saved, loop.tracker = loop.tracker, None
+    loop.lib.vk_event_record(ev[i][0], loop.stream)
     loop.step(i)
-    loop.tracker = saved
+    loop.lib.vk_event_record(ev[i][1], loop.stream)
 torch.cuda.synchronize()
 ms = np.array([loop.elapsed_ms(e0, e1) for e0, e1 in ev[10:]])
-print(f"track: median {1e3 * np.median(ms):.1f} us, full-level steps run {np.median(steps[9:]):.0f} of 20 "
-      f"-> {1e3 * np.median(ms) / (15 + np.median(steps[9:])):.2f} us per step over both levels (incl. the pyramid launch)")
-print("per frame (us, full-level steps):", [(round(1e3 * float(m)), int(n)) for m, n in zip(ms[:16], steps[9:25])])
-err = np.abs(loop.tracked.matrix() - poses[frames - 2].matrix()).max()
-print(f"last tracked pose vs the keyframe's pose: max |diff| {err:.2e}")
+steps = np.array(loop.gn_steps[9:])
+errors = [bench.pose_error(p, seq.truth[i]) for i, p in enumerate(loop.tracked_poses)]
+print(f"per frame: median {1e3 * np.median(ms):.1f} us; full-level steps: median {np.median(steps):.0f} (min {steps.min()}, max {steps.max()}); "
+      f"pose error max {1e3 * max(e[0] for e in errors):.2f} mm / {max(e[1] for e in errors):.3f} deg")

@@ -143,7 +143,10 @@ struct Retry
 };
 
 // files a lost key once: hundreds of rays cross the same block and each of them finds out that
-// it lost, so the list is fronted by a set (linear probing from a multiplicative hash)
+// it lost, so the list is fronted by a set (linear probing from a multiplicative hash).
+// (Measured, r03: as a function of its own — the code leaves the request pass, but its call sites
+// spill through scratch memory: 18.6 us against 15.7 inlined; recording contests at all costs the
+// request pass ~1.5 us, profiles/r03_c_* against r03_h_*.)
 __device__ __forceinline__ void file_loser(const Retry& retry, unsigned long long key)
 {
   uint32_t at = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(VK_RETRY_SLOTS - 1);
@@ -428,10 +431,8 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
 // its own) — both walk the depth image one lane per pixel, and as a launch of its own the
 // mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
 // depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
-// (7 waves per SIMD = at most 72 VGPRs, what the kernel had before it recorded contests: at 6
-// waves it ran 1 us longer, profiles/r03_*)
 template <bool DEFER, bool PREP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREP ? 5 : 7))) void create_requests_kernel(RequestParams P, Retry retry)
+__global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, Retry retry)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
