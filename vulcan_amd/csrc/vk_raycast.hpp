@@ -422,16 +422,13 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
         // silhouette — the room scene of the tracking workload, where 1 % of the waves live 75-105 us
         // and the launch with them, profiles/r03_e_wave_times_room.txt: reading the table entries of
         // the next four positions together and taking the trips through the absent ones in one go.
-        // Inside this loop: room 104 -> 91 us, but the fusion benchmark's raycast 31.9 -> 34.0 us;
-        // as a phase before the loop (leading absent blocks only): no loss, no gain — the long empty
+        // Inside this loop the fusion benchmark's raycast went from 31.9 to 34.0 us; as a second
+        // instantiation chosen per wave by the depth of its bounds cell neither scene changed (31.8 /
+        // 89.7 us against 31.4 / 89.6); as a phase before the loop nothing either — the long empty
         // runs come AFTER the ray has grazed the object's band. The same blocks prefetched into the
-        // directory instead: room 100 -> 112 us. The slow waves are slow because their lanes are out
-        // of phase — some sample while others still march — not because of the table reads: a ray
-        // waits for at most 10 of them on 48 trips.)
-        // (Measured and rejected, r02: resolving the corners and issuing their loads together
-        // with the nearest-voxel read on every trip, to save the second round trip of a
-        // sampling step — 34.7 us against 30.9: the lanes that do not sample add lookups and
-        // eight loads each.)
+        // directory instead: room 90 -> 104 us. The slow waves are slow because their lanes are out
+        // of phase — some sample while others still march — not because of the table reads: with the
+        // reads batched a ray waits for at most 10 of them on 48 trips, and lives as long.)
         if (!refine) sample = (nearest <= 0.1f && nearest >= -0.5f);
         sdf = nearest;
         if (sample)
