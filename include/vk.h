@@ -117,13 +117,20 @@ enum {
   VK_CTR_ORIGIN_SEEN = 16, /* internal: a ray met block (0,0,0) while the main entry of its bucket was
                               unallocated — such an entry compares equal to that block (volume.cu:186-191),
                               so the block counts as present until the entry is taken by another block */
+  VK_CTR_POSTED     = 17, /* internal: buckets that received their first request in the current request pass
+                             (may exceed VK_POSTED_SLOTS: then the handle pass scans the request flags instead) */
+  VK_CTR_ARRIVALS   = 18, /* internal [2], one 64-bit word: the arrivals of the workgroups of the handle + visibility
+                             launch of vk_volume_set_view* (zero between calls) */
   VK_CTR_PUBLIC     = 24, /* what vk_volume_read_counters_sync copies */
   /* behind the counters, for vk_volume_set_view_rounds: the blocks whose request lost its bucket in
    * the round before — two open-addressing sets of VK_RETRY_SLOTS 64-bit request keys (current
    * round / next round) and, for each, the list of the slots in use (VK_RETRY_KEYS ints) */
   VK_RETRY_SLOTS    = 65536,
   VK_RETRY_KEYS     = 8192,
-  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192
+  /* then the buckets with a request of the current request pass, in order of arrival (bit 31: an
+   * EXCESS request): what the handle pass of vk_volume_set_view* works from when there are few */
+  VK_POSTED_SLOTS   = 2048,
+  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192 + 2048
 };
 
 enum {

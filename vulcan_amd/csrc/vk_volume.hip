@@ -99,14 +99,38 @@ __device__ __forceinline__ unsigned long long request_key(int type, int bx, int 
 // 0/1/2 the reference would hold. Bit 2 never survives the call.
 constexpr uint8_t kTouched = 4;
 
-template <bool DEFER>
-__device__ __forceinline__ void mark_visible(uint8_t* vis, uint32_t index)
+// how a request pass marks an entry visible: plainly (the staged entry points), with the touched
+// bit (the fused SetView's first round, decoded by its visibility pass), or plainly AND, when the
+// entry was not visible yet, entered in the visible list (the fused SetView's later rounds, which
+// run after the visibility pass)
+enum { MARK_PLAIN = 0, MARK_DEFER = 1, MARK_APPEND = 2 };
+
+template <int MARK>
+__device__ __forceinline__ void mark_visible(const vk_volume& v, uint32_t index)
 {
   // the reference stores unconditionally (volume.cu:190); reading first keeps
   // hundreds of rays that cross the same block from all storing the same byte
+  uint8_t* vis = v.block_visibility;
   const uint8_t old = vis[index];
-  if (DEFER) { if (!(old & kTouched)) vis[index] = old | kTouched; }
-  else if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE;
+  if (MARK == MARK_DEFER) { if (!(old & kTouched)) vis[index] = old | kTouched; }
+  else if (MARK == MARK_PLAIN) { if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE; }
+  else if (old != VK_VISIBILITY_TRUE)
+  {
+    // exactly one of the lanes that find the entry not visible lists it: the byte is swapped in
+    // its word (the buffer is 4-byte aligned, check_volume; rare path)
+    uint32_t* word = reinterpret_cast<uint32_t*>(vis) + (index >> 2);
+    const int shift = 8 * (int)(index & 3u);
+    uint32_t seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;)
+    {
+      if (((seen >> shift) & 0xffu) == (uint32_t)VK_VISIBILITY_TRUE) return;
+      const uint32_t want = (seen & ~(0xffu << shift)) | ((uint32_t)VK_VISIBILITY_TRUE << shift);
+      const uint32_t got = atomicCAS(word, seen, want);
+      if (got == seen) break;
+      seen = got;
+    }
+    v.visible_blocks[atomicAdd(&v.counters[VK_CTR_VISIBLE], 1)] = (int)index;
+  }
 }
 
 // What the fused SetView (vk_volume_set_view_rounds) keeps of a request pass so that its later
@@ -127,6 +151,16 @@ __host__ __device__ inline int* retry_slots(int32_t* counters, int which)
 {
   return counters + VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + which * VK_RETRY_KEYS;
 }
+
+// ... and behind those the buckets that received their first request of the current request pass
+// (bit 31: the request is an EXCESS one — every ray that asks for a bucket sees the same main entry,
+// so the first poster's type is the bucket's type)
+__host__ __device__ inline int* posted_list(int32_t* counters)
+{
+  return counters + VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS;
+}
+constexpr uint32_t kPostedExcess = 0x80000000u;
+constexpr uint32_t kPostedBucket = 0x7fffffffu;
 
 struct Retry
 {
@@ -185,7 +219,7 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
     if (seen == 0ull && retry.posted)
     {
       const int at = atomicAdd(retry.posted_count, 1);
-      if (at < retry.posted_capacity) retry.posted[at] = (int)h;
+      if (at < retry.posted_capacity) retry.posted[at] = (int)(h | (type == VK_ALLOC_EXCESS ? kPostedExcess : 0u));
     }
   }
   if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
@@ -193,13 +227,13 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 
 // volume.cu:183-239: what one ray does with one crossed block once the bucket's
 // main entry is known
-template <bool DEFER>
+template <int MARK>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
     int bx, int by, int bz, const Retry& retry)
 {
   if (entry_is(entry, bx, by, bz))
   {
-    mark_visible<DEFER>(v.block_visibility, hash_code);
+    mark_visible<MARK>(v, hash_code);
     // An unallocated main entry holds block (0,0,0) and compares equal to it (volume.cu:186-191):
     // the origin block counts as present without ever having been requested — until another
     // block takes that entry, from when on its rays do request it. It is the one block a later
@@ -210,7 +244,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   }
   else if (entry.data == -1)
   {
-    mark_visible<DEFER>(v.block_visibility, hash_code);
+    mark_visible<MARK>(v, hash_code);
     post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry);
   }
   else
@@ -226,7 +260,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
 
       if (entry_is(entry, bx, by, bz))
       {
-        mark_visible<DEFER>(v.block_visibility, index);
+        mark_visible<MARK>(v, index);
         found = true;
         break;
       }
@@ -266,7 +300,7 @@ struct RequestParams
 // ref: volume.cu:87-301, the walk of one depth pixel (x, y). Called by WHOLE waves whose 64
 // lanes hold 64 consecutive pixels of one row (lanes past the image stay in: their neighbours
 // read their registers), so that the depth read is one coalesced 256-byte load.
-template <bool DEFER>
+template <int MARK>
 __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int y, const Retry& retry)
 {
   const vk_volume& v = P.v;
@@ -380,7 +414,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block<DEFER>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry);
+    probe_block<MARK>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
@@ -388,7 +422,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    probe_block<DEFER>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, retry);
+    probe_block<MARK>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, retry);
 
     if (tmax_x < tmax_y)
     {
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
     }
   }
 
-  if (y < P.height) request_walk<DEFER>(P, x, y, retry);   // whole wave
+  if (y < P.height) request_walk<DEFER ? MARK_DEFER : MARK_PLAIN>(P, x, y, retry);   // whole wave
 
   if (PREP)
   {
@@ -637,7 +671,10 @@ __device__ __forceinline__ void handle_group(const vk_volume& v, int group, int 
         if (entry_index < max_count)
         {
           v.hash_entries[other_index].next = entry_index;
-          v.block_visibility[entry_index] = deferred_reset ? (uint8_t)(VK_VISIBILITY_TRUE | kTouched) : (uint8_t)VK_VISIBILITY_TRUE;
+          // (2: the fused handle + visibility launch marks the round's new excess entries by their
+          // index range, visibility_chunk; a byte written here could land after that pass's)
+          if (deferred_reset != 2)
+            v.block_visibility[entry_index] = deferred_reset ? (uint8_t)(VK_VISIBILITY_TRUE | kTouched) : (uint8_t)VK_VISIBILITY_TRUE;
         }
       }
 
@@ -664,10 +701,15 @@ __device__ __forceinline__ void handle_group(const vk_volume& v, int group, int 
   if (dropped)
   {
     atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
-    if (dropped_now) __hip_atomic_store(dropped_now, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (dropped_now)
+    {
+      __hip_atomic_store(dropped_now, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();   // rare; read by the workgroup that finishes the round in the same launch
+    }
   }
 
-  if (group == groups - 1 && threadIdx.x == 0)
+  // (2: the workgroup that finishes the round counts the requests itself, handle_visibility_kernel)
+  if (group == groups - 1 && threadIdx.x == 0 && deferred_reset != 2)
   {
     v.counters[VK_CTR_PENDING_ALL] = base_all + group_all;
     v.counters[VK_CTR_PENDING_EXCESS] = base_excess + group_excess;
@@ -762,8 +804,11 @@ constexpr int kVisThreads = 1024;
 // per workgroup-sized chunk (72 atomics for 73 216 entries with 1024 lanes, instead of the
 // reference's 10-step LDS scan + atomic per 512). One call takes the THREADS entries
 // that start at `first` (uniform call).
+// `new_lo`, `new_hi` (the fused handle + visibility launch): entries [new_lo, new_hi) are the excess
+// entries this round's handle pass creates; they are visible (volume.cu:344) whatever their byte holds.
 template <int THREADS>
-__device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int first, int finish, int deferred_reset)
+__device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int first, int finish, int deferred_reset,
+    int new_lo = 0, int new_hi = 0)
 {
   __shared__ int wave_count[THREADS / 64];
   __shared__ int block_base;
@@ -787,6 +832,7 @@ __device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int 
       visibility = (stored & kTouched) ? VK_VISIBILITY_TRUE
                  : (before == VK_VISIBILITY_TRUE ? VK_VISIBILITY_UNKNOWN : before);
     }
+    if (index >= new_lo && index < new_hi) visibility = VK_VISIBILITY_TRUE;
     visible = (visibility == VK_VISIBILITY_TRUE);
     int result = visibility;
 
@@ -891,7 +937,56 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
 constexpr int kMaxPosted = 4096;   // buckets that can receive a request in one later round
 
 
-__device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds, int retry_capacity)
+// volume.cu:365 for every bucket at once, by one 256-lane workgroup: the requests are cleared, and
+// (optionally) counted — all of them, and the EXCESS ones. Sixteen flags per load (the array is
+// 16-byte aligned, check_volume), the tail byte by byte. Ends with a barrier.
+__device__ __forceinline__ void clear_requests(const vk_volume& v, int* total_all, int* total_excess)
+{
+  __shared__ int red[2 * (kHandleThreads / 64)];
+  const int count = v.main_block_count;
+  const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
+  const int chunks = count / 16;
+  int n_all = 0, n_excess = 0;
+  for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
+  {
+    const uint4 q = flags16[c];
+    if ((q.x | q.y | q.z | q.w) == 0u) continue;
+    count_flags(q.x, n_all, n_excess);
+    count_flags(q.y, n_all, n_excess);
+    count_flags(q.z, n_all, n_excess);
+    count_flags(q.w, n_all, n_excess);
+    for (int b = 0; b < 16; ++b)
+    {
+      const int i = c * 16 + b;
+      if (v.allocation_types[i] != VK_ALLOC_NONE)
+      {
+        v.allocation_types[i] = VK_ALLOC_NONE;
+        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+      }
+    }
+  }
+  for (int i = chunks * 16 + (int)threadIdx.x; i < count; i += kHandleThreads)
+  {
+    const int type = v.allocation_types[i];
+    if (type != VK_ALLOC_NONE)
+    {
+      n_all += 1;
+      n_excess += type == VK_ALLOC_EXCESS ? 1 : 0;
+      v.allocation_types[i] = VK_ALLOC_NONE;
+      reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+    }
+  }
+  block_sum2(n_all, n_excess, red);
+  if (total_all) *total_all = n_all;
+  if (total_excess) *total_excess = n_excess;
+}
+
+// FUSED: called from the handle + visibility launch, after the first round is complete in every
+// respect (requests cleared, pointers moved, visible list built): entries are marked visible plainly
+// and entered in the visible list as they appear.
+// Returns (in lane 0) whether requests are still unanswered after the last round that ran.
+template <bool FUSED>
+__device__ __forceinline__ int later_rounds(const vk_volume& v, int max_rounds, int retry_capacity)
 {
   __shared__ int posted[kMaxPosted];
   __shared__ uint8_t posted_type[kMaxPosted];
@@ -900,38 +995,17 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
   const int count = v.main_block_count;
   const int max_count = v.main_block_count + v.excess_block_count;
 
-  // the first round's second half (finish_handle): requests cleared, pointers moved. Sixteen
-  // flags per load (the array is 16-byte aligned, check_volume), the tail byte by byte.
-  {
-    const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
-    const int chunks = count / 16;
-    for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
-    {
-      const uint4 q = flags16[c];
-      if ((q.x | q.y | q.z | q.w) == 0u) continue;
-      for (int b = 0; b < 16; ++b)
-      {
-        const int i = c * 16 + b;
-        if (v.allocation_types[i] != VK_ALLOC_NONE)
-        {
-          v.allocation_types[i] = VK_ALLOC_NONE;
-          reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
-        }
-      }
-    }
-    for (int i = chunks * 16 + (int)threadIdx.x; i < count; i += kHandleThreads)
-      if (v.allocation_types[i] != VK_ALLOC_NONE)
-      {
-        v.allocation_types[i] = VK_ALLOC_NONE;
-        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
-      }
-  }
+  // the first round's second half (finish_handle): requests cleared, pointers moved
+  if (!FUSED) clear_requests(v, nullptr, nullptr);
   if (threadIdx.x == 0)
   {
-    v.counters[VK_CTR_VOXEL_PTR] -= v.counters[VK_CTR_PENDING_ALL];
-    v.counters[VK_CTR_EXCESS_PTR] += v.counters[VK_CTR_PENDING_EXCESS];
-    v.counters[VK_CTR_PENDING_ALL] = 0;
-    v.counters[VK_CTR_PENDING_EXCESS] = 0;
+    if (!FUSED)
+    {
+      v.counters[VK_CTR_VOXEL_PTR] -= v.counters[VK_CTR_PENDING_ALL];
+      v.counters[VK_CTR_EXCESS_PTR] += v.counters[VK_CTR_PENDING_EXCESS];
+      v.counters[VK_CTR_PENDING_ALL] = 0;
+      v.counters[VK_CTR_PENDING_EXCESS] = 0;
+    }
     stop = (v.counters[VK_CTR_DROPPED_NOW] | v.counters[VK_CTR_RETRY_OVERFLOW]) != 0;
   }
   __syncthreads();
@@ -982,12 +1056,12 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
       table[slots[i]] = 0ull;                       // the set is left empty for the call after this one
       const int bx = (int16_t)(key & 0xffffull), by = (int16_t)((key >> 16) & 0xffffull), bz = (int16_t)((key >> 32) & 0xffffull);
       const uint32_t h = block_hash(bx, by, bz, (uint32_t)count);
-      probe_block<true>(v, h, load_entry(v.hash_entries, h), bx, by, bz, next);
+      probe_block<FUSED ? MARK_APPEND : MARK_DEFER>(v, h, load_entry(v.hash_entries, h), bx, by, bz, next);
     }
     if (origin_asks && threadIdx.x == 0)
     {
       const uint32_t h = block_hash(0, 0, 0, (uint32_t)count);
-      probe_block<true>(v, h, load_entry(v.hash_entries, h), 0, 0, 0, next);
+      probe_block<FUSED ? MARK_APPEND : MARK_DEFER>(v, h, load_entry(v.hash_entries, h), 0, 0, 0, next);
     }
     __threadfence();
     __syncthreads();
@@ -995,13 +1069,24 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
     if (m > kMaxPosted || __hip_atomic_load(&v.counters[VK_CTR_RETRY_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     {
       // more than this workgroup can order: the requests stay posted for the next SetView call
-      if (threadIdx.x == 0) { v.counters[VK_CTR_RETRY_OVERFLOW] = 1; stop = 1; }
+      // (which has to find them in the flags: they are on no list)
+      if (threadIdx.x == 0)
+      {
+        v.counters[VK_CTR_RETRY_OVERFLOW] = 1;
+        stop = 1;
+        if (FUSED) v.counters[VK_CTR_POSTED] = VK_POSTED_SLOTS + 1;
+      }
       __syncthreads();
       break;
     }
 
     // HandleAllocationRequests (volume.cu:304-368) in ascending bucket order
-    for (int i = (int)threadIdx.x; i < m; i += kHandleThreads) posted_type[i] = v.allocation_types[posted[i]];
+    for (int i = (int)threadIdx.x; i < m; i += kHandleThreads)
+    {
+      const int bucket = (int)((uint32_t)posted[i] & kPostedBucket);
+      posted[i] = bucket;
+      posted_type[i] = v.allocation_types[bucket];
+    }
     __syncthreads();
     const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
     const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
@@ -1034,7 +1119,13 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
         if (entry_index < max_count)
         {
           v.hash_entries[other_index].next = entry_index;
-          v.block_visibility[entry_index] = (uint8_t)(VK_VISIBILITY_TRUE | kTouched);   // decoded by the visibility pass
+          if (FUSED)
+          {
+            // the visibility pass has run: the entry is visible (volume.cu:344) and listed from now on
+            v.block_visibility[entry_index] = (uint8_t)VK_VISIBILITY_TRUE;
+            v.visible_blocks[atomicAdd(&v.counters[VK_CTR_VISIBLE], 1)] = entry_index;
+          }
+          else v.block_visibility[entry_index] = (uint8_t)(VK_VISIBILITY_TRUE | kTouched);   // decoded by the visibility pass
         }
       }
       const int voxel_index = voxel_ptr0 - rank_all;
@@ -1073,6 +1164,7 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
     current ^= 1;
   }
 
+  int still_pending = 0;
   if (threadIdx.x == 0)
   {
     const bool pending = stop || origin_block_pending(v) ||
@@ -1081,7 +1173,9 @@ __device__ __forceinline__ void later_rounds(const vk_volume& v, int max_rounds,
     v.counters[VK_CTR_CONTENDED] = pending ? 1 : 0;
     // a round that did not run because nothing was pending would have seen no request
     v.counters[VK_CTR_REQUESTS] = (rounds_run < max_rounds && !pending) ? 0 : (rounds_run > 1 ? last_posted : v.counters[VK_CTR_REQUESTS]);
+    still_pending = pending ? 1 : 0;
   }
+  return still_pending;
 }
 
 // The handle pass of the fused SetView. With losers on file (VK_CTR_CONTENDED, left by the request
@@ -1103,7 +1197,432 @@ __global__ __launch_bounds__(kHandleThreads) void handle_rounds_kernel(vk_volume
   __syncthreads();
   if (!last) return;
   __threadfence();
-  later_rounds(v, max_rounds, retry_capacity);
+  later_rounds<false>(v, max_rounds, retry_capacity);
+}
+
+// ------------------------------------------ handle + visibility in one launch ----
+
+// The handle pass and the visibility pass of a SetView do not depend on each other, with two
+// exceptions: the excess entries the handle pass creates must come out visible, and the second
+// half of the handle pass (requests cleared, pointers moved) has to wait for every reader of the
+// request flags and pointers. Both have an answer that needs no hand-off between workgroups: the
+// new entries are exactly the index range [excess pointer, excess pointer + number of EXCESS
+// requests), which a visibility workgroup that overlaps the excess region counts for itself; and
+// the workgroup that arrives LAST at a ticket (a relaxed atomic: nothing it does depends on what
+// the others WROTE) clears the requests and moves the pointers. One launch (~5 us at this size)
+// less per SetView.
+//
+// The handle pass itself works from the list of buckets the request pass posted to
+// (VK_CTR_POSTED, posted_list): a frame of a moving camera asks for tens of blocks, and ranking
+// those among themselves (request r in bucket order takes free slot voxel_pointer - r, handle_group)
+// is nothing next to counting the flags of 65 024 buckets in every workgroup. A request pass that
+// posts to more than VK_POSTED_SLOTS buckets (the first frame) is handled from the flags as before.
+//
+// With losers on file the last workgroup also replays the later rounds (later_rounds<true>); only
+// then do the workgroups fence around the ticket.
+struct FusedParams
+{
+  VisibilityParams vis;     // finish_handle / deferred_reset unused
+  int handle_wgs;           // workgroups [0, handle_wgs): the handle pass; the rest: visibility chunks
+  int max_rounds;
+  int retry_capacity;
+};
+
+constexpr int kVisPerGroup = 4 * kHandleThreads;   // entries per visibility workgroup: four per lane
+
+// The handle pass from the posted list: listed entries wg * 256 + lane, + wgs * 256, ... Each
+// request's flags are cleared with it (volume.cu:365) — no other workgroup looks at them in this
+// form — except those of `keep_bucket` (the origin block's bucket, read by every workgroup on
+// arrival in the kernel). Returns (uniform) whether a request was dropped; *excess_total (workgroup
+// 0 only): the EXCESS requests of the whole list.
+__device__ __forceinline__ int handle_listed(const vk_volume& v, int m, int wg, int wgs, uint32_t keep_bucket,
+    int voxel_ptr0, int excess_ptr0, int* excess_total)
+{
+  __shared__ __attribute__((aligned(16))) uint32_t listed[VK_POSTED_SLOTS];
+  __shared__ int red[2 * (kHandleThreads / 64)];
+  *excess_total = 0;
+  if (wg * kHandleThreads >= m) return 0;   // (uniform)
+  const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
+  const int padded = (m + 3) & ~3;
+  int n_excess = 0, unused = 0;
+  for (int i = (int)threadIdx.x; i < padded; i += kHandleThreads)
+  {
+    const uint32_t e = i < m ? list[i] : kPostedBucket;   // sentinel: before nothing
+    listed[i] = e;
+    n_excess += (int)(e >> 31);
+  }
+  if (wg == 0)
+  {
+    block_sum2(unused, n_excess, red);
+    *excess_total = n_excess;
+  }
+  else __syncthreads();
+
+  const int max_count = v.main_block_count + v.excess_block_count;
+  int dropped = 0;
+  for (int i = wg * kHandleThreads + (int)threadIdx.x; i < m; i += wgs * kHandleThreads)
+  {
+    const uint32_t mine = listed[i];
+    const uint32_t bucket = mine & kPostedBucket;
+    // (loaded before the ranks are counted: the counting hides the latency)
+    const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[bucket];
+    int next = (mine & kPostedExcess) ? v.hash_entries[bucket].next : -1;
+    // ranks in bucket order among this pass's requests
+    int rank_all = 0, rank_excess = 0;
+    for (int j = 0; j < padded; j += 4)
+    {
+      const uint4 q = *reinterpret_cast<const uint4*>(&listed[j]);
+      const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+        const int before = (e[u] & kPostedBucket) < bucket ? 1 : 0;
+        rank_all += before;
+        rank_excess += before & (int)(e[u] >> 31);
+      }
+    }
+
+    // volume.cu:316-363 for this request (as handle_group (3))
+    int entry_index = (int)bucket;
+    if (mine & kPostedExcess)
+    {
+      int other_index = (int)bucket;
+      for (int guard = 0; next != -1 && guard < max_count; ++guard)
+      {
+        other_index = next;
+        next = v.hash_entries[other_index].next;
+      }
+      entry_index = excess_ptr0 + rank_excess;
+      if (entry_index < max_count) v.hash_entries[other_index].next = entry_index;   // visible by its index (visibility_quads)
+    }
+    const int voxel_index = voxel_ptr0 - rank_all;
+    if (entry_index < max_count && voxel_index >= 0)
+    {
+      const int lo = (int)(packed & 0xffffffffull);
+      const int hi = (int)((packed >> 32) & 0xffffull);
+      reinterpret_cast<int4*>(v.hash_entries)[entry_index] = make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
+    }
+    else ++dropped;
+    if (bucket != keep_bucket)
+    {
+      v.allocation_types[bucket] = VK_ALLOC_NONE;
+      reinterpret_cast<unsigned long long*>(v.allocation_blocks)[bucket] = 0ull;
+    }
+  }
+  if (dropped) atomicAdd(&v.counters[VK_CTR_DROPPED], dropped);
+  return __syncthreads_or(dropped);
+}
+
+// How the workgroups of handle_visibility_kernel arrive: ONE 64-bit atomic add that carries
+// everything the finishing workgroup needs to know of the others — so that it has nothing to load:
+//   bits  0-31  visible entries so far (a visibility workgroup's old value is the base of its slots)
+//   bits 32-47  workgroups that have arrived
+//   bits 48-59  EXCESS requests of the round (from the handle workgroup that counted the list)
+//   bits 60-63  handle workgroups that dropped a request
+constexpr int kArrivalMaxWorkgroups = 65535;
+__device__ __forceinline__ unsigned long long arrival(int visible, int excess, int dropped)
+{
+  return (unsigned long long)(uint32_t)visible | (1ull << 32) | ((unsigned long long)(uint32_t)excess << 48) |
+         ((unsigned long long)(dropped ? 1u : 0u) << 60);
+}
+__device__ __forceinline__ unsigned long long arrive(const vk_volume& v, unsigned long long add, bool fenced)
+{
+  unsigned long long* word = reinterpret_cast<unsigned long long*>(v.counters + VK_CTR_ARRIVALS);
+  return fenced ? __hip_atomic_fetch_add(word, add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                : __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// volume.cu:25-84 as visibility_chunk (deferred reset), four consecutive entries per lane: the
+// 1024 entries from `first` (a multiple of 4) by a 256-lane workgroup, one atomic for all of them.
+// Entries [new_lo, new_hi) are the excess entries this round's handle pass creates; they are
+// visible (volume.cu:344) whatever their byte holds.
+// The workgroup's arrival (see arrival()) is the atomic that reserves its slots of the visible list;
+// returns the arrival word as it was before.
+__device__ __forceinline__ unsigned long long visibility_quads(const VisibilityParams& P, int first, int new_lo, int new_hi,
+    bool fenced)
+{
+  __shared__ int wave_total[kHandleThreads / 64];
+  __shared__ unsigned long long arrived;
+
+  const vk_volume& v = P.v;
+  const int count = v.main_block_count + v.excess_block_count;
+  const int index0 = first + 4 * (int)threadIdx.x;
+  const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
+  int n = count - index0;
+  n = n < 0 ? 0 : (n > 4 ? 4 : n);
+
+  uint32_t stored = 0;
+  if (n == 4) stored = *reinterpret_cast<const uint32_t*>(v.block_visibility + index0);
+  else for (int k = 0; k < n; ++k) stored |= (uint32_t)v.block_visibility[index0 + k] << (8 * k);
+
+  uint32_t result = stored, seen = 0;
+#pragma unroll 1
+  for (int k = 0; k < n; ++k)
+  {
+    const int index = index0 + k;
+    const int byte = (int)((stored >> (8 * k)) & 0xffu);
+    // touched this frame -> TRUE; otherwise what the reset pass would have left
+    const int before = byte & 3;
+    int visibility = (byte & kTouched) ? VK_VISIBILITY_TRUE : (before == VK_VISIBILITY_TRUE ? VK_VISIBILITY_UNKNOWN : before);
+    if (index >= new_lo && index < new_hi) visibility = VK_VISIBILITY_TRUE;
+    bool visible = (visibility == VK_VISIBILITY_TRUE);
+    int out = visibility;
+    if (visibility == VK_VISIBILITY_UNKNOWN)
+    {
+      const Entry e = load_entry(v.hash_entries, index);
+      for (int i = 0; i < 8; ++i)
+      {
+        f3 Xwp;
+        Xwp.x = block_length * (e.ox + ((i & 1) >> 0));
+        Xwp.y = block_length * (e.oy + ((i & 2) >> 1));
+        Xwp.z = block_length * (e.oz + ((i & 4) >> 2));
+        const f3 Xdp = xform_point(P.Tdw, Xwp);
+        if (Xdp.z < 0) continue;
+        float u, w;
+        project(P.k, Xdp, u, w);
+        if (u >= 0 && u <= P.width && w >= 0 && w <= P.height)
+        {
+          visible = true;
+          break;
+        }
+      }
+      if (!visible) out = VK_VISIBILITY_FALSE;
+    }
+    result = (result & ~(0xffu << (8 * k))) | ((uint32_t)out << (8 * k));
+    seen |= visible ? (1u << k) : 0u;
+  }
+  if (result != stored)
+  {
+    if (n == 4) *reinterpret_cast<uint32_t*>(v.block_visibility + index0) = result;
+    else for (int k = 0; k < n; ++k) v.block_visibility[index0 + k] = (uint8_t)(result >> (8 * k));
+  }
+
+  // compaction: lane counts -> wave scan -> one atomic per workgroup
+  const int mine = __popc(seen);
+  int incl = mine;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  if (fenced) __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    int total = 0;
+    for (int w = 0; w < kHandleThreads / 64; ++w)
+    {
+      const int c = wave_total[w];
+      wave_total[w] = total;
+      total += c;
+    }
+    arrived = arrive(v, arrival(total, 0, 0), fenced);
+  }
+  __syncthreads();
+  const unsigned long long before_us = arrived;
+  int offset = (int)(uint32_t)before_us + wave_total[wave] + incl - mine;
+  for (int k = 0; k < 4; ++k)
+    if (seen & (1u << k)) v.visible_blocks[offset++] = index0 + k;
+  __syncthreads();   // the LDS words are reused
+  return before_us;
+}
+
+__global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(FusedParams P)
+{
+  __shared__ unsigned long long arrived;
+  __shared__ int range[2];
+  __shared__ int red[2 * (kHandleThreads / 64)];
+  const vk_volume& v = P.vis.v;
+  const int main_count = v.main_block_count;
+  const int max_count = v.main_block_count + v.excess_block_count;
+  // what the previous launches left (one cache line; nothing in this launch writes it before the end)
+  const int contended = v.counters[VK_CTR_CONTENDED];
+  const int origin_seen = v.counters[VK_CTR_ORIGIN_SEEN];
+  const int posted = v.counters[VK_CTR_POSTED];
+  const int voxel_ptr0 = v.counters[VK_CTR_VOXEL_PTR];
+  const int excess_ptr0 = v.counters[VK_CTR_EXCESS_PTR];
+  const int rounds0 = v.counters[VK_CTR_ROUNDS];
+  const int overflow0 = v.counters[VK_CTR_RETRY_OVERFLOW];
+  const int filed0 = v.counters[VK_CTR_RETRY_COUNT + 0], filed1 = v.counters[VK_CTR_RETRY_COUNT + 1];
+  // Something the finishing workgroup has to READ of what the others write in this launch: only with
+  // losers on file, or when the origin block was met in an unallocated main entry that this round
+  // gives to another block. Both are known before the launch: the same answer in every workgroup.
+  const uint32_t origin_bucket = block_hash(0, 0, 0, (uint32_t)main_count);
+  const bool fenced = contended != 0 || (origin_seen != 0 && v.allocation_types[origin_bucket] != VK_ALLOC_NONE);
+  const bool losers = P.max_rounds > 1 && fenced;
+  // the requests of this round: listed, or — too many for the list — to be found in the flags
+  const bool listed = posted <= VK_POSTED_SLOTS;
+  const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
+
+  unsigned long long before_us;
+  if ((int)blockIdx.x < P.handle_wgs)
+  {
+    int excess_total = 0, dropped = 0;
+    if (listed)
+      dropped = handle_listed(v, posted, (int)blockIdx.x, P.handle_wgs, origin_bucket, voxel_ptr0, excess_ptr0, &excess_total);
+    else
+    {
+      const int groups = (main_count + kHandlePerGroup - 1) / kHandlePerGroup;
+      for (int group = (int)blockIdx.x; group < groups; group += P.handle_wgs)
+        handle_group(v, group, groups, 0, 2, v.counters + VK_CTR_DROPPED_NOW);
+    }
+    if (fenced) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) arrived = arrive(v, arrival(0, excess_total, dropped), fenced);
+    __syncthreads();
+    before_us = arrived;
+  }
+  else
+  {
+    const int first = ((int)blockIdx.x - P.handle_wgs) * kVisPerGroup;
+    int new_lo = 0, new_hi = 0;
+    if (first + kVisPerGroup > excess_ptr0 && posted > 0)
+    {
+      // this chunk may hold entries the handle pass is creating right now: how many are there?
+      int n_all = 0, n_excess = 0;
+      if (listed)
+      {
+        for (int i = (int)threadIdx.x; i < posted; i += kHandleThreads) n_excess += (int)(list[i] >> 31);
+      }
+      else
+      {
+        const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
+        const int chunks = main_count / 16;
+        for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
+        {
+          const uint4 q = flags16[c];
+          count_flags(q.x, n_all, n_excess);
+          count_flags(q.y, n_all, n_excess);
+          count_flags(q.z, n_all, n_excess);
+          count_flags(q.w, n_all, n_excess);
+        }
+        for (int i = chunks * 16 + (int)threadIdx.x; i < main_count; i += kHandleThreads)
+          n_excess += v.allocation_types[i] == VK_ALLOC_EXCESS ? 1 : 0;
+      }
+      block_sum2(n_all, n_excess, red);
+      new_lo = excess_ptr0;
+      new_hi = excess_ptr0 + n_excess < max_count ? excess_ptr0 + n_excess : max_count;
+    }
+    before_us = visibility_quads(P.vis, first, new_lo, new_hi, fenced);
+  }
+
+  // the last one to arrive finishes the round
+  if ((int)((before_us >> 32) & 0xffffull) != (int)gridDim.x - 1) return;
+  if (fenced) __threadfence();
+  // (the word after the last arrival: read back, not recomputed — every lane needs it)
+  const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(v.counters + VK_CTR_ARRIVALS),
+      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int visible_total = (int)(uint32_t)all;
+
+  if (listed && !losers)
+  {
+    // the common case: everything is known, nothing is loaded (volume.cu:365, :352, :337 and the
+    // end-of-call bookkeeping of finish_handle)
+    if (threadIdx.x == 0)
+    {
+      const int excess_total = (int)((all >> 48) & 0xfffull);
+      const int dropped = (int)(all >> 60);
+      int pending = (contended | dropped | overflow0) != 0;
+      if (origin_seen) pending |= origin_block_pending(v);
+      if (posted > 0)
+      {
+        v.allocation_types[origin_bucket] = VK_ALLOC_NONE;
+        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[origin_bucket] = 0ull;
+      }
+      v.counters[VK_CTR_VISIBLE] = visible_total;
+      v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - posted;
+      v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + excess_total;
+      // a round that is not run because nothing was pending would have seen no request
+      v.counters[VK_CTR_REQUESTS] = (P.max_rounds > 1 && !pending) ? 0 : posted;
+      v.counters[VK_CTR_POSTED] = 0;
+      v.counters[VK_CTR_UNSETTLED] = pending;
+      v.counters[VK_CTR_ROUNDS] = rounds0 + 1;
+      v.counters[VK_CTR_CONTENDED] = 0;
+      v.counters[VK_CTR_DROPPED_NOW] = 0;
+      v.counters[VK_CTR_RETRY_OVERFLOW] = 0;
+      v.counters[VK_CTR_ORIGIN_SEEN] = 0;
+      v.counters[VK_CTR_ARRIVALS] = 0;
+      v.counters[VK_CTR_ARRIVALS + 1] = 0;
+    }
+    if (filed0 | filed1)   // (max_rounds == 1 with losers: they leave the set)
+    {
+      for (int which = 0; which < 2; ++which)
+      {
+        int n = which ? filed1 : filed0;
+        if (n > VK_RETRY_KEYS) n = VK_RETRY_KEYS;
+        unsigned long long* table = retry_table(v.counters, which);
+        const int* slots = retry_slots(v.counters, which);
+        for (int i = (int)threadIdx.x; i < n; i += kHandleThreads) table[slots[i]] = 0ull;
+      }
+      if (threadIdx.x < 2) v.counters[VK_CTR_RETRY_COUNT + threadIdx.x] = 0;
+    }
+    return;
+  }
+
+  // ---- the rare cases: too many requests for the list, or losers on file
+  int total_all = posted, total_excess = (int)((all >> 48) & 0xfffull);
+  if (!listed) clear_requests(v, &total_all, &total_excess);
+  if (threadIdx.x == 0)
+  {
+    if (listed && posted > 0)
+    {
+      v.allocation_types[origin_bucket] = VK_ALLOC_NONE;
+      reinterpret_cast<unsigned long long*>(v.allocation_blocks)[origin_bucket] = 0ull;
+    }
+    if (listed && (all >> 60)) v.counters[VK_CTR_DROPPED_NOW] = 1;
+    v.counters[VK_CTR_VISIBLE] = visible_total;
+    v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - total_all;
+    v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + total_excess;
+    v.counters[VK_CTR_REQUESTS] = total_all;
+    v.counters[VK_CTR_POSTED] = 0;
+  }
+  __syncthreads();
+  int pending = 0;
+  if (losers) pending = later_rounds<true>(v, P.max_rounds, P.retry_capacity);   // (lane 0's value)
+  __syncthreads();
+
+  // end-of-call bookkeeping (as finish_handle with max_rounds), and the sets left empty
+  if (threadIdx.x == 0)
+  {
+    if (!losers)
+    {
+      // what is still unanswered: a request lost to a bucket contest or dropped, or more losers
+      // than the retry list holds
+      const int dropped_now = __hip_atomic_load(&v.counters[VK_CTR_DROPPED_NOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pending = (contended | dropped_now | overflow0 | origin_block_pending(v)) != 0;
+    }
+    v.counters[VK_CTR_UNSETTLED] = pending;
+    v.counters[VK_CTR_ROUNDS] += 1;              // the first round; later_rounds() has added the others
+    // a round that is not run because nothing was pending would have seen no request
+    if (P.max_rounds > 1 && !pending && !losers) v.counters[VK_CTR_REQUESTS] = 0;
+    range[0] = __hip_atomic_load(&v.counters[VK_CTR_RETRY_COUNT + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    range[1] = __hip_atomic_load(&v.counters[VK_CTR_RETRY_COUNT + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (int which = 0; which < 2; ++which)
+  {
+    int n = range[which];
+    if (n > VK_RETRY_KEYS) n = VK_RETRY_KEYS;
+    unsigned long long* table = retry_table(v.counters, which);
+    const int* slots = retry_slots(v.counters, which);
+    for (int i = (int)threadIdx.x; i < n; i += kHandleThreads) table[slots[i]] = 0ull;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+  {
+    v.counters[VK_CTR_CONTENDED] = 0;
+    v.counters[VK_CTR_DROPPED_NOW] = 0;
+    v.counters[VK_CTR_RETRY_OVERFLOW] = 0;
+    v.counters[VK_CTR_ORIGIN_SEEN] = 0;
+    v.counters[VK_CTR_RETRY_COUNT + 0] = 0;
+    v.counters[VK_CTR_RETRY_COUNT + 1] = 0;
+    v.counters[VK_CTR_ARRIVALS] = 0;
+    v.counters[VK_CTR_ARRIVALS + 1] = 0;
+  }
 }
 
 int check_volume(const vk_volume* v)
@@ -1130,6 +1649,15 @@ int retry_capacity()
     if (n > 0 && n < VK_RETRY_KEYS) return n;
   }
   return VK_RETRY_KEYS;
+}
+
+// VK_SETVIEW_UNFUSED=1: the fused SetView as three launches (requests, handle + later rounds,
+// visibility) instead of two — kept for comparison, and as the reference for the two-launch form
+// (also the form for a table too large for the arrival count of the two-launch form: > 67 M entries)
+bool set_view_unfused(const vk_volume* v)
+{
+  static const bool unfused = [] { const char* e = getenv("VK_SETVIEW_UNFUSED"); return e && e[0] == '1'; }();
+  return unfused || ((long long)v->main_block_count + v->excess_block_count) / 1024 + 16 > kArrivalMaxWorkgroups;
 }
 
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
@@ -1161,6 +1689,12 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
     retry.table = retry_table(v->counters, 0);
     retry.slots = retry_slots(v->counters, 0);
     retry.capacity = retry_capacity();
+    if (!set_view_unfused(v))
+    {
+      retry.posted = posted_list(v->counters);
+      retry.posted_count = v->counters + VK_CTR_POSTED;
+      retry.posted_capacity = VK_POSTED_SLOTS;
+    }
   }
   if (prep && prep_frame)
   {
@@ -1312,8 +1846,28 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     prep->prepared_threshold = prep->depth_threshold;
     prep->valid = 1;
   }
-  hipLaunchKernelGGL(handle_rounds_kernel, dim3((v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup),
-      dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
+  const int handle_groups = (v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
+  const int vis_groups = (v->main_block_count + v->excess_block_count + kVisPerGroup - 1) / kVisPerGroup;
+  if (!set_view_unfused(v))
+  {
+    // two launches: requests, then handle + visibility (+ the later rounds, if a request lost)
+    FusedParams F;
+    F.vis.v = *v;
+    F.vis.finish_handle = 0;
+    F.vis.deferred_reset = 1;
+    F.vis.width = frame->width;
+    F.vis.height = frame->height;
+    F.vis.k = frame->depth_projection;
+    F.vis.Tdw = make_rt(frame->depth_to_world.inv);
+    F.handle_wgs = handle_groups < VK_POSTED_SLOTS / kHandleThreads ? handle_groups : VK_POSTED_SLOTS / kHandleThreads;
+    F.max_rounds = max_rounds;
+    F.retry_capacity = retry_capacity();
+    hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
+  // the three-launch form (VK_SETVIEW_UNFUSED=1: kept for comparison and as the reference for the fused one)
+  hipLaunchKernelGGL(handle_rounds_kernel, dim3(handle_groups), dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
   return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
       frame->depth_to_world.inv, max_rounds, true, s);
