@@ -638,6 +638,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank % torch.cuda.device_count())   # == local_rank on a full node
     api.lib()
+    if os.environ.get("VK_BENCH_STREAM") == "side":
+        # experiment: a created stream instead of the legacy default stream torch starts on
+        torch.cuda.set_stream(torch.cuda.Stream())
 
     total = args.warmup + args.steps
     # every rank walks the same arc, offset so ranks do not share poses

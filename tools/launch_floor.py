@@ -15,6 +15,7 @@ def main():
     lib, s = api.lib(), api.stream()
     pl = C.CDLL(os.path.join(ROOT, "vulcan_amd", "lib", "libvk_probe.so"))
     pl.vk_probe_launch_floor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    pl.vk_probe_launch_floor_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     ctr = torch.zeros(8, dtype=torch.int32, device="cuda")
     sink = torch.zeros(4096 * 256, dtype=torch.float32, device="cuda")
 
@@ -35,7 +36,11 @@ def main():
             lib.vk_event_record(e1, s)
             ms = C.c_float()
             lib.vk_event_elapsed_ms(e0, e1, C.byref(ms))
-            print(f"workgroups={wgs:5d} chain={launches}: {ms.value * 1e3 / (replays * launches):6.2f} us per launch")
+            line = f"workgroups={wgs:5d} chain={launches}: {ms.value * 1e3 / (replays * launches):6.2f} us per launch"
+            us = C.c_float()
+            rc = pl.vk_probe_launch_floor_graph(ctr.data_ptr(), sink.data_ptr(), wgs, launches, replays, C.byref(us))
+            line += f" | captured in a hipGraph: {us.value:6.2f} us per launch" if rc == 0 else f" | hipGraph: HIP error {rc}"
+            print(line)
 
 
 if __name__ == "__main__":

@@ -49,6 +49,12 @@ VK_API int vk_probe_trace_steps(const vk_hash_entry* entries, const vk_voxel* vo
 VK_API int vk_probe_launch_floor(const int32_t* counters, float* sink, int workgroups, int launches, int replays,
     void* stream);
 
+/* the same chain captured once into a hipGraph on a stream of its own (the legacy default stream cannot be
+ * captured) and replayed: *us_per_launch = time per kernel over `replays` graph launches. Returns the HIP
+ * error code of the first call that fails (positive), 0 on success. */
+VK_API int vk_probe_launch_floor_graph(const int32_t* counters, float* sink, int workgroups, int launches, int replays,
+    float* us_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,4 +254,39 @@ int vk_probe_launch_floor(const int32_t* counters, float* sink, int workgroups, 
   return VK_OK;
 }
 
+int vk_probe_launch_floor_graph(const int32_t* counters, float* sink, int workgroups, int launches, int replays,
+    float* us_per_launch)
+{
+  VK_REQUIRE(counters && sink && workgroups > 0 && launches > 0 && replays > 0 && us_per_launch);
+#define VK_PROBE_TRY(expr) { const hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; }
+  hipStream_t s;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  hipEvent_t e0, e1;
+  VK_PROBE_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  VK_PROBE_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL(early_exit_kernel, dim3(workgroups), dim3(256), 0, s, counters, sink);
+  VK_PROBE_TRY(hipStreamEndCapture(s, &graph));
+  VK_PROBE_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  VK_PROBE_TRY(hipEventCreate(&e0));
+  VK_PROBE_TRY(hipEventCreate(&e1));
+  for (int r = 0; r < 20; ++r) VK_PROBE_TRY(hipGraphLaunch(exec, s));
+  VK_PROBE_TRY(hipStreamSynchronize(s));
+  VK_PROBE_TRY(hipEventRecord(e0, s));
+  for (int r = 0; r < replays; ++r) VK_PROBE_TRY(hipGraphLaunch(exec, s));
+  VK_PROBE_TRY(hipEventRecord(e1, s));
+  VK_PROBE_TRY(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  VK_PROBE_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *us_per_launch = ms * 1e3f / (float)(replays * launches);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  (void)hipStreamDestroy(s);
+#undef VK_PROBE_TRY
+  return 0;
+}
+
 }  // extern "C"
