@@ -64,6 +64,8 @@ IMAGE_BYTES = {"depth": W * H * 4,                          # depth
                "rgbd": W * H * (4 + 12 + 12 + 4)}           # + colour + normals + mask (light integrator)
 METRIC = "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels"
 LIGHT = (2.0, (0.025, 0.08, 0.0))                           # apps/vulcan/vulcan.cu:87-88
+EXTRA_NORMALS = int(os.environ.get("VK_BENCH_EXTRA_NORMALS", "0"))   # experiment only; 0 in every reported run
+NORMALS_IN_SET_VIEW = os.environ.get("VK_BENCH_NORMALS_LAUNCH", "0") != "1"   # "1": ComputeNormals as a launch of its own (A/B)
 SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan.cu:316-318
 
 
@@ -260,7 +262,11 @@ class FrameLoop:
             self.fdesc.depth = seq.depth[i].data_ptr()
             self.fdesc.color = seq.color[i].data_ptr()
         rc = 0
-        if self.mode == 2:
+        # Frame::ComputeNormals of the input frame (vulcan.cu:297): the tracker needs the normals at once;
+        # without one their first consumer is SetView's request pass, which then computes them on the way
+        # (vk_light_prep.normals_out: same image, one launch less)
+        normals_in_set_view = self.mode == 2 and self.tracker is None and NORMALS_IN_SET_VIEW
+        if self.mode == 2 and not normals_in_set_view:
             rc = lib.vk_frame_compute_normals(C.c_void_p(self.fdesc.depth), self.kproj, self.n_ptr, W, H, s)   # vulcan.cu:297
         if self.tracker is not None:
             pose = self.current
@@ -286,6 +292,8 @@ class FrameLoop:
         self.fdesc.content_id += 2                 # this step's normals (and images): new content, odd ids
         vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
         # volume.cu:430-437, three times (vulcan.cu:316-318), + light_integrator.cu:277-293
+        if normals_in_set_view:
+            self.prep.normals_out = self.n_ptr.value
         rc |= lib.vk_volume_set_view_rounds(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, s)
         if self.mode == 2:
             if lib.vk_light_prepared(self.pprep, self.fref, C.c_float(self.depth_threshold)):
@@ -303,6 +311,8 @@ class FrameLoop:
         rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, s)   # tracer.cpp:41-47
         if ev and len(ev) > 2:
             lib.vk_event_record(ev[3], s)
+        for _ in range(EXTRA_NORMALS):      # experiment: what one more launch-floor kernel costs the frame
+            rc |= lib.vk_frame_compute_normals(self.out_ptrs[0], self.kproj, self.n_ptr, W, H, s)
         if rc:
             raise self.api.VkError(f"frame {i}: C ABI returned {rc}")
 
@@ -683,7 +693,10 @@ def main():
         "config": {
             "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
             "set_view": set_view_policy,
-            "input_normals": "Frame::ComputeNormals of the input frame runs inside every timed step (vulcan.cu:297)"
+            "input_normals": ("Frame::ComputeNormals of the input frame (vulcan.cu:297) is part of every timed step: "
+                              + ("before the tracker, as a launch of its own" if wl == "rgbd-icp" or not NORMALS_IN_SET_VIEW else
+                                 "computed inside SetView's request pass (vk_light_prep.normals_out: same normal image, "
+                                 "written to the frame; one launch less)"))
                              if wl != "depth" else "not needed by DepthIntegrator (configs[1])",
             "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
             "visible_blocks_mean": float(nvis_timed.mean()),

@@ -402,6 +402,12 @@ typedef struct vk_light_prep {
   float  depth_threshold;      /* LightIntegrator::depth_threshold_ (light_integrator.cu:256) */
   float* mask;                 /* device float[capacity]                                       */
   float* records;              /* device float[4 * capacity], 16-byte aligned                  */
+  /* One-shot request, reset to NULL by the call: the frame's normal image has NOT been computed yet
+   * (Frame::ComputeNormals, frame.cu:9-122, still due) and vk_volume_set_view_prepare / _rounds is to
+   * leave it in frame->normals — which this must equal — exactly as vk_frame_compute_normals would:
+   * in its request pass when the preparation rides along (the 5-tap stencil reads the depth tile
+   * that pass has staged anyway: one launch less per frame), else by that launch. */
+  float* normals_out;
   int32_t capacity;            /* pixels the two buffers hold: a larger frame is not prepared  */
   /* set by vk_volume_set_view_prepare, compared by vk_light_prepared */
   int32_t      valid;

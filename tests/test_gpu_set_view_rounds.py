@@ -180,3 +180,62 @@ def test_bench_frame_zero(api, orc):
     assert calls in (ctr2[T.VK_CTR_ROUNDS], ctr2[T.VK_CTR_ROUNDS] + 1)
     assert_volume_equal(dv2, hv2, voxels=False)
     assert (pending_after_three == 0) == (int(ctr2[T.VK_CTR_ROUNDS]) <= 3)
+
+
+@pytest.mark.parametrize("size", [(320, 240), (200, 150)])
+def test_set_view_computes_the_frame_normals_on_the_way(api, orc, size):
+    """vk_light_prep.normals_out: Frame::ComputeNormals is still due and SetView's request pass does it
+    (the 5-tap stencil reads the depth tile that pass stages for the light mask): the normal image,
+    the preparation and the integration that follows equal the separate calls bit for bit.
+    200x150: image edges inside a workgroup's 64x4 pixels, ragged last tiles."""
+    w, h = size
+    k = T.Projection.make(272.0 * w / 320, 272.0 * w / 320, 155.6 * w / 320, 117.4 * h / 240)
+    depth = scenes.sphere(2 * w, 2 * h)[::2, ::2].copy()
+    depth[10:14, 20:40] = 0.0                      # holes: taps without a measurement
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+    pose = scenes.tracer_test_pose()
+    hf, df = frames(api, orc, depth, k, pose, color=color)
+    hf.compute_normals()
+    reference = api.Frame(depth, k, pose, color=color)
+    reference.compute_normals()
+    assert np.array_equal(reference.normals.cpu().numpy(), hf.normals, equal_nan=True)
+
+    hv, dv = make_pair(api, orc, 2048, 8192, 0.01, 0.04)
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    integ = api.LightIntegrator(dv)
+    integ.light = light
+    for i in range(2):
+        if i == 1:
+            df.normals.fill_(7.0)                   # stale content that must be replaced
+        oracle_rounds(orc, hv, hf, 3)
+        dv.set_view(df, rounds=3, compute_normals=True)
+        sync()
+        assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+        if i == 1:
+            assert integ._prep.valid == 1 and not integ._prep.normals_out
+        orc.integrate_depth(hv, hf)
+        orc.integrate_light_color(hv, hf, light, orc.light_frame_mask(hf, 0.2))
+        integ.integrate(df)
+        assert_volume_equal(dv, hv)
+
+
+def test_normals_are_computed_also_when_the_preparation_cannot_ride(api, orc):
+    """A frame without colour: the preparation does not ride along, the normals are computed by the
+    launch of their own, and the request is cleared."""
+    w, h = 320, 240
+    depth = scenes.plane(w, h, 1.5)
+    hf, df = frames(api, orc, depth, K_SMALL, scenes.tracer_test_pose())
+    hf.compute_normals()
+    hv, dv = make_pair(api, orc, 4096, 1024, 0.01, 0.04)
+    prep = T.LightPrep()
+    import torch
+    mask = torch.zeros(w * h, dtype=torch.float32, device="cuda")
+    records = torch.zeros(4 * w * h, dtype=torch.float32, device="cuda")
+    prep.mask, prep.records, prep.capacity, prep.depth_threshold = mask.data_ptr(), records.data_ptr(), w * h, 0.2
+    dv.attach_light_preparation(prep)
+    oracle_rounds(orc, hv, hf, 1)
+    dv.set_view(df, compute_normals=True)
+    sync()
+    assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+    assert prep.valid == 0 and not prep.normals_out
+    assert_volume_equal(dv, hv, voxels=False)

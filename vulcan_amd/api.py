@@ -336,12 +336,26 @@ class Volume:
         (vk_volume_set_view_prepare) for the integrate that follows."""
         self.light_prep = prep
 
-    def set_view(self, frame, rounds=1):
+    def set_view(self, frame, rounds=1, compute_normals=False):
         """Volume::SetView. `rounds` > 1: the state of that many consecutive SetView calls with this
-        frame (the reference's frame loop makes three, apps/vulcan/vulcan.cu:316-318), in one call."""
+        frame (the reference's frame loop makes three, apps/vulcan/vulcan.cu:316-318), in one call.
+        `compute_normals`: frame.compute_normals() is still due and is done by this call — inside its
+        request pass when a LightIntegrator's preparation rides along (vk_light_prep.normals_out)."""
+        import torch
         self._view_changed()
+        if compute_normals:
+            if self.light_prep is None:
+                frame.compute_normals()
+            else:
+                if frame.normals is None:
+                    frame.normals = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
+                frame.touch()                                  # the normal image's content is new
+                self.light_prep.normals_out = frame.normals.data_ptr()
         prep = _ref(self.light_prep) if self.light_prep is not None else None
-        if rounds != 1:
+        if compute_normals and prep is not None:
+            check(lib().vk_volume_set_view_rounds(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds), stream()),
+                  "vk_volume_set_view_rounds")
+        elif rounds != 1:
             check(lib().vk_volume_set_view_rounds(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds), stream()),
                   "vk_volume_set_view_rounds")
         elif prep is not None:

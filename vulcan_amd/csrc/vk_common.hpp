@@ -204,6 +204,28 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 
+// ---- Frame::ComputeNormals for one pixel (ref: frame.cu:9-122): `depth` at (x, y) and the four taps
+// two pixels away (0 = no measurement, or outside the image). Shared by compute_normals_kernel and
+// by the request pass of vk_volume_set_view_prepare when it computes the frame's normals on the way.
+__device__ __forceinline__ f3 normal_from_taps(const vk_projection& k, int x, int y, float depth,
+    float left, float right, float up, float down)
+{
+  const int pad = 2;
+  f3 normal = make3(0, 0, 0);
+  if (depth > 0)
+  {
+    const f3 z0 = unproject_d(k, (x + 0) + 0.5f, (y + 0) + 0.5f, depth);
+    const f3 x0 = (left == 0) ? z0 : scale3(unproject(k, (x - pad) + 0.5f, (y + 0) + 0.5f), left);
+    const f3 x1 = (right == 0) ? z0 : scale3(unproject(k, (x + pad) + 0.5f, (y + 0) + 0.5f), right);
+    const f3 y0 = (up == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y - pad) + 0.5f), up);
+    const f3 y1 = (down == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y + pad) + 0.5f), down);
+    const f3 dx = sub3(x0, x1);
+    const f3 dy = sub3(y0, y1);
+    if (sqnorm3(dx) > 0 && sqnorm3(dy) > 0) normal = normalized3(cross3(dy, dx));
+  }
+  return normal;
+}
+
 // ---- LightIntegrator's per-pixel preparation (ref: light_integrator.cu:16-94 frame mask,
 // :215-225 the per-pixel half of the colour kernel) — shared by frame_mask_kernel and by the
 // request pass of vk_volume_set_view_prepare. `window`: a depth tile in LDS, zero outside the

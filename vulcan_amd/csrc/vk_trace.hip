@@ -313,26 +313,10 @@ __global__ __launch_bounds__(256) void compute_normals_kernel(const float* __res
   const int pad = 2;
   const float depth = depths[y * image_width + x];
   f3 normal = make3(0, 0, 0);
-
   if (depth > 0)
-  {
-    const f3 z0 = unproject_d(k, (x + 0) + 0.5f, (y + 0) + 0.5f, depth);
-    float d;
-
-    d = depth_at(depths, image_width, image_height, x - pad, y);
-    const f3 x0 = (d == 0) ? z0 : scale3(unproject(k, (x - pad) + 0.5f, (y + 0) + 0.5f), d);
-    d = depth_at(depths, image_width, image_height, x + pad, y);
-    const f3 x1 = (d == 0) ? z0 : scale3(unproject(k, (x + pad) + 0.5f, (y + 0) + 0.5f), d);
-    d = depth_at(depths, image_width, image_height, x, y - pad);
-    const f3 y0 = (d == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y - pad) + 0.5f), d);
-    d = depth_at(depths, image_width, image_height, x, y + pad);
-    const f3 y1 = (d == 0) ? z0 : scale3(unproject(k, (x + 0) + 0.5f, (y + pad) + 0.5f), d);
-
-    const f3 dx = sub3(x0, x1);
-    const f3 dy = sub3(y0, y1);
-
-    if (sqnorm3(dx) > 0 && sqnorm3(dy) > 0) normal = normalized3(cross3(dy, dx));
-  }
+    normal = normal_from_taps(k, x, y, depth,
+        depth_at(depths, image_width, image_height, x - pad, y), depth_at(depths, image_width, image_height, x + pad, y),
+        depth_at(depths, image_width, image_height, x, y - pad), depth_at(depths, image_width, image_height, x, y + pad));
 
   const int output = y * image_width + x;
   normals[3 * output + 0] = normal.x;

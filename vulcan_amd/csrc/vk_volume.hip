@@ -295,6 +295,7 @@ struct RequestParams
   float depth_threshold;
   float* mask;
   float4* records;
+  float* normals_out;   // PREP == 2: the frame's normals are computed here (Frame::ComputeNormals) and written out
 };
 
 // ref: volume.cu:87-301, the walk of one depth pixel (x, y). Called by WHOLE waves whose 64
@@ -465,7 +466,11 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
 // its own) — both walk the depth image one lane per pixel, and as a launch of its own the
 // mask pass costs ~6 us of which ~4.5 are the launch. The workgroup's 64x4 pixels need the
 // depth window [x-1, x+5] x [y-1, y+5]: a 70x10 tile in LDS.
-template <bool DEFER, bool PREP>
+// PREP == 2: the frame's normals are not there yet — Frame::ComputeNormals (frame.cu:9-122) is a
+// 5-tap stencil on the same depth image, two pixels to each side, so the tile grows by one column
+// and one row (71x11 from (x-2, y-2)), the pass computes the normal it needs for the record itself
+// and writes it to the frame's normal image: one launch (~3.4 us of the frame) and a 3.7 MB read less.
+template <bool DEFER, int PREP>
 __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, Retry retry)
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -473,15 +478,17 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
 
   // PREP: the loads of the depth tile and of the pixel's colour and normal are issued first and
   // consumed after the request walk, which hides their latency
-  constexpr int TW = 70, TH = 10, TS = 72;
+  constexpr int HALO = (PREP == 2) ? 2 : 1;                 // columns / rows in front of the workgroup's pixels
+  constexpr int TW = 69 + HALO, TH = 9 + HALO, TS = 72;
+  constexpr int LOADS = (TW * TH + 255) / 256;
   __shared__ float tile[PREP ? TH * TS : 1];
-  float staged[3] = {0.0f, 0.0f, 0.0f};
+  float staged[LOADS] = {};
   vf3 prep_rgb = {0.0f, 0.0f, 0.0f}, prep_n = {0.0f, 0.0f, 0.0f};
   if (PREP)
   {
-    const int x0 = (int)blockIdx.x * 64 - 1, y0 = (int)blockIdx.y * 4 - 1;
+    const int x0 = (int)blockIdx.x * 64 - HALO, y0 = (int)blockIdx.y * 4 - HALO;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < LOADS; ++t)
     {
       const int i = (int)threadIdx.x + 256 * t;
       const int r = i / TW, c = i - r * TW;
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
     {
       const int index = y * P.width + x;
       prep_rgb = *reinterpret_cast<const vf3*>(P.colors + 3 * (size_t)index);
-      prep_n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
+      if (PREP == 1) prep_n = *reinterpret_cast<const vf3*>(P.normals + 3 * (size_t)index);
     }
   }
 
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
   if (PREP)
   {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < LOADS; ++t)
     {
       const int i = (int)threadIdx.x + 256 * t;
       if (i < TW * TH) tile[(i / TW) * TS + (i % TW)] = staged[t];
@@ -510,10 +517,20 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
     if (x < P.width && y < P.height)
     {
       const int index = y * P.width + x;
-      const f3 Xcn = xform_dir(P.Tcd, make3(prep_n.x, prep_n.y, prep_n.z));      // light_integrator.cu:223
+      const int lx = (int)(threadIdx.x & 63) + HALO, ly = (int)(threadIdx.x >> 6) + HALO;   // this pixel in the tile
+      f3 normal = make3(prep_n.x, prep_n.y, prep_n.z);
+      if (PREP == 2)
+      {
+        normal = normal_from_taps(P.k, x, y, tile[ly * TS + lx], tile[ly * TS + lx - 2], tile[ly * TS + lx + 2],
+            tile[(ly - 2) * TS + lx], tile[(ly + 2) * TS + lx]);
+        P.normals_out[3 * (size_t)index + 0] = normal.x;
+        P.normals_out[3 * (size_t)index + 1] = normal.y;
+        P.normals_out[3 * (size_t)index + 2] = normal.z;
+      }
+      const f3 Xcn = xform_dir(P.Tcd, normal);      // light_integrator.cu:223
       float m = 0.0f;
       if (light_color_usable(prep_rgb.x, prep_rgb.y, prep_rgb.z))
-        m = light_window_mask(tile, TS, (int)(threadIdx.x & 63) + 3, (int)(threadIdx.x >> 6) + 3, P.depth_threshold);
+        m = light_window_mask(tile, TS, lx + 2, ly + 2, P.depth_threshold);   // the window's centre: (x + 2, y + 2)
       P.mask[index] = m;
       P.records[index] = make_float4(Xcn.x, Xcn.y, Xcn.z, m);
     }
@@ -1676,6 +1693,7 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
   P.depth_threshold = 0.0f;
   P.mask = nullptr;
   P.records = nullptr;
+  P.normals_out = nullptr;
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
   // the fused SetView files the requests that lose a bucket contest (post_request) for its later rounds
   Retry retry;
@@ -1704,10 +1722,12 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
     P.depth_threshold = prep->depth_threshold;
     P.mask = prep->mask;
     P.records = reinterpret_cast<float4*>(prep->records);
-    hipLaunchKernelGGL((create_requests_kernel<true, true>), grid, dim3(256), 0, s, P, retry);
+    P.normals_out = prep->normals_out;
+    if (prep->normals_out) hipLaunchKernelGGL((create_requests_kernel<true, 2>), grid, dim3(256), 0, s, P, retry);
+    else hipLaunchKernelGGL((create_requests_kernel<true, 1>), grid, dim3(256), 0, s, P, retry);
   }
-  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, false>), grid, dim3(256), 0, s, P, retry);
-  else hipLaunchKernelGGL((create_requests_kernel<false, false>), grid, dim3(256), 0, s, P, retry);
+  else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, 0>), grid, dim3(256), 0, s, P, retry);
+  else hipLaunchKernelGGL((create_requests_kernel<false, 0>), grid, dim3(256), 0, s, P, retry);
   VK_LAUNCH_CHECK();
   return VK_OK;
 }
@@ -1828,6 +1848,18 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
       (frame->color_width <= 0 || frame->color_width == frame->width) &&
       (frame->color_height <= 0 || frame->color_height == frame->height);
   if (prep) prep->valid = 0;
+  if (prep && prep->normals_out)
+  {
+    // the frame's normals are still to be computed (vk_light_prep.normals_out): on the way when the
+    // preparation rides along, else by the launch the caller left out
+    VK_REQUIRE(prep->normals_out == frame->normals);
+    if (!ride)
+    {
+      int rn = vk_frame_compute_normals(frame->depth, &frame->depth_projection, prep->normals_out, frame->width, frame->height, stream);
+      prep->normals_out = nullptr;
+      if (rn != VK_OK) return rn;
+    }
+  }
   // three launches: the reset pass is folded into the other three (see kTouched), and so are
   // all rounds after the first (later_rounds)
   int r;
@@ -1845,6 +1877,7 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     prep->content_id = frame->content_id;
     prep->prepared_threshold = prep->depth_threshold;
     prep->valid = 1;
+    prep->normals_out = nullptr;   // done
   }
   const int handle_groups = (v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
   const int vis_groups = (v->main_block_count + v->excess_block_count + kVisPerGroup - 1) / kVisPerGroup;

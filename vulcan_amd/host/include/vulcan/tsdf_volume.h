@@ -63,6 +63,9 @@ class Volume
     // `rounds` consecutive SetView(frame) calls (the app makes three per frame, vulcan.cu:316-318)
     // in one: the later rounds run on the device, and only when the round before lost a request
     void SetView(const Frame& frame, int rounds);
+    // frame.ComputeNormals(); SetView(frame, rounds); in one call (not upstream): with a LightIntegrator
+    // attached the normals are computed inside SetView's request pass (vk_light_prep.normals_out)
+    void ComputeNormalsAndSetView(Frame& frame, int rounds = 1);
 
     // ---- storage ----
     const Buffer<HashEntry>& GetHashEntries() const;

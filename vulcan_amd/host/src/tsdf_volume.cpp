@@ -126,6 +126,22 @@ void Volume::SetView(const Frame& frame, int rounds)
   empty_ = false;
 }
 
+void Volume::ComputeNormalsAndSetView(Frame& frame, int rounds)
+{
+  vk_light_prep* prep = GetLightPreparation();
+  if (!prep)
+  {
+    frame.ComputeNormals();
+    SetView(frame, rounds);
+    return;
+  }
+  VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+  if (!frame.normal_image) frame.normal_image = std::make_shared<ColorImage>();
+  frame.normal_image->Resize(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+  prep->normals_out = reinterpret_cast<float*>(frame.normal_image->GetData());   // (GetData stamps the image: new content)
+  SetView(frame, rounds);
+}
+
 const Buffer<HashEntry>& Volume::GetHashEntries() const { return hash_entries_; }
 
 const Buffer<int>& Volume::GetAllocatedBlocks() const

@@ -1310,6 +1310,51 @@ TEST(LightIntegrator, PreparationFollowsContentNotPointers)
   ASSERT_TRUE(coloured > 1000);
 }
 
+// Volume::ComputeNormalsAndSetView (not upstream) = frame.ComputeNormals(); volume.SetView(frame, rounds):
+// with a LightIntegrator attached the normals are computed inside SetView's request pass. Same normal
+// image, same voxels.
+TEST(Volume, ComputeNormalsAndSetViewEqualsTheTwoCalls)
+{
+  const int w = 160, h = 120;
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.025f, 0.08f, 0.0f);
+  std::vector<Voxel> voxels[2];
+  std::vector<Vector3f> normals[2];
+  for (int variant = 0; variant < 2; ++variant)
+  {
+    Frame frame;
+    frame.depth_projection.SetFocalLength(136, 136);
+    frame.depth_projection.SetCenterPoint(80, 60);
+    frame.color_projection = frame.depth_projection;
+    frame.depth_image = MakeDepth(w, h, [](int x, int y) { return 1.5f + 0.001f * x + 0.0007f * y; });
+    frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+    auto volume = std::make_shared<Volume>(8192, 2048);
+    volume->SetVoxelLength(0.008f);
+    LightIntegrator integrator(volume);
+    integrator.SetLight(light);
+    for (int i = 0; i < 3; ++i)     // (the first Integrate registers the integrator's buffers with the volume)
+    {
+      if (variant == 0)
+      {
+        frame.ComputeNormals();
+        volume->SetView(frame, 3);
+      }
+      else volume->ComputeNormalsAndSetView(frame, 3);
+      integrator.Integrate(frame);
+    }
+    voxels[variant] = Download(volume->GetVoxels());
+    normals[variant].resize(size_t(w) * h);
+    frame.normal_image->CopyToHost(normals[variant].data());
+  }
+  ASSERT_TRUE(std::memcmp(normals[0].data(), normals[1].data(), normals[0].size() * sizeof(Vector3f)) == 0);
+  ASSERT_EQ(voxels[0].size(), voxels[1].size());
+  ASSERT_TRUE(std::memcmp(voxels[0].data(), voxels[1].data(), voxels[0].size() * sizeof(Voxel)) == 0);
+  size_t coloured = 0;
+  for (const Voxel& voxel : voxels[0]) coloured += voxel.color_weight > 1;
+  ASSERT_TRUE(coloured > 1000);
+}
+
 TEST(Extractor, Extract)   // extractor.h:116-134; faces are what upstream leaves unwritten (extractor.cu:392-430)
 {
   Frame frame;

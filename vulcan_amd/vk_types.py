@@ -170,7 +170,8 @@ class TrackPoll(C.Structure):
 
 
 class LightPrep(C.Structure):
-    _fields_ = [("depth_threshold", C.c_float), ("mask", C.c_void_p), ("records", C.c_void_p), ("capacity", C.c_int32),
+    _fields_ = [("depth_threshold", C.c_float), ("mask", C.c_void_p), ("records", C.c_void_p),
+                ("normals_out", C.c_void_p), ("capacity", C.c_int32),
                 ("valid", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("depth", C.c_void_p),
                 ("color", C.c_void_p), ("normals", C.c_void_p), ("prepared_threshold", C.c_float),
                 ("depth_to_color", Transform), ("content_id", C.c_uint64)]
