@@ -422,8 +422,9 @@ typedef struct vk_light_prep {
 
 /* ref: src/volume.cu:430-437 Volume::SetView (as vk_volume_set_view) + src/light_integrator.cu:
  * 277-293 — with a `prep` whose buffers are set and a frame that has colour and normals of
- * the depth image's size, the same three launches also do vk_light_prepare. prep->valid
- * tells whether they did. */
+ * the depth image's size, the same launches also do vk_light_prepare. prep->valid
+ * tells whether they did. (Two launches: the request pass; the handle pass and the visibility
+ * pass together, the handle pass working from the list of buckets the request pass posted to.) */
 VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
     void* stream);
 
@@ -432,10 +433,10 @@ VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame,
  * (or finds its bucket's main entry taken by the winner) must ask again. This entry point leaves
  * exactly the state of `max_rounds` consecutive vk_volume_set_view(_prepare) calls with the same
  * frame — every buffer, the visible set, VK_CTR_VOXEL_PTR / EXCESS_PTR / REQUESTS / DROPPED — in the
- * three launches of ONE call. What a further call changes is only this: the blocks that lost ask
+ * two launches of ONE call. What a further call changes is only this: the blocks that lost ask
  * again, the winners among them are committed, their entries become visible. The request pass
- * therefore files the losers in a list, and — only when there are any — the handle pass replays
- * the later rounds from that list before the visibility pass runs; the rays are walked once.
+ * therefore files the losers in a list, and — only when there are any — the workgroup of the second
+ * launch that finishes last replays the later rounds from that list; the rays are walked once.
  * `prep` as in vk_volume_set_view_prepare (may be NULL). max_rounds >= 1. VK_CTR_ROUNDS counts the
  * rounds that ran; VK_CTR_UNSETTLED tells whether one more call would still have work.
  * Two cases end the rounds early, with VK_CTR_UNSETTLED = 1 and the state of as many calls as

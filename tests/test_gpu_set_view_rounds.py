@@ -32,9 +32,20 @@ def assert_same_requests(dv, hv):
     return ctr
 
 
+@pytest.fixture(params=["two launches", "three launches"])
+def launches(request):
+    """The call as two launches (requests; handle + visibility, the handle pass working from the list
+    of posted buckets) and as three (VK_SETVIEW_UNFUSED=1: handle and visibility apart, the handle
+    pass counting the request flags — also the form for tables beyond 67 M entries)."""
+    if request.param == "three launches":
+        os.environ["VK_SETVIEW_UNFUSED"] = "1"
+    yield request.param
+    os.environ.pop("VK_SETVIEW_UNFUSED", None)
+
+
 @pytest.mark.parametrize("scene", ["sphere", "ramp"])
 @pytest.mark.parametrize("rounds", [2, 3, 6])
-def test_rounds_equal_consecutive_set_views(api, orc, scene, rounds):
+def test_rounds_equal_consecutive_set_views(api, orc, scene, rounds, launches):
     """A table far too small for the scene (1024 buckets for ~2 000 blocks): every round loses
     requests to bucket contests and grows chains, so each round changes the state."""
     w, h = 320, 240
@@ -74,7 +85,7 @@ def test_later_rounds_are_skipped_when_nothing_is_pending(api, orc):
     assert ran[0] in (1, 2, 3) and ran[1:] == [1, 1], ran
 
 
-def test_rounds_end_with_the_first_round_that_drops_a_request(api, orc):
+def test_rounds_end_with_the_first_round_that_drops_a_request(api, orc, launches):
     """A pool of 600 blocks for a scene that needs more. Upstream asks again on every call, drops
     again and links excess entries it never writes (volume.cu:337-356); from there on its state is
     inconsistent. The rounds therefore end with the first round that drops a request (vk.h): the
@@ -148,7 +159,7 @@ def test_rounds_with_the_light_preparation_riding_along(api, orc):
         assert_volume_equal(dv, hv)
 
 
-def test_bench_frame_zero(api, orc):
+def test_bench_frame_zero(api, orc, launches):
     """The first frame of bench.py's sequence (640x480, 5 mm, Volume(65024, 8192)) allocates ~7 k
     blocks at once: hundreds of bucket contests. rounds=3 equals the app's three SetView calls;
     with enough rounds nothing is left pending, and that state is the oracle's fixed point."""

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(Visibili
 // only the losers have anything to ask.
 //
 // vk_volume_set_view_rounds(.., max_rounds) leaves the state of `max_rounds` consecutive SetView
-// calls with the same frame in the three launches of one. What another SetView call with the same
+// calls with the same frame in the launches of one. What another SetView call with the same
 // frame changes is exactly this: every block that lost asks again (its rays walk the same blocks
 // as before, find everything else in the table, and mark visible what is already marked), the
 // winners are committed, and the entries so created become visible. So the request pass files the
@@ -1673,7 +1673,8 @@ int retry_capacity()
 // (also the form for a table too large for the arrival count of the two-launch form: > 67 M entries)
 bool set_view_unfused(const vk_volume* v)
 {
-  static const bool unfused = [] { const char* e = getenv("VK_SETVIEW_UNFUSED"); return e && e[0] == '1'; }();
+  const char* e = getenv("VK_SETVIEW_UNFUSED");     // (read per call: the tests switch it)
+  const bool unfused = e && e[0] == '1';
   return unfused || ((long long)v->main_block_count + v->excess_block_count) / 1024 + 16 > kArrivalMaxWorkgroups;
 }
 
@@ -1860,8 +1861,8 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
       if (rn != VK_OK) return rn;
     }
   }
-  // three launches: the reset pass is folded into the other three (see kTouched), and so are
-  // all rounds after the first (later_rounds)
+  // two launches (requests; handle + visibility): the reset pass is folded into them (see kTouched),
+  // and so are all rounds after the first (later_rounds)
   int r;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
            &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr,
