@@ -128,9 +128,10 @@ enum {
   VK_RETRY_SLOTS    = 65536,
   VK_RETRY_KEYS     = 8192,
   /* then the buckets with a request of the current request pass, in order of arrival (bit 31: an
-   * EXCESS request): what the handle pass of vk_volume_set_view* works from when there are few */
+   * EXCESS request), and for each the last entry of its chain: what the handle pass of
+   * vk_volume_set_view* works from when there are few */
   VK_POSTED_SLOTS   = 2048,
-  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192 + 2048
+  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192 + 2 * 2048
 };
 
 enum {

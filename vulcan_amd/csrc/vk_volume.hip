@@ -172,6 +172,7 @@ struct Retry
   int* slots;                   // where in the table each distinct key sits, in order of arrival
   int capacity;                 // entries `slots` holds
   int* posted;
+  int* posted_tail;             // optional, next to `posted`: the last entry of the bucket's chain (an EXCESS request links there)
   int* posted_count;
   int posted_capacity;
 };
@@ -201,7 +202,7 @@ __device__ __forceinline__ void file_loser(const Retry& retry, unsigned long lon
 }
 
 __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int type, int bx, int by, int bz,
-    const Retry& retry)
+    const Retry& retry, uint32_t tail)
 {
   unsigned long long* slot = reinterpret_cast<unsigned long long*>(v.allocation_blocks) + h;
   const unsigned long long key = request_key(type, bx, by, bz);
@@ -219,7 +220,11 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
     if (seen == 0ull && retry.posted)
     {
       const int at = atomicAdd(retry.posted_count, 1);
-      if (at < retry.posted_capacity) retry.posted[at] = (int)(h | (type == VK_ALLOC_EXCESS ? kPostedExcess : 0u));
+      if (at < retry.posted_capacity)
+      {
+        retry.posted[at] = (int)(h | (type == VK_ALLOC_EXCESS ? kPostedExcess : 0u));
+        if (retry.posted_tail) retry.posted_tail[at] = (int)tail;
+      }
     }
   }
   if (v.allocation_types[h] != (uint8_t)type) v.allocation_types[h] = (uint8_t)type;
@@ -245,7 +250,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   else if (entry.data == -1)
   {
     mark_visible<MARK>(v, hash_code);
-    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry);
+    post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry, hash_code);
   }
   else
   {
@@ -266,7 +271,9 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
       }
     }
 
-    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz, retry);
+    // (`index` is now the chain's last entry: the table does not change during the pass, so every ray
+    // that asks for this bucket ends its walk there)
+    if (!found) post_request(v, hash_code, VK_ALLOC_EXCESS, bx, by, bz, retry, index);
   }
 }
 
@@ -1063,6 +1070,7 @@ __device__ __forceinline__ int later_rounds(const vk_volume& v, int max_rounds, 
     next.slots = retry_slots(v.counters, current ^ 1);
     next.capacity = retry_capacity;
     next.posted = posted;
+    next.posted_tail = nullptr;
     next.posted_count = &posted_count;
     next.posted_capacity = kMaxPosted;
     unsigned long long* table = retry_table(v.counters, current);
@@ -1256,10 +1264,12 @@ __device__ __forceinline__ int handle_listed(const vk_volume& v, int m, int wg, 
     int voxel_ptr0, int excess_ptr0, int* excess_total)
 {
   __shared__ __attribute__((aligned(16))) uint32_t listed[VK_POSTED_SLOTS];
+  __shared__ int free_slot[VK_POSTED_SLOTS];
   __shared__ int red[2 * (kHandleThreads / 64)];
   *excess_total = 0;
   if (wg * kHandleThreads >= m) return 0;   // (uniform)
   const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
+  const int* tails = posted_list(v.counters) + VK_POSTED_SLOTS;
   const int padded = (m + 3) & ~3;
   int n_excess = 0, unused = 0;
   for (int i = (int)threadIdx.x; i < padded; i += kHandleThreads)
@@ -1267,6 +1277,9 @@ __device__ __forceinline__ int handle_listed(const vk_volume& v, int m, int wg, 
     const uint32_t e = i < m ? list[i] : kPostedBucket;   // sentinel: before nothing
     listed[i] = e;
     n_excess += (int)(e >> 31);
+    // the request of rank i takes free slot voxel_pointer - i: all of them are fetched now, together
+    // with the list, instead of one by one behind the ranks
+    if (i < m && voxel_ptr0 - i >= 0) free_slot[i] = v.free_voxel_blocks[voxel_ptr0 - i];
   }
   if (wg == 0)
   {
@@ -1283,7 +1296,7 @@ __device__ __forceinline__ int handle_listed(const vk_volume& v, int m, int wg, 
     const uint32_t bucket = mine & kPostedBucket;
     // (loaded before the ranks are counted: the counting hides the latency)
     const unsigned long long packed = reinterpret_cast<const unsigned long long*>(v.allocation_blocks)[bucket];
-    int next = (mine & kPostedExcess) ? v.hash_entries[bucket].next : -1;
+    const int tail = tails[i];      // of the bucket's chain, noted by the request pass (post_request)
     // ranks in bucket order among this pass's requests
     int rank_all = 0, rank_excess = 0;
     for (int j = 0; j < padded; j += 4)
@@ -1303,21 +1316,15 @@ __device__ __forceinline__ int handle_listed(const vk_volume& v, int m, int wg, 
     int entry_index = (int)bucket;
     if (mine & kPostedExcess)
     {
-      int other_index = (int)bucket;
-      for (int guard = 0; next != -1 && guard < max_count; ++guard)
-      {
-        other_index = next;
-        next = v.hash_entries[other_index].next;
-      }
       entry_index = excess_ptr0 + rank_excess;
-      if (entry_index < max_count) v.hash_entries[other_index].next = entry_index;   // visible by its index (visibility_quads)
+      if (entry_index < max_count) v.hash_entries[tail].next = entry_index;   // visible by its index (visibility_quads)
     }
     const int voxel_index = voxel_ptr0 - rank_all;
     if (entry_index < max_count && voxel_index >= 0)
     {
       const int lo = (int)(packed & 0xffffffffull);
       const int hi = (int)((packed >> 32) & 0xffffull);
-      reinterpret_cast<int4*>(v.hash_entries)[entry_index] = make_int4(lo, hi, v.free_voxel_blocks[voxel_index], -1);
+      reinterpret_cast<int4*>(v.hash_entries)[entry_index] = make_int4(lo, hi, free_slot[rank_all], -1);
     }
     else ++dropped;
     if (bucket != keep_bucket)
@@ -1355,22 +1362,30 @@ __device__ __forceinline__ unsigned long long arrive(const vk_volume& v, unsigne
 // visible (volume.cu:344) whatever their byte holds.
 // The workgroup's arrival (see arrival()) is the atomic that reserves its slots of the visible list;
 // returns the arrival word as it was before.
-__device__ __forceinline__ unsigned long long visibility_quads(const VisibilityParams& P, int first, int new_lo, int new_hi,
-    bool fenced)
+// the four visibility bytes of this lane's entries (entries past the end read as 0), and how many there are
+__device__ __forceinline__ uint32_t visibility_quad_load(const vk_volume& v, int first, int& n)
 {
-  __shared__ int wave_total[kHandleThreads / 64];
-  __shared__ unsigned long long arrived;
-
-  const vk_volume& v = P.v;
   const int count = v.main_block_count + v.excess_block_count;
   const int index0 = first + 4 * (int)threadIdx.x;
-  const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
-  int n = count - index0;
+  n = count - index0;
   n = n < 0 ? 0 : (n > 4 ? 4 : n);
-
   uint32_t stored = 0;
   if (n == 4) stored = *reinterpret_cast<const uint32_t*>(v.block_visibility + index0);
   else for (int k = 0; k < n; ++k) stored |= (uint32_t)v.block_visibility[index0 + k] << (8 * k);
+  return stored;
+}
+
+// `stored`, `n`: visibility_quad_load, issued by the caller ahead of everything else. *my_arrival:
+// what this workgroup added to the arrival word.
+__device__ __forceinline__ unsigned long long visibility_quads(const VisibilityParams& P, int first, uint32_t stored, int n,
+    int new_lo, int new_hi, bool fenced, unsigned long long* my_arrival)
+{
+  __shared__ int wave_total[kHandleThreads / 64];
+  __shared__ unsigned long long arrived, added;
+
+  const vk_volume& v = P.v;
+  const int index0 = first + 4 * (int)threadIdx.x;
+  const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
 
   uint32_t result = stored, seen = 0;
 #pragma unroll 1
@@ -1437,10 +1452,12 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
       wave_total[w] = total;
       total += c;
     }
-    arrived = arrive(v, arrival(total, 0, 0), fenced);
+    added = arrival(total, 0, 0);
+    arrived = arrive(v, added, fenced);
   }
   __syncthreads();
   const unsigned long long before_us = arrived;
+  *my_arrival = added;
   int offset = (int)(uint32_t)before_us + wave_total[wave] + incl - mine;
   for (int k = 0; k < 4; ++k)
     if (seen & (1u << k)) v.visible_blocks[offset++] = index0 + k;
@@ -1450,10 +1467,16 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
 
 __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(FusedParams P)
 {
-  __shared__ unsigned long long arrived;
+  __shared__ unsigned long long arrived, added;
   __shared__ int range[2];
   __shared__ int red[2 * (kHandleThreads / 64)];
   const vk_volume& v = P.vis.v;
+  // a visibility workgroup's bytes: asked for before anything else, they travel with the counters
+  const bool vis_group = (int)blockIdx.x >= P.handle_wgs;
+  const int vis_first = ((int)blockIdx.x - P.handle_wgs) * kVisPerGroup;
+  int vis_n = 0;
+  uint32_t vis_stored = 0;
+  if (vis_group) vis_stored = visibility_quad_load(v, vis_first, vis_n);
   const int main_count = v.main_block_count;
   const int max_count = v.main_block_count + v.excess_block_count;
   // what the previous launches left (one cache line; nothing in this launch writes it before the end)
@@ -1475,8 +1498,8 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   const bool listed = posted <= VK_POSTED_SLOTS;
   const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
 
-  unsigned long long before_us;
-  if ((int)blockIdx.x < P.handle_wgs)
+  unsigned long long before_us, my_arrival;
+  if (!vis_group)
   {
     int excess_total = 0, dropped = 0;
     if (listed)
@@ -1489,13 +1512,18 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
     }
     if (fenced) __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) arrived = arrive(v, arrival(0, excess_total, dropped), fenced);
+    if (threadIdx.x == 0)
+    {
+      added = arrival(0, excess_total, dropped);
+      arrived = arrive(v, added, fenced);
+    }
     __syncthreads();
     before_us = arrived;
+    my_arrival = added;
   }
   else
   {
-    const int first = ((int)blockIdx.x - P.handle_wgs) * kVisPerGroup;
+    const int first = vis_first;
     int new_lo = 0, new_hi = 0;
     if (first + kVisPerGroup > excess_ptr0 && posted > 0)
     {
@@ -1524,15 +1552,13 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
       new_lo = excess_ptr0;
       new_hi = excess_ptr0 + n_excess < max_count ? excess_ptr0 + n_excess : max_count;
     }
-    before_us = visibility_quads(P.vis, first, new_lo, new_hi, fenced);
+    before_us = visibility_quads(P.vis, first, vis_stored, vis_n, new_lo, new_hi, fenced, &my_arrival);
   }
 
   // the last one to arrive finishes the round
   if ((int)((before_us >> 32) & 0xffffull) != (int)gridDim.x - 1) return;
   if (fenced) __threadfence();
-  // (the word after the last arrival: read back, not recomputed — every lane needs it)
-  const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(v.counters + VK_CTR_ARRIVALS),
-      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long all = before_us + my_arrival;     // the word after the last arrival: ours
   const int visible_total = (int)(uint32_t)all;
 
   if (listed && !losers)
@@ -1711,6 +1737,7 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
     if (!set_view_unfused(v))
     {
       retry.posted = posted_list(v->counters);
+      retry.posted_tail = posted_list(v->counters) + VK_POSTED_SLOTS;
       retry.posted_count = v->counters + VK_CTR_POSTED;
       retry.posted_capacity = VK_POSTED_SLOTS;
     }

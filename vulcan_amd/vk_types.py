@@ -13,8 +13,8 @@ VK_CTR_VISIBLE, VK_CTR_VOXEL_PTR, VK_CTR_EXCESS_PTR, VK_CTR_PATCHES = 0, 1, 2, 3
 VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 5, 6, 7
 VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_PUBLIC = 8, 9, 10, 24
 VK_RETRY_SLOTS, VK_RETRY_KEYS, VK_POSTED_SLOTS = 65536, 8192, 2048
-# counters, two key sets, two slot lists, the posted buckets
-VK_CTR_COUNT = VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + VK_POSTED_SLOTS
+# counters, two key sets, two slot lists, the posted buckets and their chains' last entries
+VK_CTR_COUNT = VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
 VK_TRACK_ABORTED = -1
 VISIBILITY_UNKNOWN, VISIBILITY_FALSE, VISIBILITY_TRUE = 0, 1, 2
 ALLOC_NONE, ALLOC_MAIN, ALLOC_EXCESS = 0, 1, 2
