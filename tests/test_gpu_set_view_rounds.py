@@ -250,3 +250,36 @@ def test_normals_are_computed_also_when_the_preparation_cannot_ride(api, orc):
     assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
     assert prep.valid == 0 and not prep.normals_out
     assert_volume_equal(dv, hv, voxels=False)
+
+
+def test_the_posted_list_and_the_flag_scan_give_the_same_table(api, orc):
+    """The handle pass works from the list of posted buckets when it holds them all, and from the
+    request flags otherwise. Forced both ways on the same frames (test aid VK_POSTED_CAPACITY), at
+    the boundary: a list that holds exactly the requests of the pass, and one that is one short.
+    Odd table sizes: 1021 + 6001 entries (flag and visibility tails that are not a multiple of 4 / 16)."""
+    w, h = 320, 240
+    depth = scenes.sphere(2 * w, 2 * h)[::2, ::2].copy()
+    poses = (scenes.tracer_test_pose(), scenes.yaw(3.0) * scenes.tracer_test_pose())
+    # how many buckets the first pass posts to: the requests the first round sees
+    hv0 = orc.HostVolume(1021, 6001, voxel_length=0.01, truncation_length=0.04)
+    hf0 = orc.HostFrame(depth, K_SMALL, poses[0])
+    hv0.set_view(hf0, orc.POLICY_MAXKEY)
+    posted = int(hv0.counters[T.VK_CTR_REQUESTS])
+    assert 256 < posted < 1021
+    try:
+        for capacity in (posted, posted - 1, 0, None):
+            if capacity is None:
+                os.environ.pop("VK_POSTED_CAPACITY", None)
+            else:
+                os.environ["VK_POSTED_CAPACITY"] = str(capacity)
+            hv, dv = make_pair(api, orc, 1021, 6001, 0.01, 0.04)
+            for pose in poses:
+                hf, df = frames(api, orc, depth, K_SMALL, pose)
+                oracle_rounds(orc, hv, hf, 3)
+                dv.set_view(df, rounds=3)
+                assert_volume_equal(dv, hv, voxels=False)
+                assert_same_requests(dv, hv)
+            assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 100          # chains: EXCESS requests, new entries visible
+            assert hv.counters[T.VK_CTR_DROPPED] == 0
+    finally:
+        os.environ.pop("VK_POSTED_CAPACITY", None)

@@ -1251,6 +1251,7 @@ struct FusedParams
   int handle_wgs;           // workgroups [0, handle_wgs): the handle pass; the rest: visibility chunks
   int max_rounds;
   int retry_capacity;
+  int posted_capacity;      // entries the posted list holds (VK_POSTED_SLOTS; less as a test aid)
 };
 
 constexpr int kVisPerGroup = 4 * kHandleThreads;   // entries per visibility workgroup: four per lane
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   const bool fenced = contended != 0 || (origin_seen != 0 && v.allocation_types[origin_bucket] != VK_ALLOC_NONE);
   const bool losers = P.max_rounds > 1 && fenced;
   // the requests of this round: listed, or — too many for the list — to be found in the flags
-  const bool listed = posted <= VK_POSTED_SLOTS;
+  const bool listed = posted <= P.posted_capacity;
   const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
 
   unsigned long long before_us, my_arrival;
@@ -1683,6 +1684,17 @@ int check_volume(const vk_volume* v)
   return VK_OK;
 }
 
+// buckets the posted list holds (test aid VK_POSTED_CAPACITY: a small list sends the handle pass to the flags)
+int posted_capacity()
+{
+  if (const char* e = getenv("VK_POSTED_CAPACITY"))
+  {
+    const int n = atoi(e);
+    if (n >= 0 && n < VK_POSTED_SLOTS) return n;
+  }
+  return VK_POSTED_SLOTS;
+}
+
 // distinct keys per retry list (test aid VK_RETRY_CAPACITY: a small list overflows on purpose)
 int retry_capacity()
 {
@@ -1739,7 +1751,7 @@ int launch_create_requests(const vk_volume* v, const float* depth, int width, in
       retry.posted = posted_list(v->counters);
       retry.posted_tail = posted_list(v->counters) + VK_POSTED_SLOTS;
       retry.posted_count = v->counters + VK_CTR_POSTED;
-      retry.posted_capacity = VK_POSTED_SLOTS;
+      retry.posted_capacity = posted_capacity();
     }
   }
   if (prep && prep_frame)
@@ -1923,6 +1935,7 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     F.handle_wgs = handle_groups < VK_POSTED_SLOTS / kHandleThreads ? handle_groups : VK_POSTED_SLOTS / kHandleThreads;
     F.max_rounds = max_rounds;
     F.retry_capacity = retry_capacity();
+    F.posted_capacity = posted_capacity();
     hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
     VK_LAUNCH_CHECK();
     return VK_OK;
