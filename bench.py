@@ -359,10 +359,13 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline):
         sequence = RoomSequence(warmup + steps, T.Projection.make(*scenes.APP_INTRINSICS))
     loop = FrameLoop(workload, poses, sequence=sequence)
     # HIP events (created without the system-scope fence, vk_event_create) around the integrate
-    # launch: a pair of records costs the stream ~1.7 us, so long runs sample every 4th frame
-    stride = 1 if steps <= 64 else 4
+    # launch: a pair of records costs the stream ~2.7 us (K = 20 with every frame bracketed twice read
+    # 107.8 us per frame against 102.5), so every 8th frame is sampled — every 4th of a short run, at
+    # least five frames — and every second of those also brackets the raycast
+    stride = max(1, min(8, steps // 5))
     sampled = list(range(0, steps, stride)) if with_roofline else []
-    events = {i: tuple(loop.make_event() for _ in range(4)) for i in sampled}
+    traced = set(sampled[::2])
+    events = {i: tuple(loop.make_event() for _ in range(4 if i in traced else 2)) for i in sampled}
 
     for i in range(warmup):
         loop.step(i)
@@ -379,7 +382,7 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline):
     out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
     if with_roofline:
         integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled]
-        trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled]
+        trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled if i in traced]
         out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, sampled
     ctr = loop.vols[0]["vol"].read_counters()
     out["_counters"] = ctr
