@@ -66,6 +66,11 @@ METRIC = "RGB-D frames/sec (integrate+raycast), 640x480 @ 5 mm voxels"
 LIGHT = (2.0, (0.025, 0.08, 0.0))                           # apps/vulcan/vulcan.cu:87-88
 EXTRA_NORMALS = int(os.environ.get("VK_BENCH_EXTRA_NORMALS", "0"))   # experiment only; 0 in every reported run
 NORMALS_IN_SET_VIEW = os.environ.get("VK_BENCH_NORMALS_LAUNCH", "0") != "1"   # "1": ComputeNormals as a launch of its own (A/B)
+RIG_TIMEOUT_S = 180                                         # N > 1: the rig step (reported next to the headline) may take this long
+# N > 1: also time the rig's in-launch exchange (peer-mapped areas over xGMI, vk_icp_track_rig). Off unless asked
+# for: the path has never run on more than one GPU (this pool has single-GPU boxes), and a fault in it would take
+# the run's headline with it
+RIG_IN_LAUNCH_EXCHANGE = os.environ.get("VK_BENCH_RIG_EXCHANGE", "0") == "1"
 SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan.cu:316-318
 
 
@@ -590,6 +595,8 @@ def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
         # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
         # on a multi-GPU node the path is unmeasured on hardware
         try:
+            if not RIG_IN_LAUNCH_EXCHANGE:
+                raise RuntimeError("not run: set VK_BENCH_RIG_EXCHANGE=1 (never run on more than one GPU; DESIGN.md section 6)")
             tracker.comm = None
             c.attach_exchange()
             frame.depth_to_world = start
@@ -785,11 +792,26 @@ def main():
 
     if world > 1:
         # the rig step is reported next to the headline, never instead of it: a failure here
-        # (every rank sees the same exception or none: the calls are collective) is recorded
+        # (every rank sees the same exception or none: the calls are collective) is recorded, and
+        # a rank that waits for a peer longer than RIG_TIMEOUT_S (a collective some rank never
+        # entered) ends the run WITH the headline: rank 0 prints the line as it stands, all exit
+        import threading
+
+        def give_up():
+            result["collective"] = {"ok": False, "error": f"the rig step did not finish within {RIG_TIMEOUT_S} s; "
+                                    "the headline above was measured before it and is unaffected"}
+            if rank == 0:
+                emit(result)
+            os._exit(0)
+
+        watchdog = threading.Timer(RIG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             result["collective"] = rig_collective(rank, world, vd)
         except Exception as e:     # noqa: BLE001
             result["collective"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:400]}
+        watchdog.cancel()
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:   # the CPU leg is reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(wl, poses, args.cpu_seconds)
