@@ -105,13 +105,15 @@ constexpr uint8_t kTouched = 4;
 // run after the visibility pass)
 enum { MARK_PLAIN = 0, MARK_DEFER = 1, MARK_APPEND = 2 };
 
+// `known` >= 0: the entry's byte as the caller has already read it (with the probe's table entry, so
+// that the two reads travel together instead of one behind the other)
 template <int MARK>
-__device__ __forceinline__ void mark_visible(const vk_volume& v, uint32_t index)
+__device__ __forceinline__ void mark_visible(const vk_volume& v, uint32_t index, int known = -1)
 {
   // the reference stores unconditionally (volume.cu:190); reading first keeps
   // hundreds of rays that cross the same block from all storing the same byte
   uint8_t* vis = v.block_visibility;
-  const uint8_t old = vis[index];
+  const uint8_t old = known >= 0 ? (uint8_t)known : vis[index];
   if (MARK == MARK_DEFER) { if (!(old & kTouched)) vis[index] = old | kTouched; }
   else if (MARK == MARK_PLAIN) { if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE; }
   else if (old != VK_VISIBILITY_TRUE)
@@ -234,11 +236,11 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 // main entry is known
 template <int MARK>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
-    int bx, int by, int bz, const Retry& retry)
+    int bx, int by, int bz, const Retry& retry, int main_byte = -1)
 {
   if (entry_is(entry, bx, by, bz))
   {
-    mark_visible<MARK>(v, hash_code);
+    mark_visible<MARK>(v, hash_code, main_byte);
     // An unallocated main entry holds block (0,0,0) and compares equal to it (volume.cu:186-191):
     // the origin block counts as present without ever having been requested — until another
     // block takes that entry, from when on its rays do request it. It is the one block a later
@@ -249,7 +251,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   }
   else if (entry.data == -1)
   {
-    mark_visible<MARK>(v, hash_code);
+    mark_visible<MARK>(v, hash_code, main_byte);
     post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry, hash_code);
   }
   else
@@ -413,16 +415,23 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
     if (same) shash[sidx] = 0xffffffffu;
   }
 
+  // (the visibility byte of each bucket's main entry is asked for with the entry: most blocks are
+  // found there, and marking them visible would otherwise start with a read of its own)
   Entry sent[kProbe];
+  uint8_t sbyte[kProbe];
 #pragma unroll
   for (int sidx = 0; sidx < kProbe; ++sidx)
-    sent[sidx] = load_entry(v.hash_entries, shash[sidx] == 0xffffffffu ? 0u : shash[sidx]);
+  {
+    const uint32_t at = shash[sidx] == 0xffffffffu ? 0u : shash[sidx];
+    sent[sidx] = load_entry(v.hash_entries, at);
+    sbyte[sidx] = v.block_visibility[at];
+  }
 
 #pragma unroll
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block<MARK>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry);
+    probe_block<MARK>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry, (int)sbyte[sidx]);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
