@@ -980,22 +980,36 @@ __device__ __forceinline__ void clear_requests(const vk_volume& v, int* total_al
   const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
   const int chunks = count / 16;
   int n_all = 0, n_excess = 0;
-  for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
+  // eight 16-byte loads in flight per lane (one workgroup walks the whole array: a load per trip
+  // would be one L2 round trip per trip)
+  for (int c0 = (int)threadIdx.x; c0 < chunks; c0 += 8 * kHandleThreads)
   {
-    const uint4 q = flags16[c];
-    if ((q.x | q.y | q.z | q.w) == 0u) continue;
-    count_flags(q.x, n_all, n_excess);
-    count_flags(q.y, n_all, n_excess);
-    count_flags(q.z, n_all, n_excess);
-    count_flags(q.w, n_all, n_excess);
-    for (int b = 0; b < 16; ++b)
+    uint4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
     {
-      const int i = c * 16 + b;
-      if (v.allocation_types[i] != VK_ALLOC_NONE)
+      const int c = c0 + u * kHandleThreads;
+      q[u] = c < chunks ? flags16[c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+    {
+      if ((q[u].x | q[u].y | q[u].z | q[u].w) == 0u) continue;
+      const int c = c0 + u * kHandleThreads;
+      count_flags(q[u].x, n_all, n_excess);
+      count_flags(q[u].y, n_all, n_excess);
+      count_flags(q[u].z, n_all, n_excess);
+      count_flags(q[u].w, n_all, n_excess);
+      const uint32_t words[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
       {
-        v.allocation_types[i] = VK_ALLOC_NONE;
-        reinterpret_cast<unsigned long long*>(v.allocation_blocks)[i] = 0ull;
+        if (words[w] == 0u) continue;
+        for (int b = 0; b < 4; ++b)
+          if ((words[w] >> (8 * b)) & 0xffu)
+            reinterpret_cast<unsigned long long*>(v.allocation_blocks)[c * 16 + w * 4 + b] = 0ull;
       }
+      const_cast<uint4*>(flags16)[c] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
   for (int i = chunks * 16 + (int)threadIdx.x; i < count; i += kHandleThreads)
@@ -1512,14 +1526,10 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   if (!vis_group)
   {
     int excess_total = 0, dropped = 0;
+    // (too many requests for the list: the flags are scanned by the visibility workgroups, which are
+    // as many as there are groups of 1024 buckets, or more; these few have nothing to do then)
     if (listed)
       dropped = handle_listed(v, posted, (int)blockIdx.x, P.handle_wgs, origin_bucket, voxel_ptr0, excess_ptr0, &excess_total);
-    else
-    {
-      const int groups = (main_count + kHandlePerGroup - 1) / kHandlePerGroup;
-      for (int group = (int)blockIdx.x; group < groups; group += P.handle_wgs)
-        handle_group(v, group, groups, 0, 2, v.counters + VK_CTR_DROPPED_NOW);
-    }
     if (fenced) __threadfence();
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1561,6 +1571,15 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
       block_sum2(n_all, n_excess, red);
       new_lo = excess_ptr0;
       new_hi = excess_ptr0 + n_excess < max_count ? excess_ptr0 + n_excess : max_count;
+    }
+    if (!listed)
+    {
+      // the handle pass from the flags (handle_group), one group of 1024 buckets per visibility
+      // workgroup — before this workgroup arrives: the flags are cleared by the last arrival
+      const int groups = (main_count + kHandlePerGroup - 1) / kHandlePerGroup;
+      const int vis_groups = (int)gridDim.x - P.handle_wgs;
+      for (int group = (int)blockIdx.x - P.handle_wgs; group < groups; group += vis_groups)
+        handle_group(v, group, groups, 0, 2, v.counters + VK_CTR_DROPPED_NOW);
     }
     before_us = visibility_quads(P.vis, first, vis_stored, vis_n, new_lo, new_hi, fenced, &my_arrival);
   }
