@@ -1557,13 +1557,23 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
       {
         const uint4* flags16 = reinterpret_cast<const uint4*>(v.allocation_types);
         const int chunks = main_count / 16;
-        for (int c = (int)threadIdx.x; c < chunks; c += kHandleThreads)
+        for (int c0 = (int)threadIdx.x; c0 < chunks; c0 += 8 * kHandleThreads)   // eight loads in flight
         {
-          const uint4 q = flags16[c];
-          count_flags(q.x, n_all, n_excess);
-          count_flags(q.y, n_all, n_excess);
-          count_flags(q.z, n_all, n_excess);
-          count_flags(q.w, n_all, n_excess);
+          uint4 q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+          {
+            const int c = c0 + u * kHandleThreads;
+            q[u] = c < chunks ? flags16[c] : make_uint4(0u, 0u, 0u, 0u);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+          {
+            count_flags(q[u].x, n_all, n_excess);
+            count_flags(q[u].y, n_all, n_excess);
+            count_flags(q[u].z, n_all, n_excess);
+            count_flags(q[u].w, n_all, n_excess);
+          }
         }
         for (int i = chunks * 16 + (int)threadIdx.x; i < main_count; i += kHandleThreads)
           n_excess += v.allocation_types[i] == VK_ALLOC_EXCESS ? 1 : 0;
