@@ -102,38 +102,27 @@ __device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by,
 
 // files a resolved block in the directory: one distinct block per trip, written by a
 // single lane so that an entry is never a mix of two lanes' stores
-#ifndef VK_FILE_BUDGET
-#define VK_FILE_BUDGET 4
-#endif
 __device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
 {
-  // Filing is an optimisation (a block that is not filed is looked up in the table again), and it is
-  // serial: one trip per DISTINCT block. Rays that run through empty space behind an object's
-  // silhouette enter a new block every trip, each lane its own: a dozen distinct blocks per trip
-  // that nobody will ask for again. So at most VK_FILE_BUDGET blocks are filed per call, the
-  // allocated ones first. (rocprofv3 averages, tracking scene / fusion benchmark, tools/variants.sh:
-  // no limit 94.8 / 32.1 us, 8: 92.1 / 31.3, 4: 90.9 / 31.4, 2: 87.6 / 32.1 .. 32.3, 1: 83.5 / 33.2 —
-  // the fusion benchmark wants its absent corner blocks filed. Also measured there: the NEXT block
-  // along the ray looked up in the same round trip and kept by the lane for its next trip — half the
-  // round trips of a run through empty space, 101.8 / 33.8 us: the trips' instructions, not their
-  // table reads, are what a slow wave spends its time on.)
-  int budget = VK_FILE_BUDGET;
-  bool first = pending && data >= 0;
-  for (int pass = 0; pass < 2; ++pass)
+  // (Filing is serial, one trip per DISTINCT block, and rays that run through empty space behind an
+  // object's silhouette enter a new block every trip, each lane its own. Measured, r03: at most N
+  // blocks filed per call, the allocated ones first — rocprofv3 averages of the tracking scene / the
+  // fusion benchmark with this loop as it is 89.9 / 31.4 us; N = 8: 92.1 / 31.3, 4: 90.9 / 31.4,
+  // 2: 87.6 / 32.2, 1: 83.5 / 33.2: what the tracking scene gains the fusion benchmark loses, whose
+  // absent corner blocks want to be filed. Also measured: the NEXT block along the ray looked up in
+  // the same round trip and kept by the lane for its next trip — half the table round trips of an
+  // empty run, 101.8 / 33.8 us: the trips' instructions, not their reads, are what a slow wave
+  // spends its time on.)
+  while (__any(pending))
   {
-    bool todo = pass == 0 ? first : (pending && data < 0);
-    while (budget > 0 && __any(todo))
-    {
-      --budget;
-      const unsigned long long mask = __ballot(todo);
-      const int leader = __ffsll((long long)mask) - 1;
-      const int ubx = __builtin_amdgcn_readlane(bx, leader);
-      const int uby = __builtin_amdgcn_readlane(by, leader);
-      const int ubz = __builtin_amdgcn_readlane(bz, leader);
-      const int udata = __builtin_amdgcn_readlane(data, leader);
-      if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
-      if (bx == ubx && by == uby && bz == ubz) todo = false;
-    }
+    const unsigned long long mask = __ballot(pending);
+    const int leader = __ffsll((long long)mask) - 1;
+    const int ubx = __builtin_amdgcn_readlane(bx, leader);
+    const int uby = __builtin_amdgcn_readlane(by, leader);
+    const int ubz = __builtin_amdgcn_readlane(bz, leader);
+    const int udata = __builtin_amdgcn_readlane(data, leader);
+    if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
+    if (bx == ubx && by == uby && bz == ubz) pending = false;
   }
   wave_lds_fence();   // later reads of the directory, by any lane, see these entries
 }
