@@ -104,15 +104,14 @@ __device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by,
 // single lane so that an entry is never a mix of two lanes' stores
 __device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
 {
-  // (Filing is serial, one trip per DISTINCT block, and rays that run through empty space behind an
-  // object's silhouette enter a new block every trip, each lane its own. Measured, r03: at most N
-  // blocks filed per call, the allocated ones first — rocprofv3 averages of the tracking scene / the
-  // fusion benchmark with this loop as it is 89.9 / 31.4 us; N = 8: 92.1 / 31.3, 4: 90.9 / 31.4,
-  // 2: 87.6 / 32.2, 1: 83.5 / 33.2: what the tracking scene gains the fusion benchmark loses, whose
-  // absent corner blocks want to be filed. Also measured: the NEXT block along the ray looked up in
-  // the same round trip and kept by the lane for its next trip — half the table round trips of an
-  // empty run, 101.8 / 33.8 us: the trips' instructions, not their reads, are what a slow wave
-  // spends its time on.)
+  // (Filing is serial: one trip per DISTINCT block. Measured, r03, tracking scene / fusion benchmark:
+  // a limit of N blocks per call, the allocated ones first — 8: 92.1 / 31.3 us, 4: 90.9 / 31.4,
+  // 2: 87.6 / 32.2, 1: 83.5 / 33.2 against 90.9 / 31.5 without a limit: the fusion benchmark wants the
+  // absent CORNER blocks of its samples filed. What does help both is not filing the absent blocks
+  // the MARCH runs through, find_block. Also measured: the NEXT block along the ray looked up in the
+  // same round trip and kept by the lane for its next trip — half the table round trips of an empty
+  // run, 101.8 / 33.8 us: the trips' instructions, not their reads, are what a slow wave spends its
+  // time on.)
   while (__any(pending))
   {
     const unsigned long long mask = __ballot(pending);
@@ -128,7 +127,10 @@ __device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int
 }
 
 // slot of block (bx, by, bz) for the lanes with `active` set; -1 = absent
-__device__ __forceinline__ int lookup_block(const PointParams& P, int4* dir, bool active, int bx, int by, int bz)
+// `file_absent`: whether a block that turns out not to be allocated is filed as well (a later
+// request for it is then answered from the directory)
+__device__ __forceinline__ int lookup_block(const PointParams& P, int4* dir, bool active, int bx, int by, int bz,
+    bool file_absent = true)
 {
   const int4 e = dir[dir_index(bx, by, bz)];
   int data = e.w;
@@ -137,7 +139,7 @@ __device__ __forceinline__ int lookup_block(const PointParams& P, int4* dir, boo
   {
     // directory misses probe the global table, all lanes in parallel, then file their answers
     if (missed) data = probe_table(P, bx, by, bz);
-    file_blocks(dir, missed, bx, by, bz, data);
+    file_blocks(dir, missed && (file_absent || data >= 0), bx, by, bz, data);
   }
   return data;
 }
@@ -145,7 +147,12 @@ __device__ __forceinline__ int lookup_block(const PointParams& P, int4* dir, boo
 __device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cache, int4* dir, int bx, int by, int bz)
 {
   if (cache.valid && cache.bx == bx && cache.by == by && cache.bz == bz) return cache.data;
-  const int data = lookup_block(P, dir, true, bx, by, bz);
+  // The block a ray is IN, when it is not allocated, is not filed: filing is serial in the number of
+  // distinct blocks, the ray leaves an absent block with its next trip, and rays that run through
+  // empty space (past an object's silhouette towards a far wall: dozens of trips, every lane its own
+  // block) would file a dozen blocks per trip that nobody asks for again. rocprofv3 averages, r03,
+  // tracking scene / fusion benchmark: 90.9 / 31.5 us with those filed, 77.8 / 30.9 without.
+  const int data = lookup_block(P, dir, true, bx, by, bz, false);
   cache.bx = bx; cache.by = by; cache.bz = bz; cache.data = data; cache.valid = true;
   return data;
 }
