@@ -147,9 +147,10 @@ typedef struct vk_volume {
   vk_voxel*      voxels;             /* [max_block_count * 512]      voxels_            */
   vk_hash_entry* hash_entries;       /* [max_block_count]            hash_entries_      */
   int32_t*       free_voxel_blocks;  /* [max_block_count]            free_voxel_blocks_ */
-  uint8_t*       allocation_types;   /* [main_block_count]           allocation_types_  */
+  uint8_t*       allocation_types;   /* [main_block_count], 16-byte aligned             allocation_types_  */
   vk_block*      allocation_blocks;  /* [main_block_count], 8-byte aligned  allocation_blocks_ */
-  uint8_t*       block_visibility;   /* [max_block_count]            block_visibility_  */
+  uint8_t*       block_visibility;   /* [max_block_count], 4-byte aligned, the allocation padded to a multiple of
+                                        4 bytes (the last bytes are accessed as part of their word)  block_visibility_  */
   int32_t*       visible_blocks;     /* [max_block_count]            visible_blocks_    */
   int32_t*       counters;           /* [VK_CTR_COUNT]               (volume.cu:17-21)  */
   int32_t        main_block_count;
