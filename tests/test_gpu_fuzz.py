@@ -48,10 +48,17 @@ def test_random_configuration(api, orc, seed):
         pose = random_pose(rng, 0.3) * pose
         hf, df = frames(api, orc, depth, k, pose, color=color)
         hf.compute_normals()
-        df.compute_normals()
         for _ in range(2):
             hv.set_view(hf, orc.POLICY_MAXKEY)
-            dv.set_view(df)
+        if seed % 2 == 1 and hv.counters[T.VK_CTR_DROPPED] == 0:
+            # the two calls as one, the frame's normals computed on the way (inside the request pass
+            # once the light integrator has registered its buffers, by a launch of their own otherwise)
+            dv.set_view(df, rounds=2, compute_normals=True)
+            assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+        else:
+            df.compute_normals()
+            for _ in range(2):
+                dv.set_view(df)
         orc.integrate_depth(hv, hf)
         if mode == 1:
             orc.integrate_color(hv, hf)
