@@ -8,7 +8,9 @@ mask, depth, shaded colour: configs[2]'s integrators) -> Tracer::Trace — the c
 reference's frame loop (apps/vulcan/vulcan.cu:297,316-325) — through the C ABI
 (include/vk.h), into Volume(65024, 8192) (vulcan.cu:12-13). The three SetView calls are ONE
 vk_volume_set_view_rounds(.., 3): same state, the later rounds run on the device and only
-when the round before lost a request. The camera sits at the centre of a 2 m sphere and yaws
+when the round before lost a request; in `rgbd` (no tracker reads the normals first) that
+call also computes the frame's normals, in its request pass (vk_light_prep.normals_out: the
+same normal image, written to the frame). The camera sits at the centre of a 2 m sphere and yaws
 0.5 deg per frame: the depth image (resident in HBM) is the same closed form every frame
 while new blocks are allocated every frame.
 
