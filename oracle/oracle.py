@@ -482,3 +482,24 @@ def light_system(key, frm, terms, Tcm, translation_enabled=True):
     lib().orc_light_tracker_compute_system(C.byref(kv), C.byref(fv), C.byref(terms), C.byref(Tcm),
                                            int(translation_enabled), _p(h), _p(g))
     return h, g
+
+
+def light_track(key, frame, light, max_iterations=20, depth_threshold=0.2, translation_enabled=True):
+    """Tracker::Track for LightTracker (tracker.cpp:53-63 with light_tracker.cpp:34-41 as BeginSolve:
+    the frame mask and both intensity images are made once, then Gauss-Newton until max_iterations
+    or |update| < 1e-6). Updates frame.depth_to_world; returns (pose, iterations run)."""
+    key_side, frame_side = ColorSide(key, False), ColorSide(frame, True)
+    mask = light_frame_mask(frame, depth_threshold)
+    key_Twc = (key.depth_to_color * key.depth_to_world.inverse()).inverse()
+    p = T.ColorPose()
+    p.depth_to_world = frame.depth_to_world
+    lib().orc_color_tracker_tcm(C.byref(frame.depth_to_color), C.byref(key_Twc), C.byref(p))
+    it = 0
+    while it < max_iterations:
+        h, g = light_system(key_side, frame_side, light_terms(frame, light, mask), p.Tcm, translation_enabled)
+        _, norm = color_solve_update(h, g, frame.depth_to_color, key_Twc, p, translation_enabled)
+        it += 1
+        if norm < 1e-6:
+            break
+    frame.depth_to_world = T.Transform.from_buffer_copy(bytes(p.depth_to_world))
+    return frame.depth_to_world, it

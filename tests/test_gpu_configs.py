@@ -28,45 +28,54 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ------------------------------------------------------------------ configs[2] --
 
 def test_rgbd_bench_sequence_matches_oracle(api, orc):
-    """The exact `bench.py --workload rgbd` frame loop (640x480, 5 mm, Volume(65024, 8192),
-    light (2, (.025,.08,0)) as in apps/vulcan/vulcan.cu:87-88): 5 frames, bit for bit."""
-    import torch
+    """The exact step `bench.py --workload rgbd` times — bench.FrameLoop.step itself, i.e. ONE
+    vk_volume_set_view_rounds(.., 3) that also computes the input frame's normals and prepares the
+    light integrator's records (vk_light_prep.normals_out), vk_integrate_ahead with those records and
+    the raycast bounds riding along, vk_trace_ahead — at 640x480, 5 mm, Volume(65024, 8192), light
+    (2, (.025,.08,0)) as in apps/vulcan/vulcan.cu:87-88, six frames from the empty volume. Oracle side:
+    Frame::ComputeNormals, three SetView calls, the frame mask, depth and shaded-colour passes, Trace
+    (vulcan.cu:297,316-325). Every image of every frame and, at the end, every voxel byte."""
     sys.path.insert(0, ROOT)
     import bench
+    count = 6
     k = T.Projection.make(*scenes.APP_INTRINSICS)
     depth = bench.sphere_room_depth(k)
     color = scenes.checker_color(bench.W, bench.H, 0.1, 0.9)
-    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    light = T.Light.make(*bench.LIGHT)
+    poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(count)]
+    assert bench.SET_VIEW_ROUNDS == 3 and bench.NORMALS_IN_SET_VIEW
+    loop = bench.FrameLoop("rgbd", poses)
+    dv, tracer = loop.vols[0]["vol"], loop.vols[0]["tracer"]
     orc.set_threads(16)
-    hv, dv = make_pair(api, orc, bench.MAIN, bench.EXCESS, bench.VOXEL, bench.TRUNC)
-    hf, df = frames(api, orc, depth, k, T.Transform.identity(), color=color)
-    hf.compute_normals()
-    df.compute_normals()
-    sync()
-    assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
-    out = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, T.Transform.identity())
-    integ, tracer = api.LightIntegrator(dv), api.Tracer(dv)
-    integ.light = light
-    for i in range(5):
-        pose = scenes.orbit_pose(i, bench.YAW_STEP)
-        hf.depth_to_world = df.depth_to_world = out.depth_to_world = pose
-        hv.set_view(hf, orc.POLICY_MAXKEY)
+    hv = orc.HostVolume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    hf = orc.HostFrame(depth, k, T.Transform.identity(), color=color)
+    rounds_before = 0
+    for i in range(count):
+        hf.depth_to_world = poses[i]
+        hf.compute_normals()                                  # vulcan.cu:297
+        for _ in range(3):                                    # vulcan.cu:316-318
+            hv.set_view(hf, orc.POLICY_MAXKEY)
         orc.integrate_depth(hv, hf)
         mask = orc.light_frame_mask(hf, 0.2)
         orc.integrate_light_color(hv, hf, light, mask)
         odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
-        dv.set_view(df)
-        integ.integrate(df)                 # mask kernel + fused depth/shaded-colour pass + bounds ahead
-        tracer.trace(out)
+        loop.frame.normals.fill_(-7.0)                        # whatever the step leaves here, it computed itself
+        loop.step(i)
         sync()
-        assert tracer.view_bounds.valid == 1
-        assert np.array_equal(integ.frame_mask.cpu().numpy(), mask)
+        ctr = dv.read_counters()
+        rounds_before, rounds = int(ctr[T.VK_CTR_ROUNDS]), int(ctr[T.VK_CTR_ROUNDS]) - rounds_before
+        assert 1 <= rounds <= 3
+        if i == 0:
+            assert rounds > 1                                 # 7 k blocks at once: some lose their bucket
+        assert tracer.view_bounds.valid == 1                  # the bounds came with the integrate launch
+        assert np.array_equal(loop.frame.normals.cpu().numpy(), hf.normals, equal_nan=True)
+        assert np.array_equal(loop.mask.cpu().numpy(), mask)
         assert dv.visible_count == hv.visible_count > 5000
         assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
-        assert np.array_equal(out.depth.cpu().numpy(), odepth)
-        assert np.array_equal(out.color.cpu().numpy(), ocolor)
-        assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
-    assert_volume_equal(dv, hv)
+        assert np.array_equal(loop.key.depth.cpu().numpy(), odepth)
+        assert np.array_equal(loop.key.color.cpu().numpy(), ocolor)
+        assert np.array_equal(loop.key.normals.cpu().numpy(), onormals, equal_nan=True)
+        assert_volume_equal(dv, hv, voxels=(i == count - 1))
     got = dv.host_voxels()
     assert (got["color_weight"] > 0).sum() > 500000          # the colour pass really ran
     orc.set_threads(1)

@@ -110,21 +110,12 @@ def test_masked_pixels_fall_back_to_point_to_plane(orc, scene):
 
 
 def _track(orc, key, key_side, frm, frm_side, light, pose, tracks, iterations=20):
-    """Tracker::Track x `tracks` with LightTracker::BeginSolve's mask (light_tracker.cpp:34-41)."""
-    mask = orc.light_frame_mask(frm, 0.2)
-    key_Twc = (key.depth_to_color * key.depth_to_world.inverse()).inverse()
+    """Tracker::Track x `tracks` with LightTracker::BeginSolve's mask (light_tracker.cpp:34-41):
+    orc.light_track is the loop the closed-loop GPU test also runs."""
+    probe = orc.HostFrame(frm.depth, frm.depth_projection, pose, color=frm.color, normals=frm.normals)
     for _ in range(tracks):
-        p = T.ColorPose()
-        p.depth_to_world = pose
-        orc.lib().orc_color_tracker_tcm(C.byref(frm.depth_to_color), C.byref(key_Twc), C.byref(p))
-        for _ in range(iterations):
-            probe = orc.HostFrame(frm.depth, frm.depth_projection, p.depth_to_world)
-            h, g = orc.light_system(key_side, frm_side, orc.light_terms(probe, light, mask), p.Tcm, True)
-            _, norm = orc.color_solve_update(h, g, frm.depth_to_color, key_Twc, p, True)
-            if norm < 1e-6:
-                break
-        pose = p.depth_to_world
-    return pose
+        orc.light_track(key, probe, light, iterations)
+    return probe.depth_to_world
 
 
 def test_track_holds_and_recovers_the_pose(orc, scene):

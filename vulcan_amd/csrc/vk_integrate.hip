@@ -70,10 +70,14 @@ constexpr int kTileF4 = 640;  // float4 per voxel block
 __device__ __forceinline__ float exact_quotient(float a, double inv_b) { return (float)((double)a * inv_b); }
 
 // The running averages divide by a weight: a small integer (the weights are capped at 16 by
-// default, integrator.cu:7-13). RN64(1 / n) for n < kReciprocals sits in LDS, filled once per
+// default, integrator.cu:7-13; the shipped app caps the distance weight at 100,
+// apps/vulcan/vulcan.cu:92). RN64(1 / n) for n < kReciprocals sits in LDS, filled once per
 // workgroup with the correctly rounded double division; a wave that meets a larger weight takes
-// the plain division.
-constexpr int kReciprocals = 33;    // weights 0 .. 31 divide by 1 .. 32
+// the plain division (tests/test_gpu_weights.py runs both sides of that test).
+constexpr int kReciprocals = 129;   // weights 0 .. 127 divide by 1 .. 128
+constexpr uint32_t kLargeWeightBits = 0xff80ff80u;   // set in a weight pair when either is negative or >= 128
+// one byte per 16-byte piece of a half tile
+constexpr int kChangedBytes = 320;
 
 // light.h:53-60
 __device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 normal)
@@ -179,9 +183,9 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
   tile4[2 * 64 + lane] = r2;
   tile4[3 * 64 + lane] = r3;
   tile4[4 * 64 + lane] = r4;
-  // one byte per 16-byte piece of the half tile (320 used): set by the lane that
-  // changes a dword of the piece, read at write-back by the lane that owns the piece
-  reinterpret_cast<uint2*>(changed)[lane] = make_uint2(0u, 0u);
+  // one byte per 16-byte piece of the half tile: set by the lane that changes a dword
+  // of the piece, read at write-back by the lane that owns the piece
+  if (lane < kChangedBytes / 8) reinterpret_cast<uint2*>(changed)[lane] = make_uint2(0u, 0u);
   wave_lds_fence();   // float4-per-lane layout written, voxel-per-lane layout read
 
   float old_d[4];
@@ -194,9 +198,9 @@ __device__ __forceinline__ void unit_update(const IntegrateParams& P, int lane, 
     old_w[k] = __float_as_uint(vox[4]);
   }
 
-  // every weight of the wave's voxels below kReciprocals (bits 5..14 of both 16-bit halves clear;
+  // every weight of the wave's voxels below kReciprocals - 1 (bits 7..14 of both 16-bit halves clear;
   // a negative weight has bit 15 set): the divisions by weight + 1 use the reciprocal table
-  const bool small_weights = !__any(((old_w[0] | old_w[1] | old_w[2] | old_w[3]) & 0xffe0ffe0u) != 0u);
+  const bool small_weights = !__any(((old_w[0] | old_w[1] | old_w[2] | old_w[3]) & kLargeWeightBits) != 0u);
 
   bool dirty = false;
   float dist[4];   // the voxel's current distance after the depth pass (or as stored)
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
   constexpr int kTileInts = kPipeWavesPerGroup * kHalfF4 * 4;
   constexpr int kPoolInts = AHEAD ? (2 * kAheadMaxCells > kTileInts ? 2 * kAheadMaxCells : kTileInts) : kTileInts;
   __shared__ __attribute__((aligned(16))) int pool[kPoolInts];
-  __shared__ __attribute__((aligned(8))) uint8_t changed_bytes[kPipeWavesPerGroup][512];
+  __shared__ __attribute__((aligned(8))) uint8_t changed_bytes[kPipeWavesPerGroup][kChangedBytes];
   __shared__ double reciprocal[kReciprocals];
 
   int group = (int)blockIdx.x, groups = (int)gridDim.x;
