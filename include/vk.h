@@ -121,6 +121,9 @@ enum {
                              (may exceed VK_POSTED_SLOTS: then the handle pass scans the request flags instead) */
   VK_CTR_ARRIVALS   = 18, /* internal [2], one 64-bit word: the arrivals of the workgroups of the handle + visibility
                              launch of vk_volume_set_view* (zero between calls) */
+  VK_CTR_BANDED     = 20, /* internal: the banded visible lists (below) hold exactly VK_CTR_VISIBLE entries — set to that
+                             count by the handle + visibility launch of vk_volume_set_view* when it has listed every
+                             visible entry in them, to -1 by everything else that writes the visible list */
   VK_CTR_PUBLIC     = 24, /* what vk_volume_read_counters_sync copies */
   /* behind the counters, for vk_volume_set_view_rounds: the blocks whose request lost its bucket in
    * the round before — two open-addressing sets of VK_RETRY_SLOTS 64-bit request keys (current
@@ -131,7 +134,13 @@ enum {
    * EXCESS request), and for each the last entry of its chain: what the handle pass of
    * vk_volume_set_view* works from when there are few */
   VK_POSTED_SLOTS   = 2048,
-  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192 + 2 * 2048
+  /* then the visible entries once more, binned by the image row band of a depth pixel whose ray touched the block
+   * (VK_BANDS bands of height / VK_BANDS rows): VK_BANDS counts, then VK_BANDS lists of VK_BAND_SLOTS entry indices.
+   * The integrate kernels deal the bands to the XCDs, so that each XCD's L2 holds the image rows its blocks project
+   * to (round 4). A band with more entries than slots makes the integrate kernels use the plain list. */
+  VK_BANDS          = 8,
+  VK_BAND_SLOTS     = 16384,
+  VK_CTR_COUNT      = 24 + 2 * 2 * 65536 + 2 * 8192 + 2 * 2048 + 8 + 8 * 16384
 };
 
 enum {

@@ -44,6 +44,21 @@ namespace vk
 
 constexpr int kWave = 64;       // CDNA4 wavefront
 constexpr int kCUs = 256;       // MI355X compute units
+constexpr int kXCDs = 8;        // accelerator dies; workgroup g of a launch runs on XCD g % kXCDs, each with its own L2
+
+// Behind the counters, the retry sets and the posted list (vk.h): the banded visible lists — VK_BANDS counts, then
+// VK_BANDS lists of VK_BAND_SLOTS entry indices (written by vk_volume.hip's visibility pass, read by vk_integrate.hip)
+__host__ __device__ inline int32_t* band_counts(int32_t* counters)
+{
+  return counters + VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS;
+}
+__host__ __device__ inline const int32_t* band_counts(const int32_t* counters)
+{
+  return counters + VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS;
+}
+__host__ __device__ inline int32_t* band_lists(int32_t* counters) { return band_counts(counters) + VK_BANDS; }
+__host__ __device__ inline const int32_t* band_lists(const int32_t* counters) { return band_counts(counters) + VK_BANDS; }
+static_assert(VK_BANDS == kXCDs, "one band of image rows per XCD");
 
 // 8- and 12-byte loads of packed floats at 4-byte aligned addresses (gfx950 global
 // loads only need dword alignment): a 12-byte Vector3f is one dwordx3 load

@@ -20,6 +20,9 @@
 #ifndef VK_INTEGRATE_NT_STORES
 #define VK_INTEGRATE_NT_STORES 0
 #endif
+#ifndef VK_INTEGRATE_PLAIN_LIST
+#define VK_INTEGRATE_PLAIN_LIST 0   // 1: never use the banded visible lists (A/B measurements, tools/build_variant.sh)
+#endif
 
 // Four waves per SIMD (<= 128 VGPRs) for every variant: the RGB-D kernel is bound by the
 // latency of its image gathers and division chains, and ran 42 us at three waves
@@ -438,19 +441,67 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
 
   const int lane = lane_id();
   const int wave_in_group = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wave = group * kPipeWavesPerGroup + wave_in_group;
-  const int total_waves = groups * kPipeWavesPerGroup;
   const int count = P.counters[VK_CTR_VISIBLE];
   float4* tile4 = reinterpret_cast<float4*>(pool) + wave_in_group * kHalfF4;
   uint8_t* changed = changed_bytes[wave_in_group];
 
-  for (int first = wave; first < count; first += 64 * total_waves)
+  // Which blocks this wave takes. Plainly: item wave, wave + total_waves, ... of the visible list. With the banded
+  // lists of the visibility pass (vk.h VK_BANDS; valid when VK_CTR_BANDED equals the count, every band within its
+  // slots, the counts adding up): the lists are read as ONE list in band order and XCD x (workgroup g runs on XCD
+  // g % 8) takes the x-th eighth of it — equal shares, each a contiguous range of image rows, so that the depth
+  // pixels, records and colours an XCD's blocks gather from are one eighth of the images (plus the rows of the bands'
+  // overlap) and stay in that XCD's 4 MB L2. Dealt round robin, every L2 streamed all 9.8 MB of images for itself:
+  // 3.6 fetches of every image byte per launch (profiles/r03_integrate_rgbd_traffic.json).
+  int lo = 0, hi = count, stride = groups * kPipeWavesPerGroup, first_item = group * kPipeWavesPerGroup + wave_in_group;
+  int band_end[VK_BANDS];
+  bool banded = !VK_INTEGRATE_PLAIN_LIST && groups >= kXCDs && count > 0 && P.counters[VK_CTR_BANDED] == count;
+  if (banded)
+  {
+    const int32_t* sizes = band_counts(P.counters);
+    int total = 0;
+#pragma unroll
+    for (int b = 0; b < VK_BANDS; ++b)
+    {
+      const int n = sizes[b];
+      banded = banded && n >= 0 && n <= VK_BAND_SLOTS;
+      total += n;
+      band_end[b] = total;
+    }
+    banded = banded && total == count;
+  }
+  if (banded)
+  {
+    const int xcd = group % kXCDs, local_group = group / kXCDs;
+    const int local_groups = (groups - xcd + kXCDs - 1) / kXCDs;
+    lo = (int)(((long long)count * xcd) / kXCDs);
+    hi = (int)(((long long)count * (xcd + 1)) / kXCDs);
+    stride = local_groups * kPipeWavesPerGroup;
+    first_item = lo + local_group * kPipeWavesPerGroup + wave_in_group;
+  }
+  const int32_t* lists = band_lists(P.counters);
+
+  for (int first = first_item; first < hi; first += 64 * stride)
   {
     // lane j holds the hash entry of this wave's j-th block of the group
-    const int mine = first + lane * total_waves;
+    const int mine = first + lane * stride;
     int4 my_entry = make_int4(0, 0, -1, -1);
-    if (mine < count) my_entry = reinterpret_cast<const int4*>(P.entries)[P.visible[mine]];
-    int blocks = (count - first + total_waves - 1) / total_waves;
+    if (mine < hi)
+    {
+      int entry_index;
+      if (banded)
+      {
+        int b = 0;
+#pragma unroll
+        for (int i = 0; i < VK_BANDS - 1; ++i) b += mine >= band_end[i] ? 1 : 0;
+        int before = 0;
+#pragma unroll
+        for (int i = 0; i < VK_BANDS - 1; ++i) before = (b == i + 1) ? band_end[i] : before;
+        entry_index = lists[b * VK_BAND_SLOTS + (mine - before)];
+      }
+      else entry_index = P.visible[mine];
+      my_entry = reinterpret_cast<const int4*>(P.entries)[entry_index];
+    }
+    int blocks = (hi - first + stride - 1) / stride;
     if (blocks > 64) blocks = 64;
     const int units = 2 * blocks;   // unit s = (block s >> 1, half s & 1)
 

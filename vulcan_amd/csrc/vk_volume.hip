@@ -98,6 +98,16 @@ __device__ __forceinline__ unsigned long long request_key(int type, int bx, int 
 // anyway — decodes (bit 2 ? TRUE : the reset of the old value) and stores the plain
 // 0/1/2 the reference would hold. Bit 2 never survives the call.
 constexpr uint8_t kTouched = 4;
+// Bits 3..6 of a touched byte: 1 + the image row band (of VK_BANDS) of the depth pixel whose ray set the bit, 0 when
+// whatever touched the entry had no pixel (the handle pass). The visibility pass bins the visible entries by it
+// (banded_lists below) on its way to storing the plain 0/1/2; like bit 2 the tag never survives the call. Any of the
+// rays that cross a block may win the byte: a block projects to a few rows, every answer is as good.
+__device__ __forceinline__ uint32_t band_tag(int y, int height)
+{
+  int band = (int)(((long long)y * VK_BANDS) / (height > 0 ? height : 1));
+  band = band < 0 ? 0 : (band >= VK_BANDS ? VK_BANDS - 1 : band);
+  return (uint32_t)(band + 1) << 3;
+}
 
 // how a request pass marks an entry visible: plainly (the staged entry points), with the touched
 // bit (the fused SetView's first round, decoded by its visibility pass), or plainly AND, when the
@@ -108,13 +118,13 @@ enum { MARK_PLAIN = 0, MARK_DEFER = 1, MARK_APPEND = 2 };
 // `known` >= 0: the entry's byte as the caller has already read it (with the probe's table entry, so
 // that the two reads travel together instead of one behind the other)
 template <int MARK>
-__device__ __forceinline__ void mark_visible(const vk_volume& v, uint32_t index, int known = -1)
+__device__ __forceinline__ void mark_visible(const vk_volume& v, uint32_t index, int known = -1, uint32_t tag = 0)
 {
   // the reference stores unconditionally (volume.cu:190); reading first keeps
   // hundreds of rays that cross the same block from all storing the same byte
   uint8_t* vis = v.block_visibility;
   const uint8_t old = known >= 0 ? (uint8_t)known : vis[index];
-  if (MARK == MARK_DEFER) { if (!(old & kTouched)) vis[index] = old | kTouched; }
+  if (MARK == MARK_DEFER) { if (!(old & kTouched)) vis[index] = (uint8_t)((old & 3u) | kTouched | tag); }
   else if (MARK == MARK_PLAIN) { if (old != VK_VISIBILITY_TRUE) vis[index] = VK_VISIBILITY_TRUE; }
   else if (old != VK_VISIBILITY_TRUE)
   {
@@ -236,11 +246,11 @@ __device__ __forceinline__ void post_request(const vk_volume& v, uint32_t h, int
 // main entry is known
 template <int MARK>
 __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_code, Entry entry,
-    int bx, int by, int bz, const Retry& retry, int main_byte = -1)
+    int bx, int by, int bz, const Retry& retry, int main_byte = -1, uint32_t tag = 0)
 {
   if (entry_is(entry, bx, by, bz))
   {
-    mark_visible<MARK>(v, hash_code, main_byte);
+    mark_visible<MARK>(v, hash_code, main_byte, tag);
     // An unallocated main entry holds block (0,0,0) and compares equal to it (volume.cu:186-191):
     // the origin block counts as present without ever having been requested — until another
     // block takes that entry, from when on its rays do request it. It is the one block a later
@@ -251,7 +261,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
   }
   else if (entry.data == -1)
   {
-    mark_visible<MARK>(v, hash_code, main_byte);
+    mark_visible<MARK>(v, hash_code, main_byte, tag);
     post_request(v, hash_code, VK_ALLOC_MAIN, bx, by, bz, retry, hash_code);
   }
   else
@@ -267,7 +277,7 @@ __device__ __forceinline__ void probe_block(const vk_volume& v, uint32_t hash_co
 
       if (entry_is(entry, bx, by, bz))
       {
-        mark_visible<MARK>(v, index);
+        mark_visible<MARK>(v, index, -1, tag);
         found = true;
         break;
       }
@@ -317,6 +327,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   const uint32_t K = (uint32_t)v.main_block_count;
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
   const float truncation_length = v.truncation_length;
+  const uint32_t tag = MARK == MARK_DEFER ? band_tag(y, P.height) : 0u;   // the same for the wave's 64 pixels of a row
 
   f3 direction = unproject(P.k, x + 0.5f, y + 0.5f);
   direction = xform_dir(P.Twd, direction);
@@ -431,7 +442,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int sidx = 0; sidx < kProbe; ++sidx)
   {
     if (shash[sidx] == 0xffffffffu) continue;
-    probe_block<MARK>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry, (int)sbyte[sidx]);
+    probe_block<MARK>(v, shash[sidx], sent[sidx], sbx[sidx], sby[sidx], sbz[sidx], retry, (int)sbyte[sidx], tag);
   }
 
   // A segment of 2*trunc crosses a bounded number of blocks; the cap only
@@ -439,7 +450,7 @@ __device__ __forceinline__ void request_walk(const RequestParams& P, int x, int 
   for (int guard = 0; walking && guard < 4096; ++guard)
   {
     const uint32_t hash_code = block_hash(bx, by, bz, K);
-    probe_block<MARK>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, retry);
+    probe_block<MARK>(v, hash_code, load_entry(v.hash_entries, hash_code), bx, by, bz, retry, -1, tag);
 
     if (tmax_x < tmax_y)
     {
@@ -491,6 +502,8 @@ __global__ __launch_bounds__(256) void create_requests_kernel(RequestParams P, R
 {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  // the banded visible lists start empty: the visibility pass of this SetView fills them
+  if (DEFER && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < VK_BANDS) band_counts(P.v.counters)[threadIdx.x] = 0;
 
   // PREP: the loads of the depth tile and of the pixel's colour and normal are issued first and
   // consumed after the request walk, which hides their latency
@@ -928,6 +941,7 @@ __device__ __forceinline__ void visibility_chunk(const VisibilityParams& P, int 
 __global__ __launch_bounds__(kVisThreads) void update_visibility_kernel(VisibilityParams P)
 {
   visibility_chunk<kVisThreads>(P, (int)blockIdx.x * kVisThreads, P.finish_handle, P.deferred_reset);
+  if (blockIdx.x == 0 && threadIdx.x == 0) P.v.counters[VK_CTR_BANDED] = -1;   // this pass writes the plain list only
   if (P.finish_handle && blockIdx.x == 0)
   {
     // the fused SetView: losers that no later round consumed (max_rounds reached, or the rounds
@@ -1406,12 +1420,17 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
 {
   __shared__ int wave_total[kHandleThreads / 64];
   __shared__ unsigned long long arrived, added;
+  // the visible entries binned by image row band (vk.h VK_BANDS): a workgroup's entries take their places in its
+  // share of each band's list by LDS atomics, the shares come from one 8-lane atomic per workgroup
+  __shared__ int band_fill[VK_BANDS], band_base[VK_BANDS];
 
   const vk_volume& v = P.v;
   const int index0 = first + 4 * (int)threadIdx.x;
   const float block_length = VK_BLOCK_RESOLUTION * v.voxel_length;
+  if (threadIdx.x < VK_BANDS) band_fill[threadIdx.x] = 0;
+  __syncthreads();
 
-  uint32_t result = stored, seen = 0;
+  uint32_t result = stored, seen = 0, bands = 0;   // bands: three bits per entry
 #pragma unroll 1
   for (int k = 0; k < n; ++k)
   {
@@ -1423,6 +1442,10 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
     if (index >= new_lo && index < new_hi) visibility = VK_VISIBILITY_TRUE;
     bool visible = (visibility == VK_VISIBILITY_TRUE);
     int out = visibility;
+    // the band a ray left with the touched bit; entries nobody's ray touched (the handle pass's new ones, the
+    // excess range) are spread evenly
+    const int tagged = (byte & kTouched) ? ((byte >> 3) & 15) : 0;
+    int band = tagged ? tagged - 1 : (index & (VK_BANDS - 1));
     if (visibility == VK_VISIBILITY_UNKNOWN)
     {
       const Entry e = load_entry(v.hash_entries, index);
@@ -1439,6 +1462,7 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
         if (u >= 0 && u <= P.width && w >= 0 && w <= P.height)
         {
           visible = true;
+          band = vclampi(f2i(w * (float)VK_BANDS / (float)P.height), 0, VK_BANDS - 1);   // the row of that corner
           break;
         }
       }
@@ -1446,6 +1470,16 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
     }
     result = (result & ~(0xffu << (8 * k))) | ((uint32_t)out << (8 * k));
     seen |= visible ? (1u << k) : 0u;
+    bands |= (uint32_t)band << (3 * k);
+  }
+  // this lane's places in the workgroup's share of each band's list
+  uint32_t places = 0, places_hi = 0;   // sixteen bits per entry (a workgroup holds 1024 entries)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    if (!(seen & (1u << k))) continue;
+    const uint32_t at = (uint32_t)atomicAdd(&band_fill[(bands >> (3 * k)) & 7u], 1);   // < 1024
+    if (k < 2) places |= at << (16 * k); else places_hi |= at << (16 * (k - 2));
   }
   if (result != stored)
   {
@@ -1479,12 +1513,26 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
     added = arrival(total, 0, 0);
     arrived = arrive(v, added, fenced);
   }
+  // (another wave, beside lane 0's arrival: the workgroup's share of each band's list)
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + VK_BANDS)
+  {
+    const int b = (int)threadIdx.x - 64;
+    const int n_band = band_fill[b];
+    band_base[b] = n_band > 0 ? atomicAdd(&band_counts(v.counters)[b], n_band) : 0;
+  }
   __syncthreads();
   const unsigned long long before_us = arrived;
   *my_arrival = added;
   int offset = (int)(uint32_t)before_us + wave_total[wave] + incl - mine;
+  int32_t* lists = band_lists(v.counters);
   for (int k = 0; k < 4; ++k)
-    if (seen & (1u << k)) v.visible_blocks[offset++] = index0 + k;
+    if (seen & (1u << k))
+    {
+      v.visible_blocks[offset++] = index0 + k;
+      const int b = (int)((bands >> (3 * k)) & 7u);
+      const int at = band_base[b] + (int)(((k < 2 ? places : places_hi) >> (16 * (k & 1))) & 0xffffu);
+      if (at < VK_BAND_SLOTS) lists[b * VK_BAND_SLOTS + at] = index0 + k;   // (a band past its slots: the count says so)
+    }
   __syncthreads();   // the LDS words are reused
   return before_us;
 }
@@ -1616,6 +1664,7 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
         reinterpret_cast<unsigned long long*>(v.allocation_blocks)[origin_bucket] = 0ull;
       }
       v.counters[VK_CTR_VISIBLE] = visible_total;
+      v.counters[VK_CTR_BANDED] = visible_total;     // every visible entry is in a banded list as well
       v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - posted;
       v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + excess_total;
       // a round that is not run because nothing was pending would have seen no request
@@ -1657,6 +1706,8 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
     }
     if (listed && (all >> 60)) v.counters[VK_CTR_DROPPED_NOW] = 1;
     v.counters[VK_CTR_VISIBLE] = visible_total;
+    // later rounds append to the plain list only: the banded lists are complete if none runs
+    v.counters[VK_CTR_BANDED] = losers ? -1 : visible_total;
     v.counters[VK_CTR_VOXEL_PTR] = voxel_ptr0 - total_all;
     v.counters[VK_CTR_EXCESS_PTR] = excess_ptr0 + total_excess;
     v.counters[VK_CTR_REQUESTS] = total_all;

@@ -14,7 +14,9 @@ VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 
 VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_PUBLIC = 8, 9, 10, 24
 VK_RETRY_SLOTS, VK_RETRY_KEYS, VK_POSTED_SLOTS = 65536, 8192, 2048
 # counters, two key sets, two slot lists, the posted buckets and their chains' last entries
-VK_CTR_COUNT = VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
+VK_CTR_BANDED, VK_BANDS, VK_BAND_SLOTS = 20, 8, 16384
+VK_CTR_COUNT = (VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
+                + VK_BANDS + VK_BANDS * VK_BAND_SLOTS)
 VK_TRACK_ABORTED = -1
 VISIBILITY_UNKNOWN, VISIBILITY_FALSE, VISIBILITY_TRUE = 0, 1, 2
 ALLOC_NONE, ALLOC_MAIN, ALLOC_EXCESS = 0, 1, 2
