@@ -74,6 +74,7 @@ RIG_TIMEOUT_S = 180                                         # N > 1: the rig ste
 # the run's headline with it
 RIG_IN_LAUNCH_EXCHANGE = os.environ.get("VK_BENCH_RIG_EXCHANGE", "0") == "1"
 SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan.cu:316-318
+ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
 def sphere_room_depth(k):
@@ -356,23 +357,16 @@ def visible_counts(poses, depths=None):
     return np.array(out, dtype=np.float64), per_frame
 
 
-def run_workload(workload, poses, warmup, steps, vd, with_roofline):
-    """W untimed + K timed frames; returns the JSON fields of that workload."""
+def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frames=0):
+    """W untimed + K timed frames (+ `sample_frames` untimed frames with event brackets: the roofline sample);
+    returns the JSON fields of that workload."""
     import torch
     from vulcan_amd import vk_types as T
     import scenes
     sequence = None
     if workload == "rgbd-icp":
-        sequence = RoomSequence(warmup + steps, T.Projection.make(*scenes.APP_INTRINSICS))
+        sequence = RoomSequence(warmup + steps + sample_frames, T.Projection.make(*scenes.APP_INTRINSICS))
     loop = FrameLoop(workload, poses, sequence=sequence)
-    # HIP events (created without the system-scope fence, vk_event_create) around the integrate
-    # launch: a pair of records costs the stream ~2.7 us (K = 20 with every frame bracketed twice read
-    # 107.8 us per frame against 102.5), so every 8th frame is sampled — every 4th of a short run, at
-    # least five frames — and every second of those also brackets the raycast
-    stride = max(1, min(8, steps // 5))
-    sampled = list(range(0, steps, stride)) if with_roofline else []
-    traced = set(sampled[::2])
-    events = {i: tuple(loop.make_event() for _ in range(4 if i in traced else 2)) for i in sampled}
 
     for i in range(warmup):
         loop.step(i)
@@ -380,30 +374,52 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        loop.step(warmup + i, events.get(i))
+        loop.step(warmup + i)
     torch.cuda.synchronize()
     vd.barrier()
     elapsed = vd.max_over_ranks(time.perf_counter() - t0, device="cuda")
     frames_all = vd.sum_over_ranks(steps, device="cuda")
+
+    # The roofline sample: ROOFLINE_SAMPLE_FRAMES more frames of the same sequence, AFTER the timed region, with HIP
+    # events (created without the system-scope fence, vk_event_create) around the integrate launch of every frame and
+    # around the raycast of every second one. A pair of records costs the stream ~2.7 us, so inside the timed region
+    # they cost frames/s (round 3 sampled five frames of the driver's K = 20 run there: 0.48 against rocprofv3's 0.52
+    # for the same kernel); out here they cost nothing that is reported, and 120 launches are averaged whatever K is.
+    sampled = list(range(steps, steps + sample_frames)) if with_roofline else []
+    traced = set(sampled[::2])
+    events = {i: tuple(loop.make_event() for _ in range(4 if i in traced else 2)) for i in sampled}
+    for i in sampled:
+        loop.step(warmup + i, events[i])
+    # what a pair of event records reads with nothing between them (stated next to the sample, never subtracted)
+    pair_us = None
+    if with_roofline:
+        pairs = [(loop.make_event(), loop.make_event()) for _ in range(32)]
+        for e0, e1 in pairs:
+            loop.lib.vk_event_record(e0, loop.stream)
+            loop.lib.vk_event_record(e1, loop.stream)
+    torch.cuda.synchronize()
+    if with_roofline:
+        pair_us = float(np.mean([loop.elapsed_ms(e0, e1) for e0, e1 in pairs]) * 1e3)
 
     out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
     if with_roofline:
         integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled]
         trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled if i in traced]
         out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, sampled
+        out["_event_pair_us"] = pair_us
     ctr = loop.vols[0]["vol"].read_counters()
     out["_counters"] = ctr
     out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps)
     if loop.tracker is not None:
         # the closed loop, scored against the ground truth it never saw
         errors = [pose_error(p, sequence.truth[i]) for i, p in enumerate(loop.tracked_poses)]
-        timed = errors[warmup:]
-        steps_timed = np.array(loop.gn_steps[max(0, warmup - 1):], dtype=np.int64)
+        timed = errors[warmup:warmup + steps]
+        steps_timed = np.array(loop.gn_steps[max(0, warmup - 1):warmup + steps - 1], dtype=np.int64)
         hist = np.bincount(steps_timed, minlength=21)
         out["tracked_pose_drives_fusion"] = True
         out["pose_error_max"] = {"translation_m": max(e[0] for e in timed), "rotation_deg": max(e[1] for e in timed)}
-        out["pose_error_last_frame"] = {"translation_m": errors[-1][0], "rotation_deg": errors[-1][1]}
-        motion = pose_error(sequence.truth[-1], sequence.truth[0])
+        out["pose_error_last_frame"] = {"translation_m": timed[-1][0], "rotation_deg": timed[-1][1]}
+        motion = pose_error(sequence.truth[warmup + steps - 1], sequence.truth[0])
         out["camera_motion_over_run"] = {"translation_m": motion[0], "rotation_deg": motion[1]}
         out["gn_steps_median"] = float(np.median(steps_timed))
         out["gn_steps_histogram_full_resolution_level"] = {str(n): int(c) for n, c in enumerate(hist) if c}
@@ -664,23 +680,24 @@ def main():
         # experiment: a created stream instead of the legacy default stream torch starts on
         torch.cuda.set_stream(torch.cuda.Stream())
 
-    total = args.warmup + args.steps
+    total = args.warmup + args.steps + ROOFLINE_SAMPLE_FRAMES
     # every rank walks the same arc, offset so ranks do not share poses
     poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
     wl = args.workload
-    res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True)
+    res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True, sample_frames=ROOFLINE_SAMPLE_FRAMES)
 
     tracked, depths = res.pop("_tracked", None), res.pop("_depths", None)
     nvis, rounds_per_frame = visible_counts(tracked or poses, depths)
-    nvis_timed = nvis[args.warmup:]
+    nvis_timed = nvis[args.warmup:]                   # the timed frames, then the roofline sample's
     image_bytes = IMAGE_BYTES["depth" if wl == "depth" else "rgbd"]
     alg = nvis_timed * BYTES_PER_BLOCK + image_bytes
     sampled = res.pop("_sampled")
     integ_ms, trace_ms = np.array(res.pop("_integrate_ms")), np.array(res.pop("_trace_ms"))
     achieved = float(alg[sampled].sum() / (integ_ms.sum() * 1e-3) / 1e9)
     ctr = res.pop("_counters")
-    frame_bytes = float(alg.mean())
-    voxel_ws = float(nvis_timed.mean()) * 10240
+    pair_us = res.pop("_event_pair_us")
+    frame_bytes = float(alg[:args.steps].mean())
+    voxel_ws = float(nvis_timed[:args.steps].mean()) * 10240
 
     sphere = ", camera at the centre of a 2 m sphere yawing 0.5 deg/frame"
     names = {"rgbd": "BASELINE configs[2] fusion+raycast: 640x480 RGB-D, Frame::ComputeNormals + SetView x3 + LightIntegrator "
@@ -698,6 +715,7 @@ def main():
         "rounds_run_per_frame": res.pop("set_view_rounds_run_per_frame"),
         "frames_that_needed_more_than_one_round": int((rounds_per_frame > 1).sum()),
     }
+    traffic_bytes, traffic_source = pmc_traffic(wl)
     result = {
         "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
@@ -711,16 +729,19 @@ def main():
                                  "written to the frame; one launch less)"))
                              if wl != "depth" else "not needed by DepthIntegrator (configs[1])",
             "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
-            "visible_blocks_mean": float(nvis_timed.mean()),
+            "visible_blocks_mean": float(nvis_timed[:args.steps].mean()),
             "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
             "dropped_requests": int(ctr[T.VK_CTR_DROPPED]), "parallelism": f"replica volume per GPU x{world}",
         },
         "roofline": {
             "kernel": "integrate_pipelined_kernel<depth%s> (vk_integrate_ahead)" % ("" if wl == "depth" else "+light colour"),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(wl),
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": float(alg[sampled].mean()),
             "avg_launch_us": float(integ_ms.mean() * 1e3), "launches_timed": len(sampled),
+            "sample": f"HIP events around every integrate launch of {len(sampled)} further frames of the same sequence, "
+                      "right after the timed region (no event is recorded inside it)",
+            "event_pair_us": pair_us,      # two records with nothing between them; included in avg_launch_us, not subtracted
             # where the bytes come from at this size: a frame's voxel working set is ~75 MB and
             # consecutive frames overlap almost entirely, so it lives in the 256 MiB Infinity Cache
             "memory_level": "infinity-cache assisted" if voxel_ws < L3_BYTES else "hbm",
@@ -750,7 +771,7 @@ def main():
             ray["algorithmic_bytes"] = W * H * 16 + 4800 * 8 + nhit * 10240
             ray["algorithmic_GBps"] = ray["algorithmic_bytes"] / (ray["avg_us"] * 1e-6) / 1e9
             ray["bound"] = "latency / VALU issue (dependent hash -> voxel loads per march step), not bandwidth"
-            ray["traffic"] = pmc_traffic("raycast")
+            ray["traffic"], ray["traffic_source"] = pmc_traffic("raycast")
     del loop
     torch.cuda.empty_cache()
 
@@ -770,7 +791,8 @@ def main():
             if other == wl:
                 continue
             k_steps, k_warm = min(args.steps, 100), min(args.warmup, 10)
-            o, oloop = run_workload(other, poses[:k_warm + k_steps], k_warm, k_steps, vd, with_roofline=True)
+            o, oloop = run_workload(other, poses[:k_warm + k_steps + 40], k_warm, k_steps, vd, with_roofline=True, sample_frames=40)
+            o.pop("_event_pair_us", None)
             ims, tms, smp = np.array(o.pop("_integrate_ms")), np.array(o.pop("_trace_ms")), o.pop("_sampled")
             o.pop("_counters")
             onvis = nvis
@@ -779,8 +801,8 @@ def main():
                 oloop = None
                 torch.cuda.empty_cache()
                 onvis, _ = visible_counts(o.pop("_tracked"), o.pop("_depths"))
-                o["visible_blocks_mean"] = float(onvis[k_warm:].mean())
-            oalg = onvis[k_warm:k_warm + k_steps] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if other == "depth" else "rgbd"]
+                o["visible_blocks_mean"] = float(onvis[k_warm:k_warm + k_steps].mean())
+            oalg = onvis[k_warm:k_warm + k_steps + 40] * BYTES_PER_BLOCK + IMAGE_BYTES["depth" if other == "depth" else "rgbd"]
             o["workload"] = names[other]
             o["unit"] = "frames/s"
             o["integrate_avg_us"] = float(ims.mean() * 1e3)
@@ -832,9 +854,11 @@ def pmc_traffic(workload):
     tag = {"depth": "integrate", "raycast": "raycast"}.get(workload, "integrate_rgbd")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_traffic.json")))
     if not files:
-        return None
+        return None, "no PMC measurement on file for this workload"
     with open(files[-1]) as f:
-        return json.load(f)["bytes_per_launch"]
+        value = json.load(f)["bytes_per_launch"]
+    return value, (f"profiles/{os.path.basename(files[-1])}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/traffic.sh, "
+                   "read from that file — NOT measured in this run")
 
 
 def cpu_baseline(workload, poses, seconds):

@@ -199,10 +199,42 @@ typedef struct vk_frame {
   uint64_t      content_id;
 } vk_frame;
 
+/* -------------------------------------------------------------- test aids -- */
+
+/* Process-wide switches with which the test suites force paths that real input reaches rarely, and two
+ * measurement options. Nothing on a call path reads the environment: a caller sets these once (any thread,
+ * before the calls they concern); the library reads them with relaxed atomic loads. No reference counterpart. */
+typedef struct vk_test_hooks {
+  int32_t posted_capacity;    /* buckets the posted list of vk_volume_set_view* holds; < 0: VK_POSTED_SLOTS. A small
+                                 list sends the handle pass to the request flags */
+  int32_t retry_capacity;     /* distinct keys per retry list; <= 0: VK_RETRY_KEYS. A small list overflows on purpose */
+  int32_t set_view_unfused;   /* 1: vk_volume_set_view* as three launches (requests, handle + later rounds,
+                                 visibility) instead of two: the second implementation the tests compare with */
+  int32_t force_loop_abort;   /* 1: every one-launch Gauss-Newton loop ends at once with VK_TRACK_ABORTED, as after the
+                                 exchange timeout, so that the launch-per-stage fallback can be tested */
+  int32_t loop_grid_cap;      /* > 0: at most this many workgroups per loop kernel (a device with fewer CUs) */
+  int32_t loop_cooperative;   /* 1: loop kernels go through hipLaunchCooperativeKernel (the runtime then refuses a
+                                 grid that cannot be resident; +4..6.5 us per Track) */
+} vk_test_hooks;
+
+VK_API int vk_test_hooks_set(const vk_test_hooks* hooks);   /* NULL: everything back to its default */
+VK_API int vk_test_hooks_get(vk_test_hooks* out);
+
 /* ------------------------------------------------------ library / device -- */
 
 VK_API const char* vk_error_string(int code);
 VK_API int vk_version(void);                       /* 100*major + minor */
+
+/* The binary interface has changed between rounds (struct fields, the size of the counters block — VK_CTR_COUNT ints,
+ * of which vk_volume_read_counters_sync copies VK_CTR_PUBLIC = 24 —, the meaning of vk_frame.content_id), and a caller
+ * built against an older vk.h would hand the library buffers that are too small. VK_ABI_VERSION counts those changes;
+ * vk_abi_check compares what the CALLER was compiled against with what the LIBRARY was: call it once after loading
+ *   vk_abi_check(VK_ABI_VERSION, sizeof(vk_volume), sizeof(vk_frame), VK_CTR_COUNT)
+ * and refuse to go on unless it returns VK_OK (VK_ERR_UNSUPPORTED otherwise). The class layer (vulcan_amd/host) and the
+ * Python binding do. New struct fields are appended; a change of VK_CTR_COUNT bumps the version. No reference counterpart. */
+#define VK_ABI_VERSION 4
+VK_API int vk_abi_version(void);
+VK_API int vk_abi_check(int header_abi_version, size_t sizeof_vk_volume, size_t sizeof_vk_frame, int ctr_count);
 VK_API int vk_device_count(int* count);
 VK_API int vk_set_device(int device);
 VK_API int vk_device_name(char* out, size_t bytes);
@@ -633,7 +665,7 @@ VK_API int vk_track_wait(const vk_track_poll* poll, void* stream);
  * returns VK_ERR_UNSUPPORTED), a later level of the same coarse-to-fine Track does not run,
  * and the host's way out is the same call again from the start pose with `reduce` =
  * vk_reduce_nothing, i.e. the launch-per-stage loop, which waits for nobody (the class layer and
- * vulcan_amd/api.py do exactly that). With VK_LOOP_COOPERATIVE=1 in the environment the loop
+ * vulcan_amd/api.py do exactly that). With vk_test_hooks.loop_cooperative set the loop
  * kernels are launched with hipLaunchCooperativeKernel, which refuses a grid that cannot be
  * resident instead of letting the kernel find out. Tracks issued on different streams of
  * one device are run one after the other by the library (a loop launch fills the device); two

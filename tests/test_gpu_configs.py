@@ -440,9 +440,9 @@ def test_set_view_prepares_the_light_integrator(api, orc):
     sync()
 
 
-def test_fewer_workgroups_than_pixel_groups_gives_the_same_bits(api, orc, monkeypatch):
+def test_fewer_workgroups_than_pixel_groups_gives_the_same_bits(api, orc):
     """The one-launch loops publish one slot per pixel GROUP: when the device holds fewer workgroups
-    than the image has groups (fewer CUs, lower occupancy — forced here with VK_LOOP_GRID_CAP), a
+    than the image has groups (fewer CUs, lower occupancy — forced here with vk_test_hooks.loop_grid_cap), a
     workgroup takes several groups and the poses come out bit for bit the same."""
     import color_scenes as cs
     w, h = 640, 480
@@ -473,10 +473,9 @@ def test_fewer_workgroups_than_pixel_groups_gives_the_same_bits(api, orc, monkey
         return out
 
     full = run()
-    for cap in ("100", "7", "1"):
-        monkeypatch.setenv("VK_LOOP_GRID_CAP", cap)
-        assert run() == full, cap
-    monkeypatch.delenv("VK_LOOP_GRID_CAP")
+    for cap in (100, 7, 1):
+        with api.test_hooks(loop_grid_cap=cap):
+            assert run() == full, cap
 
 
 def test_two_streams_track_concurrently(api, orc):

@@ -2,7 +2,7 @@
 gives up (VK_TRACK_ABORTED, vk.h) — two processes on one GPU, or a foreign kernel that holds
 compute units while the loop spins. The hosts' way out: the same Track again from the start pose
 on the launch-per-stage path, which waits for nobody. The abort is forced here through the test
-aid VK_TEST_FORCE_LOOP_ABORT (the loop kernels end at once, as after the exchange timeout); the
+aid vk_test_hooks.force_loop_abort (the loop kernels end at once, as after the exchange timeout); the
 result must equal the launch-per-stage path's bit for bit. Run once; never looped.
 """
 import os
@@ -19,12 +19,9 @@ from vulcan_amd import vk_types as T
 pytestmark = pytest.mark.gpu
 
 
-class forced_abort:
-    def __enter__(self):
-        os.environ["VK_TEST_FORCE_LOOP_ABORT"] = "1"
-
-    def __exit__(self, *exc):
-        del os.environ["VK_TEST_FORCE_LOOP_ABORT"]
+def forced_abort():
+    from vulcan_amd import api as a
+    return a.test_hooks(force_loop_abort=1)
 
 
 def depth_pair(api):
@@ -130,8 +127,8 @@ def test_cpp_class_layer_falls_back(api):
     under a forced abort: their re-authored Track tests pass on the fallback path."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "vulcan_amd", "host", "bin", "host_tests")
-    env = dict(os.environ, VK_TEST_FORCE_LOOP_ABORT="1")
-    out = subprocess.run([exe, "Track"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env).stdout
+    out = subprocess.run([exe, "Track", "--force-loop-abort"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=600).stdout
     assert " 0 failed" in out, out
     for name in ("DepthTracker.Track", "PyramidTracker.Track", "ColorTracker.Track", "LightTracker.Track"):
         assert f"[  OK  ] {name}" in out, out

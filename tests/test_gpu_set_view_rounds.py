@@ -35,12 +35,14 @@ def assert_same_requests(dv, hv):
 @pytest.fixture(params=["two launches", "three launches"])
 def launches(request):
     """The call as two launches (requests; handle + visibility, the handle pass working from the list
-    of posted buckets) and as three (VK_SETVIEW_UNFUSED=1: handle and visibility apart, the handle
+    of posted buckets) and as three (vk_test_hooks.set_view_unfused: handle and visibility apart, the handle
     pass counting the request flags — also the form for tables beyond 67 M entries)."""
+    from vulcan_amd import api as a
     if request.param == "three launches":
-        os.environ["VK_SETVIEW_UNFUSED"] = "1"
-    yield request.param
-    os.environ.pop("VK_SETVIEW_UNFUSED", None)
+        with a.test_hooks(set_view_unfused=1):
+            yield request.param
+    else:
+        yield request.param
 
 
 @pytest.mark.parametrize("scene", ["sphere", "ramp"])
@@ -113,20 +115,17 @@ def test_rounds_end_with_the_first_round_that_drops_a_request(api, orc, launches
 
 
 def test_a_retry_list_that_is_too_small_ends_the_rounds(api, orc):
-    """More lost requests than the retry list holds (forced: VK_RETRY_CAPACITY=64): the rounds
+    """More lost requests than the retry list holds (forced: vk_test_hooks.retry_capacity = 64): the rounds
     stop, the state is ONE SetView call's with VK_CTR_UNSETTLED = 1, and later calls settle it."""
     w, h = 320, 240
     hf, df = frames(api, orc, scenes.ramp(w, h), K_SMALL, scenes.tracer_test_pose())
     hv, dv = make_pair(api, orc, 2048, 8192, 0.01, 0.04)
-    os.environ["VK_RETRY_CAPACITY"] = "64"
-    try:
+    with api.test_hooks(retry_capacity=64):
         oracle_rounds(orc, hv, hf, 1)
         dv.set_view(df, rounds=4)
         assert_volume_equal(dv, hv, voxels=False)
         ctr = dv.read_counters()
         assert ctr[T.VK_CTR_UNSETTLED] == 1 and ctr[T.VK_CTR_ROUNDS] == 1
-    finally:
-        del os.environ["VK_RETRY_CAPACITY"]
     for _ in range(6):
         oracle_rounds(orc, hv, hf, 4)
         dv.set_view(df, rounds=4)
@@ -254,7 +253,7 @@ def test_normals_are_computed_also_when_the_preparation_cannot_ride(api, orc):
 
 def test_the_posted_list_and_the_flag_scan_give_the_same_table(api, orc):
     """The handle pass works from the list of posted buckets when it holds them all, and from the
-    request flags otherwise. Forced both ways on the same frames (test aid VK_POSTED_CAPACITY), at
+    request flags otherwise. Forced both ways on the same frames (vk_test_hooks.posted_capacity), at
     the boundary: a list that holds exactly the requests of the pass, and one that is one short.
     Odd table sizes: 1021 + 6001 entries (flag and visibility tails that are not a multiple of 4 / 16)."""
     w, h = 320, 240
@@ -266,12 +265,8 @@ def test_the_posted_list_and_the_flag_scan_give_the_same_table(api, orc):
     hv0.set_view(hf0, orc.POLICY_MAXKEY)
     posted = int(hv0.counters[T.VK_CTR_REQUESTS])
     assert 256 < posted < 1021
-    try:
-        for capacity in (posted, posted - 1, 0, None):
-            if capacity is None:
-                os.environ.pop("VK_POSTED_CAPACITY", None)
-            else:
-                os.environ["VK_POSTED_CAPACITY"] = str(capacity)
+    for capacity in (posted, posted - 1, 0, -1):                             # -1: the library's own capacity
+        with api.test_hooks(posted_capacity=capacity):
             hv, dv = make_pair(api, orc, 1021, 6001, 0.01, 0.04)
             for pose in poses:
                 hf, df = frames(api, orc, depth, K_SMALL, pose)
@@ -281,5 +276,3 @@ def test_the_posted_list_and_the_flag_scan_give_the_same_table(api, orc):
                 assert_same_requests(dv, hv)
             assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 100          # chains: EXCESS requests, new entries visible
             assert hv.counters[T.VK_CTR_DROPPED] == 0
-    finally:
-        os.environ.pop("VK_POSTED_CAPACITY", None)

@@ -23,6 +23,8 @@ _PP = C.POINTER(C.c_void_p)
 _SIGNATURES = {
     "vk_error_string": ([_I], C.c_char_p),
     "vk_version": ([], _I),
+    "vk_abi_version": ([], _I),
+    "vk_abi_check": ([_I, _SZ, _SZ, _I], _I),
     "vk_device_count": ([C.POINTER(_I)], _I),
     "vk_set_device": ([_I], _I),
     "vk_device_name": ([C.c_char_p, _SZ], _I),
@@ -104,9 +106,33 @@ _SIGNATURES = {
     "vk_detect_workspace_bytes": ([C.c_int32], _SZ),
     "vk_detect_filter": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
+    "vk_test_hooks_set": ([_P], _I),
+    "vk_test_hooks_get": ([_P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn
+
+
+class test_hooks:
+    """`with api.test_hooks(set_view_unfused=1): ...` — vk_test_hooks (vk.h) for the duration of the block: the
+    test suites' switches (a small posted / retry list, the three-launch SetView, a forced loop abort, a capped
+    loop grid) and the cooperative-launch option. The library reads no environment variable on a call path."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.saved = T.TestHooks()
+        check(lib().vk_test_hooks_get(C.byref(self.saved)), "vk_test_hooks_get")
+        new = T.TestHooks.from_buffer_copy(bytes(self.saved))
+        for name, value in self.fields.items():
+            setattr(new, name, int(value))
+        check(lib().vk_test_hooks_set(C.byref(new)), "vk_test_hooks_set")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().vk_test_hooks_set(C.byref(self.saved)), "vk_test_hooks_set")
+        return False
 
 
 class TrackAborted(RuntimeError):
@@ -133,6 +159,10 @@ def lib():
         for name, (argtypes, restype) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.argtypes, fn.restype = argtypes, restype
+        # the structs and sizes of vk_types.py against the ones the library was compiled with (vk.h VK_ABI_VERSION)
+        if handle.vk_abi_check(T.VK_ABI_VERSION, C.sizeof(T.Volume), C.sizeof(T.Frame), T.VK_CTR_COUNT) != 0:
+            raise VkError(f"{LIB_PATH} has binary interface version {handle.vk_abi_version()}, these bindings were written "
+                          f"for {T.VK_ABI_VERSION} (or a struct / VK_CTR_COUNT differs): rebuild the library")
         _LIB = handle
     return _LIB
 

@@ -39,6 +39,11 @@
 
 static inline hipStream_t vk_s(void* stream) { return reinterpret_cast<hipStream_t>(stream); }
 
+// a field of vk_test_hooks (vk.h), by position; defined in vk_runtime.hip
+enum { VK_HOOK_POSTED_CAPACITY = 0, VK_HOOK_RETRY_CAPACITY, VK_HOOK_SET_VIEW_UNFUSED, VK_HOOK_FORCE_LOOP_ABORT,
+       VK_HOOK_LOOP_GRID_CAP, VK_HOOK_LOOP_COOPERATIVE };
+int vk_hook(int field);
+
 namespace vk
 {
 

@@ -243,21 +243,19 @@ struct Exchange
 // process-wide source of launch tags (vk_runtime.hip): 22 bits, never 0
 uint32_t vk_next_loop_epoch();
 
-// test aid (VK_TEST_FORCE_LOOP_ABORT=1): the next loop launches behave as if a workgroup's sums had
+// test aid (vk_test_hooks.force_loop_abort): the next loop launches behave as if a workgroup's sums had
 // never arrived — they end with VK_TRACK_ABORTED at once — so that the hosts' way out of an
 // aborted Track (the launch-per-stage loop) can be tested without starving a real launch
 inline int vk_forced_loop_abort()
 {
-  const char* e = getenv("VK_TEST_FORCE_LOOP_ABORT");
-  return (e && e[0] == '1') ? 1 : 0;
+  return vk_hook(VK_HOOK_FORCE_LOOP_ABORT) == 1 ? 1 : 0;
 }
 
-// VK_LOOP_COOPERATIVE=1: loop kernels go through hipLaunchCooperativeKernel, which refuses a grid
+// vk_test_hooks.loop_cooperative: loop kernels go through hipLaunchCooperativeKernel, which refuses a grid
 // that cannot be resident at once instead of letting the kernel find out (measured: see DESIGN.md)
 inline bool vk_loop_cooperative()
 {
-  static const int on = [] { const char* e = getenv("VK_LOOP_COOPERATIVE"); return (e && e[0] == '1') ? 1 : 0; }();
-  return on != 0;
+  return vk_hook(VK_HOOK_LOOP_COOPERATIVE) == 1;
 }
 
 template <typename Kernel, typename A, typename B>
@@ -305,11 +303,8 @@ inline int resident_workgroups(Kernel kernel, int threads)
   }
   // test aid: a smaller grid than the device could hold (workgroups then take several pixel
   // groups each — the path a device with fewer CUs, or larger images, would take)
-  if (const char* cap = getenv("VK_LOOP_GRID_CAP"))
-  {
-    const int n = atoi(cap);
-    if (n > 0 && n < capacity) capacity = n;
-  }
+  const int cap = vk_hook(VK_HOOK_LOOP_GRID_CAP);
+  if (cap > 0 && cap < capacity) capacity = cap;
   return capacity;
 }
 

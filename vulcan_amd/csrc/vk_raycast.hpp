@@ -41,13 +41,6 @@ struct PointParams
   int image_width, image_height, bounds_width, bounds_height;
   uint8_t* touched;           // COUNT only: one byte per pool slot
   int* march_steps;           // COUNT only (optional): trips through the march loop, per pixel
-#ifdef VK_TRACE_TRAILING_NORMALS
-  // experiment: the normal image computed inside this launch, tile by tile, by
-  // the wave that finishes last in a tile's neighbourhood
-  float* normals;
-  int* tile_done;             // [tiles] epoch of the launch that finished the tile, then [tiles] epoch that claimed its normals
-  int epoch;
-#endif
 };
 
 // a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).
@@ -529,10 +522,6 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
 
   const int pixel = y * P.image_width + x;
   if (COUNT) { if (P.march_steps) P.march_steps[pixel] = trips; }
-#ifdef VK_TRACE_TRAILING_NORMALS
-  if (P.normals) __hip_atomic_store(P.depths + pixel, final_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
-  else
-#endif
   P.depths[pixel] = final_depth;
   P.colors[3 * pixel + 0] = color.x;
   P.colors[3 * pixel + 1] = color.y;

@@ -30,6 +30,36 @@ uint32_t vk_next_loop_epoch()
 }
 
 
+// vk_test_hooks (vk.h): one copy per library image, every field an atomic of its own
+namespace
+{
+std::atomic<int32_t> g_hooks[6] = {{-1}, {0}, {0}, {0}, {0}, {0}};
+}
+int vk_hook(int field) { return g_hooks[field].load(std::memory_order_relaxed); }
+
+extern "C" {
+int vk_test_hooks_set(const vk_test_hooks* h)
+{
+  const vk_test_hooks defaults = {-1, 0, 0, 0, 0, 0};
+  if (!h) h = &defaults;
+  const int32_t v[6] = {h->posted_capacity, h->retry_capacity, h->set_view_unfused, h->force_loop_abort,
+                        h->loop_grid_cap, h->loop_cooperative};
+  for (int i = 0; i < 6; ++i) g_hooks[i].store(v[i], std::memory_order_relaxed);
+  return VK_OK;
+}
+int vk_test_hooks_get(vk_test_hooks* out)
+{
+  VK_REQUIRE(out);
+  out->posted_capacity = vk_hook(0);
+  out->retry_capacity = vk_hook(1);
+  out->set_view_unfused = vk_hook(2);
+  out->force_loop_abort = vk_hook(3);
+  out->loop_grid_cap = vk_hook(4);
+  out->loop_cooperative = vk_hook(5);
+  return VK_OK;
+}
+}
+
 // Loop kernels (one launch per Gauss-Newton loop) need all their workgroups on the device at
 // the same time, and one of them fills it. Two of them started at the same moment on two
 // streams could each get a part of the device and wait for the rest — for two seconds, until
@@ -96,6 +126,15 @@ const char* vk_error_string(int code)
 }
 
 int vk_version(void) { return 100; }
+
+int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+int vk_abi_check(int header_abi_version, size_t sizeof_vk_volume, size_t sizeof_vk_frame, int ctr_count)
+{
+  const bool same = header_abi_version == VK_ABI_VERSION && sizeof_vk_volume == sizeof(vk_volume) &&
+      sizeof_vk_frame == sizeof(vk_frame) && ctr_count == VK_CTR_COUNT;
+  return same ? VK_OK : VK_ERR_UNSUPPORTED;
+}
 
 int vk_device_count(int* count)
 {

@@ -290,58 +290,6 @@ __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(Point
     bound = reinterpret_cast<const float2*>(P.bounds)[cell];
   }
 
-#ifdef VK_TRACE_TRAILING_NORMALS
-  if (P.normals)
-  {
-    if (tile >= tiles) return;
-    if (inside) march_ray<false, POOL32>(P, bdir, x, y, bound);
-    // this tile's depths are out (written through; the count says they have arrived) ...
-    __builtin_amdgcn_s_waitcnt(0);
-    int* done = P.tile_done;
-    int* claimed = P.tile_done + tiles;
-    if (lane == 0) __hip_atomic_store(done + tile, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_s_waitcnt(0);
-    // ... and so may be the last of a neighbourhood: candidates c = this tile and its four edge
-    // neighbours; lane 5 c + m asks for member m of candidate c (a tile outside the image counts as done)
-    const int cx[5] = {0, -1, 1, 0, 0}, cy[5] = {0, 0, 0, -1, 1};
-    bool ready = true;
-    if (lane < 25)
-    {
-      const int c = lane / 5, m = lane % 5;
-      const int nx = tile_x + cx[c], ny = tile_y + cy[c];
-      const int mx = nx + cx[m], my = ny + cy[m];
-      if (nx < 0 || nx >= tiles_x || ny < 0 || ny >= tiles_y) ready = false;
-      else if (mx >= 0 && mx < tiles_x && my >= 0 && my < tiles_y)
-        ready = __hip_atomic_load(done + my * tiles_x + mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch;
-    }
-    const unsigned long long votes = __ballot(ready);
-    for (int c = 0; c < 5; ++c)
-    {
-      if (((votes >> (5 * c)) & 31ull) != 31ull) continue;      // (uniform)
-      const int nx = tile_x + cx[c], ny = tile_y + cy[c];
-      const int n = ny * tiles_x + nx;
-      int mine = 0;
-      if (lane == 0) mine = atomicMax(claimed + n, P.epoch) < P.epoch ? 1 : 0;
-      if (!__builtin_amdgcn_readfirstlane(mine)) continue;
-      const int px_ = nx * kPointsTile + (lane & 7), py_ = ny * kPointsTile + (lane >> 3);
-      if (px_ >= P.image_width || py_ >= P.image_height) continue;
-      const float* depths = P.depths;
-      auto tap = [&](int ax, int ay) -> float
-      {
-        if (ax < 0 || ax >= P.image_width || ay < 0 || ay >= P.image_height) return 0.0f;
-        return __hip_atomic_load(depths + ay * P.image_width + ax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      };
-      const float d = tap(px_, py_);
-      const float l = tap(px_ - 2, py_), r = tap(px_ + 2, py_), u = tap(px_, py_ - 2), dn = tap(px_, py_ + 2);
-      const f3 normal = normal_from_taps(P.k, px_, py_, d, l, r, u, dn);
-      const int output = py_ * P.image_width + px_;
-      P.normals[3 * output + 0] = normal.x;
-      P.normals[3 * output + 1] = normal.y;
-      P.normals[3 * output + 2] = normal.z;
-    }
-    return;
-  }
-#endif
   if (!inside) return;
   march_ray<false, POOL32>(P, bdir, x, y, bound);
 }
@@ -470,28 +418,6 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
   const int tiles = ((image_width + kPointsTile - 1) / kPointsTile) * ((image_height + kPointsTile - 1) / kPointsTile);
-#ifdef VK_TRACE_TRAILING_NORMALS
-  // experiment only: one static flag array, one stream at a time
-  static int* flags = nullptr;
-  static int flag_tiles = 0, epoch = 0;
-  P.normals = nullptr;
-  P.tile_done = nullptr;
-  P.epoch = 0;
-  if (normals && kPointsWaves == 1)
-  {
-    if (flag_tiles < tiles)
-    {
-      if (flags) (void)hipFree(flags);
-      VK_CHECK(hipMalloc(&flags, sizeof(int) * 2 * tiles));
-      VK_CHECK(hipMemset(flags, 0, sizeof(int) * 2 * tiles));
-      flag_tiles = tiles;
-      epoch = 0;
-    }
-    P.normals = normals;
-    P.tile_done = flags;
-    P.epoch = ++epoch;
-  }
-#endif
   int chunk = (tiles + 7) / 8;
   if (VK_POINTS_ORDER == 1) chunk = 2 * ((chunk + 1) / 2);
   const dim3 grid(8 * chunk);   // padded so every XCD gets an equal share
@@ -669,14 +595,8 @@ int vk_trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ah
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
            (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s
-#ifdef VK_TRACE_TRAILING_NORMALS
-           , out_normals
-#endif
            )) != VK_OK)
     return rc;
-#ifdef VK_TRACE_TRAILING_NORMALS
-  return VK_OK;
-#endif
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 

@@ -1387,6 +1387,15 @@ __device__ __forceinline__ unsigned long long arrival(int visible, int excess, i
   return (unsigned long long)(uint32_t)visible | (1ull << 32) | ((unsigned long long)(uint32_t)excess << 48) |
          ((unsigned long long)(dropped ? 1u : 0u) << 60);
 }
+// Memory order. With `fenced` the arrival is acquire-release at agent scope and the workgroups fence around it (a
+// write-back and an invalidation of the XCD's L2: the price of a hand-off between workgroups on this part, which is why
+// it is paid only when the last workgroup has to READ what the others wrote). Without, the arrival is RELAXED, and what
+// the last workgroup then does is store over things the others have read (the origin bucket's request, the counters,
+// the arrival word itself). That the others' reads come first is not the memory model's promise but this hardware's:
+// a workgroup's arrival is issued by lane 0 after a workgroup barrier, every value a lane of it read from those
+// locations has been consumed by then (the arrival's addend and the slots it reserves are computed from them, so the
+// loads have returned), and a CU issues a wave's memory operations in order. A port to a part that lets a load
+// complete after a younger atomic of another lane of its workgroup would have to arrive with release semantics.
 __device__ __forceinline__ unsigned long long arrive(const vk_volume& v, unsigned long long add, bool fenced)
 {
   unsigned long long* word = reinterpret_cast<unsigned long long*>(v.counters + VK_CTR_ARRIVALS);
@@ -1564,10 +1573,13 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   // losers on file, or when the origin block was met in an unallocated main entry that this round
   // gives to another block. Both are known before the launch: the same answer in every workgroup.
   const uint32_t origin_bucket = block_hash(0, 0, 0, (uint32_t)main_count);
-  const bool fenced = contended != 0 || (origin_seen != 0 && v.allocation_types[origin_bucket] != VK_ALLOC_NONE);
-  const bool losers = P.max_rounds > 1 && fenced;
   // the requests of this round: listed, or — too many for the list — to be found in the flags
   const bool listed = posted <= P.posted_capacity;
+  const bool contest = contended != 0 || (origin_seen != 0 && v.allocation_types[origin_bucket] != VK_ALLOC_NONE);
+  // (the flag-scan form also arrives with release / acquire: its last workgroup reads VK_CTR_DROPPED_NOW, which the
+  // others wrote, and clears the flags all of them read; it is the rare form, the fences cost it nothing that matters)
+  const bool fenced = contest || !listed;
+  const bool losers = P.max_rounds > 1 && contest;
   const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
 
   unsigned long long before_us, my_arrival;
@@ -1773,35 +1785,26 @@ int check_volume(const vk_volume* v)
   return VK_OK;
 }
 
-// buckets the posted list holds (test aid VK_POSTED_CAPACITY: a small list sends the handle pass to the flags)
+// buckets the posted list holds (vk_test_hooks.posted_capacity: a small list sends the handle pass to the flags)
 int posted_capacity()
 {
-  if (const char* e = getenv("VK_POSTED_CAPACITY"))
-  {
-    const int n = atoi(e);
-    if (n >= 0 && n < VK_POSTED_SLOTS) return n;
-  }
-  return VK_POSTED_SLOTS;
+  const int n = vk_hook(VK_HOOK_POSTED_CAPACITY);
+  return (n >= 0 && n < VK_POSTED_SLOTS) ? n : VK_POSTED_SLOTS;
 }
 
-// distinct keys per retry list (test aid VK_RETRY_CAPACITY: a small list overflows on purpose)
+// distinct keys per retry list (vk_test_hooks.retry_capacity: a small list overflows on purpose)
 int retry_capacity()
 {
-  if (const char* env = getenv("VK_RETRY_CAPACITY"))
-  {
-    const int n = atoi(env);
-    if (n > 0 && n < VK_RETRY_KEYS) return n;
-  }
-  return VK_RETRY_KEYS;
+  const int n = vk_hook(VK_HOOK_RETRY_CAPACITY);
+  return (n > 0 && n < VK_RETRY_KEYS) ? n : VK_RETRY_KEYS;
 }
 
-// VK_SETVIEW_UNFUSED=1: the fused SetView as three launches (requests, handle + later rounds,
+// vk_test_hooks.set_view_unfused: the fused SetView as three launches (requests, handle + later rounds,
 // visibility) instead of two — kept for comparison, and as the reference for the two-launch form
 // (also the form for a table too large for the arrival count of the two-launch form: > 67 M entries)
 bool set_view_unfused(const vk_volume* v)
 {
-  const char* e = getenv("VK_SETVIEW_UNFUSED");     // (read per call: the tests switch it)
-  const bool unfused = e && e[0] == '1';
+  const bool unfused = vk_hook(VK_HOOK_SET_VIEW_UNFUSED) == 1;
   return unfused || ((long long)v->main_block_count + v->excess_block_count) / 1024 + 16 > kArrivalMaxWorkgroups;
 }
 
@@ -2029,7 +2032,7 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     VK_LAUNCH_CHECK();
     return VK_OK;
   }
-  // the three-launch form (VK_SETVIEW_UNFUSED=1: kept for comparison and as the reference for the fused one)
+  // the three-launch form (vk_test_hooks.set_view_unfused: kept for comparison and as the reference for the fused one)
   hipLaunchKernelGGL(handle_rounds_kernel, dim3(handle_groups), dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
   return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,

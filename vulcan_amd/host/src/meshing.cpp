@@ -90,50 +90,68 @@ Exporter::Exporter(const std::string& file) : file_(file) {}
 
 const std::string& Exporter::GetFile() const { return file_; }
 
-// ref: exporter.cpp:19-71, line for line: the vertex colours are upstream's debug ramp over z
-// (marked "REMOVE" there), kept so that the files are byte-compatible
+// ASCII PLY with the bytes of upstream's writer (ref: exporter.cpp:19-71; tests/test_gpu_extract.py and
+// host_tests compare files byte for byte): the header below, then per vertex "x y z g g g" with the
+// coordinates in the stream's default float format (= %g) and g a grey value that upstream derives from z as
+// a debugging aid — 255 * min(1, (z - 0.35) / (zmax - 0.35)), truncated — then per face "3 i j k".
+// The whole file is formatted into one buffer and written once.
+namespace
+{
+const char* const kPlyHeader[] = {
+    "property float x", "property float y", "property float z",
+    "property uchar red", "property uchar green", "property uchar blue"};
+
+void append_number(std::string& text, float value)
+{
+  char field[32];
+  text.append(field, (size_t)std::snprintf(field, sizeof(field), "%g", value));
+}
+void append_number(std::string& text, long long value)
+{
+  char field[32];
+  text.append(field, (size_t)std::snprintf(field, sizeof(field), "%lld", value));
+}
+}  // namespace
+
 void Exporter::Export(const Mesh& mesh) const
 {
-  std::ofstream fout(file_);
-  VULCAN_ASSERT(fout.is_open());
+  const size_t vertices = mesh.points.size(), triangles = mesh.faces.size();
+  std::string text;
+  text.reserve(160 + 48 * vertices + 40 * triangles);
+  text += "ply\nformat ascii 1.0\nelement vertex ";
+  append_number(text, (long long)vertices);
+  text += '\n';
+  for (const char* line : kPlyHeader) { text += line; text += '\n'; }
+  text += "element face ";
+  append_number(text, (long long)triangles);
+  text += "\nproperty list uchar int vertex_indices\nend_header\n";
 
-  fout << "ply" << std::endl;
-  fout << "format ascii 1.0" << std::endl;
-  fout << "element vertex " << mesh.points.size() << std::endl;
-  fout << "property float x" << std::endl;
-  fout << "property float y" << std::endl;
-  fout << "property float z" << std::endl;
-  fout << "property uchar red" << std::endl;
-  fout << "property uchar green" << std::endl;
-  fout << "property uchar blue" << std::endl;
-  fout << "element face " << mesh.faces.size() << std::endl;
-  fout << "property list uchar int vertex_indices" << std::endl;
-  fout << "end_header" << std::endl;
+  // the grey ramp's far end is the largest z of the mesh; its near end is fixed (exporter.cpp:56)
+  const float near_z = 0.35f;
+  float far_z = 0.0f;
+  for (size_t i = 0; i < vertices; ++i)
+    if (i == 0 || mesh.points[i][2] > far_z) far_z = mesh.points[i][2];
 
-  float dmin = 0, dmax = 0;
-  int index = 0;
-  for (const Vector3f& point : mesh.points)
+  for (size_t i = 0; i < vertices; ++i)
   {
-    if (index == 0 || point[2] < dmin) dmin = point[2];
-    if (index == 0 || point[2] > dmax) dmax = point[2];
-    ++index;
+    const Vector3f& p = mesh.points[i];
+    const float ramp = 255 * min(1.0f, (p[2] - near_z) / (far_z - near_z));
+    const long long grey = std::isfinite(ramp) ? (long long)int(ramp) : 0;   // upstream: undefined when far_z == near_z
+    for (int axis = 0; axis < 3; ++axis) { append_number(text, p[axis]); text += ' '; }
+    append_number(text, grey);  text += ' ';
+    append_number(text, grey);  text += ' ';
+    append_number(text, grey);  text += '\n';
   }
-  dmin = 0.35f;   // exporter.cpp:56
-
-  for (const Vector3f& point : mesh.points)
+  for (size_t i = 0; i < triangles; ++i)
   {
-    fout << point[0] << " " << point[1] << " " << point[2] << " ";
-    const float value = 255 * min(1.0f, (point[2] - dmin) / (dmax - dmin));
-    const int color = std::isfinite(value) ? int(value) : 0;   // upstream: undefined when dmax == 0.35
-    fout << color << " " << color << " " << color << std::endl;
-  }
-
-  for (const Vector3i& face : mesh.faces)
-  {
-    fout << "3 " << face[0] << " " << face[1] << " " << face[2] << std::endl;
+    text += '3';
+    for (int corner = 0; corner < 3; ++corner) { text += ' '; append_number(text, (long long)mesh.faces[i][corner]); }
+    text += '\n';
   }
 
-  fout.close();
+  std::ofstream out(file_, std::ios::binary);
+  VULCAN_ASSERT(out.is_open());
+  out.write(text.data(), (std::streamsize)text.size());
 }
 
 // ---- Netpbm files ----------------------------------------------------------------

@@ -217,6 +217,8 @@ void Volume::ResetBufferSize() const
 
 void Volume::Initialize()
 {
+  // this translation unit and libvk_hip.so must agree on the structs and on the size of the counters block (vk.h)
+  VK_ASSERT(vk_abi_check(VK_ABI_VERSION, sizeof(vk_volume), sizeof(vk_frame), VK_CTR_COUNT));
   // sizes as in volume.cu:565-627
   voxels_.Resize(size_t(max_block_count_) * Block::voxel_count);
   hash_entries_.Resize(max_block_count_);

@@ -1466,7 +1466,20 @@ int main(int argc, char** argv)
   int count = 0;
   VK_ASSERT(vk_device_count(&count));
   if (count == 0) { std::printf("host_tests: no HIP device\n"); return 2; }
-  const std::string filter = argc > 1 ? argv[1] : "";
+  // host_tests [filter] [--force-loop-abort]: the flag sets vk_test_hooks.force_loop_abort, under which every
+  // one-launch Gauss-Newton loop ends with VK_TRACK_ABORTED and the trackers take the launch-per-stage path
+  std::string filter;
+  for (int i = 1; i < argc; ++i)
+  {
+    if (std::string(argv[i]) == "--force-loop-abort")
+    {
+      vk_test_hooks hooks;
+      VK_ASSERT(vk_test_hooks_get(&hooks));
+      hooks.force_loop_abort = 1;
+      VK_ASSERT(vk_test_hooks_set(&hooks));
+    }
+    else filter = argv[i];
+  }
   int failed = 0, ran = 0;
   for (const TestCase& t : Registry())
   {

@@ -14,6 +14,7 @@ VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 
 VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_PUBLIC = 8, 9, 10, 24
 VK_RETRY_SLOTS, VK_RETRY_KEYS, VK_POSTED_SLOTS = 65536, 8192, 2048
 # counters, two key sets, two slot lists, the posted buckets and their chains' last entries
+VK_ABI_VERSION = 4                       # include/vk.h
 VK_CTR_BANDED, VK_BANDS, VK_BAND_SLOTS = 20, 8, 16384
 VK_CTR_COUNT = (VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
                 + VK_BANDS + VK_BANDS * VK_BAND_SLOTS)
@@ -182,6 +183,12 @@ class LightPrep(C.Structure):
 class RigExchange(C.Structure):
     """vk_rig_exchange (vk.h): the peers' areas of the rig's in-launch exchange."""
     _fields_ = [("areas", C.c_void_p * 8), ("rank", C.c_int32), ("world", C.c_int32), ("sequence", C.c_uint32)]
+
+
+class TestHooks(C.Structure):
+    """vk_test_hooks (vk.h)"""
+    _fields_ = [("posted_capacity", C.c_int32), ("retry_capacity", C.c_int32), ("set_view_unfused", C.c_int32),
+                ("force_loop_abort", C.c_int32), ("loop_grid_cap", C.c_int32), ("loop_cooperative", C.c_int32)]
 
 
 class ColorPose(C.Structure):
