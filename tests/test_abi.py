@@ -33,7 +33,7 @@ def test_every_entry_point_cites_the_reference():
     text = open(HEADER).read()
     for name in declared():
         if re.match(r"vk_(error_string|version|device_|set_device|stream_|malloc|free|memcpy|memset|event_|probe_|trace_bounds_floats|"
-                    r"icp_workspace|trace_compute_block_bounds|test_hooks_)", name):
+                    r"icp_workspace|trace_compute_block_bounds|test_hooks_|abi_)", name):
             continue
         head = text[:text.index(name + "(")]
         comment = head[head.rindex("/*"):]
