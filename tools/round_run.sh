@@ -11,7 +11,7 @@ if [ "${2:-tests}" = "tests" ]; then
   tail -2 $out/pytest_gpu.txt
 fi
 : > $out/fuse_sequence.txt
-for m in 0 1 2; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 $m >> $out/fuse_sequence.txt 2>&1; done
+for m in 0 1 2 3; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 $m >> $out/fuse_sequence.txt 2>&1; done
 grep "^frames" $out/fuse_sequence.txt
 timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 python3 -c "

@@ -7,13 +7,15 @@
 //   integrator.Integrate(frame) -> tracer.Trace(keyframe)       (vulcan.cu:297-325)
 // The three SetView calls are one SetView(frame, 3) (same state, tsdf_volume.h).
 //
-//   fuse_sequence [frames=200] [mode=0|1|2]
+//   fuse_sequence [frames=200] [mode=0|1|2|3]
 //     0  DepthIntegrator + Tracer, no tracking                    (BASELINE configs[1]):
 //        camera at the centre of a 2 m sphere, yawing 0.5 degree per frame
 //     1  PyramidTracker<DepthTracker> in front of mode 0          (configs[2] tracking)
-//     2  PyramidTracker<LightTracker> + LightIntegrator + Tracer: what the shipped
-//        app is configured to run (vulcan.cu:87-111)
-//   Modes 1 and 2 run CLOSED LOOP in the room scene (room_scene.h): every frame is tracked
+//     2  PyramidTracker<LightTracker> (15 + 20 Gauss-Newton steps) + LightIntegrator (default weight
+//        caps 16 / 16) + Tracer: the line upstream keeps commented out (vulcan.cu:109)
+//     3  the shipped app's configuration, exactly (vulcan.cu:89-111): a plain LightTracker with
+//        SetMaxIterations(1), LightIntegrator with SetMaxDistanceWeight(100) / SetMaxColorWeight(16)
+//   Modes 1 to 3 run CLOSED LOOP in the room scene (room_scene.h): every frame is tracked
 //   from the previous tracked pose against the previous raycast, then fused and raycast at
 //   the tracked pose; the true poses only score the result.
 // Prints one human-readable line and one JSON line.
@@ -67,11 +69,20 @@ int main(int argc, char** argv)
   Tracer tracer(volume);
   PyramidTracker<DepthTracker> depth_tracker;
   PyramidTracker<LightTracker> light_tracker;
+  LightTracker app_tracker;                       // vulcan.cu:106-111: no pyramid, one step per frame
   Light light;
   light.SetIntensity(2.0f);                       // vulcan.cu:87-88
   light.SetPosition(0.025f, 0.08f, 0.0f);
   light_integrator.SetLight(light);
   std::const_pointer_cast<LightTracker>(light_tracker.GetTracker())->SetLight(light);
+  app_tracker.SetLight(light);
+  app_tracker.SetMaxIterations(1);                // vulcan.cu:111
+  const bool photometric = mode == 2 || mode == 3;
+  if (mode == 3)
+  {
+    light_integrator.SetMaxDistanceWeight(100);   // vulcan.cu:92-93
+    light_integrator.SetMaxColorWeight(16);
+  }
 
   Frame frame;
   frame.depth_projection.SetFocalLength(544.162f, 544.3847f);
@@ -142,9 +153,10 @@ int main(int argc, char** argv)
     if (track && i > 0)
     {
       // start from the previous pose, refine against the raycast keyframe (vulcan.cu:300-311)
-      if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); }
-      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.Track(frame); }
-      const int run = mode == 2 ? light_tracker.GetTracker()->GetIterationsRun() : depth_tracker.GetTracker()->GetIterationsRun();
+      int run = 0;
+      if (mode == 3) { app_tracker.SetKeyframe(keyframe); app_tracker.Track(frame); run = app_tracker.GetIterationsRun(); }
+      else if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); run = light_tracker.GetTracker()->GetIterationsRun(); }
+      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.Track(frame); run = depth_tracker.GetTracker()->GetIterationsRun(); }
       steps_run.push_back(run);
       if (run >= 0 && run < 64) ++steps_histogram[run];
       PoseError(frame.depth_to_world_transform, truth[i], last_translation, last_rotation);
@@ -157,7 +169,7 @@ int main(int argc, char** argv)
     }
 
     volume->SetView(frame, 3);         // vulcan.cu:316-318: three SetView calls
-    if (mode == 2) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
+    if (photometric) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
     keyframe->depth_to_world_transform = frame.depth_to_world_transform;
     tracer.Trace(*keyframe);           // :325
   }
@@ -168,7 +180,7 @@ int main(int argc, char** argv)
   volume->GetCounters(counters);
   std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  tracking %s\n", frames,
       seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
-      counters[VK_CTR_DROPPED], mode == 0 ? "off" : (mode == 1 ? "depth" : "light"));
+      counters[VK_CTR_DROPPED], mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
 
@@ -187,8 +199,9 @@ int main(int argc, char** argv)
       "\"pose_error_last_frame\": {\"translation_m\": %.6f, \"rotation_deg\": %.5f}, "
       "\"camera_motion_over_run\": {\"translation_m\": %.4f, \"rotation_deg\": %.3f}, \"gn_steps_median\": %d, "
       "\"gn_steps_histogram_full_resolution_level\": {",
-      mode, mode == 0 ? "none" : (mode == 1 ? "PyramidTracker<DepthTracker>" : "PyramidTracker<LightTracker>"),
-      mode == 2 ? "LightIntegrator" : "DepthIntegrator", frames, frames / seconds, 1e6 * seconds / frames,
+      mode, mode == 0 ? "none" : (mode == 1 ? "PyramidTracker<DepthTracker>" : (mode == 2 ? "PyramidTracker<LightTracker>" :
+          "LightTracker, SetMaxIterations(1) (apps/vulcan/vulcan.cu:106-111)")),
+      mode == 3 ? "LightIntegrator, weight caps 100 / 16 (vulcan.cu:92-93)" : (mode == 2 ? "LightIntegrator" : "DepthIntegrator"), frames, frames / seconds, 1e6 * seconds / frames,
       double(counters[VK_CTR_ROUNDS]) / frames, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
       counters[VK_CTR_DROPPED], track ? "true" : "false", worst_translation, worst_rotation, last_translation,
       last_rotation, motion_translation, motion_rotation, median);
