@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20, help="Gauss-Newton steps per frame (the app: 1)")
     ap.add_argument("--size", default="320x240")
     ap.add_argument("--tracker", default="light", choices=["light", "depth"])
+    ap.add_argument("--cycle", type=int, default=240, help="frames per cycle of the camera's path (240: the bench's motion)")
+    ap.add_argument("--ambient", type=float, default=0.0, help="ambient term added to the shaded colour (0: the lamp alone)")
     args = ap.parse_args()
     import torch
     import scenes
@@ -43,7 +45,7 @@ def main():
     k = T.Projection.make(*(np.float32(w / 640.0) * np.float32(v) for v in scenes.APP_INTRINSICS))
     light = T.Light.make(*LIGHT)
     params = T.Integrator(0.1, 5.0, 100.0, 16.0)             # vulcan.cu:92-93
-    truth = [scenes.room_pose(30 + i) for i in range(args.frames)]
+    truth = [scenes.room_pose(30 * args.cycle // 240 + i, frames_per_cycle=args.cycle) for i in range(args.frames)]
     inputs = [scenes.room_frame(k, p, w, h, light=LIGHT) for p in truth]
     orc.set_threads(min(16, os.cpu_count() or 1))
 
@@ -61,7 +63,8 @@ def main():
                       normals=torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")) for _ in range(2)]
     opose = dpose = truth[0]
     hkey = None
-    print(f"# {args.tracker} tracker, {args.steps} steps per frame, {w}x{h}, {args.frames} frames of the room sequence")
+    print(f"# {args.tracker} tracker, {args.steps} steps per frame, {w}x{h}, {args.frames} frames of the room sequence, "
+          f"{args.cycle} frames per cycle")
     print("# frame | oracle error mm / deg | device error mm / deg | max |device pose - oracle pose| | dropped requests (device)")
     for i, (depth, color) in enumerate(inputs):
         hf = orc.HostFrame(depth, k, opose, color=color)
