@@ -585,59 +585,91 @@ def rig_collective(rank, world, vd):
 def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
     """The same rig step through the shipped C binding (libvk_comm.so: vk_comm_* over RCCL,
     no Python between the Gauss-Newton iterations). Failure here is reported, not fatal: the
-    torch.distributed numbers above stand on their own."""
-    try:
-        import torch
-        import torch.distributed as dist
-        from vulcan_amd import comm
-        c = comm.Communicator.from_torch_group(rank, world)
-        seen = c.rccl_count()                       # what RCCL itself says, not the launcher's environment
-        if seen != world:
-            raise RuntimeError(f"ncclCommCount says {seen} ranks, WORLD_SIZE is {world}")
-        tracker.reduce_hook = None
+    torch.distributed numbers above stand on their own. Every step that can fail on ONE rank alone
+    (creating the communicator, RCCL's own rank count, attaching the exchange) is followed by
+    vd.all_ok: the ranks agree on the outcome before any of them enters the next collective, so
+    all of them take the same branch and none waits in a collective another rank never reaches."""
+    import torch
+    import torch.distributed as dist
+    from vulcan_amd import api, comm
+
+    def local(step):
+        """run a rank-local step; (value, error text or None)"""
+        try:
+            return step(), None
+        except Exception as e:     # noqa: BLE001  (reported in the JSON line)
+            return None, f"{type(e).__name__}: {e}"[:300]
+
+    def agreed(error, what):
+        if vd.all_ok(error is None, device="cuda"):
+            return None
+        return {"ok": False, "error": error or f"another rank failed in: {what}"}
+
+    c, error = local(lambda: comm.Communicator.from_torch_group(rank, world))
+    failed = agreed(error, "vk_comm_init")
+    if failed:
+        return failed
+    seen, error = local(c.rccl_count)              # what RCCL itself says, not the launcher's environment
+    if error is None and seen != world:
+        error = f"ncclCommCount says {seen} ranks, WORLD_SIZE is {world}"
+    failed = agreed(error, "vk_comm_count")
+    if failed:
+        c.close()
+        return failed
+
+    tracker.reduce_hook = None
+    frame.depth_to_world = start
+    c.track(tracker, frame)
+    torch.cuda.synchronize()
+    vd.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
         frame.depth_to_world = start
         c.track(tracker, frame)
-        torch.cuda.synchronize()
-        vd.barrier()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            frame.depth_to_world = start
-            c.track(tracker, frame)
-        torch.cuda.synchronize()
-        ms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
-        us = c.time_allreduce(200)
-        us = vd.max_over_ranks(us, device="cuda")
-        it = int(tracker.state.cpu()[0])
-        out = {"ok": True, "ranks_rccl": seen, "allreduce_us": us, "track_ms_per_frame": ms, "iterations_per_frame": it}
-        # the same Track with the ranks' sums exchanged INSIDE the one-launch loop (peer-mapped areas,
-        # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
-        # on a multi-GPU node the path is unmeasured on hardware (DESIGN.md section 6)
-        try:
-            if not RIG_IN_LAUNCH_EXCHANGE:
-                raise RuntimeError("not run: set VK_BENCH_RIG_EXCHANGE=1 (never run on more than one GPU; DESIGN.md section 6)")
-            tracker.comm = None
-            c.attach_exchange()
-            frame.depth_to_world = start
-            c.track_rig(tracker, frame)
-            torch.cuda.synchronize()
-            vd.barrier()
-            t0 = time.perf_counter()
-            for _ in range(20):
+    torch.cuda.synchronize()
+    ms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
+    us = vd.max_over_ranks(c.time_allreduce(200), device="cuda")
+    out = {"ok": True, "ranks_rccl": seen, "allreduce_us": us, "track_ms_per_frame": ms,
+           "iterations_per_frame": int(tracker.state.cpu()[0])}
+
+    # the same Track with the ranks' sums exchanged INSIDE the one-launch loop (peer-mapped areas,
+    # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
+    # on a multi-GPU node the path is unmeasured on hardware over xGMI (DESIGN.md section 6; two processes on
+    # one GPU: tests/test_gpu_rig_two_ranks.py)
+    if not RIG_IN_LAUNCH_EXCHANGE:
+        out["in_launch_exchange"] = {"ok": False, "error": "not run: set VK_BENCH_RIG_EXCHANGE=1 (never run on more than "
+                                     "one GPU; DESIGN.md section 6)"}
+    else:
+        tracker.comm = None
+        c.agree = comm.agree_over_torch_group()
+        _, error = local(c.attach_exchange)        # collective, and so is its outcome (vk_comm.h); agreed once more anyway
+        failed = agreed(error, "vk_comm_exchange_attach")
+        if failed:
+            out["in_launch_exchange"] = failed
+        else:
+            def timed():
                 frame.depth_to_world = start
-                got = c.track_rig(tracker, frame)
-            torch.cuda.synchronize()
-            xms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
-            upd = tracker.update.clone()
-            gathered = [torch.empty_like(upd) for _ in range(world)]
-            dist.all_gather(gathered, upd)
-            out["in_launch_exchange"] = {"ok": True, "track_ms_per_frame": xms, "iterations_per_frame": int(tracker.state.cpu()[0]),
-                                         "update_identical_on_all_ranks": bool(all(torch.equal(g, gathered[0]) for g in gathered))}
-        except Exception as e:     # noqa: BLE001
-            out["in_launch_exchange"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
-        c.close()
-        return out
-    except Exception as e:     # noqa: BLE001  (reported in the JSON line)
-        return {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+                c.track_rig(tracker, frame)        # raises TrackAborted on EVERY rank if any rank gave up (c.agree)
+                torch.cuda.synchronize()
+                vd.barrier()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    frame.depth_to_world = start
+                    c.track_rig(tracker, frame)
+                torch.cuda.synchronize()
+                return vd.max_over_ranks((time.perf_counter() - t1) / 20 * 1e3, device="cuda")
+            xms, error = local(timed)
+            failed = agreed(error, "vk_icp_track_rig")
+            if failed:
+                out["in_launch_exchange"] = failed
+            else:
+                upd = tracker.update.clone()
+                gathered = [torch.empty_like(upd) for _ in range(world)]
+                dist.all_gather(gathered, upd)
+                out["in_launch_exchange"] = {"ok": True, "track_ms_per_frame": xms, "iterations_per_frame": int(tracker.state.cpu()[0]),
+                                             "update_identical_on_all_ranks": bool(all(torch.equal(g, gathered[0]) for g in gathered))}
+    c.close()
+    return out
 
 
 # --------------------------------------------------------------------------- main ----
@@ -815,18 +847,20 @@ def main():
         result["other_workloads"] = others
 
     if world > 1:
-        # the rig step is reported next to the headline, never instead of it: a failure here
-        # (every rank sees the same exception or none: the calls are collective) is recorded, and
-        # a rank that waits for a peer longer than RIG_TIMEOUT_S (a collective some rank never
-        # entered) ends the run WITH the headline: rank 0 prints the line as it stands, all exit
+        # the rig step is reported next to the headline, never instead of it: a failure here is
+        # recorded (vk_comm_rig makes the ranks agree on every step that can fail on one of them
+        # alone before the next collective), and a rank that still waits for a peer longer than
+        # RIG_TIMEOUT_S ends the run WITH the headline and a non-zero exit code
         import threading
 
         def give_up():
+            # the headline is printed (it was measured before the rig step and is unaffected), and the run FAILS:
+            # the launcher and the driver see a non-zero exit code, not a success
             result["collective"] = {"ok": False, "error": f"the rig step did not finish within {RIG_TIMEOUT_S} s; "
                                     "the headline above was measured before it and is unaffected"}
             if rank == 0:
                 emit(result)
-            os._exit(0)
+            os._exit(3)
 
         watchdog = threading.Timer(RIG_TIMEOUT_S, give_up)
         watchdog.daemon = True

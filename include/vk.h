@@ -693,8 +693,9 @@ typedef struct vk_rig_exchange {
   unsigned long long* areas[VK_RIG_MAX_RANKS]; /* areas[r]: rank r's area as mapped into THIS process (areas[rank]:
                                                   its own); each of the size vk_rig_area_bytes returns, zeroed once, fine-grained */
   int32_t  rank, world;
-  uint32_t sequence;      /* names the Track: the same on every rank, different from the Track before (the
-                             caller adds 1 per Track), 22 bits, never 0 */
+  uint32_t sequence;      /* names the Track: the same on every rank, 22 bits, never 0; after EVERY Track it entered
+                             (an aborted one too) a rank moves it on with vk_comm_exchange_next_sequence
+                             (vk_comm.h): 1, 2, ... 2^22 - 2, 1, ... — the parity alternates across the wrap */
 } vk_rig_exchange;
 
 /* bytes of one rank's area (ref: none — the reference has no multi-GPU code) */

@@ -34,6 +34,8 @@ extern "C" {
 #define VK_COMM_ID_BYTES 128        /* sizeof(ncclUniqueId) */
 #define VK_COMM_ERR_NO_RCCL (-4)    /* librccl could not be loaded */
 #define VK_COMM_SYSTEM_FLOATS 48    /* hessian[36] | gradient[6] | pad[6] */
+#define VK_COMM_ERR_PEER (-5)       /* a collective step failed on ANOTHER rank: every rank returns an error, the same way */
+#define VK_COMM_IPC_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
 
 /* Rank 0 creates the id and hands it to the other ranks by whatever the host
  * application uses (a file, MPI, a socket, torch.distributed). ncclGetUniqueId. */
@@ -64,14 +66,33 @@ VK_API int vk_comm_reduce_hook(float* system_dev, int count, void* comm, void* s
  * allocates its area (fine-grained device memory, zeroed), the ranks exchange the areas' IPC handles
  * (hipIpcGetMemHandle, one ncclAllGather) and map each other's (hipIpcOpenMemHandle with lazy peer
  * access, i.e. direct stores over xGMI). Fills *exchange (a vk_rig_exchange: areas[0 .. world), rank,
- * world, sequence = 1); the caller adds 1 to `sequence` after every Track, on every rank. With a
- * loopback communicator (world == 1) only the own area is made. The all-reduce hook above remains
- * the fallback (a rank that cannot map a peer returns the HIP error, and the caller keeps the hook).
+ * world, sequence = 1); after every Track it entered — aborted ones included — every rank moves `sequence`
+ * on with vk_comm_exchange_next_sequence. With a loopback communicator (world == 1) only the own area is made.
+ * The all-reduce hook above remains the fallback for a rig whose attach failed.
  * HIP is resolved at run time like RCCL ($VK_HIP_RUNTIME_LIBRARY, else libamdhip64.so).
- * NOT exercised with more than one rank on hardware: this pool hands out single-GPU boxes. */
+ * The RESULT is collective too: the ranks' outcomes are combined (one ncclAllReduce, min) before anyone returns, so
+ * either every rank holds a complete exchange and VK_OK, or every rank has detached and returns an error — its own,
+ * or VK_COMM_ERR_PEER when it was another rank's mapping that failed. Nobody is left on the all-reduce hook alone.
+ * NOT exercised with more than one GPU on hardware: this pool hands out single-GPU boxes (two processes on one GPU
+ * run the path below, tests/test_gpu_rig_two_ranks.py). */
 VK_API int vk_comm_exchange_attach(void* comm, void* exchange /* vk_rig_exchange* */);
 
-/* unmaps the peers' areas and frees the own one (call on every rank, before vk_comm_destroy) */
+/* The same exchange for a host that moves the handles itself (MPI, a socket, torch.distributed over gloo — and
+ * then also for ranks that share a device, which RCCL refuses): no communicator involved.
+ *   1. vk_comm_exchange_create: allocates and zeroes this rank's area, fills *exchange (rank, world, sequence = 1,
+ *      areas[rank]) and writes the area's IPC handle (VK_COMM_IPC_HANDLE_BYTES) to handle_out;
+ *   2. the host gathers all ranks' handles, in rank order;
+ *   3. vk_comm_exchange_attach_handles: maps the peers' areas (handles[rank] is skipped). On failure the exchange is
+ *      detached. The ranks must agree on the outcome through their own channel before any of them starts a Track.
+ * vk_comm_exchange_detach(NULL, exchange) undoes both. */
+VK_API int vk_comm_exchange_create(void* exchange /* vk_rig_exchange* */, int rank, int world, void* handle_out);
+VK_API int vk_comm_exchange_attach_handles(void* exchange /* vk_rig_exchange* */, const void* handles /* world x 64 bytes */);
+
+/* The Track number that follows `sequence` (vk_rig_exchange.sequence): 1, 2, ... 2^22 - 2, 1, ... — every rank advances
+ * after every Track it entered, aborted ones included (vulcan_amd/csrc/vk_rig_protocol.h rig_next_sequence). */
+VK_API unsigned vk_comm_exchange_next_sequence(unsigned sequence);
+
+/* unmaps the peers' areas and frees the own one (call on every rank, before vk_comm_destroy); comm may be NULL */
 VK_API int vk_comm_exchange_detach(void* comm, void* exchange /* vk_rig_exchange* */);
 
 VK_API int vk_comm_destroy(void* comm);

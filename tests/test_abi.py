@@ -99,7 +99,7 @@ def test_comm_library_exports_and_loopback():
     from vulcan_amd import comm
     text = open(os.path.join(ROOT, "include", "vk_comm.h")).read()
     names = sorted(set(re.findall(r"VK_API\s+[\w\s\*]+?\b(vk_comm_\w+)\s*\(", text)))
-    assert names == sorted(comm.EXPORTS) and len(names) == 10
+    assert names == sorted(comm.EXPORTS) and len(names) == 13
     out = subprocess.run(["nm", "-D", "--defined-only", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     assert sorted(l.split()[-1] for l in out.splitlines() if " T vk_" in l) == names
     assert "rccl" not in subprocess.run(["ldd", comm.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout   # bound at run time
@@ -110,6 +110,11 @@ def test_comm_library_exports_and_loopback():
     assert lib.vk_comm_init(C.byref(h), None, 0, 2) == -1          # world > 1 needs an id
     assert lib.vk_comm_allreduce_system(None, None, 48, None) == -1
     assert lib.vk_comm_exchange_attach(None, None) == -1 and lib.vk_comm_exchange_detach(None, None) == -1
+    assert lib.vk_comm_exchange_create(None, 0, 1, None) == -1 and lib.vk_comm_exchange_attach_handles(None, None) == -1
+    # 1, 2, ... 2^22 - 2, 1: never 0, and the parity alternates across the wrap (vk_rig_protocol.h)
+    last = (1 << 22) - 2
+    assert lib.vk_comm_exchange_next_sequence(1) == 2 and lib.vk_comm_exchange_next_sequence(last - 1) == last
+    assert lib.vk_comm_exchange_next_sequence(last) == 1 and last % 2 == 0
     assert b"invalid argument" in lib.vk_comm_error_string(-1)
     c = comm.Communicator(None, 0, 1)
     r, w = C.c_int(-1), C.c_int(-1)

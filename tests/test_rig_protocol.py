@@ -25,6 +25,22 @@ def test_protocol_rehearsal(world, tracks, steps):
     assert proc.returncode == 0 and " 0 failure(s)" in proc.stdout, proc.stdout[-2000:]
 
 
+@pytest.mark.parametrize("world,tracks,steps,start,abort_every", [
+    (2, 600, 1, (1 << 22) - 300, 0),        # the wrap 2^22 - 2 -> 1 with one step per Track: the parities must alternate across it
+    (4, 60, 6, (1 << 22) - 20, 0),
+    (2, 120, 8, 1, 5),                      # every fifth Track aborted half way: the Tracks after it are intact
+    (3, 90, 4, (1 << 22) - 40, 4),          # aborts and the wrap together
+    (8, 24, 3, 7, 3)])
+def test_sequence_wrap_and_aborted_tracks(world, tracks, steps, start, abort_every):
+    """the sequence number advances after EVERY Track, aborted ones included (a retry under the old number would
+    accept the aborted attempt's words), and wraps 2^22 - 2 -> 1 so that the parity that picks the buffers alternates."""
+    proc = subprocess.run([EXE, str(world), str(tracks), str(steps), "3", str(start), str(abort_every)], stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert proc.returncode == 0 and " 0 failure(s)" in proc.stdout, proc.stdout[-2000:]
+    if abort_every:
+        assert f" {tracks // abort_every} aborted" in proc.stdout, proc.stdout
+
+
 def test_layout_is_spelled_the_same_everywhere():
     from vulcan_amd import vk_types as T
     header = open(os.path.join(ROOT, "vulcan_amd", "csrc", "vk_rig_protocol.h")).read()

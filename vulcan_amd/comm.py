@@ -14,14 +14,30 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvk_comm.so")
 ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 EXPORTS = ("vk_comm_unique_id", "vk_comm_init", "vk_comm_rank", "vk_comm_allreduce_system",
            "vk_comm_reduce_hook", "vk_comm_count", "vk_comm_exchange_attach", "vk_comm_exchange_detach", "vk_comm_destroy",
-           "vk_comm_error_string")
+           "vk_comm_error_string", "vk_comm_exchange_create", "vk_comm_exchange_attach_handles",
+           "vk_comm_exchange_next_sequence")
 _LIB = None
 
 
 class CommError(RuntimeError):
     pass
+
+
+def agree_over_torch_group(group=None):
+    """An `agree` for Communicator (see there): logical OR of a flag over a torch.distributed group."""
+    import torch
+    import torch.distributed as dist
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(int(t.item()))
+    return agree
 
 
 def lib():
@@ -48,6 +64,9 @@ def lib():
         h.vk_comm_count.argtypes, h.vk_comm_count.restype = [P, C.POINTER(I)], I
         h.vk_comm_exchange_attach.argtypes, h.vk_comm_exchange_attach.restype = [P, P], I
         h.vk_comm_exchange_detach.argtypes, h.vk_comm_exchange_detach.restype = [P, P], I
+        h.vk_comm_exchange_create.argtypes, h.vk_comm_exchange_create.restype = [P, I, I, P], I
+        h.vk_comm_exchange_attach_handles.argtypes, h.vk_comm_exchange_attach_handles.restype = [P, P], I
+        h.vk_comm_exchange_next_sequence.argtypes, h.vk_comm_exchange_next_sequence.restype = [C.c_uint], C.c_uint
         h.vk_comm_destroy.argtypes, h.vk_comm_destroy.restype = [P], I
         h.vk_comm_error_string.argtypes, h.vk_comm_error_string.restype = [I], C.c_char_p
         _LIB = h
@@ -73,6 +92,14 @@ class Communicator:
         self.rank, self.world = rank, world
         # the C function itself, passed as vk_icp_reduce_fn: nothing of Python runs per iteration
         self.hook_fn = C.cast(lib().vk_comm_reduce_hook, C.c_void_p)
+
+    @classmethod
+    def without_rccl(cls, rank, world):
+        """A rank of a rig that exchanges only through attach_exchange_with (its own channel for the handles, the
+        peer-mapped areas for the sums): no RCCL communicator, hence no all-reduce hook."""
+        self = cls.__new__(cls)
+        self.handle, self.rank, self.world, self.hook_fn = C.c_void_p(), rank, world, None
+        return self
 
     @classmethod
     def from_torch_group(cls, rank, world):
@@ -109,23 +136,62 @@ class Communicator:
 
     # -- the exchange inside the one-launch loop (vk_rig_exchange, vk_icp_track_rig)
     exchange = None
+    # Optional: `agree(flag) -> bool`, a collective "did ANY rank say True?" over the application's own channel (e.g.
+    # agree_over_torch_group). With it, a Track that aborted on one rank raises TrackAborted on EVERY rank, so that
+    # they can fall back together; without it only the rank that aborted raises, and the others' next collective
+    # step would wait for it.
+    agree = None
 
     def attach_exchange(self):
-        """Collective: every rank's area mapped into every rank (vk_comm_exchange_attach)."""
+        """Collective: every rank's area mapped into every rank (vk_comm_exchange_attach); the outcome is the
+        same on all ranks."""
         from . import vk_types as T
         x = T.RigExchange()
         check(lib().vk_comm_exchange_attach(self.handle, C.byref(x)), "vk_comm_exchange_attach")
         self.exchange = x
         return x
 
+    def attach_exchange_with(self, all_gather, agree):
+        """The same for ranks that move the IPC handles themselves (and may share a device, which RCCL refuses):
+        `all_gather(bytes) -> [bytes per rank, in rank order]` and `agree(flag) -> bool` (True if any rank passed
+        True) are the application's own collectives, e.g. torch.distributed over gloo."""
+        from . import vk_types as T
+        x = T.RigExchange()
+        handle = C.create_string_buffer(IPC_HANDLE_BYTES)
+        rc = lib().vk_comm_exchange_create(C.byref(x), self.rank, self.world, handle)
+        if agree(rc != 0):                                   # a rank without an area: nobody goes on
+            if rc == 0:
+                lib().vk_comm_exchange_detach(None, C.byref(x))
+            raise CommError(f"vk_comm_exchange_create failed on a rank (here: {rc})")
+        handles = all_gather(handle.raw)
+        assert len(handles) == self.world and all(len(b) == IPC_HANDLE_BYTES for b in handles)
+        rc = lib().vk_comm_exchange_attach_handles(C.byref(x), C.create_string_buffer(b"".join(handles), IPC_HANDLE_BYTES * self.world))
+        if agree(rc != 0):
+            if rc == 0:
+                lib().vk_comm_exchange_detach(None, C.byref(x))
+            raise CommError(f"vk_comm_exchange_attach_handles failed on a rank (here: {rc})")
+        self.exchange, self.agree = x, agree
+        return x
+
     def track_rig(self, tracker, frame):
-        """DepthTracker::Track on the rig with the ranks' sums exchanged inside the launch; every
-        rank calls it for the same Track (the sequence number advances here, identically)."""
+        """DepthTracker::Track on the rig with the ranks' sums exchanged inside the launch; every rank calls it
+        for the same Track. The sequence number moves on HERE, on every rank, whether the Track ended with a pose or
+        with VK_TRACK_ABORTED (vk_rig_protocol.h rig_next_sequence): a retry never meets the aborted attempt's words
+        under their own tags, and the ranks' numbers cannot drift apart."""
         from . import api
         if self.exchange is None:
             self.attach_exchange()
-        out = api.track_rig(tracker, frame, self.exchange)
-        self.exchange.sequence = (self.exchange.sequence % ((1 << 22) - 1)) + 1
+        aborted, out = False, None
+        try:
+            out = api.track_rig(tracker, frame, self.exchange)
+        except api.TrackAborted:
+            aborted = True
+        finally:
+            self.exchange.sequence = lib().vk_comm_exchange_next_sequence(self.exchange.sequence)
+        if self.agree is not None:
+            aborted = bool(self.agree(aborted))              # collective: everybody learns of anybody's abort
+        if aborted:
+            raise api.TrackAborted("a rank of the rig gave up waiting for a peer's sums (VK_TRACK_ABORTED)")
         return out
 
     def detach_exchange(self):

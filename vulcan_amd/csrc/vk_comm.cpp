@@ -19,7 +19,7 @@ enum { VK_OK_ = 0, VK_ERR_ARGUMENT_ = -1 };
 struct UniqueId { char internal[VK_COMM_ID_BYTES]; };
 typedef void* Comm;
 typedef int Result;               // ncclResult_t, ncclSuccess == 0
-enum { kFloat32 = 7, kSum = 0 };  // ncclFloat32, ncclSum
+enum { kFloat32 = 7, kSum = 0, kMin = 3 };  // ncclFloat32, ncclSum, ncclMin
 
 struct Rccl
 {
@@ -131,6 +131,37 @@ struct RigExchange
   int32_t rank, world;
   uint32_t sequence;
 };
+enum { kRigLastSequence = (1u << 22) - 2u };      // vk_rig_protocol.h VK_RIG_LAST_SEQUENCE
+
+// this rank's area: fine-grained device memory, zeroed (a zero word carries no tag)
+int make_area(const Hip* h, RigExchange* x, int rank, int world)
+{
+  memset(x, 0, sizeof(*x));
+  x->rank = rank;
+  x->world = world;
+  x->sequence = 1;
+  void* own = nullptr;
+  int rc = h->ExtMallocWithFlags(&own, kRigAreaBytes, kMallocFinegrained);
+  if (rc != 0) return rc;
+  rc = h->Memset(own, 0, kRigAreaBytes);
+  if (rc == 0) rc = h->DeviceSynchronize();
+  if (rc != 0) { h->Free(own); return rc; }
+  x->areas[rank] = static_cast<unsigned long long*>(own);
+  return 0;
+}
+
+int map_peers(const Hip* h, RigExchange* x, const IpcHandle* all)
+{
+  for (int r = 0; r < x->world; ++r)
+  {
+    if (r == x->rank) continue;
+    void* peer = nullptr;
+    const int rc = h->IpcOpenMemHandle(&peer, all[r], kIpcLazyPeerAccess);
+    if (rc != 0) return rc;
+    x->areas[r] = static_cast<unsigned long long*>(peer);
+  }
+  return 0;
+}
 
 inline int from_nccl(Result r) { return r == 0 ? VK_OK_ : 1000 + r; }
 
@@ -210,60 +241,102 @@ int vk_comm_exchange_attach(void* comm, void* exchange)
   if (c->world > kRigMaxRanks) return VK_ERR_ARGUMENT_;
   const Hip* h = hip();
   if (!h) return VK_COMM_ERR_NO_RCCL;
-  memset(x, 0, sizeof(*x));
-  x->rank = c->rank;
-  x->world = c->world;
-  x->sequence = 1;
-  void* own = nullptr;
-  int rc = h->ExtMallocWithFlags(&own, kRigAreaBytes, kMallocFinegrained);
-  if (rc != 0) return rc;
-  rc = h->Memset(own, 0, kRigAreaBytes);
-  if (rc == 0) rc = h->DeviceSynchronize();
-  if (rc != 0) { h->Free(own); return rc; }
-  x->areas[c->rank] = static_cast<unsigned long long*>(own);
-  if (c->world == 1 || !c->comm) return VK_OK_;
+  int rc = make_area(h, x, c->rank, c->world);
+  if (c->world == 1 || !c->comm) return rc;          // a loopback: nobody to agree with
+  if (!g_rccl.AllGather) { vk_comm_exchange_detach(comm, exchange); return VK_COMM_ERR_NO_RCCL; }
 
-  // every rank's handle to every rank: one all-gather of 64 bytes per rank, through device memory
-  if (!g_rccl.AllGather) { h->Free(own); x->areas[c->rank] = nullptr; return VK_COMM_ERR_NO_RCCL; }
+  // From here on every rank makes the SAME collective calls whatever happened to it locally (a rank that failed
+  // sends a zeroed handle and maps nothing), and the last one combines the outcomes: min over ranks of "I am
+  // complete". A rank that returned early would leave its peers inside a collective for ever.
+  // Every rank's handle to every rank: one all-gather of 64 bytes per rank, through device memory.
   IpcHandle mine;
-  rc = h->IpcGetMemHandle(&mine, own);
+  memset(&mine, 0, sizeof(mine));
+  if (rc == 0) rc = h->IpcGetMemHandle(&mine, x->areas[c->rank]);
   void* staging = nullptr;
-  if (rc == 0) rc = h->Malloc(&staging, (size_t)kIpcHandleBytes * (size_t)(c->world + 1));
-  if (rc != 0) { h->Free(own); x->areas[c->rank] = nullptr; return rc; }
+  const size_t staging_bytes = (size_t)kIpcHandleBytes * (size_t)(c->world + 1) + 2 * sizeof(float);
+  const int staging_rc = h->Malloc(&staging, staging_bytes);
+  if (staging_rc != 0)
+  {
+    // no device memory for the collective's buffers at all: this rank cannot even take part (its peers' calls
+    // then fail or time out inside RCCL, which reports it); nothing better can be done from here
+    vk_comm_exchange_detach(comm, exchange);
+    return staging_rc;
+  }
   char* send = static_cast<char*>(staging);
   char* recv = send + kIpcHandleBytes;
-  rc = h->Memcpy(send, &mine, kIpcHandleBytes, kCopyDefault);
-  if (rc == 0)
-  {
-    const Result nr = g_rccl.AllGather(send, recv, kIpcHandleBytes, kInt8, c->comm, nullptr);
-    rc = nr == 0 ? h->DeviceSynchronize() : 1000 + nr;
-  }
+  float* verdict = reinterpret_cast<float*>(recv + (size_t)kIpcHandleBytes * (size_t)c->world);
+  int step = h->Memcpy(send, &mine, kIpcHandleBytes, kCopyDefault);
+  if (rc == 0) rc = step;
+  Result nr = g_rccl.AllGather(send, recv, kIpcHandleBytes, kInt8, c->comm, nullptr);
+  step = nr == 0 ? h->DeviceSynchronize() : 1000 + nr;
+  if (rc == 0) rc = step;
   IpcHandle all[kRigMaxRanks];
-  if (rc == 0) rc = h->Memcpy(all, recv, (size_t)kIpcHandleBytes * (size_t)c->world, kCopyDefault);
-  h->Free(staging);
-  for (int r = 0; rc == 0 && r < c->world; ++r)
+  step = h->Memcpy(all, recv, (size_t)kIpcHandleBytes * (size_t)c->world, kCopyDefault);
+  if (rc == 0) rc = step;
+  if (rc == 0) rc = map_peers(h, x, all);
+
+  const float complete = rc == 0 ? 1.0f : 0.0f;
+  float everyone = 0.0f;
+  step = h->Memcpy(verdict, &complete, sizeof(float), kCopyDefault);
+  if (step == 0)
   {
-    if (r == c->rank) continue;
-    void* peer = nullptr;
-    rc = h->IpcOpenMemHandle(&peer, all[r], kIpcLazyPeerAccess);
-    if (rc == 0) x->areas[r] = static_cast<unsigned long long*>(peer);
+    nr = g_rccl.AllReduce(verdict, verdict + 1, 1, kFloat32, kMin, c->comm, nullptr);
+    step = nr == 0 ? h->DeviceSynchronize() : 1000 + nr;
   }
-  if (rc != 0) { vk_comm_exchange_detach(comm, exchange); return rc; }
+  if (step == 0) step = h->Memcpy(&everyone, verdict + 1, sizeof(float), kCopyDefault);
+  h->Free(staging);
+  if (rc == 0 && step != 0) rc = step;
+  if (rc == 0 && everyone != 1.0f) rc = VK_COMM_ERR_PEER;
+  if (rc != 0) vk_comm_exchange_detach(comm, exchange);
+  return rc;
+}
+
+int vk_comm_exchange_create(void* exchange, int rank, int world, void* handle_out)
+{
+  if (!exchange || !handle_out || world < 1 || world > kRigMaxRanks || rank < 0 || rank >= world) return VK_ERR_ARGUMENT_;
+  const Hip* h = hip();
+  if (!h) return VK_COMM_ERR_NO_RCCL;
+  RigExchange* x = static_cast<RigExchange*>(exchange);
+  int rc = make_area(h, x, rank, world);
+  IpcHandle mine;
+  memset(&mine, 0, sizeof(mine));
+  if (rc == 0) rc = h->IpcGetMemHandle(&mine, x->areas[rank]);
+  if (rc != 0) { vk_comm_exchange_detach(nullptr, exchange); return rc; }
+  memcpy(handle_out, &mine, kIpcHandleBytes);
   return VK_OK_;
+}
+
+int vk_comm_exchange_attach_handles(void* exchange, const void* handles)
+{
+  if (!exchange || !handles) return VK_ERR_ARGUMENT_;
+  RigExchange* x = static_cast<RigExchange*>(exchange);
+  if (x->world < 1 || x->world > kRigMaxRanks || x->rank < 0 || x->rank >= x->world || !x->areas[x->rank]) return VK_ERR_ARGUMENT_;
+  const Hip* h = hip();
+  if (!h) return VK_COMM_ERR_NO_RCCL;
+  IpcHandle all[kRigMaxRanks];
+  memcpy(all, handles, (size_t)kIpcHandleBytes * (size_t)x->world);
+  const int rc = map_peers(h, x, all);
+  if (rc != 0) vk_comm_exchange_detach(nullptr, exchange);
+  return rc;
+}
+
+unsigned vk_comm_exchange_next_sequence(unsigned sequence)
+{
+  return sequence >= (unsigned)kRigLastSequence ? 1u : sequence + 1u;
 }
 
 int vk_comm_exchange_detach(void* comm, void* exchange)
 {
-  if (!comm || !exchange) return VK_ERR_ARGUMENT_;
-  Communicator* c = static_cast<Communicator*>(comm);
+  if (!exchange) return VK_ERR_ARGUMENT_;
   RigExchange* x = static_cast<RigExchange*>(exchange);
+  const int rank = comm ? static_cast<Communicator*>(comm)->rank : x->rank;
   const Hip* h = hip();
   if (!h) return VK_COMM_ERR_NO_RCCL;
   (void)h->DeviceSynchronize();          // no loop kernel may still be writing into a peer
   for (int r = 0; r < kRigMaxRanks; ++r)
   {
     if (!x->areas[r]) continue;
-    if (r == c->rank) (void)h->Free(x->areas[r]); else (void)h->IpcCloseMemHandle(x->areas[r]);
+    if (r == rank) (void)h->Free(x->areas[r]); else (void)h->IpcCloseMemHandle(x->areas[r]);
     x->areas[r] = nullptr;
   }
   return VK_OK_;
@@ -284,6 +357,7 @@ const char* vk_comm_error_string(int code)
   if (code == VK_OK_) return "success";
   if (code == VK_ERR_ARGUMENT_) return "invalid argument [vk error -1]";
   if (code == VK_COMM_ERR_NO_RCCL) return "librccl could not be loaded (set VK_RCCL_LIBRARY) [vk error -4]";
+  if (code == VK_COMM_ERR_PEER) return "another rank failed in the same collective call [vk error -5]";
   if (code >= 1000 && g_rccl.GetErrorString) return g_rccl.GetErrorString(code - 1000);
   return "unknown error";
 }

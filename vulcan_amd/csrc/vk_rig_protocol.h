@@ -40,6 +40,13 @@
 #define VK_RIG_FN inline
 #endif
 
+// The sequence number after `sequence`: every rank takes this step after EVERY Track it has entered, whether the Track
+// ended with a pose or with VK_TRACK_ABORTED (a retry under the old number would meet the aborted attempt's words,
+// whose tags it shares). 1, 2, ... VK_RIG_LAST_SEQUENCE, 1, ...: the last number is even, so the numbers' parity — which
+// picks the buffers, see above — alternates across the wrap as well; 0 is never used (a zeroed area carries no tag).
+#define VK_RIG_LAST_SEQUENCE ((1u << 22) - 2u)
+VK_RIG_FN uint32_t rig_next_sequence(uint32_t sequence) { return sequence >= VK_RIG_LAST_SEQUENCE ? 1u : sequence + 1u; }
+
 VK_RIG_FN size_t rig_area_words() { return (size_t)4 * VK_RIG_MAX_RANKS * VK_RIG_WORDS; }
 
 VK_RIG_FN size_t rig_word_index(uint32_t sequence, int step, int sender, int word)

@@ -75,3 +75,14 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def all_ok(ok, device="cpu"):
+    """True when EVERY rank passed True: what the ranks call after a step that can fail on one of them alone (a
+    rank-local check, an allocation, a mapping) and before the next collective, so that all of them take the same
+    branch — a rank that raised on its own would leave the others inside that collective for ever."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
