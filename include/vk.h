@@ -265,6 +265,22 @@ VK_API int vk_event_destroy(void* event);
 VK_API int vk_event_record(void* event, void* stream);
 VK_API int vk_event_elapsed_ms(void* start, void* stop, float* ms);  /* blocking on stop */
 
+/* The input side of a frame (ref: include/vulcan/image.h:100-123 — Image::Load ends in a blocking cudaMemcpy —
+ * called once per camera frame at apps/vulcan/vulcan.cu:220,232). Here a frame can be uploaded while the one
+ * before it is being fused: the copy is enqueued on a stream of its own from pinned host memory (vk_malloc_host)
+ * and returns at once; an ORDERING event (vk_event_create_ordering: no timing) recorded behind it is what the compute
+ * stream waits for (vk_stream_wait_event) before the frame's first kernel, and an event recorded on the compute
+ * stream behind the frame's last reader is what the copy stream waits for before it overwrites the image two frames
+ * later. `publishes`: 1 when the work in front of the event WROTE what the waiter reads (the upload: default fences);
+ * 0 when it only read what the waiter overwrites (the frame's kernels: no system-scope release — with one, every
+ * record behind the integrate kernel wrote the device's caches back and the streamed frame took 357 us instead of
+ * 114, tools/stream_input_probe.py). vk_event_synchronize blocks the HOST (before it refills a staging buffer).
+ * vulcan_amd/host/include/vulcan/upload.h (FrameUploader) and bench.py --stream-input are built from these. */
+VK_API int vk_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, void* stream);
+VK_API int vk_event_create_ordering(void** event, int publishes);
+VK_API int vk_stream_wait_event(void* stream, void* event);
+VK_API int vk_event_synchronize(void* event);
+
 /* ----------------------------------------------------------------- volume -- */
 
 /* ref: src/volume.cu:552-627 Volume::Initialize + 9 Create* — fills voxels

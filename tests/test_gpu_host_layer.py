@@ -31,14 +31,15 @@ def test_cpp_frame_loop_runs_and_tracks():
     m = re.search(r"frames 60 .* fps ([\d.]+) +visible (\d+) +allocated (\d+) +dropped (\d+)", out)
     assert m, out
     assert int(m.group(2)) > 3000 and int(m.group(4)) == 0
-    # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: the shipped app's
-    # set-up (PyramidTracker<LightTracker> + LightIntegrator). Closed loop in the room scene
+    # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: PyramidTracker<LightTracker> +
+    # LightIntegrator (the line upstream keeps commented out); mode 3, the shipped app's own set-up, is run by
+    # tools/round_run.sh (its one-step tracker lags this fast camera: profiles/). Closed loop in the room scene
     # (room_scene.h): the camera turns ~24 degrees and moves ~0.35 m over 60 frames, every frame
     # is fused and raycast at its TRACKED pose, and the true poses only score the result.
     import json
     for mode, label in (("1", "depth"), ("2", "light")):
         out = subprocess.run([exe, "60", mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
-        assert re.search(r"dropped 0 +tracking " + label, out), out
+        assert re.search(r"dropped 0 +input resident +tracking " + label, out), out
         line = [text for text in out.splitlines() if text.startswith("{")]
         assert line, out
         rec = json.loads(line[-1])

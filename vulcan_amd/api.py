@@ -43,6 +43,10 @@ _SIGNATURES = {
     "vk_event_destroy": ([_P], _I),
     "vk_event_record": ([_P, _P], _I),
     "vk_event_elapsed_ms": ([_P, _P, C.POINTER(_F)], _I),
+    "vk_memcpy_h2d_async": ([_P, _P, _SZ, _P], _I),
+    "vk_event_create_ordering": ([_PP, _I], _I),
+    "vk_stream_wait_event": ([_P, _P], _I),
+    "vk_event_synchronize": ([_P], _I),
     "vk_volume_initialize": ([_P, _P], _I),
     "vk_volume_reset_block_visibility": ([_P, _P], _I),
     "vk_volume_create_allocation_requests": ([_P, _P, _I, _I, _P, _P, _P], _I),

@@ -272,6 +272,37 @@ int vk_event_record(void* event, void* stream)
   return VK_OK;
 }
 
+int vk_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, void* stream)
+{
+  if (bytes == 0) return VK_OK;
+  VK_REQUIRE(dst && src_pinned);
+  VK_CHECK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, vk_s(stream)));
+  return VK_OK;
+}
+
+int vk_event_create_ordering(void** event, int publishes)
+{
+  VK_REQUIRE(event);
+  hipEvent_t e;
+  VK_CHECK(hipEventCreateWithFlags(&e, publishes ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence)));
+  *event = e;
+  return VK_OK;
+}
+
+int vk_stream_wait_event(void* stream, void* event)
+{
+  VK_REQUIRE(event);
+  VK_CHECK(hipStreamWaitEvent(vk_s(stream), reinterpret_cast<hipEvent_t>(event), 0));
+  return VK_OK;
+}
+
+int vk_event_synchronize(void* event)
+{
+  VK_REQUIRE(event);
+  VK_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+  return VK_OK;
+}
+
 int vk_event_elapsed_ms(void* start, void* stop, float* ms)
 {
   VK_REQUIRE(ms);

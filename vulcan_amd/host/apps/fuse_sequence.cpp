@@ -7,7 +7,10 @@
 //   integrator.Integrate(frame) -> tracer.Trace(keyframe)       (vulcan.cu:297-325)
 // The three SetView calls are one SetView(frame, 3) (same state, tsdf_volume.h).
 //
-//   fuse_sequence [frames=200] [mode=0|1|2|3]
+//   fuse_sequence [frames=200] [mode=0|1|2|3] [stream=0|1]
+//     stream = 1 (mode 0): every frame's depth image is UPLOADED from pinned host memory while the frame before it is
+//     fused (FrameUploader, vulcan/upload.h) instead of waiting in device memory — upstream uploads each frame with a
+//     blocking copy (image.h:100-123, vulcan.cu:220,232)
 //     0  DepthIntegrator + Tracer, no tracking                    (BASELINE configs[1]):
 //        camera at the centre of a 2 m sphere, yawing 0.5 degree per frame
 //     1  PyramidTracker<DepthTracker> in front of mode 0          (configs[2] tracking)
@@ -24,6 +27,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include <vulcan/vulcan.h>
@@ -53,6 +57,7 @@ int main(int argc, char** argv)
   const int frames = argc > 1 ? std::atoi(argv[1]) : 200;
   const int mode = argc > 2 ? std::atoi(argv[2]) : 0;
   const bool track = mode != 0;
+  const bool stream_input = argc > 3 && std::atoi(argv[3]) == 1 && mode == 0;
   const int w = 640, h = 480;
   const float radius = 2.0f;
 
@@ -133,6 +138,14 @@ int main(int argc, char** argv)
   keyframe->color_image = std::make_shared<ColorImage>(w, h);
   keyframe->normal_image = std::make_shared<ColorImage>(w, h);
 
+  std::unique_ptr<FrameUploader> uploader;
+  if (stream_input)
+  {
+    uploader.reset(new FrameUploader(w, h, false));
+    std::copy(depth.begin(), depth.end(), uploader->StagingDepth());    // frame 0 on its way before the clock starts
+    uploader->Submit();
+  }
+
   std::vector<int> steps_histogram(64, 0);
   std::vector<int> steps_run;
   double worst_translation = 0, worst_rotation = 0, last_translation = 0, last_rotation = 0;
@@ -147,6 +160,18 @@ int main(int argc, char** argv)
     {
       frame.depth_image = depth_images[i];
       frame.color_image = color_images[i];
+    }
+    if (stream_input)
+    {
+      // frame i + 1 crosses the bus while frame i is fused. The staging buffers were filled before the clock started
+      // (a camera driver writes them by DMA; copying 1.2 MB with the CPU here would time the CPU): both hold the frame
+      if (i + 1 < frames)
+      {
+        if (i + 1 < FrameUploader::slot_count) std::copy(depth.begin(), depth.end(), uploader->StagingDepth());
+        else uploader->StagingDepth();             // waits until the buffer's last copy has left it, as a writer would
+        uploader->Submit();
+      }
+      uploader->Acquire(frame);
     }
     if (mode != 0) frame.ComputeNormals();        // vulcan.cu:297 (DepthIntegrator alone needs none)
 
@@ -170,6 +195,7 @@ int main(int argc, char** argv)
 
     volume->SetView(frame, 3);         // vulcan.cu:316-318: three SetView calls
     if (photometric) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
+    if (stream_input) uploader->Release();         // the frame's images have no reader after Integrate
     keyframe->depth_to_world_transform = frame.depth_to_world_transform;
     tracer.Trace(*keyframe);           // :325
   }
@@ -178,9 +204,9 @@ int main(int argc, char** argv)
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int32_t counters[VK_CTR_PUBLIC];
   volume->GetCounters(counters);
-  std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  tracking %s\n", frames,
+  std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  input %s  tracking %s\n", frames,
       seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
-      counters[VK_CTR_DROPPED], mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
+      counters[VK_CTR_DROPPED], stream_input ? "uploaded per frame" : "resident", mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
 

@@ -85,6 +85,15 @@ class ImageStorage
       Touch();
     }
 
+    // not upstream (whose Load / CopyFromHost block): the copy is ENQUEUED on `copy_stream` from pinned host memory
+    // (vk_malloc_host) and the call returns; the caller orders it against the kernels that read the image with events
+    // (vk.h "the input side of a frame"; FrameUploader in upload.h does all of that)
+    void CopyFromHostAsync(const Pixel* pinned_pixels, void* copy_stream)
+    {
+      VK_ASSERT(vk_memcpy_h2d_async(data_, pinned_pixels, GetBytes(), copy_stream));
+      Touch();
+    }
+
     void CopyToHost(Pixel* pixels) const
     {
       VK_ASSERT(vk_memcpy_d2h(pixels, data_, GetBytes(), Device::GetStream()));

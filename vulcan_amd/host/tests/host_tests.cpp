@@ -1461,6 +1461,47 @@ TEST(Sequence, RoundTrip)   // image.h:100-133,228-253 Load / Save on PGM / PPM;
   for (int i = 0; i < 6; ++i) ASSERT_EQ(want[i], r[i]);
 }
 
+// ---- FrameUploader (upload.h): no upstream test — upstream uploads with a blocking copy (image.h:100-123) ----
+
+TEST(FrameUploader, DeliversEveryFrameInOrderThroughTwoSlots)
+{
+  const int w = 64, h = 48, frames = 7;
+  FrameUploader uploader(w, h, true);
+  Frame frame;
+  auto fill = [&](int i) {
+    float* d = uploader.StagingDepth();
+    Vector3f* c = uploader.StagingColor();
+    for (int p = 0; p < w * h; ++p)
+    {
+      d[p] = 1.0f + 0.001f * i + 1e-6f * p;
+      c[p] = Vector3f(0.1f * i, 0.5f + 1e-5f * p, 0.25f);
+    }
+  };
+  fill(0);
+  uploader.Submit();
+  for (int i = 0; i < frames; ++i)
+  {
+    if (i + 1 < frames) { fill(i + 1); uploader.Submit(); }           // frame i + 1 crosses while frame i is used
+    uploader.Acquire(frame);
+    ASSERT_EQ(w, frame.depth_image->GetWidth());
+    // a reader on the compute stream: the normals of the uploaded depth image (any kernel would do)
+    frame.depth_projection.SetFocalLength(60.0f, 60.0f);
+    frame.depth_projection.SetCenterPoint(32.0f, 24.0f);
+    frame.ComputeNormals();
+    std::vector<float> depth = Download(*frame.depth_image);
+    std::vector<Vector3f> color(size_t(w) * h);
+    frame.color_image->CopyToHost(color.data());
+    uploader.Release();
+    for (int p = 0; p < w * h; p += 97)
+    {
+      ASSERT_EQ(1.0f + 0.001f * i + 1e-6f * p, depth[p]);
+      ASSERT_EQ(0.1f * i, color[p][0]);
+      ASSERT_EQ(0.5f + 1e-5f * p, color[p][1]);
+    }
+  }
+  ASSERT_EQ(frames, uploader.GetSubmitted());
+}
+
 int main(int argc, char** argv)
 {
   int count = 0;
