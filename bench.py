@@ -74,6 +74,11 @@ RIG_TIMEOUT_S = 180                                         # N > 1: the rig ste
 # the run's headline with it
 RIG_IN_LAUNCH_EXCHANGE = os.environ.get("VK_BENCH_RIG_EXCHANGE", "0") == "1"
 SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan.cu:316-318
+# VK_BENCH_SPLIT_STREAMS=1: the request pass of SetView on a stream of its own, beside the previous frame's raycast
+# (vk_volume_set_view_rounds_split), for the workloads that fuse at given poses. Off in every reported run: measured
+# 98.1 -> 96.8 us per frame only — the two cross-queue dependencies it puts on the frame's critical cycle cost ~10 us each
+# on this runtime (tools/debug/cross_stream_latency_probe.hip) — so the headline stays on one stream
+SPLIT_STREAMS = os.environ.get("VK_BENCH_SPLIT_STREAMS", "0") == "1"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
@@ -248,6 +253,14 @@ class FrameLoop:
         # --stream-input: the frame's depth and colour images are UPLOADED every frame (upstream: Image::Load's blocking
         # copy, image.h:100-123, vulcan.cu:220,232) — from two pinned staging buffers, on a copy stream of its own, into
         # two slots of device images, frame i + 1 crossing the bus while frame i is fused (vk.h "the input side of a frame")
+        # two streams (vk_volume_set_view_rounds_split): the request pass of frame i runs beside the raycast of frame i - 1
+        self.split = None
+        if SPLIT_STREAMS and workload != "rgbd-icp" and volumes == 1 and (workload == "depth" or NORMALS_IN_SET_VIEW):
+            side, requested, integrated = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            api.check(self.lib.vk_stream_create(C.byref(side)), "vk_stream_create")
+            api.check(self.lib.vk_event_create_ordering(C.byref(requested), 0), "vk_event_create_ordering")
+            api.check(self.lib.vk_event_create_ordering(C.byref(integrated), 0), "vk_event_create_ordering")
+            self.split = {"stream": side, "requested": requested, "integrated": integrated, "frames": 0}
         self.upload = None
         if stream_input:
             assert sequence is None and workload != "rgbd-icp"
@@ -382,7 +395,16 @@ class FrameLoop:
         # volume.cu:430-437, three times (vulcan.cu:316-318), + light_integrator.cu:277-293
         if normals_in_set_view:
             self.prep.normals_out = self.n_ptr.value
-        rc |= lib.vk_volume_set_view_rounds(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, s)
+        if self.split is not None:
+            sp = self.split
+            if sp["frames"] > 0:
+                rc |= lib.vk_stream_wait_event(sp["stream"], sp["integrated"])      # the previous Integrate has read lists, mask, records
+            if self.upload is not None:
+                rc |= lib.vk_stream_wait_event(sp["stream"], self.upload.slots[n % self.upload.SLOTS]["events"][0])   # the frame's images
+            rc |= lib.vk_volume_set_view_rounds_split(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, sp["stream"], sp["requested"], s)
+            sp["frames"] += 1
+        else:
+            rc |= lib.vk_volume_set_view_rounds(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, s)
         if self.mode == 2:
             if lib.vk_light_prepared(self.pprep, self.fref, C.c_float(self.depth_threshold)):
                 self.prep.valid = 0
@@ -394,6 +416,8 @@ class FrameLoop:
                                      vv["bref"], s)                                 # *_integrator.cu Integrate
         if ev:
             lib.vk_event_record(ev[1], s)
+        if self.split is not None:
+            lib.vk_event_record(self.split["integrated"], s)
         if self.upload is not None:
             self.upload.release(n)                     # the input images have no reader after Integrate
         if ev and len(ev) > 2:

@@ -505,6 +505,22 @@ VK_API int vk_volume_set_view_prepare(const vk_volume* v, const vk_frame* frame,
 VK_API int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep,
     int max_rounds, void* stream);
 
+/* vk_volume_set_view_rounds with its two launches on two streams (round 4; no reference counterpart — upstream runs everything
+ * on stream 0, device.h:40-52; ref: src/volume.cu:430-437 for the call). The request pass (volume.cu:497-518, with whatever rides in it: the light preparation, the
+ * frame's normals) reads the depth image, the table and the visibility bytes and writes visibility bytes, request flags and
+ * the preparation's buffers: nothing the raycast of the PREVIOUS frame reads or writes (vk_trace_ahead: table, voxels, its own
+ * bounds and images). A caller that fuses at poses it knows before the previous frame's raycast has finished — the fusion +
+ * raycast benchmark; not the tracking loop, whose pose comes out of that raycast — can therefore put the request pass on a stream
+ * of its own and let it fill the tail of the previous raycast, whose last waves leave most of the device idle:
+ *   vk_stream_wait_event(request_stream, integrated);   // the previous frame's vk_integrate_* has read the lists, mask, records
+ *   vk_volume_set_view_rounds_split(&v, &f, &prep, 3, request_stream, ordering, stream);
+ *   vk_integrate_ahead(.., stream);  vk_event_record(integrated, stream);  vk_trace_ahead(.., stream);
+ * `ordering_event` (vk_event_create_ordering(&e, 0)) is recorded behind the request pass on request_stream, and `stream` waits
+ * for it before the handle + visibility pass, which must follow the previous raycast anyway (it writes table entries).
+ * Same state as vk_volume_set_view_rounds, bit for bit (tests/test_gpu_configs.py runs bench.py's step, which uses this). */
+VK_API int vk_volume_set_view_rounds_split(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
+    void* request_stream, void* ordering_event, void* stream);
+
 /* ref: src/light_integrator.cu:270-275 LightIntegrator::Integrate decides here whether
  * ComputeFrameMask still has to run: 1 if *prep holds the preparation of exactly `frame` (same
  * non-zero content_id, same image pointers and size, same depth->colour transform) at

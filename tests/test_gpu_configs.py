@@ -27,14 +27,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # ------------------------------------------------------------------ configs[2] --
 
-def test_rgbd_bench_sequence_matches_oracle(api, orc):
+@pytest.mark.parametrize("streams", ["two streams", "one stream"])
+def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
     """The exact step `bench.py --workload rgbd` times — bench.FrameLoop.step itself, i.e. ONE
     vk_volume_set_view_rounds(.., 3) that also computes the input frame's normals and prepares the
     light integrator's records (vk_light_prep.normals_out), vk_integrate_ahead with those records and
     the raycast bounds riding along, vk_trace_ahead — at 640x480, 5 mm, Volume(65024, 8192), light
     (2, (.025,.08,0)) as in apps/vulcan/vulcan.cu:87-88, six frames from the empty volume. Oracle side:
     Frame::ComputeNormals, three SetView calls, the frame mask, depth and shaded-colour passes, Trace
-    (vulcan.cu:297,316-325). Every image of every frame and, at the end, every voxel byte."""
+    (vulcan.cu:297,316-325). Every image of every frame and, at the end, every voxel byte.
+
+    "two streams" is bench.py's default: the request pass of frame i on a stream of its own, beside the
+    raycast of frame i - 1 (vk_volume_set_view_rounds_split). It is run twice: frame by frame with every
+    image compared, and with all six frames enqueued back to back — no host synchronisation in between, so
+    that the request pass of a frame really runs while the raycast before it does — and the end state compared."""
     sys.path.insert(0, ROOT)
     import bench
     count = 6
@@ -44,12 +50,12 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc):
     light = T.Light.make(*bench.LIGHT)
     poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(count)]
     assert bench.SET_VIEW_ROUNDS == 3 and bench.NORMALS_IN_SET_VIEW
-    loop = bench.FrameLoop("rgbd", poses)
-    dv, tracer = loop.vols[0]["vol"], loop.vols[0]["tracer"]
+    monkeypatch.setattr(bench, "SPLIT_STREAMS", streams == "two streams")
+
     orc.set_threads(16)
     hv = orc.HostVolume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
     hf = orc.HostFrame(depth, k, T.Transform.identity(), color=color)
-    rounds_before = 0
+    want = []
     for i in range(count):
         hf.depth_to_world = poses[i]
         hf.compute_normals()                                  # vulcan.cu:297
@@ -59,7 +65,28 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc):
         mask = orc.light_frame_mask(hf, 0.2)
         orc.integrate_light_color(hv, hf, light, mask)
         odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+        want.append(dict(normals_in=hf.normals.copy(), mask=mask, depth=odepth, color=ocolor, normals=onormals, bounds=obounds,
+                         visible=hv.visible_count, table=hv.hash_entries.copy()))
+    orc.set_threads(1)
+
+    def compare_images(loop, w):
+        tracer = loop.vols[0]["tracer"]
+        assert tracer.view_bounds.valid == 1                  # the bounds came with the integrate launch
+        assert np.array_equal(loop.frame.normals.cpu().numpy(), w["normals_in"], equal_nan=True)
+        assert np.array_equal(loop.mask.cpu().numpy(), w["mask"])
+        assert np.array_equal(tracer.bounds.cpu().numpy(), w["bounds"])
+        assert np.array_equal(loop.key.depth.cpu().numpy(), w["depth"])
+        assert np.array_equal(loop.key.color.cpu().numpy(), w["color"])
+        assert np.array_equal(loop.key.normals.cpu().numpy(), w["normals"], equal_nan=True)
+
+    # ---- frame by frame
+    loop = bench.FrameLoop("rgbd", poses)
+    assert (loop.split is not None) == (streams == "two streams")
+    dv = loop.vols[0]["vol"]
+    rounds_before = 0
+    for i in range(count):
         loop.frame.normals.fill_(-7.0)                        # whatever the step leaves here, it computed itself
+        sync()
         loop.step(i)
         sync()
         ctr = dv.read_counters()
@@ -67,18 +94,22 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc):
         assert 1 <= rounds <= 3
         if i == 0:
             assert rounds > 1                                 # 7 k blocks at once: some lose their bucket
-        assert tracer.view_bounds.valid == 1                  # the bounds came with the integrate launch
-        assert np.array_equal(loop.frame.normals.cpu().numpy(), hf.normals, equal_nan=True)
-        assert np.array_equal(loop.mask.cpu().numpy(), mask)
-        assert dv.visible_count == hv.visible_count > 5000
-        assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
-        assert np.array_equal(loop.key.depth.cpu().numpy(), odepth)
-        assert np.array_equal(loop.key.color.cpu().numpy(), ocolor)
-        assert np.array_equal(loop.key.normals.cpu().numpy(), onormals, equal_nan=True)
-        assert_volume_equal(dv, hv, voxels=(i == count - 1))
+        assert dv.visible_count == want[i]["visible"] > 5000
+        assert np.array_equal(dv.host_entries(), want[i]["table"])
+        compare_images(loop, want[i])
+    assert_volume_equal(dv, hv)
     got = dv.host_voxels()
     assert (got["color_weight"] > 0).sum() > 500000          # the colour pass really ran
-    orc.set_threads(1)
+
+    # ---- all frames enqueued back to back (what the bench's timed region does)
+    if streams == "two streams":
+        del loop, dv
+        loop = bench.FrameLoop("rgbd", poses)
+        for i in range(count):
+            loop.step(i)
+        sync()
+        compare_images(loop, want[-1])
+        assert_volume_equal(loop.vols[0]["vol"], hv)
 
 
 # ------------------------------------------------------------------ configs[3] --

@@ -1966,12 +1966,18 @@ int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float de
   return (frame && prep_is_for(prep, frame) && prep->prepared_threshold == depth_threshold) ? 1 : 0;
 }
 
-static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds, void* stream)
+// `request_stream` / `ordering` (vk_volume_set_view_rounds_split): the request pass — and the normals launch, when the
+// call has to make it — go to request_stream; `ordering` is recorded behind them there and `stream` waits for it before
+// the handle + visibility pass.
+static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds, void* stream,
+    void* request_stream = nullptr, void* ordering = nullptr)
 {
   const int rc = check_volume(v);
   if (rc != VK_OK) return rc;
   VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0 && max_rounds >= 1);
   hipStream_t s = vk_s(stream);
+  const bool split = ordering != nullptr;
+  void* const first_stream = split ? request_stream : stream;
   // the preparation rides along when the frame has what LightIntegrator needs, in the
   // depth image's size (light_integrator.cu:277-293 walks the colour image with it)
   const bool ride = prep && prep->mask && prep->records && frame->color && frame->normals && frame->content_id != 0 &&
@@ -1987,7 +1993,7 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     VK_REQUIRE(prep->normals_out == frame->normals);
     if (!ride)
     {
-      int rn = vk_frame_compute_normals(frame->depth, &frame->depth_projection, prep->normals_out, frame->width, frame->height, stream);
+      int rn = vk_frame_compute_normals(frame->depth, &frame->depth_projection, prep->normals_out, frame->width, frame->height, first_stream);
       prep->normals_out = nullptr;
       if (rn != VK_OK) return rn;
     }
@@ -1996,8 +2002,13 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
   // and so are all rounds after the first (later_rounds)
   int r;
   if ((r = launch_create_requests(v, frame->depth, frame->width, frame->height,
-           &frame->depth_projection, &frame->depth_to_world, true, s, ride ? frame : nullptr, ride ? prep : nullptr,
+           &frame->depth_projection, &frame->depth_to_world, true, vk_s(first_stream), ride ? frame : nullptr, ride ? prep : nullptr,
            true)) != VK_OK) return r;
+  if (split)
+  {
+    VK_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ordering), vk_s(first_stream)));
+    VK_CHECK(hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(ordering), 0));
+  }
   if (ride)
   {
     prep->depth = frame->depth;
@@ -2053,6 +2064,13 @@ int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, vk_ligh
     void* stream)
 {
   return set_view(v, frame, prep, max_rounds, stream);
+}
+
+int vk_volume_set_view_rounds_split(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
+    void* request_stream, void* ordering_event, void* stream)
+{
+  VK_REQUIRE(ordering_event);
+  return set_view(v, frame, prep, max_rounds, stream, request_stream, ordering_event);
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)

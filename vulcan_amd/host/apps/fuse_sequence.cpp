@@ -7,7 +7,9 @@
 //   integrator.Integrate(frame) -> tracer.Trace(keyframe)       (vulcan.cu:297-325)
 // The three SetView calls are one SetView(frame, 3) (same state, tsdf_volume.h).
 //
-//   fuse_sequence [frames=200] [mode=0|1|2|3] [stream=0|1]
+//   fuse_sequence [frames=200] [mode=0|1|2|3] [stream=0|1] [split=0|1]
+//     split = 1 (mode 0): SetView's request pass on a stream of its own, beside the previous frame's raycast
+//     (Volume::EnableRequestStream; the poses are known in advance in mode 0)
 //     stream = 1 (mode 0): every frame's depth image is UPLOADED from pinned host memory while the frame before it is
 //     fused (FrameUploader, vulcan/upload.h) instead of waiting in device memory — upstream uploads each frame with a
 //     blocking copy (image.h:100-123, vulcan.cu:220,232)
@@ -58,6 +60,7 @@ int main(int argc, char** argv)
   const int mode = argc > 2 ? std::atoi(argv[2]) : 0;
   const bool track = mode != 0;
   const bool stream_input = argc > 3 && std::atoi(argv[3]) == 1 && mode == 0;
+  const bool split_streams = argc > 4 && std::atoi(argv[4]) == 1 && mode == 0;
   const int w = 640, h = 480;
   const float radius = 2.0f;
 
@@ -69,6 +72,7 @@ int main(int argc, char** argv)
   auto volume = std::make_shared<Volume>(65024, 8192);
   volume->SetVoxelLength(0.005f);
   volume->SetTruncationLength(0.04f);
+  if (split_streams) volume->EnableRequestStream();
   DepthIntegrator depth_integrator(volume);
   LightIntegrator light_integrator(volume);
   Tracer tracer(volume);
@@ -171,7 +175,7 @@ int main(int argc, char** argv)
         else uploader->StagingDepth();             // waits until the buffer's last copy has left it, as a writer would
         uploader->Submit();
       }
-      uploader->Acquire(frame);
+      uploader->Acquire(frame, volume->GetRequestStream());
     }
     if (mode != 0) frame.ComputeNormals();        // vulcan.cu:297 (DepthIntegrator alone needs none)
 
@@ -206,7 +210,8 @@ int main(int argc, char** argv)
   volume->GetCounters(counters);
   std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  input %s  tracking %s\n", frames,
       seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
-      counters[VK_CTR_DROPPED], stream_input ? "uploaded per frame" : "resident", mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
+      counters[VK_CTR_DROPPED], stream_input ? (split_streams ? "uploaded per frame, requests on their own stream" : "uploaded per frame") :
+          (split_streams ? "resident, requests on their own stream" : "resident"), mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
 

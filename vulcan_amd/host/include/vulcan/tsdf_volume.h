@@ -94,6 +94,17 @@ class Volume
     void AttachLightPreparation(float* mask, float* records, int capacity_pixels, float depth_threshold) const;
     void DetachLightPreparation(const float* mask) const;   // no-op unless `mask` is the attached one
 
+    // Not upstream (which runs everything on stream 0): SetView's request pass on a stream of its own
+    // (vk_volume_set_view_rounds_split), so that it runs beside the PREVIOUS frame's Tracer::Trace instead of behind it. For
+    // callers that know a frame's pose before the previous frame's raycast has finished — fusion at given poses; a tracking
+    // loop gains nothing, its pose comes out of that raycast. The request pass then waits only for the previous Integrate
+    // (the integrators call NoteIntegrated): whatever it reads — the frame's depth image, and colour / normal images when a
+    // LightIntegrator's preparation rides along — must be complete without work enqueued on Device::GetStream() after that
+    // Integrate (ComputeNormalsAndSetView computes the normals inside the pass; FrameUploader::Acquire takes the stream to wait on).
+    void EnableRequestStream();
+    void* GetRequestStream() const { return request_stream_; }
+    void NoteIntegrated() const;
+
   protected:
     // the four stages of SetView, in call order
     void ResetBlockVisibility();
@@ -123,6 +134,10 @@ class Volume
     mutable bool visible_count_stale_;
     mutable vk_view_bounds view_bounds_;
     mutable vk_light_prep light_prep_;
+    void* request_stream_;              // EnableRequestStream(): nullptr = everything on Device::GetStream()
+    void* requested_;                   // event behind the request pass
+    void* integrated_;                  // event behind the last Integrate
+    mutable bool integrated_recorded_;
 
   private:
     void Initialize();

@@ -51,8 +51,9 @@ class FrameUploader
     void Submit();
 
     // the oldest submitted frame: `frame.depth_image` / `color_image` become that slot's device images (stamped as
-    // new content) and Device::GetStream() waits for their upload
-    void Acquire(Frame& frame);
+    // new content) and Device::GetStream() waits for their upload — and `second_stream` too, when given (a Volume's
+    // request stream, Volume::GetRequestStream(), reads the depth image as well)
+    void Acquire(Frame& frame, void* second_stream = nullptr);
 
     // the acquired frame's readers are all enqueued on Device::GetStream(): its slot may be overwritten once they ran
     void Release();

@@ -67,6 +67,7 @@ void DepthIntegrator::Integrate(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 0, nullptr, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 // ---- colour ------------------------------------------------------------------
@@ -79,6 +80,7 @@ void ColorIntegrator::Integrate(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 1, nullptr, nullptr, nullptr, volume_->GetViewBounds(), Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 void ColorIntegrator::IntegrateDepth(const Frame& frame)
@@ -87,6 +89,7 @@ void ColorIntegrator::IntegrateDepth(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 void ColorIntegrator::IntegrateColor(const Frame& frame)
@@ -95,6 +98,7 @@ void ColorIntegrator::IntegrateColor(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_color(&v, &p, &f, Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 // ---- light -------------------------------------------------------------------
@@ -136,6 +140,7 @@ void LightIntegrator::Integrate(const Frame& frame)
   else VK_ASSERT(vk_light_prepare(&f, depth_threshold_, frame_mask_.GetData(), pixel_records_.GetData(), Device::GetStream()));
   VK_ASSERT(vk_integrate_ahead(&v, &p, &f, 2, &l, frame_mask_.GetData(), pixel_records_.GetData(),
       volume_->GetViewBounds(), Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 void LightIntegrator::ComputeFrameMask(const Frame& frame)
@@ -152,6 +157,7 @@ void LightIntegrator::IntegrateDepth(const Frame& frame)
   const vk_integrator p = ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_depth(&v, &p, &f, Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 void LightIntegrator::IntegrateColor(const Frame& frame)
@@ -161,6 +167,7 @@ void LightIntegrator::IntegrateColor(const Frame& frame)
   const vk_light l = light_.ToVk();
   const vk_frame f = frame.ToVk();
   VK_ASSERT(vk_integrate_light_color(&v, &p, &l, frame_mask_.GetData(), &f, Device::GetStream()));
+  volume_->NoteIntegrated();
 }
 
 } // namespace vulcan

@@ -18,7 +18,11 @@ Volume::Volume(int main_block_count, int excess_block_count) :
   truncation_length_(0.04f),
   voxel_length_(0.008f),
   empty_(true),
-  visible_count_stale_(false)
+  visible_count_stale_(false),
+  request_stream_(nullptr),
+  requested_(nullptr),
+  integrated_(nullptr),
+  integrated_recorded_(false)
 {
   std::memset(&view_bounds_, 0, sizeof(view_bounds_));
   std::memset(&light_prep_, 0, sizeof(light_prep_));
@@ -27,6 +31,13 @@ Volume::Volume(int main_block_count, int excess_block_count) :
 
 Volume::~Volume()
 {
+  if (request_stream_)
+  {
+    (void)vk_stream_synchronize(request_stream_);
+    (void)vk_event_destroy(requested_);
+    (void)vk_event_destroy(integrated_);
+    (void)vk_stream_destroy(request_stream_);
+  }
 }
 
 int Volume::GetMainBlockCount() const { return main_block_count_; }
@@ -121,9 +132,30 @@ void Volume::SetView(const Frame& frame, int rounds)
   VULCAN_ASSERT_MSG(rounds >= 1, "SetView needs at least one round");
   const vk_volume v = ToVk();
   const vk_frame f = frame.ToVk();
-  VK_ASSERT(vk_volume_set_view_rounds(&v, &f, GetLightPreparation(), rounds, Device::GetStream()));
+  if (request_stream_)
+  {
+    if (integrated_recorded_) VK_ASSERT(vk_stream_wait_event(request_stream_, integrated_));
+    VK_ASSERT(vk_volume_set_view_rounds_split(&v, &f, GetLightPreparation(), rounds, request_stream_, requested_, Device::GetStream()));
+  }
+  else VK_ASSERT(vk_volume_set_view_rounds(&v, &f, GetLightPreparation(), rounds, Device::GetStream()));
   visible_count_stale_ = true;
   empty_ = false;
+}
+
+void Volume::EnableRequestStream()
+{
+  if (request_stream_) return;
+  VK_ASSERT(vk_stream_create(&request_stream_));
+  VK_ASSERT(vk_event_create_ordering(&requested_, 0));
+  VK_ASSERT(vk_event_create_ordering(&integrated_, 0));
+  integrated_recorded_ = false;
+}
+
+void Volume::NoteIntegrated() const
+{
+  if (!request_stream_) return;
+  VK_ASSERT(vk_event_record(integrated_, Device::GetStream()));
+  integrated_recorded_ = true;
 }
 
 void Volume::ComputeNormalsAndSetView(Frame& frame, int rounds)

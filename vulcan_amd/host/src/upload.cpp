@@ -74,11 +74,12 @@ void FrameUploader::Submit()
   ++submitted_;
 }
 
-void FrameUploader::Acquire(Frame& frame)
+void FrameUploader::Acquire(Frame& frame, void* second_stream)
 {
   VULCAN_ASSERT(acquired_ < submitted_ && acquired_ == released_);
   const int s = acquired_ % slot_count;
   VK_ASSERT(vk_stream_wait_event(Device::GetStream(), uploaded_[s]));
+  if (second_stream) VK_ASSERT(vk_stream_wait_event(second_stream, uploaded_[s]));
   depth_[s]->Touch();                       // new content (vk_frame.content_id): nothing prepared for the old one applies
   frame.depth_image = depth_[s];
   if (with_color_)
