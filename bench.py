@@ -79,6 +79,11 @@ SET_VIEW_ROUNDS = 3                                         # apps/vulcan/vulcan
 # 98.1 -> 96.8 us per frame only — the two cross-queue dependencies it puts on the frame's critical cycle cost ~10 us each
 # on this runtime (tools/debug/cross_stream_latency_probe.hip) — so the headline stays on one stream
 SPLIT_STREAMS = os.environ.get("VK_BENCH_SPLIT_STREAMS", "0") == "1"
+# VK_BENCH_REQUESTS_AHEAD (default 1; "0" = A/B): fusion at GIVEN poses knows frame i + 1 while it raycasts frame i, so the
+# request pass of SetView(i + 1) rides behind the raycast's workgroups in the same launch (vk_trace_ahead_requests) and
+# SetView(i + 1) is left with its handle + visibility launch. Same work, same results (tests/test_gpu_configs.py); one
+# launch boundary less per frame. Not for rgbd-icp: its next pose comes out of this raycast.
+REQUESTS_AHEAD = os.environ.get("VK_BENCH_REQUESTS_AHEAD", "1") != "0"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
@@ -194,7 +199,7 @@ class FrameLoop:
     """One rank's replica volume and frame loop, calling the C ABI with descriptors built
     once, the way a C++ caller would (the api.* wrappers rebuild ctypes structs per call)."""
 
-    def __init__(self, workload, poses, volumes=1, sequence=None, stream_input=False):
+    def __init__(self, workload, poses, volumes=1, sequence=None, stream_input=False, requests_ahead=None):
         import torch
         from vulcan_amd import api, vk_types as T
         import scenes
@@ -265,6 +270,14 @@ class FrameLoop:
         if stream_input:
             assert sequence is None and workload != "rgbd-icp"
             self.upload = self.Upload(self, self.depth_np, self.color_np)
+        # the request pass of the NEXT frame behind this frame's raycast (REQUESTS_AHEAD): a second frame descriptor
+        # (frame i + 1: the same resident images, the next pose, the next content id) and the record SetView checks
+        self.ahead = None
+        if ((REQUESTS_AHEAD if requests_ahead is None else requests_ahead) and self.split is None and not stream_input and workload != "rgbd-icp" and volumes == 1
+                and (workload == "depth" or NORMALS_IN_SET_VIEW)):
+            self.ahead = T.RequestsAhead()
+            self.ndesc = T.Frame.from_buffer_copy(bytes(self.fdesc))
+            self.nref, self.aref = C.byref(self.ndesc), C.byref(self.ahead)
         self.tracker = None
         self.tracked_poses, self.gn_steps = [], []
         if workload == "rgbd-icp":
@@ -403,6 +416,8 @@ class FrameLoop:
                 rc |= lib.vk_stream_wait_event(sp["stream"], self.upload.slots[n % self.upload.SLOTS]["events"][0])   # the frame's images
             rc |= lib.vk_volume_set_view_rounds_split(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, sp["stream"], sp["requested"], s)
             sp["frames"] += 1
+        elif self.ahead is not None:
+            rc |= lib.vk_volume_set_view_rounds_ahead(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, self.aref, s)
         else:
             rc |= lib.vk_volume_set_view_rounds(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, s)
         if self.mode == 2:
@@ -422,7 +437,17 @@ class FrameLoop:
             self.upload.release(n)                     # the input images have no reader after Integrate
         if ev and len(ev) > 2:
             lib.vk_event_record(ev[2], s)
-        rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, s)   # tracer.cpp:41-47
+        if self.ahead is not None and i + 1 < len(self.poses):
+            # Trace(i) + the request pass of SetView(i + 1), one launch
+            self.ndesc.depth, self.ndesc.color = self.fdesc.depth, self.fdesc.color
+            self.ndesc.depth_to_world = self.poses[i + 1]
+            self.ndesc.content_id = self.fdesc.content_id + 2
+            if normals_in_set_view:
+                self.prep.normals_out = self.n_ptr.value
+            rc |= lib.vk_trace_ahead_requests(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, self.nref, self.pprep,
+                                              self.aref, s)
+        else:
+            rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, s)   # tracer.cpp:41-47
         if ev and len(ev) > 2:
             lib.vk_event_record(ev[3], s)
         for _ in range(EXTRA_NORMALS):      # experiment: what one more launch-floor kernel costs the frame
@@ -463,7 +488,7 @@ def visible_counts(poses, depths=None):
     return np.array(out, dtype=np.float64), per_frame
 
 
-def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frames=0, stream_input=False):
+def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frames=0, stream_input=False, requests_ahead=None):
     """W untimed + K timed frames (+ `sample_frames` untimed frames with event brackets: the roofline sample);
     returns the JSON fields of that workload."""
     import torch
@@ -472,7 +497,7 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
     sequence = None
     if workload == "rgbd-icp":
         sequence = RoomSequence(warmup + steps + sample_frames, T.Projection.make(*scenes.APP_INTRINSICS))
-    loop = FrameLoop(workload, poses, sequence=sequence, stream_input=stream_input)
+    loop = FrameLoop(workload, poses, sequence=sequence, stream_input=stream_input, requests_ahead=requests_ahead)
 
     for i in range(warmup):
         loop.step(i)
@@ -869,6 +894,13 @@ def main():
                                  "computed inside SetView's request pass (vk_light_prep.normals_out: same normal image, "
                                  "written to the frame; one launch less)"))
                              if wl != "depth" else "not needed by DepthIntegrator (configs[1])",
+            "requests_ahead": ("the request pass of SetView(i + 1) rides behind the workgroups of Trace(i) in one launch "
+                               "(vk_trace_ahead_requests; the poses are given, so frame i + 1 is known), SetView(i + 1) launches "
+                               "its handle + visibility pass only: the same passes per frame, one launch boundary less; the step "
+                               "without it is other_workloads['%s-requests-inside-set-view']" % wl)
+                              if loop.ahead is not None else
+                              "no: SetView makes its own request pass" + (" (the next pose comes out of this frame's raycast)"
+                                                                          if wl == "rgbd-icp" else ""),
             "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
             "visible_blocks_mean": float(nvis_timed[:args.steps].mean()),
             "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
@@ -889,7 +921,9 @@ def main():
             "voxel_working_set_bytes": voxel_ws,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
             "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9,     # per GPU: integrate bytes / frame wall time
-            "raycast": {"kernel": "compute_points_kernel + compute_normals_kernel (vk_trace_ahead)",
+            "raycast": {"kernel": ("trace_and_request_kernel (the raycast + the NEXT frame's request pass, one launch) + "
+                                   "compute_normals_kernel (vk_trace_ahead_requests)") if loop.ahead is not None else
+                                  "compute_points_kernel + compute_normals_kernel (vk_trace_ahead)",
                         "avg_us": float(trace_ms.mean() * 1e3)},
         },
     }
@@ -951,6 +985,17 @@ def main():
             o["integrate_frac_of_8TBps"] = o["integrate_GBps"] / HBM_PEAK_GBS
             o["raycast_avg_us"] = float(tms.mean() * 1e3)
             others[other] = o
+            del oloop
+            torch.cuda.empty_cache()
+        if wl != "rgbd-icp" and REQUESTS_AHEAD:
+            # A/B: the same step with SetView making its own request pass (what a caller that does not know frame i + 1 runs)
+            k_steps, k_warm = min(args.steps, 200), min(args.warmup, 20)
+            o, oloop = run_workload(wl, poses[:k_warm + k_steps], k_warm, k_steps, vd, with_roofline=False, requests_ahead=False)
+            assert oloop.ahead is None
+            o.pop("_counters")
+            o["workload"] = names[wl] + " — vk_volume_set_view_rounds + vk_trace_ahead (no request pass made ahead)"
+            o["unit"] = "frames/s"
+            others[wl + "-requests-inside-set-view"] = o
             del oloop
             torch.cuda.empty_cache()
         result["other_workloads"] = others

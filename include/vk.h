@@ -571,6 +571,42 @@ VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
 VK_API int vk_trace_ahead(const vk_volume* v, const vk_frame* frame,
     vk_view_bounds* ahead, float* depths, float* colors, float* normals, void* stream);
 
+/* The request pass of a frame's SetView done AHEAD, in the previous frame's raycast launch (round 4; no reference
+ * counterpart; ref: src/volume.cu:430-437,497-518 and src/tracer.cpp:41-47 for the two calls it joins). A raycast launch is as
+ * long as its slowest wave and leaves most of the device idle for its last third; the request pass of the NEXT frame reads
+ * and writes nothing the raycast touches (see vk_volume_set_view_rounds_split), so for a caller that knows the next frame — its
+ * images and its pose — when it raycasts this one (fusion at given poses; not the tracking loop, whose next pose comes out of
+ * this raycast) the pass can ride behind the raycast's workgroups in the SAME launch:
+ *   vk_trace_ahead_requests(&v, &key_i, &bounds, depth, color, normals, &frame_next, &prep, &ahead, stream);   // Trace(i) + requests(i+1)
+ *   ...
+ *   vk_volume_set_view_rounds_ahead(&v, &frame_next, &prep, 3, &ahead, stream);    // SetView(i+1): the handle + visibility pass only
+ * `ahead` is a caller-owned record (zero it once) that names the frame the pass was made for; vk_volume_set_view_rounds_ahead
+ * uses the pass only for that very frame (same volume, images, size, intrinsics, pose and non-zero content_id, same riding
+ * preparation); with a record that is not valid (zeroed, already used, or vk_trace_ahead_requests could not make the pass:
+ * no content_id, normals asked for without a riding preparation) it runs the whole call, so the outcome is
+ * vk_volume_set_view_rounds', bit for bit (tests/test_gpu_configs.py runs bench.py's step, which uses this). A VALID record
+ * for another frame is refused (VK_ERR_ARGUMENT, nothing launched, the record kept): that frame's requests are in the volume,
+ * and handled together with this frame's they would allocate in an order no sequence of upstream calls gives — the announced
+ * frame has to be fused first. Between the two calls nothing else may run a SetView stage on the volume. `next_prep` as in vk_volume_set_view_prepare (may be NULL): the light preparation — and, with normals_out, the
+ * next frame's normals — ride with the pass as they do in SetView. */
+typedef struct vk_requests_ahead {
+  const void*   counters;          /* the volume the pass was made on */
+  const float*  depth;
+  const void*   prep;              /* the vk_light_prep that rode along, or NULL */
+  int32_t       width, height;
+  vk_projection depth_projection;
+  vk_transform  depth_to_world;
+  uint64_t      content_id;
+  int32_t       valid;
+  int32_t       pad_;
+} vk_requests_ahead;
+
+VK_API int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bounds* ahead, float* out_depth,
+    float* out_color, float* out_normals, const vk_frame* next_frame, vk_light_prep* next_prep,
+    vk_requests_ahead* requests, void* stream);
+VK_API int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
+    vk_requests_ahead* requests, void* stream);
+
 /* ------------------------------------------------------------------- image -- */
 
 /* ref: src/image.cu:101-165,183-211 Image::Downsample (nearest or 2x2 box) */

@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # ------------------------------------------------------------------ configs[2] --
 
-@pytest.mark.parametrize("streams", ["two streams", "one stream"])
+@pytest.mark.parametrize("streams", ["requests ahead", "two streams", "one stream"])
 def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
     """The exact step `bench.py --workload rgbd` times — bench.FrameLoop.step itself, i.e. ONE
     vk_volume_set_view_rounds(.., 3) that also computes the input frame's normals and prepares the
@@ -37,10 +37,13 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
     Frame::ComputeNormals, three SetView calls, the frame mask, depth and shaded-colour passes, Trace
     (vulcan.cu:297,316-325). Every image of every frame and, at the end, every voxel byte.
 
-    "two streams" is bench.py's default: the request pass of frame i on a stream of its own, beside the
-    raycast of frame i - 1 (vk_volume_set_view_rounds_split). It is run twice: frame by frame with every
-    image compared, and with all six frames enqueued back to back — no host synchronisation in between, so
-    that the request pass of a frame really runs while the raycast before it does — and the end state compared."""
+    "requests ahead" is bench.py's default: the request pass of frame i + 1 (with its normals and the light
+    preparation) rides behind the raycast of frame i in one launch (vk_trace_ahead_requests), and SetView(i + 1)
+    launches only its handle + visibility pass (vk_volume_set_view_rounds_ahead). "two streams"
+    (VK_BENCH_SPLIT_STREAMS=1): the request pass of frame i on a stream of its own, beside the raycast of frame
+    i - 1 (vk_volume_set_view_rounds_split). Both are run twice: frame by frame with every image compared, and with
+    all six frames enqueued back to back — no host synchronisation in between, so that the request pass of a frame
+    really runs while the raycast before it does — and the end state compared."""
     sys.path.insert(0, ROOT)
     import bench
     count = 6
@@ -51,6 +54,8 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
     poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(count)]
     assert bench.SET_VIEW_ROUNDS == 3 and bench.NORMALS_IN_SET_VIEW
     monkeypatch.setattr(bench, "SPLIT_STREAMS", streams == "two streams")
+    monkeypatch.setattr(bench, "REQUESTS_AHEAD", streams == "requests ahead")
+    ahead = streams == "requests ahead"
 
     orc.set_threads(16)
     hv = orc.HostVolume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
@@ -69,11 +74,13 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
                          visible=hv.visible_count, table=hv.hash_entries.copy()))
     orc.set_threads(1)
 
-    def compare_images(loop, w):
+    def compare_images(loop, w, w_in=None):
+        # (requests ahead: the input normals and the mask in memory are already the NEXT frame's, w_in)
+        w_in = w if w_in is None else w_in
         tracer = loop.vols[0]["tracer"]
         assert tracer.view_bounds.valid == 1                  # the bounds came with the integrate launch
-        assert np.array_equal(loop.frame.normals.cpu().numpy(), w["normals_in"], equal_nan=True)
-        assert np.array_equal(loop.mask.cpu().numpy(), w["mask"])
+        assert np.array_equal(loop.frame.normals.cpu().numpy(), w_in["normals_in"], equal_nan=True)
+        assert np.array_equal(loop.mask.cpu().numpy(), w_in["mask"])
         assert np.array_equal(tracer.bounds.cpu().numpy(), w["bounds"])
         assert np.array_equal(loop.key.depth.cpu().numpy(), w["depth"])
         assert np.array_equal(loop.key.color.cpu().numpy(), w["color"])
@@ -82,13 +89,21 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
     # ---- frame by frame
     loop = bench.FrameLoop("rgbd", poses)
     assert (loop.split is not None) == (streams == "two streams")
+    assert (loop.ahead is not None) == ahead
     dv = loop.vols[0]["vol"]
     rounds_before = 0
     for i in range(count):
-        loop.frame.normals.fill_(-7.0)                        # whatever the step leaves here, it computed itself
+        if not ahead or i == 0:
+            loop.frame.normals.fill_(-7.0)                    # whatever the step leaves here, it computed itself
+            loop.mask.fill_(-7.0)
         sync()
         loop.step(i)
         sync()
+        if ahead:
+            # the record names the next frame (none behind the last one), and SetView used the previous one
+            assert loop.ahead.valid == (1 if i + 1 < count else 0)
+            if i + 1 < count:
+                assert loop.ahead.content_id == loop.fdesc.content_id + 2 and loop.prep.valid == 1
         ctr = dv.read_counters()
         rounds_before, rounds = int(ctr[T.VK_CTR_ROUNDS]), int(ctr[T.VK_CTR_ROUNDS]) - rounds_before
         assert 1 <= rounds <= 3
@@ -96,13 +111,13 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
             assert rounds > 1                                 # 7 k blocks at once: some lose their bucket
         assert dv.visible_count == want[i]["visible"] > 5000
         assert np.array_equal(dv.host_entries(), want[i]["table"])
-        compare_images(loop, want[i])
+        compare_images(loop, want[i], want[min(i + 1, count - 1)] if ahead else None)
     assert_volume_equal(dv, hv)
     got = dv.host_voxels()
     assert (got["color_weight"] > 0).sum() > 500000          # the colour pass really ran
 
     # ---- all frames enqueued back to back (what the bench's timed region does)
-    if streams == "two streams":
+    if streams != "one stream":
         del loop, dv
         loop = bench.FrameLoop("rgbd", poses)
         for i in range(count):
@@ -110,6 +125,39 @@ def test_rgbd_bench_sequence_matches_oracle(api, orc, streams, monkeypatch):
         sync()
         compare_images(loop, want[-1])
         assert_volume_equal(loop.vols[0]["vol"], hv)
+
+
+def test_requests_ahead_record_for_another_frame_is_refused(api):
+    """vk_volume_set_view_rounds_ahead with a VALID record made for another pose returns VK_ERR_ARGUMENT and launches nothing
+    (the announced frame's requests are in the volume); with the announced frame it goes through, and a record that is
+    not valid means the whole call."""
+    sys.path.insert(0, ROOT)
+    import bench
+    poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(4)]
+    loop = bench.FrameLoop("depth", poses)
+    assert loop.ahead is not None
+    loop.step(0)
+    sync()
+    assert loop.ahead.valid == 1
+    vv, lib = loop.vols[0], loop.lib
+    before = vv["vol"].read_counters().copy()
+    announced = T.Transform.from_buffer_copy(bytes(loop.ndesc.depth_to_world))
+    loop.fdesc.depth_to_world = poses[2]                     # not the frame the pass was made for
+    loop.fdesc.content_id += 2
+    rc = lib.vk_volume_set_view_rounds_ahead(vv["vref"], loop.fref, None, 3, loop.aref, loop.stream)
+    sync()
+    assert rc == -1 and loop.ahead.valid == 1        # VK_ERR_ARGUMENT
+    assert np.array_equal(vv["vol"].read_counters(), before)
+    loop.fdesc.depth_to_world = announced
+    rc = lib.vk_volume_set_view_rounds_ahead(vv["vref"], loop.fref, None, 3, loop.aref, loop.stream)
+    sync()
+    assert rc == 0 and loop.ahead.valid == 0
+    after = vv["vol"].read_counters()
+    assert after[T.VK_CTR_ROUNDS] > before[T.VK_CTR_ROUNDS]
+    # an invalid record: the whole call
+    rc = lib.vk_volume_set_view_rounds_ahead(vv["vref"], loop.fref, None, 3, loop.aref, loop.stream)
+    sync()
+    assert rc == 0
 
 
 # ------------------------------------------------------------------ configs[3] --

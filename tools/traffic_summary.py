@@ -6,7 +6,9 @@ raycast kernel, with the gfx950 correction from MI355X_MICROARCH.md (FETCH_SIZE 
 import csv, glob, json, os, sys
 
 out, workload = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "rgbd")
-KERNELS = {"integrate": "integrate_pipelined_kernel", "raycast": "compute_points_kernel"}
+# (the raycast is compute_points_kernel, or — bench.py's default at given poses — trace_and_request_kernel, which also makes
+# the next frame's request pass: its bytes then include that pass's, i.e. the depth image read and the normals written)
+KERNELS = {"integrate": ("integrate_pipelined_kernel",), "raycast": ("compute_points_kernel", "trace_and_request_kernel")}
 res = {k: {} for k in KERNELS}
 calib = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -16,8 +18,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != c:
                 continue
-            for k, pat in KERNELS.items():
-                if pat in r["Kernel_Name"]:
+            for k, pats in KERNELS.items():
+                if any(pat in r["Kernel_Name"] for pat in pats):
                     vals[k].append(float(r["Counter_Value"]))
             if "fill_voxels_kernel" in r["Kernel_Name"]:
                 fill.append(float(r["Counter_Value"]))
@@ -36,7 +38,7 @@ cmd = f"tools/traffic.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 b
 for k in KERNELS:
     fetch, n = res[k]["FETCH_SIZE"]
     write, _ = res[k]["WRITE_SIZE"]
-    doc = {"kernel": KERNELS[k], "workload": workload, "command": cmd, "launches_averaged": n,
+    doc = {"kernel": " | ".join(KERNELS[k]), "workload": workload, "command": cmd, "launches_averaged": n,
            "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
            "WRITE_calibration": "fill_voxels_kernel writes 749.7 MB; WRITE_SIZE reported %s KB in this run" % calib["WRITE_SIZE"],
            "note": "fabric-side request bytes; Infinity-Cache hits are counted, not excluded."}

@@ -92,6 +92,8 @@ _SIGNATURES = {
     "vk_volume_set_view_prepare": ([_P, _P, _P, _P], _I),
     "vk_volume_set_view_rounds": ([_P, _P, _P, _I, _P], _I),
     "vk_volume_set_view_rounds_split": ([_P, _P, _P, _I, _P, _P, _P], _I),
+    "vk_trace_ahead_requests": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_volume_set_view_rounds_ahead": ([_P, _P, _P, _I, _P, _P], _I),
     "vk_light_prepared": ([_P, _P, C.c_float], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),

@@ -9,6 +9,7 @@
 // (positive floats order like their bit patterns), skipping the patch list.
 #include "vk_bounds.hpp"
 #include "vk_raycast.hpp"
+#include "vk_requests.hpp"
 
 using namespace vk;
 
@@ -231,11 +232,12 @@ __device__ __forceinline__ float2 merged_bound_wave(const float2* __restrict__ p
 constexpr int kPointsWaves = VK_POINTS_WAVES;
 constexpr int kPointsTile = (kPointsWaves == 4) ? 16 : 8;     // pixels per workgroup edge
 
-template <bool POOL32>
-__global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(PointParams P)
+// The work of ONE workgroup of the raycast: WAVES = 1: an 8 x 8 tile; WAVES = 4: 2 x 2 of them. `group` of `groups`
+// workgroups (the launch's own blockIdx / gridDim, or the leading part of a launch that has other work behind it).
+template <bool POOL32, int WAVES>
+__device__ __forceinline__ void points_group(const PointParams& P, const int group, const int groups, int4 (*directories)[kDirEntries])
 {
-  __shared__ int4 directories[kPointsWaves][kDirEntries];
-
+  constexpr int TILE = (WAVES == 4) ? 16 : 8;     // pixels per workgroup edge
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   int4* bdir = directories[wave];
@@ -246,23 +248,23 @@ __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(Point
   // with its own L2, and neighbouring tiles march through the same voxel blocks.
   // Workgroup w therefore takes tile (w % 8) * chunk + w / 8, which gives every XCD
   // one contiguous band of the image (placement only affects speed).
-  const int tiles_x = (P.image_width + kPointsTile - 1) / kPointsTile, tiles_y = (P.image_height + kPointsTile - 1) / kPointsTile;
+  const int tiles_x = (P.image_width + TILE - 1) / TILE, tiles_y = (P.image_height + TILE - 1) / TILE;
   const int tiles = tiles_x * tiles_y;
   const int chunk = (tiles + 7) / 8;
   int tile;
-  if (VK_POINTS_ORDER == 0) tile = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (VK_POINTS_ORDER == 0) tile = (group & 7) * chunk + (group >> 3);
   else if (VK_POINTS_ORDER == 1)
   {
     // two half bands per XCD, k and k + 8 of 16: rays near the image border graze the
     // surface and take more steps, so every XCD gets one outer and one inner strip
     const int half = (chunk + 1) / 2;
-    const int i = blockIdx.x >> 3, k = blockIdx.x & 7;
+    const int i = group >> 3, k = group & 7;
     tile = (i < half) ? k * half + i : (8 + k) * half + (i - half);
   }
-  else tile = blockIdx.x;                                        // plain round robin
+  else tile = group;                                        // plain round robin
   const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const int x = tile_x * kPointsTile + (kPointsWaves == 4 ? (wave & 1) * 8 : 0) + (lane & 7);
-  const int y = tile_y * kPointsTile + (kPointsWaves == 4 ? (wave >> 1) * 8 : 0) + (lane >> 3);
+  const int x = tile_x * TILE + (WAVES == 4 ? (wave & 1) * 8 : 0) + (lane & 7);
+  const int y = tile_y * TILE + (WAVES == 4 ? (wave >> 1) * 8 : 0) + (lane >> 3);
 
   // This wave's bound first: with a wave-uniform cell (always, when a bounds cell is
   // 8x8 pixels) the kBoundsGroups partial grids are merged by the wave as a whole.
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(Point
 
     // publish the merged grid (Tracer::bounds_) — every cell, whether or not a
     // pixel maps to it
-    const int threads = gridDim.x * kPointsWaves * 64;
-    for (int c = blockIdx.x * kPointsWaves * 64 + threadIdx.x; c < cells; c += threads)
+    const int threads = groups * WAVES * 64;
+    for (int c = group * WAVES * 64 + threadIdx.x; c < cells; c += threads)
       P.bounds_out[c] = merged_bound(P.partials, cells, c);
   }
   else
@@ -292,6 +294,34 @@ __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(Point
 
   if (!inside) return;
   march_ray<false, POOL32>(P, bdir, x, y, bound);
+}
+
+template <bool POOL32>
+__global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(PointParams P)
+{
+  __shared__ int4 directories[kPointsWaves][kDirEntries];
+  points_group<POOL32, kPointsWaves>(P, (int)blockIdx.x, (int)gridDim.x, directories);
+}
+
+// The raycast of one frame with the REQUEST PASS OF THE NEXT FRAME'S SetView behind it in the same launch
+// (vk_trace_ahead_requests): the first `trace_groups` workgroups are the raycast's (16 x 16 pixels each), the rest are the
+// request pass's (64 x 4 pixels each, vk_requests.hpp), dispatched as the raycast's waves retire. The raycast is as long as
+// its slowest wave (mean wave life 17 us, launch 31 us) and leaves most of the device idle for its
+// last third; as a launch of its own the request pass (17 us) would start only after that. The two touch disjoint state:
+// the raycast reads the table, the voxels and its bounds; the request pass reads the table and the visibility bytes and
+// writes visibility bytes, request flags and the light preparation's buffers.
+template <bool POOL32, int PREP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void trace_and_request_kernel(PointParams P,
+    RequestParams R, Retry retry, int trace_groups, int request_groups_x)
+{
+  __shared__ int4 directories[4][kDirEntries];
+  if ((int)blockIdx.x < trace_groups)
+  {
+    points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
+    return;
+  }
+  const int g = (int)blockIdx.x - trace_groups;
+  requests_group<true, PREP>(R, retry, g % request_groups_x, g / request_groups_x);
 }
 
 // ------------------------------------------------------------------ normals ----
@@ -392,7 +422,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
     const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
     int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
-    hipStream_t s, float* normals = nullptr)
+    hipStream_t s, float* normals = nullptr, const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr,
+    int next_prep = 0)
 {
   PointParams P;
   P.entries = entries;
@@ -417,6 +448,23 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.image_height = image_height;
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
+  if (next_requests)
+  {
+    // the next frame's request pass behind the raycast's workgroups (trace_and_request_kernel): 16 x 16 pixel tiles
+    const int tiles16 = ((image_width + 15) / 16) * ((image_height + 15) / 16);
+    int chunk16 = (tiles16 + 7) / 8;
+    if (VK_POINTS_ORDER == 1) chunk16 = 2 * ((chunk16 + 1) / 2);
+    const int trace_groups = 8 * chunk16;
+    const int gx = (next_requests->width + 63) / 64, gy = (next_requests->height + 3) / 4;
+    const dim3 grid2(trace_groups + gx * gy);
+    const bool pool32 = pool_bytes <= 0xffffffffull;
+#define VK_LAUNCH_TR(POOL, PREP) hipLaunchKernelGGL((trace_and_request_kernel<POOL, PREP>), grid2, dim3(256), 0, s, P, *next_requests, *next_retry, trace_groups, gx)
+    if (pool32) { if (next_prep == 2) VK_LAUNCH_TR(true, 2); else if (next_prep == 1) VK_LAUNCH_TR(true, 1); else VK_LAUNCH_TR(true, 0); }
+    else { if (next_prep == 2) VK_LAUNCH_TR(false, 2); else if (next_prep == 1) VK_LAUNCH_TR(false, 1); else VK_LAUNCH_TR(false, 0); }
+#undef VK_LAUNCH_TR
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
   const int tiles = ((image_width + kPointsTile - 1) / kPointsTile) * ((image_height + kPointsTile - 1) / kPointsTile);
   int chunk = (tiles + 7) / 8;
   if (VK_POINTS_ORDER == 1) chunk = 2 * ((chunk + 1) / 2);
@@ -568,8 +616,8 @@ int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float m
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 
-int vk_trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
-    float* out_color, float* out_normals, void* stream)
+static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
+    float* out_color, float* out_normals, void* stream, const RequestParams* next_requests, const Retry* next_retry, int next_prep)
 {
   VK_REQUIRE(v && frame && ahead && ahead->scratch && out_depth && out_color && out_normals);
   VK_REQUIRE(v->hash_entries && v->voxels && v->visible_blocks && v->counters);
@@ -594,10 +642,49 @@ int vk_trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ah
   if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
-           (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s
-           )) != VK_OK)
+           (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s,
+           nullptr, next_requests, next_retry, next_prep)) != VK_OK)
     return rc;
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
+}
+
+int vk_trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
+    float* out_color, float* out_normals, void* stream)
+{
+  return trace_ahead(v, frame, ahead, out_depth, out_color, out_normals, stream, nullptr, nullptr, 0);
+}
+
+int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bounds* ahead, float* out_depth,
+    float* out_color, float* out_normals, const vk_frame* next, vk_light_prep* next_prep, vk_requests_ahead* requests,
+    void* stream)
+{
+  VK_REQUIRE(v && next && requests);
+  requests->valid = 0;
+  // the pass is made ahead only in the form SetView itself would give it without further launches: a frame that names
+  // its content, and — when its normals are still to be computed — a preparation that rides (the normals come with it)
+  const bool ride = prep_rides(next_prep, next);
+  const bool possible = next->depth && next->width > 0 && next->height > 0 && next->content_id != 0 && v->counters &&
+      v->allocation_types && v->allocation_blocks && v->block_visibility &&
+      !(next_prep && next_prep->normals_out && (!ride || next_prep->normals_out != next->normals));
+  if (!possible) return vk_trace_ahead(v, view, ahead, out_depth, out_color, out_normals, stream);
+  RequestParams R;
+  Retry retry;
+  const int with_prep = build_request_pass(R, retry, v, next->depth, next->width, next->height, &next->depth_projection,
+      &next->depth_to_world, ride ? next : nullptr, ride ? next_prep : nullptr, true);
+  if (next_prep) next_prep->valid = 0;
+  const int rc = trace_ahead(v, view, ahead, out_depth, out_color, out_normals, stream, &R, &retry, with_prep);
+  if (rc != VK_OK) return rc;
+  if (ride) prep_note_made(next_prep, next);
+  requests->counters = v->counters;
+  requests->depth = next->depth;
+  requests->prep = ride ? next_prep : nullptr;
+  requests->width = next->width;
+  requests->height = next->height;
+  requests->depth_projection = next->depth_projection;
+  requests->depth_to_world = next->depth_to_world;
+  requests->content_id = next->content_id;
+  requests->valid = 1;
+  return VK_OK;
 }
 
 }  // extern "C"

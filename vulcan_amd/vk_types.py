@@ -185,6 +185,13 @@ class RigExchange(C.Structure):
     _fields_ = [("areas", C.c_void_p * 8), ("rank", C.c_int32), ("world", C.c_int32), ("sequence", C.c_uint32)]
 
 
+class RequestsAhead(C.Structure):
+    """vk_requests_ahead (vk.h): the frame a request pass was made for ahead of its SetView"""
+    _fields_ = [("counters", C.c_void_p), ("depth", C.c_void_p), ("prep", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
+                ("depth_projection", Projection), ("depth_to_world", Transform), ("content_id", C.c_uint64),
+                ("valid", C.c_int32), ("pad_", C.c_int32)]
+
+
 class TestHooks(C.Structure):
     """vk_test_hooks (vk.h)"""
     _fields_ = [("posted_capacity", C.c_int32), ("retry_capacity", C.c_int32), ("set_view_unfused", C.c_int32),
