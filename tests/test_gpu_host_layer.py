@@ -31,6 +31,11 @@ def test_cpp_frame_loop_runs_and_tracks():
     m = re.search(r"frames 60 .* fps ([\d.]+) +visible (\d+) +allocated (\d+) +dropped (\d+)", out)
     assert m, out
     assert int(m.group(2)) > 3000 and int(m.group(4)) == 0
+    # the same loop with every raycast announcing the next frame (Tracer::Trace(keyframe, next_frame)): the same map
+    out = subprocess.run([exe, "60", "0", "0", "0", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+    ahead = re.search(r"frames 60 .* fps ([\d.]+) +visible (\d+) +allocated (\d+) +dropped (\d+) +input resident, requests made ahead", out)
+    assert ahead, out
+    assert ahead.group(2, 3, 4) == m.group(2, 3, 4)
     # mode 1: PyramidTracker<DepthTracker> in front of every frame; mode 2: PyramidTracker<LightTracker> +
     # LightIntegrator (the line upstream keeps commented out); mode 3, the shipped app's own set-up, is run by
     # tools/round_run.sh (its one-step tracker lags this fast camera: profiles/). Closed loop in the room scene

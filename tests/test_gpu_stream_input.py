@@ -24,7 +24,8 @@ def test_streamed_input_equals_resident_input(api):
     import bench
     count = 10                     # every slot is used more than once
     poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(count)]
-    resident = bench.FrameLoop("rgbd", poses)
+    # (no request pass made ahead: the images alternate, and FrameLoop announces the next frame with the current images)
+    resident = bench.FrameLoop("rgbd", poses, requests_ahead=False)
     streamed = bench.FrameLoop("rgbd", poses, stream_input=True)
     # the slots' staging buffers hold different frames: even frames the bench's image, odd frames a dimmer one
     # 3 mm further away; the resident loop is handed the same alternation

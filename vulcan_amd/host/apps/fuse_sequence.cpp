@@ -7,7 +7,9 @@
 //   integrator.Integrate(frame) -> tracer.Trace(keyframe)       (vulcan.cu:297-325)
 // The three SetView calls are one SetView(frame, 3) (same state, tsdf_volume.h).
 //
-//   fuse_sequence [frames=200] [mode=0|1|2|3] [stream=0|1] [split=0|1]
+//   fuse_sequence [frames=200] [mode=0|1|2|3] [stream=0|1] [split=0|1] [ahead=0|1]
+//     ahead = 1 (mode 0): every raycast also makes the NEXT frame's request pass, in its own launch
+//     (Tracer::Trace(keyframe, next_frame)); SetView is then left with its handle + visibility launch
 //     split = 1 (mode 0): SetView's request pass on a stream of its own, beside the previous frame's raycast
 //     (Volume::EnableRequestStream; the poses are known in advance in mode 0)
 //     stream = 1 (mode 0): every frame's depth image is UPLOADED from pinned host memory while the frame before it is
@@ -61,6 +63,7 @@ int main(int argc, char** argv)
   const bool track = mode != 0;
   const bool stream_input = argc > 3 && std::atoi(argv[3]) == 1 && mode == 0;
   const bool split_streams = argc > 4 && std::atoi(argv[4]) == 1 && mode == 0;
+  const bool requests_ahead = argc > 5 && std::atoi(argv[5]) == 1 && mode == 0 && !split_streams && !stream_input;
   const int w = 640, h = 480;
   const float radius = 2.0f;
 
@@ -201,9 +204,18 @@ int main(int argc, char** argv)
     if (photometric) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
     if (stream_input) uploader->Release();         // the frame's images have no reader after Integrate
     keyframe->depth_to_world_transform = frame.depth_to_world_transform;
-    tracer.Trace(*keyframe);           // :325
+    if (requests_ahead && i + 1 < frames)
+    {
+      Frame next = frame;              // the same resident images, the next pose
+      next.depth_to_world_transform = truth[i + 1];
+      tracer.Trace(*keyframe, next);   // :325, + the request pass of the next SetView
+    }
+    else tracer.Trace(*keyframe);      // :325
   }
 
+  // how long the host needed to ENQUEUE the frames (mode 0 never waits for the device inside the loop): when this is
+  // close to the total, the loop is bound by the host's launch calls, not by the kernels
+  const double enqueue_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   Device::Synchronize();
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int32_t counters[VK_CTR_PUBLIC];
@@ -211,8 +223,9 @@ int main(int argc, char** argv)
   std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  input %s  tracking %s\n", frames,
       seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
       counters[VK_CTR_DROPPED], stream_input ? (split_streams ? "uploaded per frame, requests on their own stream" : "uploaded per frame") :
-          (split_streams ? "resident, requests on their own stream" : "resident"), mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
+          (split_streams ? "resident, requests on their own stream" : (requests_ahead ? "resident, requests made ahead" : "resident")), mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
+  std::printf("host enqueue %.1f us per frame of %.1f\n", 1e6 * enqueue_seconds / frames, 1e6 * seconds / frames);
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
 
   double motion_translation = 0, motion_rotation = 0;

@@ -48,6 +48,15 @@ class Tracer
     // intrinsics already set on the frame
     void Trace(Frame& frame);
 
+    // Not upstream: Trace(frame), and in the same launch the request pass of the volume's NEXT SetView — for a caller that
+    // knows the next frame (images and pose) while it raycasts this one: fusion at given poses, not a tracking loop, whose
+    // next pose comes out of this raycast. `next_frame` must then be the very next frame passed to Volume::SetView,
+    // unchanged (any other SetView throws). With `next_needs_normals` the pass also computes next_frame's normal image
+    // (Frame::ComputeNormals), which needs a LightIntegrator attached to the volume (its preparation rides along, as in
+    // Volume::ComputeNormalsAndSetView); without one the normals are computed by a launch of their own first.
+    // The results are those of Trace(frame); ...; SetView(next_frame), bit for bit (vk_trace_ahead_requests).
+    void Trace(Frame& frame, Frame& next_frame, bool next_needs_normals = false);
+
   protected:
     void ComputePatches(const Frame& frame);
     void ComputeBounds(const Frame& frame);
@@ -67,6 +76,7 @@ class Tracer
 
   private:
     void Initialize();
+    void TraceWith(Frame& frame, Frame* next, bool next_needs_normals);
 };
 
 // ---- stage functions (device pointers in, device pointers out) -----------------

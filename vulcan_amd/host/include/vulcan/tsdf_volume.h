@@ -105,6 +105,12 @@ class Volume
     void* GetRequestStream() const { return request_stream_; }
     void NoteIntegrated() const;
 
+    // Not upstream: the record of a request pass made AHEAD of its SetView (vk_requests_ahead) — by
+    // Tracer::Trace(keyframe, next_frame), inside the raycast's own launch. SetView(next_frame) then launches only its
+    // handle + visibility pass; any other SetView while the record is valid throws (the announced frame's requests
+    // are in the volume and have to be handled first).
+    vk_requests_ahead* GetRequestsAhead() const { return &requests_ahead_; }
+
   protected:
     // the four stages of SetView, in call order
     void ResetBlockVisibility();
@@ -134,6 +140,7 @@ class Volume
     mutable bool visible_count_stale_;
     mutable vk_view_bounds view_bounds_;
     mutable vk_light_prep light_prep_;
+    mutable vk_requests_ahead requests_ahead_;
     void* request_stream_;              // EnableRequestStream(): nullptr = everything on Device::GetStream()
     void* requested_;                   // event behind the request pass
     void* integrated_;                  // event behind the last Integrate

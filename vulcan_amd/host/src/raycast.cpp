@@ -87,6 +87,16 @@ void Tracer::SetDepthRange(float min, float max) { SetDepthRange(Vector2f(min, m
 
 void Tracer::Trace(Frame& frame)
 {
+  TraceWith(frame, nullptr, false);
+}
+
+void Tracer::Trace(Frame& frame, Frame& next_frame, bool next_needs_normals)
+{
+  TraceWith(frame, &next_frame, next_needs_normals);
+}
+
+void Tracer::TraceWith(Frame& frame, Frame* next, bool next_needs_normals)
+{
   VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
   const int w = frame.depth_image->GetWidth();
   const int h = frame.depth_image->GetHeight();
@@ -106,9 +116,36 @@ void Tracer::Trace(Frame& frame)
     volume_->AttachViewBounds(scratch, bounds_width_, bounds_height_, depth_range_);
     ahead = volume_->GetViewBounds();
   }
-  VK_ASSERT(vk_trace_ahead(&v, &f, ahead, frame.depth_image->GetData(),
-      reinterpret_cast<float*>(frame.color_image->GetData()),
-      reinterpret_cast<float*>(frame.normal_image->GetData()), Device::GetStream()));
+  float* depth_out = frame.depth_image->GetData();
+  float* color_out = reinterpret_cast<float*>(frame.color_image->GetData());
+  float* normals_out = reinterpret_cast<float*>(frame.normal_image->GetData());
+  if (!next || volume_->GetRequestStream())
+  {
+    VK_ASSERT(vk_trace_ahead(&v, &f, ahead, depth_out, color_out, normals_out, Device::GetStream()));
+    if (next && next_needs_normals) next->ComputeNormals();
+    return;
+  }
+  VULCAN_ASSERT_MSG(next->depth_image, "missing depth image");
+  vk_light_prep* prep = volume_->GetLightPreparation();
+  if (next_needs_normals)
+  {
+    if (!prep) next->ComputeNormals();
+    else
+    {
+      if (!next->normal_image) next->normal_image = std::make_shared<ColorImage>();
+      next->normal_image->Resize(next->depth_image->GetWidth(), next->depth_image->GetHeight());
+      prep->normals_out = reinterpret_cast<float*>(next->normal_image->GetData());   // (GetData stamps the image: new content)
+    }
+  }
+  const vk_frame n = next->ToVk();
+  VK_ASSERT(vk_trace_ahead_requests(&v, &f, ahead, depth_out, color_out, normals_out, &n, prep, volume_->GetRequestsAhead(),
+      Device::GetStream()));
+  if (prep && prep->normals_out && volume_->GetRequestsAhead()->valid != 1)
+  {
+    // the pass could not be made ahead (vk.h): the normals are then the caller's launch, as in Frame::ComputeNormals
+    prep->normals_out = nullptr;
+    next->ComputeNormals();
+  }
 }
 
 void Tracer::ComputePatches(const Frame& frame)

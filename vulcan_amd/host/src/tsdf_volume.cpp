@@ -26,6 +26,7 @@ Volume::Volume(int main_block_count, int excess_block_count) :
 {
   std::memset(&view_bounds_, 0, sizeof(view_bounds_));
   std::memset(&light_prep_, 0, sizeof(light_prep_));
+  std::memset(&requests_ahead_, 0, sizeof(requests_ahead_));
   Initialize();
 }
 
@@ -134,10 +135,18 @@ void Volume::SetView(const Frame& frame, int rounds)
   const vk_frame f = frame.ToVk();
   if (request_stream_)
   {
+    VULCAN_ASSERT_MSG(requests_ahead_.valid != 1, "a request pass made ahead and a request stream exclude each other");
     if (integrated_recorded_) VK_ASSERT(vk_stream_wait_event(request_stream_, integrated_));
     VK_ASSERT(vk_volume_set_view_rounds_split(&v, &f, GetLightPreparation(), rounds, request_stream_, requested_, Device::GetStream()));
   }
-  else VK_ASSERT(vk_volume_set_view_rounds(&v, &f, GetLightPreparation(), rounds, Device::GetStream()));
+  else
+  {
+    // (with a record that is not valid this is vk_volume_set_view_rounds)
+    const int code = vk_volume_set_view_rounds_ahead(&v, &f, GetLightPreparation(), rounds, &requests_ahead_, Device::GetStream());
+    VULCAN_ASSERT_MSG(!(code == VK_ERR_ARGUMENT && requests_ahead_.valid == 1),
+        "SetView of another frame than the one Tracer::Trace(keyframe, next_frame) announced");
+    VK_ASSERT(code);
+  }
   visible_count_stale_ = true;
   empty_ = false;
 }

@@ -1461,6 +1461,90 @@ TEST(Sequence, RoundTrip)   // image.h:100-133,228-253 Load / Save on PGM / PPM;
   for (int i = 0; i < 6; ++i) ASSERT_EQ(want[i], r[i]);
 }
 
+// ---- Tracer::Trace(frame, next_frame): no upstream counterpart; must equal Trace(frame) ... SetView(next_frame) ----
+
+TEST(Tracer, TraceAnnouncingTheNextFrameEqualsTheTwoCalls)
+{
+  const int w = 160, h = 120, frames = 4;
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.025f, 0.08f, 0.0f);
+  for (int photometric = 0; photometric < 2; ++photometric)
+  {
+    std::vector<Voxel> voxels[2];
+    std::vector<HashEntry> entries[2];
+    std::vector<float> depths[2];
+    std::vector<Vector3f> normals[2];
+    for (int variant = 0; variant < 2; ++variant)
+    {
+      Frame frame;
+      frame.depth_projection.SetFocalLength(136, 136);
+      frame.depth_projection.SetCenterPoint(80, 60);
+      frame.color_projection = frame.depth_projection;
+      frame.depth_image = MakeDepth(w, h, [](int x, int y) { return 1.5f + 0.001f * x + 0.0007f * y; });
+      frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+      auto pose = [](int i) { return Transform::Translate(0.01f * i, -0.004f * i, 0.002f * i); };
+      auto volume = std::make_shared<Volume>(8192, 2048);
+      volume->SetVoxelLength(0.008f);
+      DepthIntegrator depth_integrator(volume);
+      LightIntegrator light_integrator(volume);
+      light_integrator.SetLight(light);
+      Tracer tracer(volume);
+      Frame keyframe;
+      keyframe.depth_projection = keyframe.color_projection = frame.depth_projection;
+      keyframe.depth_image = std::make_shared<Image>(w, h);
+      bool announced = false;
+      for (int i = 0; i < frames; ++i)
+      {
+        frame.depth_to_world_transform = pose(i);
+        if (photometric && !announced) frame.ComputeNormals();
+        volume->SetView(frame, 3);
+        ASSERT_EQ(0, volume->GetRequestsAhead()->valid);
+        if (photometric) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);
+        keyframe.depth_to_world_transform = frame.depth_to_world_transform;
+        // (the first Integrate registers the light integrator's buffers with the volume: frame 0 announces like the rest)
+        if (variant == 1 && i + 1 < frames)
+        {
+          Frame next = frame;
+          next.depth_to_world_transform = pose(i + 1);
+          tracer.Trace(keyframe, next, photometric != 0);
+          ASSERT_EQ(1, volume->GetRequestsAhead()->valid);
+          frame.normal_image = next.normal_image;
+          announced = true;
+          if (i == 1)
+          {
+            // any other frame is refused while the announced one is pending, and nothing is lost by the attempt
+            Frame other = next;
+            other.depth_to_world_transform = pose(7);
+            bool thrown = false;
+            try { volume->SetView(other, 3); } catch (const Exception&) { thrown = true; }
+            ASSERT_TRUE(thrown);
+            ASSERT_EQ(1, volume->GetRequestsAhead()->valid);
+          }
+        }
+        else
+        {
+          tracer.Trace(keyframe);
+          announced = false;
+        }
+      }
+      voxels[variant] = Download(volume->GetVoxels());
+      entries[variant] = Download(volume->GetHashEntries());
+      depths[variant] = Download(*keyframe.depth_image);
+      normals[variant].resize(size_t(w) * h);
+      keyframe.normal_image->CopyToHost(normals[variant].data());
+    }
+    ASSERT_EQ(voxels[0].size(), voxels[1].size());
+    ASSERT_TRUE(std::memcmp(voxels[0].data(), voxels[1].data(), voxels[0].size() * sizeof(Voxel)) == 0);
+    ASSERT_TRUE(std::memcmp(entries[0].data(), entries[1].data(), entries[0].size() * sizeof(HashEntry)) == 0);
+    ASSERT_TRUE(std::memcmp(depths[0].data(), depths[1].data(), depths[0].size() * sizeof(float)) == 0);
+    ASSERT_TRUE(std::memcmp(normals[0].data(), normals[1].data(), normals[0].size() * sizeof(Vector3f)) == 0);
+    size_t seen = 0;
+    for (const Voxel& voxel : voxels[0]) seen += (photometric ? voxel.color_weight : voxel.distance_weight) > 1;
+    ASSERT_TRUE(seen > 1000);
+  }
+}
+
 // ---- FrameUploader (upload.h): no upstream test — upstream uploads with a blocking copy (image.h:100-123) ----
 
 TEST(FrameUploader, DeliversEveryFrameInOrderThroughTwoSlots)
