@@ -44,6 +44,14 @@ VK_API int vk_probe_trace_steps(const vk_hash_entry* entries, const vk_voxel* vo
     const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
     int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, int* march_steps, void* stream);
 
+/* as vk_probe_trace_steps; `trip_log` (optional, device u64[waves x trip_log_passes], zeroed by the caller, with `touched`
+ * only): one word per wave and pass through the march loop, see PointParams::trip_log (vk_raycast.hpp) */
+VK_API int vk_probe_trace_log(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
+    const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
+    int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, int* march_steps,
+    unsigned long long* trip_log, int trip_log_passes, void* stream);
+
 /* launch floor: `replays` x `launches` kernels of `workgroups` x 256 lanes that read counters[0] (device, 0)
  * and leave, in stream order */
 VK_API int vk_probe_launch_floor(const int32_t* counters, float* sink, int workgroups, int launches, int replays,

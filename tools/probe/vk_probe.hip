@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void block_rmw_kernel(float4* __restrict__ vox
 __global__ __launch_bounds__(256) void count_points_kernel(PointParams P, unsigned long long* wave_clocks)
 {
   const unsigned long long t0 = wall_clock64();
-  __shared__ int4 directories[4][kDirEntries];
+  __shared__ int4 directories[4][kDirWords];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   int4* bdir = directories[wave];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void count_points_kernel(PointParams P, unsign
     const int px = P.bounds_width * x / P.image_width;
     const int py = P.bounds_height * y / P.image_height;
     const float2 bound = reinterpret_cast<const float2*>(P.bounds)[py * P.bounds_width + px];
-    if (P.touched) march_ray<true, false>(P, bdir, x, y, bound);
+    if (P.touched) march_ray<true, false>(P, bdir, x, y, bound, (int)blockIdx.x * 4 + wave);
     else march_ray<false, true>(P, bdir, x, y, bound);
   }
   // per-wave start / end on the 100 MHz wall clock (distribution of wave lifetimes)
@@ -195,6 +195,16 @@ int vk_probe_trace_steps(const vk_hash_entry* entries, const vk_voxel* voxels, c
     const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
     int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, int* march_steps, void* stream)
 {
+  return vk_probe_trace_log(entries, voxels, bounds, block_count, block_length, voxel_length, trunc_length, Twc, projection,
+      depths, colors, image_width, image_height, bounds_width, bounds_height, touched, wave_clocks, march_steps, nullptr, 0, stream);
+}
+
+int vk_probe_trace_log(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
+    int block_count, float block_length, float voxel_length, float trunc_length, const vk_transform* Twc,
+    const vk_projection* projection, float* depths, float* colors, int image_width, int image_height,
+    int bounds_width, int bounds_height, uint8_t* touched, unsigned long long* wave_clocks, int* march_steps,
+    unsigned long long* trip_log, int trip_log_passes, void* stream)
+{
   VK_REQUIRE(entries && voxels && bounds && Twc && projection && depths && colors && (touched || wave_clocks));
   VK_REQUIRE(block_count > 0 && image_width > 0 && image_height > 0 && bounds_width > 0 && bounds_height > 0);
   PointParams P;
@@ -220,6 +230,8 @@ int vk_probe_trace_steps(const vk_hash_entry* entries, const vk_voxel* voxels, c
   P.bounds_height = bounds_height;
   P.touched = touched;
   P.march_steps = march_steps;
+  P.trip_log = trip_log;
+  P.trip_log_passes = trip_log_passes;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
   hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P, wave_clocks);
   VK_LAUNCH_CHECK();

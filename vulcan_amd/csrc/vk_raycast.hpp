@@ -21,6 +21,7 @@
 
 #include "vk_common.hpp"
 
+
 namespace vk
 {
 
@@ -41,6 +42,11 @@ struct PointParams
   int image_width, image_height, bounds_width, bounds_height;
   uint8_t* touched;           // COUNT only: one byte per pool slot
   int* march_steps;           // COUNT only (optional): trips through the march loop, per pixel
+  // COUNT only (optional): one word per wave and pass through the march loop, trip_log[wave * trip_log_passes + pass] =
+  // wall clock (32 bits, 10 ns) << 32 | lanes still marching << 24 | of those: whose last trip found no block << 16 |
+  // whose last trip took a sample << 8
+  unsigned long long* trip_log;
+  int trip_log_passes;
 };
 
 // a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).
@@ -71,6 +77,7 @@ struct BlockCache
 // and over, so here a block is resolved against the global table about once per wave
 // and every later use, by any lane, is one LDS read.
 constexpr int kDirEntries = 64;
+constexpr int kDirWords = kDirEntries + 16;   // in int4: the entries, then one tag word per entry (file_blocks)
 constexpr int kMaxChain = 1 << 24;
 
 // Entry = the block's coordinates modulo 4 per axis: any 4x4x4 neighbourhood of blocks
@@ -83,38 +90,67 @@ __device__ __forceinline__ int dir_index(int bx, int by, int bz)
 
 // tracer.cu:364-371: walk the chain until the block matches or the chain ends; a hit
 // needs the match AND IsAllocated().
+// One 16-byte load per entry, all of it at once: left alone, the compiler reads the coordinates and `next` inside the walk
+// and comes back for `data` once the block has matched — a second, dependent read on every lookup (the ISA of round 3).
+__device__ __forceinline__ Entry load_whole_entry(const vk_hash_entry* entries, uint32_t index)
+{
+  int4 raw = reinterpret_cast<const int4*>(entries)[index];
+  asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));
+  Entry e;
+  e.ox = (int16_t)(raw.x & 0xffff);
+  e.oy = (int16_t)((uint32_t)raw.x >> 16);
+  e.oz = (int16_t)(raw.y & 0xffff);
+  e.pad = (int16_t)((uint32_t)raw.y >> 16);
+  e.data = raw.z;
+  e.next = raw.w;
+  return e;
+}
+
 __device__ __forceinline__ int probe_table(const PointParams& P, int bx, int by, int bz)
 {
-  Entry entry = load_entry(P.entries, block_hash(bx, by, bz, P.K));
+  Entry entry = load_whole_entry(P.entries, block_hash(bx, by, bz, P.K));
   // a chain is at most the excess region long; the cap only guarantees that a wave
   // leaves the loop if it is handed a corrupt table (a cycle would otherwise hang the GPU)
   for (int guard = 0; !entry_is(entry, bx, by, bz) && entry.next != -1 && guard < kMaxChain; ++guard)
-    entry = load_entry(P.entries, (uint32_t)entry.next);
+    entry = load_whole_entry(P.entries, (uint32_t)entry.next);
   return (entry_is(entry, bx, by, bz) && entry.data != -1) ? entry.data : -1;
 }
 
-// files a resolved block in the directory: one distinct block per trip, written by a
-// single lane so that an entry is never a mix of two lanes' stores
+// files resolved blocks in the directory, every lane its own at once. Two lanes may want the same entry (the same block, or
+// two blocks that share it): they first write their lane number into the entry's TAG word, read it back — a wave's LDS
+// operations execute in order, so all of them read the one that stayed — and only that lane writes the entry: an entry is
+// never a mix of two lanes' stores, and a block that lost is simply looked up again when it is next needed.
+// (Until round 4 the lanes filed one DISTINCT block per trip through a ballot / readlane loop, ~15 instructions per block:
+// a wave that meets a surface files 20 to 60 blocks in a pass, 1 to 2 us of its 4 to 6 — tools/trip_log.py. r03 on that
+// loop, tracking scene / fusion benchmark: a limit of N blocks per call, the allocated ones first — 8: 92.1 / 31.3 us,
+// 4: 90.9 / 31.4, 2: 87.6 / 32.2, 1: 83.5 / 33.2 against 90.9 / 31.5 without a limit; not filing the absent blocks the
+// MARCH runs through, find_block: 77.8 / 30.9.)
+#ifndef VK_DIR_SERIAL_FILING
+#define VK_DIR_SERIAL_FILING 0
+#endif
 __device__ __forceinline__ void file_blocks(int4* dir, bool pending, int bx, int by, int bz, int data)
 {
-  // (Filing is serial: one trip per DISTINCT block. Measured, r03, tracking scene / fusion benchmark:
-  // a limit of N blocks per call, the allocated ones first — 8: 92.1 / 31.3 us, 4: 90.9 / 31.4,
-  // 2: 87.6 / 32.2, 1: 83.5 / 33.2 against 90.9 / 31.5 without a limit: the fusion benchmark wants the
-  // absent CORNER blocks of its samples filed. What does help both is not filing the absent blocks
-  // the MARCH runs through, find_block. Also measured: the NEXT block along the ray looked up in the
-  // same round trip and kept by the lane for its next trip — half the table round trips of an empty
-  // run, 101.8 / 33.8 us: the trips' instructions, not their reads, are what a slow wave spends its
-  // time on.)
-  while (__any(pending))
+  if (VK_DIR_SERIAL_FILING)
   {
-    const unsigned long long mask = __ballot(pending);
-    const int leader = __ffsll((long long)mask) - 1;
-    const int ubx = __builtin_amdgcn_readlane(bx, leader);
-    const int uby = __builtin_amdgcn_readlane(by, leader);
-    const int ubz = __builtin_amdgcn_readlane(bz, leader);
-    const int udata = __builtin_amdgcn_readlane(data, leader);
-    if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
-    if (bx == ubx && by == uby && bz == ubz) pending = false;
+    while (__any(pending))
+    {
+      const unsigned long long mask = __ballot(pending);
+      const int leader = __ffsll((long long)mask) - 1;
+      const int ubx = __builtin_amdgcn_readlane(bx, leader);
+      const int uby = __builtin_amdgcn_readlane(by, leader);
+      const int ubz = __builtin_amdgcn_readlane(bz, leader);
+      const int udata = __builtin_amdgcn_readlane(data, leader);
+      if (lane_id() == leader) dir[dir_index(ubx, uby, ubz)] = make_int4(ubx, uby, ubz, udata);
+      if (bx == ubx && by == uby && bz == ubz) pending = false;
+    }
+  }
+  else if (__any(pending))
+  {
+    int* tags = reinterpret_cast<int*>(dir + kDirEntries);
+    const int entry = dir_index(bx, by, bz);
+    if (pending) tags[entry] = lane_id();
+    wave_lds_fence();
+    if (pending && tags[entry] == lane_id()) dir[entry] = make_int4(bx, by, bz, data);
   }
   wave_lds_fence();   // later reads of the directory, by any lane, see these entries
 }
@@ -366,7 +402,7 @@ __device__ __forceinline__ f3 corner_color(const PointParams& P, const Corners<P
 // ref: tracer.cu:317-451 for the pixel (x, y) of this lane; `bound` is its cell's
 // (near, far). Writes depth and colour.
 template <bool COUNT, bool POOL32>
-__device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int x, int y, float2 bound)
+__device__ __forceinline__ void march_ray_nested(const PointParams& P, int4* bdir, int x, int y, float2 bound, int log_wave = -1)
 {
   float final_depth = 0;
   f3 color = make3(0, 0, 0);
@@ -396,13 +432,29 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
     // `refine` set, so the lanes of a wave share ONE lookup site and ONE sampling site
     // whatever phase each ray is in.
     bool refine = false;
+    bool in_band = false;       // COUNT only (trip_log): the last trip took a sample
+    int log_pass = 0;           // COUNT only
+    int absent_run = 0;         // COUNT only (trip_log): trips in a row through blocks that are not there
 
     for (;;)
     {
       const int bx = f2i(floorf(div_uniform(p.x, P.inv_block_length)));
       const int by = f2i(floorf(div_uniform(p.y, P.inv_block_length)));
       const int bz = f2i(floorf(div_uniform(p.z, P.inv_block_length)));
+      if (COUNT)
+      {
+        if (P.trip_log && log_wave >= 0)
+        {
+          const unsigned long long marching = __ballot(1), running = __ballot(absent_run >= 1), sampling = __ballot(in_band);
+          if (log_pass < P.trip_log_passes && lane_id() == __ffsll((long long)marching) - 1)
+            P.trip_log[(size_t)log_wave * P.trip_log_passes + log_pass] = ((unsigned long long)(uint32_t)wall_clock64() << 32) |
+                ((unsigned long long)__popcll(marching) << 24) | ((unsigned long long)__popcll(running) << 16) |
+                ((unsigned long long)__popcll(sampling) << 8);
+          ++log_pass;
+        }
+      }
       const int data = find_block(P, cache, bdir, bx, by, bz);
+      absent_run = (data < 0 && !refine) ? absent_run + 1 : 0;
       if (COUNT) ++trips;
       bool done = false;
 
@@ -418,12 +470,12 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
         const float wz = div_uniform(p.z - bz * P.block_length, P.inv_voxel_length);
 
         float nearest = 0.0f;
+        // int(w) can reach 8 on a block face: clamped, see DESIGN.md
+        const int vx = vmini(f2i(wx), 7);
+        const int vy = vmini(f2i(wy), 7);
+        const int vz = vmini(f2i(wz), 7);
         if (!refine)
         {
-          // int(w) can reach 8 on a block face: clamped, see DESIGN.md
-          const int vx = vmini(f2i(wx), 7);
-          const int vy = vmini(f2i(wy), 7);
-          const int vz = vmini(f2i(wz), 7);
           const global_floats pool = (global_floats)reinterpret_cast<const float*>(P.voxels);
           if (POOL32)
             nearest = *(global_floats)((const char __attribute__((address_space(1)))*)pool +
@@ -457,6 +509,7 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
           const Corners<POOL32> C = resolve_corners<COUNT, POOL32>(P, bdir, bx, by, bz, data, wx, wy, wz);
           sdf = corner_distance(P, C);
         }
+        in_band = sample;
 
         if (sample)
         {
@@ -526,6 +579,12 @@ __device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int 
   P.colors[3 * pixel + 0] = color.x;
   P.colors[3 * pixel + 1] = color.y;
   P.colors[3 * pixel + 2] = color.z;
+}
+
+template <bool COUNT, bool POOL32>
+__device__ __forceinline__ void march_ray(const PointParams& P, int4* bdir, int x, int y, float2 bound, int log_wave = -1)
+{
+  march_ray_nested<COUNT, POOL32>(P, bdir, x, y, bound, log_wave);
 }
 
 }  // namespace vk

@@ -235,7 +235,7 @@ constexpr int kPointsTile = (kPointsWaves == 4) ? 16 : 8;     // pixels per work
 // The work of ONE workgroup of the raycast: WAVES = 1: an 8 x 8 tile; WAVES = 4: 2 x 2 of them. `group` of `groups`
 // workgroups (the launch's own blockIdx / gridDim, or the leading part of a launch that has other work behind it).
 template <bool POOL32, int WAVES>
-__device__ __forceinline__ void points_group(const PointParams& P, const int group, const int groups, int4 (*directories)[kDirEntries])
+__device__ __forceinline__ void points_group(const PointParams& P, const int group, const int groups, int4 (*directories)[kDirWords])
 {
   constexpr int TILE = (WAVES == 4) ? 16 : 8;     // pixels per workgroup edge
   const int lane = lane_id();
@@ -299,7 +299,7 @@ __device__ __forceinline__ void points_group(const PointParams& P, const int gro
 template <bool POOL32>
 __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(PointParams P)
 {
-  __shared__ int4 directories[kPointsWaves][kDirEntries];
+  __shared__ int4 directories[kPointsWaves][kDirWords];
   points_group<POOL32, kPointsWaves>(P, (int)blockIdx.x, (int)gridDim.x, directories);
 }
 
@@ -314,7 +314,7 @@ template <bool POOL32, int PREP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void trace_and_request_kernel(PointParams P,
     RequestParams R, Retry retry, int trace_groups, int request_groups_x)
 {
-  __shared__ int4 directories[4][kDirEntries];
+  __shared__ int4 directories[4][kDirWords];
   if ((int)blockIdx.x < trace_groups)
   {
     points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
@@ -439,6 +439,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.inv_voxel_length = 1.0 / (double)voxel_length;
   P.touched = nullptr;
   P.march_steps = nullptr;
+  P.trip_log = nullptr;
+  P.trip_log_passes = 0;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
   P.k = *projection;
