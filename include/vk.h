@@ -232,7 +232,7 @@ VK_API int vk_version(void);                       /* 100*major + minor */
  *   vk_abi_check(VK_ABI_VERSION, sizeof(vk_volume), sizeof(vk_frame), VK_CTR_COUNT)
  * and refuse to go on unless it returns VK_OK (VK_ERR_UNSUPPORTED otherwise). The class layer (vulcan_amd/host) and the
  * Python binding do. New struct fields are appended; a change of VK_CTR_COUNT bumps the version. No reference counterpart. */
-#define VK_ABI_VERSION 4
+#define VK_ABI_VERSION 5
 VK_API int vk_abi_version(void);
 VK_API int vk_abi_check(int header_abi_version, size_t sizeof_vk_volume, size_t sizeof_vk_frame, int ctr_count);
 VK_API int vk_device_count(int* count);
@@ -553,6 +553,13 @@ typedef struct vk_view_bounds {
   const void*   visible_blocks;   /* which volume */
   vk_projection projection;
   vk_transform  depth_to_world;
+  /* kept by vk_trace_ahead / vk_trace_ahead_requests (the caller only zeroes them with the record): the raycast's normals
+   * are computed by trailing workgroups of the SAME launch, which wait per 8-pixel row of tiles for the counters behind
+   * the bounds in `scratch`; these say for which scratch and image size the counters count, and how many launches far */
+  const float*  counted_scratch;
+  int32_t       counted_width, counted_height;
+  uint32_t      trace_launches;
+  int32_t       pad_;
 } vk_view_bounds;
 
 /* vk_integrate_depth / _depth_color / _depth_light (color_mode 0 / 1 / 2; `light`

@@ -232,6 +232,8 @@ int vk_probe_trace_log(const vk_hash_entry* entries, const vk_voxel* voxels, con
   P.march_steps = march_steps;
   P.trip_log = trip_log;
   P.trip_log_passes = trip_log_passes;
+  P.rows_done = nullptr;
+  P.rows_target = 0;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
   hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P, wave_clocks);
   VK_LAUNCH_CHECK();

@@ -47,6 +47,10 @@ struct PointParams
   // whose last trip took a sample << 8
   unsigned long long* trip_log;
   int trip_log_passes;
+  // The normals of the raycast by trailing workgroups of the same launch (vk_trace.hip normals_group): one counter per
+  // 8-pixel row of tiles, bumped by every wave that has written its tile's depths; nullptr = nobody waits for them.
+  uint32_t* rows_done;
+  uint32_t rows_target;        // a row is complete once (int)(rows_done[row] - rows_target) >= 0
 };
 
 // a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).
@@ -575,7 +579,9 @@ __device__ __forceinline__ void march_ray_nested(const PointParams& P, int4* bdi
 
   const int pixel = y * P.image_width + x;
   if (COUNT) { if (P.march_steps) P.march_steps[pixel] = trips; }
-  P.depths[pixel] = final_depth;
+  // (with readers in the same launch, on other XCDs: written through to where they all see it)
+  if (P.rows_done) __hip_atomic_store(&P.depths[pixel], final_depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else P.depths[pixel] = final_depth;
   P.colors[3 * pixel + 0] = color.x;
   P.colors[3 * pixel + 1] = color.y;
   P.colors[3 * pixel + 2] = color.z;

@@ -227,6 +227,15 @@ __device__ __forceinline__ float2 merged_bound_wave(const float2* __restrict__ p
 // (r02 variants, rocprofv3 averages of 120 launches: 2x2 tiles per workgroup in one band per
 // XCD 31.25 us; single tiles 31.46; two half bands per XCD 31.06 / 30.71 with single tiles;
 // plain round robin 32.21.)
+constexpr int kNormalRows = 128;          // counters behind the bounds in the scratch: 8-pixel rows of tiles, up to 1024 rows
+constexpr int kNormalRowStride = 16;      // words: a 64-byte line per counter (the waves' increments and the waiting groups'
+                                          // polls of ONE row meet on a line; with 16 counters to a line the polls of a few
+                                          // hundred waiting groups held up the increments they were waiting for)
+constexpr int kNormalWaitPolls = 1 << 16; // x s_sleep(32): some 60 ms
+
+#ifndef VK_TRACE_NORMALS_RIDE
+#define VK_TRACE_NORMALS_RIDE 1
+#endif
 #define VK_POINTS_WAVES 1
 #define VK_POINTS_ORDER 1
 constexpr int kPointsWaves = VK_POINTS_WAVES;
@@ -292,8 +301,15 @@ __device__ __forceinline__ void points_group(const PointParams& P, const int gro
     bound = reinterpret_cast<const float2*>(P.bounds)[cell];
   }
 
-  if (!inside) return;
-  march_ray<false, POOL32>(P, bdir, x, y, bound);
+  if (inside) march_ray<false, POOL32>(P, bdir, x, y, bound);
+  if (P.rows_done && tile < tiles)
+  {
+    // this wave's tile is written (its depths through to memory, march_ray): one more of its row of tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_fetch_add(&P.rows_done[(tile_y * (TILE / 8) + (WAVES == 4 ? (wave >> 1) : 0)) * kNormalRowStride], 1u,
+          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <bool POOL32>
@@ -303,16 +319,62 @@ __global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(Point
   points_group<POOL32, kPointsWaves>(P, (int)blockIdx.x, (int)gridDim.x, directories);
 }
 
+// The raycast's normals (Frame::ComputeNormals of the traced frame, frame.cu:9-122) by TRAILING WORKGROUPS OF THE SAME
+// LAUNCH: 64 x 4 pixels each, like compute_normals_kernel. A pixel's taps lie two pixels up, down, left and right, so a
+// group needs two 8-pixel rows of tiles complete; it waits for their counters (PointParams::rows_done, bumped by every
+// raycast wave behind its tile's depths), then reads the depths where the raycast's waves — on any XCD — wrote them
+// through to. The groups come last in the grid, i.e. they are dispatched when every raycast workgroup already has its
+// place on the device, so whatever they wait for is running or done; the wait is bounded all the same (a launch whose
+// counters were left in a bad state by an aborted one writes wrong normals for a frame instead of hanging the device).
+// As a launch of its own the pass costs 5 us of launch floor behind a raycast whose last third leaves the device idle.
+// Used when the next frame's request pass sits between the raycast's workgroups and these (vk_trace_ahead_requests): the
+// groups are then dispatched late and find most rows complete. Dispatched right behind the raycast's workgroups they wait
+// from the first microsecond on, and the launch lasted 46.3 us instead of 29 + 5 (sphere) and 84.4 instead of 69.7 + 5
+// (tracking scene): vk_trace_ahead keeps its two launches.
+__device__ __forceinline__ float depth_through(const float* depths, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? __hip_atomic_load(&depths[y * w + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+}
+
+__device__ __forceinline__ void normals_group(const PointParams& P, float* __restrict__ normals, int group_x, int group_y)
+{
+  if (threadIdx.x == 0)
+  {
+    const int first = vmaxi(group_y * 4 - 2, 0) >> 3, last = vmini(group_y * 4 + 5, P.image_height - 1) >> 3;
+    int polls = 0;
+    for (int row = first; row <= last; ++row)
+      while ((int)(__hip_atomic_load(&P.rows_done[row * kNormalRowStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.rows_target) < 0 &&
+             ++polls < kNormalWaitPolls)
+        __builtin_amdgcn_s_sleep(32);
+  }
+  __syncthreads();
+  const int x = group_x * 64 + (threadIdx.x & 63);
+  const int y = group_y * 4 + (threadIdx.x >> 6);
+  if (x >= P.image_width || y >= P.image_height) return;
+  const int pad = 2;
+  const float depth = depth_through(P.depths, P.image_width, P.image_height, x, y);
+  f3 normal = make3(0, 0, 0);
+  if (depth > 0)
+    normal = normal_from_taps(P.k, x, y, depth,
+        depth_through(P.depths, P.image_width, P.image_height, x - pad, y), depth_through(P.depths, P.image_width, P.image_height, x + pad, y),
+        depth_through(P.depths, P.image_width, P.image_height, x, y - pad), depth_through(P.depths, P.image_width, P.image_height, x, y + pad));
+  const int output = y * P.image_width + x;
+  normals[3 * output + 0] = normal.x;
+  normals[3 * output + 1] = normal.y;
+  normals[3 * output + 2] = normal.z;
+}
+
 // The raycast of one frame with the REQUEST PASS OF THE NEXT FRAME'S SetView behind it in the same launch
-// (vk_trace_ahead_requests): the first `trace_groups` workgroups are the raycast's (16 x 16 pixels each), the rest are the
-// request pass's (64 x 4 pixels each, vk_requests.hpp), dispatched as the raycast's waves retire. The raycast is as long as
+// (vk_trace_ahead_requests): the first `trace_groups` workgroups are the raycast's (16 x 16 pixels each), the next are the
+// request pass's (64 x 4 pixels each, vk_requests.hpp), dispatched as the raycast's waves retire, the last the normals'
+// (`normals`, or nullptr). The raycast is as long as
 // its slowest wave (mean wave life 17 us, launch 31 us) and leaves most of the device idle for its
 // last third; as a launch of its own the request pass (17 us) would start only after that. The two touch disjoint state:
 // the raycast reads the table, the voxels and its bounds; the request pass reads the table and the visibility bytes and
 // writes visibility bytes, request flags and the light preparation's buffers.
 template <bool POOL32, int PREP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void trace_and_request_kernel(PointParams P,
-    RequestParams R, Retry retry, int trace_groups, int request_groups_x)
+    RequestParams R, Retry retry, int trace_groups, int request_groups_x, int request_groups, float* normals)
 {
   __shared__ int4 directories[4][kDirWords];
   if ((int)blockIdx.x < trace_groups)
@@ -321,7 +383,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void t
     return;
   }
   const int g = (int)blockIdx.x - trace_groups;
-  requests_group<true, PREP>(R, retry, g % request_groups_x, g / request_groups_x);
+  if (g < request_groups)
+  {
+    requests_group<true, PREP>(R, retry, g % request_groups_x, g / request_groups_x);
+    return;
+  }
+  const int n = g - request_groups, normal_groups_x = (P.image_width + 63) / 64;
+  normals_group(P, normals, n % normal_groups_x, n / normal_groups_x);
 }
 
 // ------------------------------------------------------------------ normals ----
@@ -418,12 +486,14 @@ int launch_block_bounds(PatchParams& P, float* bounds, float2* partials, bool me
   return VK_OK;
 }
 
+// `normals` with `rows_done`: the normals of the traced frame by trailing workgroups of the raycast's launch (normals_group);
+// the caller has set the counters' target. `next_requests`: the next frame's request pass in the same launch as well.
 int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const float* bounds,
     const float2* partials, int block_count, float block_length, float voxel_length, float trunc_length,
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
     int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
-    hipStream_t s, float* normals = nullptr, const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr,
-    int next_prep = 0)
+    hipStream_t s, float* normals = nullptr, uint32_t* rows_done = nullptr, uint32_t rows_target = 0,
+    const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr, int next_prep = 0)
 {
   PointParams P;
   P.entries = entries;
@@ -441,6 +511,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.march_steps = nullptr;
   P.trip_log = nullptr;
   P.trip_log_passes = 0;
+  P.rows_done = (normals && rows_done && next_requests) ? rows_done : nullptr;
+  P.rows_target = rows_target;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
   P.k = *projection;
@@ -450,17 +522,19 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.image_height = image_height;
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
+  const bool pool32 = pool_bytes <= 0xffffffffull;   // a pool under 4 GiB is addressed with 32-bit offsets from a scalar base
   if (next_requests)
   {
-    // the next frame's request pass behind the raycast's workgroups (trace_and_request_kernel): 16 x 16 pixel tiles
+    // workgroups of 256: 16 x 16 pixel tiles of the raycast, then 64 x 4 pixel groups of the request pass and the normals
     const int tiles16 = ((image_width + 15) / 16) * ((image_height + 15) / 16);
     int chunk16 = (tiles16 + 7) / 8;
     if (VK_POINTS_ORDER == 1) chunk16 = 2 * ((chunk16 + 1) / 2);
     const int trace_groups = 8 * chunk16;
+    const int normal_groups = P.rows_done ? ((image_width + 63) / 64) * ((image_height + 3) / 4) : 0;
     const int gx = (next_requests->width + 63) / 64, gy = (next_requests->height + 3) / 4;
-    const dim3 grid2(trace_groups + gx * gy);
-    const bool pool32 = pool_bytes <= 0xffffffffull;
-#define VK_LAUNCH_TR(POOL, PREP) hipLaunchKernelGGL((trace_and_request_kernel<POOL, PREP>), grid2, dim3(256), 0, s, P, *next_requests, *next_retry, trace_groups, gx)
+    const dim3 grid2(trace_groups + gx * gy + normal_groups);
+    float* fused_normals = P.rows_done ? normals : nullptr;
+#define VK_LAUNCH_TR(POOL, PREP) hipLaunchKernelGGL((trace_and_request_kernel<POOL, PREP>), grid2, dim3(256), 0, s, P, *next_requests, *next_retry, trace_groups, gx, gx * gy, fused_normals)
     if (pool32) { if (next_prep == 2) VK_LAUNCH_TR(true, 2); else if (next_prep == 1) VK_LAUNCH_TR(true, 1); else VK_LAUNCH_TR(true, 0); }
     else { if (next_prep == 2) VK_LAUNCH_TR(false, 2); else if (next_prep == 1) VK_LAUNCH_TR(false, 1); else VK_LAUNCH_TR(false, 0); }
 #undef VK_LAUNCH_TR
@@ -471,8 +545,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   int chunk = (tiles + 7) / 8;
   if (VK_POINTS_ORDER == 1) chunk = 2 * ((chunk + 1) / 2);
   const dim3 grid(8 * chunk);   // padded so every XCD gets an equal share
-  // a pool under 4 GiB is addressed with 32-bit offsets from a scalar base
-  if (pool_bytes <= 0xffffffffull)
+  if (pool32)
     hipLaunchKernelGGL(compute_points_kernel<true>, grid, dim3(kPointsWaves * 64), 0, s, P);
   else
     hipLaunchKernelGGL(compute_points_kernel<false>, grid, dim3(kPointsWaves * 64), 0, s, P);
@@ -581,7 +654,8 @@ size_t vk_trace_bounds_floats(int bounds_width, int bounds_height)
 {
   if (bounds_width <= 0 || bounds_height <= 0) return 0;
   const size_t cells = (size_t)bounds_width * bounds_height;
-  return 2 * cells * (cells <= (size_t)kBoundsMaxCells ? 1 + kBoundsGroups : 1);
+  // the merged grid, the private grids of the fused bounds pass, and the row counters of the raycast's normals (normals_group)
+  return 2 * cells * (cells <= (size_t)kBoundsMaxCells ? 1 + kBoundsGroups : 1) + kNormalRows * kNormalRowStride;
 }
 
 int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float max_depth,
@@ -641,12 +715,38 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
     if (partials) view_record(ahead, v, frame);
   }
 
+  // the normals in the raycast's own launch (normals_group): counters behind the grids in the scratch, one per 8-pixel row
+  // of tiles, never reset — launch n of this scratch and image size waits for n times the waves of a row
+  const int rows = 2 * ((frame->height + 15) / 16), waves_per_row = 2 * ((frame->width + 15) / 16);
+  // (only with the next frame's request pass between the raycast's workgroups and the normals': dispatched right behind
+  // the raycast's, the waiting groups cost it 12 to 17 us — profiles/r04_trace_normals_ride.txt)
+  const bool normals_ride = VK_TRACE_NORMALS_RIDE && next_requests && partials && rows <= kNormalRows;
+  uint32_t* rows_done = nullptr;
+  uint32_t rows_target = 0;
+  if (normals_ride)
+  {
+    rows_done = reinterpret_cast<uint32_t*>(bounds + 2 * (size_t)cells * (1 + kBoundsGroups));
+    if (ahead->counted_scratch != bounds || ahead->counted_width != frame->width || ahead->counted_height != frame->height)
+    {
+      VK_CHECK(hipMemsetAsync(rows_done, 0, kNormalRows * kNormalRowStride * sizeof(uint32_t), s));
+      ahead->counted_scratch = bounds;
+      ahead->counted_width = frame->width;
+      ahead->counted_height = frame->height;
+      ahead->trace_launches = 0;
+    }
+    rows_target = (ahead->trace_launches + 1u) * (uint32_t)waves_per_row;   // (wraps with the counters)
+  }
   if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
            (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s,
-           nullptr, next_requests, next_retry, next_prep)) != VK_OK)
+           normals_ride ? out_normals : nullptr, rows_done, rows_target, next_requests, next_retry, next_prep)) != VK_OK)
     return rc;
+  if (normals_ride)
+  {
+    ++ahead->trace_launches;
+    return VK_OK;
+  }
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 
