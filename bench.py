@@ -921,8 +921,8 @@ def main():
             "voxel_working_set_bytes": voxel_ws,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
             "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9,     # per GPU: integrate bytes / frame wall time
-            "raycast": {"kernel": ("trace_and_request_kernel (the raycast + the NEXT frame's request pass, one launch) + "
-                                   "compute_normals_kernel (vk_trace_ahead_requests)") if loop.ahead is not None else
+            "raycast": {"kernel": ("trace_and_request_kernel: the raycast, the NEXT frame's request pass and the raycast's "
+                                   "normals in one launch (vk_trace_ahead_requests)") if loop.ahead is not None else
                                   "compute_points_kernel + compute_normals_kernel (vk_trace_ahead)",
                         "avg_us": float(trace_ms.mean() * 1e3)},
         },
@@ -946,7 +946,13 @@ def main():
             ray["algorithmic_bytes"] = W * H * 16 + 4800 * 8 + nhit * 10240
             ray["algorithmic_GBps"] = ray["algorithmic_bytes"] / (ray["avg_us"] * 1e-6) / 1e9
             ray["bound"] = "latency / VALU issue (dependent hash -> voxel loads per march step), not bandwidth"
-            ray["traffic"], ray["traffic_source"] = pmc_traffic("raycast")
+            # (with the next frame's request pass and the normals in the launch, the counters are that launch's)
+            fused = "trace_and_request_kernel" in ray["kernel"]
+            ray["traffic"], ray["traffic_source"] = pmc_traffic("raycast+requests" if fused else "raycast")
+            if fused:
+                # + the request pass: depth image read, normals + mask + records written; + the raycast's normals written
+                ray["algorithmic_bytes_of_the_launch"] = ray["algorithmic_bytes"] + W * H * (4 + 12 + 4 + 16) + W * H * 12
+                ray["algorithmic_GBps"] = ray["algorithmic_bytes_of_the_launch"] / (ray["avg_us"] * 1e-6) / 1e9
     del loop
     torch.cuda.empty_cache()
 
@@ -1057,7 +1063,7 @@ def pmc_traffic(workload):
     cannot be collected from inside an unprofiled run, so the newest measurement on file for
     this workload is reported; None when there is none."""
     import glob
-    tag = {"depth": "integrate", "raycast": "raycast"}.get(workload, "integrate_rgbd")
+    tag = {"depth": "integrate", "raycast": "raycast", "raycast+requests": "trace_and_request"}.get(workload, "integrate_rgbd")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{tag}_traffic.json")))
     if not files:
         return None, "no PMC measurement on file for this workload"

@@ -12,6 +12,8 @@ if [ "${2:-tests}" = "tests" ]; then
 fi
 : > $out/fuse_sequence.txt
 for m in 0 1 2 3; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 $m >> $out/fuse_sequence.txt 2>&1; done
+# mode 0 with every raycast announcing the next frame (Tracer::Trace(keyframe, next_frame)): the class layer's form of bench.py's step
+timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 0 0 0 1 >> $out/fuse_sequence.txt 2>&1
 # the photometric loops once more over half a cycle of the camera's path: what they allocate then fits the app's pool
 for m in 2 3; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 120 $m >> $out/fuse_sequence.txt 2>&1; done
 grep "^frames" $out/fuse_sequence.txt
