@@ -276,3 +276,43 @@ def test_the_posted_list_and_the_flag_scan_give_the_same_table(api, orc):
                 assert_same_requests(dv, hv)
             assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 100          # chains: EXCESS requests, new entries visible
             assert hv.counters[T.VK_CTR_DROPPED] == 0
+
+
+@pytest.mark.parametrize("hooks", [{}, {"posted_capacity": 0}, {"set_view_unfused": 1}])
+def test_a_request_pass_made_behind_the_raycast_gives_the_same_table(api, orc, hooks):
+    """vk_trace_ahead_requests + vk_volume_set_view_rounds_ahead (Tracer.trace(frame, next_frame=) and the set_view that
+    follows it) against the oracle's Trace and three SetView calls — on a table far too small for the scene (1024 buckets for
+    ~2 000 blocks: every round loses requests, chains grow), with the handle pass working from the posted list, from the
+    request flags (posted_capacity 0) and with handle and visibility as launches of their own (set_view_unfused): the pass made
+    ahead must leave the later rounds exactly what the pass inside SetView leaves them. Every frame's raycast (depth, colour, normals) is compared as well."""
+    w, h = 320, 240
+    depth = scenes.sphere(2 * w, 2 * h)[::2, ::2].copy()
+    poses = [scenes.yaw(2.0 * i) * scenes.tracer_test_pose() for i in range(4)]
+    with api.test_hooks(**hooks):
+        hv, dv = make_pair(api, orc, 1024, 16384, 0.01, 0.04)
+        integ, tracer = api.DepthIntegrator(dv), api.Tracer(dv)
+        pairs = [frames(api, orc, depth, K_SMALL, pose) for pose in poses]
+        for i, pose in enumerate(poses):
+            hf, df = pairs[i]
+            before = int(dv.read_counters()[T.VK_CTR_ROUNDS])
+            oracle_rounds(orc, hv, hf, 3)
+            assert (dv.requests_ahead is not None and dv.requests_ahead.valid == 1) == (i > 0)
+            dv.set_view(df, rounds=3)
+            assert dv.requests_ahead is None or dv.requests_ahead.valid == 0
+            assert_volume_equal(dv, hv, voxels=False)
+            ctr = assert_same_requests(dv, hv)
+            assert 1 <= int(ctr[T.VK_CTR_ROUNDS]) - before <= 3
+            orc.integrate_depth(hv, hf)
+            integ.integrate(df)
+            odepth, ocolor, onormals, _ = orc.trace(hv, hf)
+            out = api.Frame(np.zeros((h, w), np.float32), K_SMALL, pose)
+            if i + 1 < len(poses):
+                tracer.trace(out, next_frame=pairs[i + 1][1])     # the very frame the next set_view is handed
+            else:
+                tracer.trace(out)
+            sync()
+            assert np.array_equal(out.depth.cpu().numpy(), odepth)
+            assert np.array_equal(out.color.cpu().numpy(), ocolor)
+            assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
+        assert_volume_equal(dv, hv)
+        assert hv.counters[T.VK_CTR_EXCESS_PTR] > hv.main + 500   # chains exercised

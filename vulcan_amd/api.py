@@ -367,6 +367,7 @@ class Volume:
 
     # -- Volume::SetView and its four protected stages (volume.cu:430-535)
     light_prep = None      # T.LightPrep of an attached LightIntegrator (attach_light_preparation)
+    requests_ahead = None  # T.RequestsAhead: the frame Tracer.trace(.., next_frame=) announced (vk_requests_ahead)
 
     def attach_light_preparation(self, prep):
         """A LightIntegrator's mask / record buffers: set_view fills them in its own request pass
@@ -389,7 +390,12 @@ class Volume:
                 frame.touch()                                  # the normal image's content is new
                 self.light_prep.normals_out = frame.normals.data_ptr()
         prep = _ref(self.light_prep) if self.light_prep is not None else None
-        if compute_normals and prep is not None:
+        if self.requests_ahead is not None and self.requests_ahead.valid == 1:
+            # Tracer.trace(frame, next_frame=...) announced a frame: its request pass is made, this must be its SetView
+            # (vk_volume_set_view_rounds_ahead refuses any other frame)
+            check(lib().vk_volume_set_view_rounds_ahead(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds),
+                                                        _ref(self.requests_ahead), stream()), "vk_volume_set_view_rounds_ahead")
+        elif compute_normals and prep is not None:
             check(lib().vk_volume_set_view_rounds(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds), stream()),
                   "vk_volume_set_view_rounds")
         elif rounds != 1:
@@ -574,8 +580,11 @@ class Tracer:
         self.view_bounds = vb
         volume.attach_view_bounds(vb)
 
-    def trace(self, frame):
-        """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals."""
+    def trace(self, frame, next_frame=None, next_needs_normals=False):
+        """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals. `next_frame` (not upstream): the frame the
+        volume's next set_view will be called with — its request pass (and, with `next_needs_normals` and a LightIntegrator's
+        preparation attached, its normal image) is made behind the raycast's workgroups, in the same launch
+        (vk_trace_ahead_requests)."""
         import torch
         if frame.color is None:
             frame.color = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
@@ -585,8 +594,29 @@ class Tracer:
         if (vb.min_depth, vb.max_depth) != tuple(np.float32(d) for d in self.depth_range):
             vb.min_depth, vb.max_depth = self.depth_range
             vb.valid = 0
-        check(lib().vk_trace_ahead(_ref(self.volume.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth),
-                                   _ptr(frame.color), _ptr(frame.normals), stream()), "vk_trace_ahead")
+        if next_frame is None:
+            check(lib().vk_trace_ahead(_ref(self.volume.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth),
+                                       _ptr(frame.color), _ptr(frame.normals), stream()), "vk_trace_ahead")
+            frame.touch()
+            return
+        v = self.volume
+        if v.requests_ahead is None:
+            v.requests_ahead = T.RequestsAhead()
+        prep = v.light_prep
+        if next_needs_normals:
+            if prep is None:
+                next_frame.compute_normals()
+            else:
+                if next_frame.normals is None:
+                    next_frame.normals = torch.empty((next_frame.height, next_frame.width, 3), dtype=torch.float32, device=next_frame.device)
+                next_frame.touch()
+                prep.normals_out = next_frame.normals.data_ptr()
+        check(lib().vk_trace_ahead_requests(_ref(v.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth), _ptr(frame.color),
+                                            _ptr(frame.normals), _ref(next_frame.desc()), _ref(prep) if prep is not None else None,
+                                            _ref(v.requests_ahead), stream()), "vk_trace_ahead_requests")
+        if prep is not None and prep.normals_out and v.requests_ahead.valid != 1:
+            prep.normals_out = None                        # the pass could not be made ahead: the normals as a launch of their own
+            next_frame.compute_normals()
         frame.touch()
 
     # the tracer.cuh free functions, for the stage-by-stage tests
