@@ -1,7 +1,9 @@
 """Seeded random configurations, device vs oracle, bit for bit: voxel and truncation
 lengths that are not the defaults (block length != truncation), odd table sizes, tilted
 poses, depth images with holes and out-of-range values, depth-only / colour / light
-integration, raycasts from a second pose."""
+integration, raycasts from a second pose, every fourth seed with the next frame's request pass made behind the raycast."""
+import copy
+
 import numpy as np
 import pytest
 
@@ -44,13 +46,29 @@ def test_random_configuration(api, orc, seed):
     if mode == 2:
         integ.light = light
     pose = random_pose(rng)
+    announced = None
     for frame_index in range(3):
         pose = random_pose(rng, 0.3) * pose
-        hf, df = frames(api, orc, depth, k, pose, color=color)
+        if announced is None:
+            hf, df = frames(api, orc, depth, k, pose, color=color)
+        else:
+            hf, df = announced
+            assert bytes(hf.depth_to_world) == bytes(pose)
         hf.compute_normals()
         for _ in range(2):
             hv.set_view(hf, orc.POLICY_MAXKEY)
-        if seed % 2 == 1 and hv.counters[T.VK_CTR_DROPPED] == 0:
+        if announced is not None:
+            # the previous raycast made this frame's request pass (and its normals): SetView is left with the rest
+            assert dv.requests_ahead.valid == 1
+            assert np.array_equal(df.normals.cpu().numpy(), hf.normals, equal_nan=True)
+            if hv.counters[T.VK_CTR_DROPPED] == 0:
+                dv.set_view(df, rounds=2)
+            else:
+                dv.set_view(df)                                     # (rounds end at a dropped request: two calls then)
+                dv.set_view(df)
+            assert dv.requests_ahead.valid == 0
+            announced = None
+        elif seed % 2 == 1 and hv.counters[T.VK_CTR_DROPPED] == 0:
             # the two calls as one, the frame's normals computed on the way (inside the request pass
             # once the light integrator has registered its buffers, by a launch of their own otherwise)
             dv.set_view(df, rounds=2, compute_normals=True)
@@ -71,7 +89,14 @@ def test_random_configuration(api, orc, seed):
         hf.depth_to_world = view
         want = orc.trace(hv, hf)
         out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, view)
-        tracer.trace(out)
+        if seed % 4 == 3 and frame_index < 2:
+            # every fourth seed: the raycast announces the next frame (vk_trace_ahead_requests) — the pose the loop will draw
+            # next, from a copy of the generator
+            next_pose = random_pose(copy.deepcopy(rng), 0.3) * pose
+            announced = frames(api, orc, depth, k, next_pose, color=color)
+            tracer.trace(out, next_frame=announced[1], next_needs_normals=True)
+        else:
+            tracer.trace(out)
         sync()
         assert np.array_equal(tracer.bounds.cpu().numpy(), want[3])
         assert np.array_equal(out.depth.cpu().numpy(), want[0])
