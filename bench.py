@@ -380,7 +380,9 @@ class FrameLoop:
         # without one their first consumer is SetView's request pass, which then computes them on the way
         # (vk_light_prep.normals_out: same image, one launch less)
         normals_in_set_view = self.mode == 2 and self.tracker is None and NORMALS_IN_SET_VIEW
-        if self.mode == 2 and not normals_in_set_view:
+        # (a tracked frame: the normals are computed by the launch that builds the tracker's pyramid, vk_icp_pyramid_track_frame)
+        normals_with_pyramid = self.tracker is not None and i > 0
+        if self.mode == 2 and not normals_in_set_view and not normals_with_pyramid:
             rc = lib.vk_frame_compute_normals(C.c_void_p(self.fdesc.depth), self.kproj, self.n_ptr, W, H, s)   # vulcan.cu:297
         if self.tracker is not None:
             pose = self.current
@@ -390,8 +392,9 @@ class FrameLoop:
                 # made from that pose; the tracked pose is read back, as Tracker::EndSolve does
                 a = self.track_args
                 self.frame_view.depths = self.fdesc.depth
-                rc |= lib.vk_transform_upload(self.pose_dev, C.byref(pose), s)
-                rc |= lib.vk_icp_pyramid_track(a[0], C.byref(pose), *a[2:], s)
+                # frame.ComputeNormals() + Tracker::BeginSolve's pose upload + PyramidTracker::Track (vulcan.cu:297-311), one call:
+                # the start pose and the frame's normal image travel with the pyramid's launch
+                rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), 1, *a[4:], s)
                 rc |= lib.vk_track_wait(a[-1], s)                   # Tracker::EndSolve: the pose, from pinned memory
                 if rc:
                     raise self.api.VkError(f"frame {i}: tracking returned {rc}")
@@ -890,7 +893,8 @@ def main():
             "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
             "set_view": set_view_policy,
             "input_normals": ("Frame::ComputeNormals of the input frame (vulcan.cu:297) is part of every timed step: "
-                              + ("before the tracker, as a launch of its own" if wl == "rgbd-icp" or not NORMALS_IN_SET_VIEW else
+                              + ("by the launch that builds the tracker's pyramid (vk_icp_pyramid_track_frame)" if wl == "rgbd-icp" else
+                                 "as a launch of its own" if not NORMALS_IN_SET_VIEW else
                                  "computed inside SetView's request pass (vk_light_prep.normals_out: same normal image, "
                                  "written to the frame; one launch less)"))
                              if wl != "depth" else "not needed by DepthIntegrator (configs[1])",

@@ -801,6 +801,17 @@ VK_API int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform*
     float* system, int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce,
     void* reduce_user, const vk_track_poll* poll, void* stream);
 
+/* vk_icp_pyramid_track for the frame loop (apps/vulcan/vulcan.cu:297-311: frame.ComputeNormals(); tracker->Track(frame)), with
+ * two launches of that sequence folded into the pyramid's own: `Twc_start` (host, may be NULL) is stored to Twc_dev by the
+ * pyramid launch (instead of vk_transform_upload before the call), and with `frame_normals_due` the frame's normal image
+ * frame->normals is COMPUTED by it (ref: src/frame.cu:9-122 Frame::ComputeNormals — vk_frame_compute_normals' bits; the
+ * half-resolution normals are computed at the pixels they are sampled from, which is the same normal) instead of read.
+ * Everything else as vk_icp_pyramid_track. */
+VK_API int vk_icp_pyramid_track_frame(const vk_icp_view* keyframe, const vk_transform* Twm,
+    const vk_icp_view* frame, vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due,
+    float* pyramid, float* workspace, float* system, int32_t* state_dev, float* update_dev,
+    vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream);
+
 /* ------------------------------------------------------------ colour tracker -- */
 
 /* ref: src/image.cu:10-19,235-247 ColorImage::ConvertTo — intensity = (r+g+b)/3.

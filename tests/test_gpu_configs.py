@@ -210,6 +210,18 @@ def test_pyramid_tracker_matches_oracle(api, orc, size):
     df.depth_to_world = start
     again = tracker.track(df)
     assert bytes(again) == bytes(got)
+    # frame.compute_normals() + track() as one call (vk_icp_pyramid_track_frame: the normal image and the start pose travel with
+    # the launch that builds the pyramid): the same normal image, the same half-resolution level, the same pose, bit for bit
+    want_normals = df.normals.cpu().numpy().copy()
+    half_before = tracker._pyramid.cpu().numpy().copy()
+    df.normals.fill_(-3.0)
+    tracker._pyramid.fill_(-5.0)
+    df.depth_to_world = start
+    fused = tracker.track(df, compute_normals=True)
+    sync()
+    assert bytes(fused) == bytes(got)
+    assert np.array_equal(df.normals.cpu().numpy(), want_normals, equal_nan=True)
+    assert np.array_equal(tracker._pyramid.cpu().numpy(), half_before, equal_nan=True)
 
 
 # ------------------------------------------------- colour image of another size --

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "vk_transform_upload": ([_P, _P, _P], _I),
     "vk_icp_pyramid_floats": ([_I, _I, _I, _I], _SZ),
     "vk_icp_pyramid_track": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_icp_pyramid_track_frame": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_track_wait": ([_P, _P], _I),
     "vk_reduce_nothing": ([_P, _I, _P, _P], _I),
     "vk_rig_area_bytes": ([], _SZ),
@@ -1046,10 +1047,23 @@ class PyramidTracker:
         self.tracker = tracker or DepthTracker(device)
         self.keyframe = None
 
-    def track(self, frame):
+    def track(self, frame, compute_normals=False):
+        """`compute_normals` (not upstream): frame.compute_normals() is still due; with a DepthTracker it is done by the launch
+        that builds the pyramid (vk_icp_pyramid_track_frame)."""
         t = self.tracker
         if isinstance(t, DepthTracker):
-            return self._track_depth(frame)
+            if compute_normals:
+                import torch
+                if frame.normals is None:
+                    frame.normals = torch.empty((frame.height, frame.width, 3), dtype=torch.float32, device=frame.device)
+                frame.touch()
+            self._normals_due = bool(compute_normals)
+            try:
+                return self._track_depth(frame)
+            finally:
+                self._normals_due = False
+        if compute_normals:
+            frame.compute_normals()
         half_frame = frame.downsample()
         half_key = self.keyframe.downsample()
         t.max_iterations, t.translation_enabled = 15, True
@@ -1072,12 +1086,14 @@ class PyramidTracker:
         n = int(lib().vk_icp_pyramid_floats(key.width, key.height, frame.width, frame.height))
         if getattr(self, "_pyramid", None) is None or self._pyramid.numel() < n:
             self._pyramid = torch.empty(n, dtype=torch.float32, device=t.device)
-        check(lib().vk_transform_upload(_ptr(t.pose), _ref(frame.depth_to_world), stream()), "vk_transform_upload")
         t.max_iterations, t.translation_enabled, t.keyframe = 20, True, key
-        check(lib().vk_icp_pyramid_track(_ref(t._view(key)), _ref(key.depth_to_world), _ref(t._view(frame)),
-                                         _ptr(t.pose), _ptr(self._pyramid), _ptr(t._workspace(frame)), _ptr(t.system),
-                                         _ptr(t.state), _ptr(t.update), *t._c_hook(), t._poll(), stream()),
-              "vk_icp_pyramid_track")
+        due = 1 if getattr(self, "_normals_due", False) else 0
+        self._normals_due = False                  # (a second attempt after an aborted loop finds them computed)
+        check(lib().vk_icp_pyramid_track_frame(_ref(t._view(key)), _ref(key.depth_to_world), _ref(t._view(frame)),
+                                               _ptr(t.pose), _ref(frame.depth_to_world), due, _ptr(self._pyramid),
+                                               _ptr(t._workspace(frame)), _ptr(t.system), _ptr(t.state), _ptr(t.update),
+                                               *t._c_hook(), t._poll(), stream()),
+              "vk_icp_pyramid_track_frame")
         out = t._wait_pose()
         frame.depth_to_world = out
         return out

@@ -719,18 +719,65 @@ struct LevelParams
   float* dst_depth[2];
   float* dst_normals[2];
   int src_w[2], dst_w[2], dst_h[2];
+  // vk_icp_pyramid_track_frame: the FRAME's normal image is still to be computed (Frame::ComputeNormals, frame.cu:9-122) —
+  // blockIdx.z == 2 writes it, and the frame's half-resolution normals are computed at the pixels they are sampled from
+  // instead of copied (nearest sampling: the same pixel's normal, bit for bit) — and the pose the Track starts from is
+  // stored by workgroup 0 (vk_transform_upload's launch)
+  float* frame_normals_out;        // nullptr: the frame's normals exist
+  int src_h_frame;
+  vk_projection frame_k;
+  vk_transform* pose_out;          // nullptr: the pose is on the device already
+  vk_transform pose_start;
 };
+
+__device__ __forceinline__ float level_depth_at(const float* depths, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? depths[y * w + x] : 0.0f;
+}
+
+// the normal of pixel (x, y) of a full-resolution depth image: compute_normals_kernel's expressions (vk_trace.hip)
+__device__ __forceinline__ f3 level_normal(const float* depths, const vk_projection& k, int w, int h, int x, int y)
+{
+  const int pad = 2;
+  const float depth = depths[y * w + x];
+  f3 normal = make3(0, 0, 0);
+  if (depth > 0)
+    normal = normal_from_taps(k, x, y, depth, level_depth_at(depths, w, h, x - pad, y), level_depth_at(depths, w, h, x + pad, y),
+        level_depth_at(depths, w, h, x, y - pad), level_depth_at(depths, w, h, x, y + pad));
+  return normal;
+}
 
 __global__ __launch_bounds__(256) void pyramid_level_kernel(LevelParams L)
 {
+  if (L.pose_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 32)
+  {
+    if (threadIdx.x < 16) L.pose_out->m[threadIdx.x] = L.pose_start.m[threadIdx.x];
+    else L.pose_out->inv[threadIdx.x - 16] = L.pose_start.inv[threadIdx.x - 16];
+  }
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (blockIdx.z == 2)
+  {
+    // the frame's own normal image, every pixel
+    if (x >= L.src_w[1] || y >= L.src_h_frame) return;
+    const f3 n = level_normal(L.src_depth[1], L.frame_k, L.src_w[1], L.src_h_frame, x, y);
+    float* out = L.frame_normals_out + 3 * ((size_t)y * L.src_w[1] + x);
+    out[0] = n.x;  out[1] = n.y;  out[2] = n.z;
+    return;
+  }
   const int side = blockIdx.z;
-  const int dst_x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int dst_y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int dst_x = x, dst_y = y;
   if (dst_x >= L.dst_w[side] || dst_y >= L.dst_h[side]) return;
   const int src = (2 * dst_y) * L.src_w[side] + 2 * dst_x;
   const int dst = dst_y * L.dst_w[side] + dst_x;
   L.dst_depth[side][dst] = L.src_depth[side][src];
-  const vf3 n = *reinterpret_cast<const vf3*>(L.src_normals[side] + 3 * src);
+  vf3 n;
+  if (side == 1 && L.frame_normals_out)
+  {
+    const f3 computed = level_normal(L.src_depth[1], L.frame_k, L.src_w[1], L.src_h_frame, 2 * dst_x, 2 * dst_y);
+    n = vf3{computed.x, computed.y, computed.z};
+  }
+  else n = *reinterpret_cast<const vf3*>(L.src_normals[side] + 3 * src);
   *reinterpret_cast<vf3*>(L.dst_normals[side] + 3 * dst) = n;
 }
 
@@ -962,9 +1009,9 @@ size_t vk_icp_pyramid_floats(int key_width, int key_height, int frame_width, int
   return 4 * ((size_t)(key_width / 2) * (key_height / 2) + (size_t)(frame_width / 2) * (frame_height / 2));
 }
 
-int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
-    vk_transform* Twc_dev, float* pyramid, float* workspace, float* system, int32_t* state_dev,
-    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
+static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, float* pyramid, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
 {
   VK_REQUIRE(keyframe && Twm && frame && Twc_dev && pyramid && workspace && system && state_dev);
   VK_REQUIRE(keyframe->depths && keyframe->normals && frame->depths && frame->normals);
@@ -998,9 +1045,19 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
     half[side].projection.cx = full[side]->projection.cx * 0.5f;
     half[side].projection.cy = full[side]->projection.cy * 0.5f;
   }
-  const int gw = half[0].width > half[1].width ? half[0].width : half[1].width;
-  const int gh = half[0].height > half[1].height ? half[0].height : half[1].height;
-  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2), dim3(256), 0, s, L);
+  int gw = half[0].width > half[1].width ? half[0].width : half[1].width;
+  int gh = half[0].height > half[1].height ? half[0].height : half[1].height;
+  L.frame_normals_out = frame_normals_due ? const_cast<float*>(frame->normals) : nullptr;
+  L.src_h_frame = frame->height;
+  L.frame_k = frame->projection;
+  L.pose_out = Twc_start ? Twc_dev : nullptr;
+  if (Twc_start) L.pose_start = *Twc_start;
+  if (frame_normals_due)
+  {
+    gw = gw > frame->width ? gw : frame->width;
+    gh = gh > frame->height ? gh : frame->height;
+  }
+  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, frame_normals_due ? 3 : 2), dim3(256), 0, s, L);
   VK_LAUNCH_CHECK();
 
   // :79-83 half level, 15 steps; :85-89 full level, 20 steps, from the pose the half level left.
@@ -1031,6 +1088,22 @@ int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
   VK_CHECK(hipMemsetAsync(state_dev, 0, 2 * sizeof(int32_t), s));
   return vk_icp_track(keyframe, Twm, frame, Twc_dev, 20, 1, workspace, system, state_dev, update_dev,
       reduce, reduce_user, poll, stream);
+}
+
+int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, float* pyramid, float* workspace, float* system, int32_t* state_dev,
+    float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
+{
+  return pyramid_track(keyframe, Twm, frame, Twc_dev, nullptr, 0, pyramid, workspace, system, state_dev, update_dev, reduce,
+      reduce_user, poll, stream);
+}
+
+int vk_icp_pyramid_track_frame(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, float* pyramid, float* workspace, float* system,
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
+{
+  return pyramid_track(keyframe, Twm, frame, Twc_dev, Twc_start, frame_normals_due, pyramid, workspace, system, state_dev,
+      update_dev, reduce, reduce_user, poll, stream);
 }
 
 int vk_reduce_nothing(float*, int, void*, void*) { return 0; }

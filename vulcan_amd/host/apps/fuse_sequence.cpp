@@ -180,7 +180,8 @@ int main(int argc, char** argv)
       }
       uploader->Acquire(frame, volume->GetRequestStream());
     }
-    if (mode != 0) frame.ComputeNormals();        // vulcan.cu:297 (DepthIntegrator alone needs none)
+    // vulcan.cu:297 (DepthIntegrator alone needs none; with the pyramid depth tracker they are computed by its first launch)
+    if (mode != 0 && !(mode == 1 && i > 0)) frame.ComputeNormals();
 
     if (track && i > 0)
     {
@@ -188,7 +189,7 @@ int main(int argc, char** argv)
       int run = 0;
       if (mode == 3) { app_tracker.SetKeyframe(keyframe); app_tracker.Track(frame); run = app_tracker.GetIterationsRun(); }
       else if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); run = light_tracker.GetTracker()->GetIterationsRun(); }
-      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.Track(frame); run = depth_tracker.GetTracker()->GetIterationsRun(); }
+      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.ComputeNormalsAndTrack(frame); run = depth_tracker.GetTracker()->GetIterationsRun(); }
       steps_run.push_back(run);
       if (run >= 0 && run < 64) ++steps_histogram[run];
       PoseError(frame.depth_to_world_transform, truth[i], last_translation, last_rotation);

@@ -112,7 +112,8 @@ class DepthTracker : public Tracker
     void ApplyUpdate(Frame& frame, const Vector6f& x) const override;
 
     // PyramidTracker<DepthTracker>::Track as one call into the C ABI (vk_icp_pyramid_track)
-    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame);
+    // `normals_due`: frame.normal_image is still to be computed (Frame::ComputeNormals) and is, by the pyramid's launch
+    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due = false);
 
   protected:
     int GetResidualCount(const Frame& frame) const override;
@@ -219,6 +220,9 @@ class PyramidTracker
     void SetKeyframe(std::shared_ptr<const Frame> keyframe);
 
     void Track(Frame& frame);
+    // frame.ComputeNormals(); Track(frame); (vulcan.cu:297-311) in one call — not upstream: with a DepthTracker the normal
+    // image is computed by the launch that builds the pyramid (vk_icp_pyramid_track_frame), same bits
+    void ComputeNormalsAndTrack(Frame& frame);
 
   protected:
     void TrackLevels(Frame& frame);   // the generic two-level loop (pyramid_tracker.cpp:52-90)

@@ -242,8 +242,15 @@ void DepthTracker::TrackOnDevice(Frame& frame)
       DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
-void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame)
+void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due)
 {
+  if (normals_due)
+  {
+    VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+    if (!frame.normal_image) frame.normal_image = std::make_shared<ColorImage>();
+    frame.normal_image->Resize(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
+    frame.normal_image->GetData();                 // (stamps the image: new content)
+  }
   keyframe_ = keyframe;
   max_iterations_ = 20;          // what pyramid_tracker.cpp:85-86 leaves behind
   translation_enabled_ = true;
@@ -260,10 +267,11 @@ void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& fr
   {
     const vk_transform pose = frame.depth_to_world_transform.ToVk();
     poll_.host_state[3] = 0;
-    VK_ASSERT(vk_transform_upload(pose_.GetData(), &pose, Device::GetStream()));
     HookAdapter adapter = { reduce_hook_, reduce_user_ };
-    VK_ASSERT(vk_icp_pyramid_track(&key, &Twm, &frm, pose_.GetData(), pyramid_.GetData(), workspace_.GetData(),
-        system_.GetData(), state_.GetData(), update_.GetData(), DeviceHook(), &adapter, &poll_, Device::GetStream()));
+    // the start pose and (first attempt) the frame's normals travel with the pyramid's launch
+    VK_ASSERT(vk_icp_pyramid_track_frame(&key, &Twm, &frm, pose_.GetData(), &pose, normals_due && attempt == 0 ? 1 : 0,
+        pyramid_.GetData(), workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(), DeviceHook(), &adapter,
+        &poll_, Device::GetStream()));
     iteration_ = max_iterations_;
     if (FinishSolve(frame, attempt == 1)) break;
     frame.depth_to_world_transform = start;      // aborted: again, one launch per stage (Tracker::Track)
@@ -633,6 +641,21 @@ void PyramidTracker<DepthTracker>::Track(Frame& frame)
 {
   VULCAN_DEBUG(keyframe_);
   tracker_->TrackPyramid(keyframe_, frame);
+  ++iter_;
+}
+
+template <typename Tracker>
+void PyramidTracker<Tracker>::ComputeNormalsAndTrack(Frame& frame)
+{
+  frame.ComputeNormals();
+  Track(frame);
+}
+
+template <>
+void PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(Frame& frame)
+{
+  VULCAN_DEBUG(keyframe_);
+  tracker_->TrackPyramid(keyframe_, frame, true);
   ++iter_;
 }
 
