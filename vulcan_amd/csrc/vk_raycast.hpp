@@ -193,6 +193,8 @@ __device__ __forceinline__ int find_block(const PointParams& P, BlockCache& cach
 // explicitly global pointers: the corner loads must not become flat loads
 typedef const float __attribute__((address_space(1)))* global_floats;
 typedef const vf3 __attribute__((address_space(1)))* global_vf3;
+typedef float vf4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef const vf4u __attribute__((address_space(1)))* global_vf4u;
 
 // The eight voxels around a sample (tracer.cu:190-256), index dz*4 + dy*2 + dx: where
 // each one is, and the fractional position between them. POOL32: the pool is smaller
@@ -212,6 +214,14 @@ struct Corners
       return *(global_floats)((const char __attribute__((address_space(1)))*)(global_floats)reinterpret_cast<const float*>(P.voxels) +
                               offset[c] + 4 * dword);
     return voxel[c][dword];
+  }
+  // colour and weights of corner c: the voxel's bytes 4..19 as ONE 16-byte load (4-byte aligned)
+  __device__ __forceinline__ vf4u tail(const PointParams& P, int c) const
+  {
+    if (POOL32)
+      return *(global_vf4u)((const char __attribute__((address_space(1)))*)(global_floats)reinterpret_cast<const float*>(P.voxels) +
+                            offset[c] + 4);
+    return *(global_vf4u)(voxel[c] + 1);
   }
   __device__ __forceinline__ vf3 rgb(const PointParams& P, int c) const
   {
@@ -358,23 +368,22 @@ __device__ __forceinline__ float corner_distance(const PointParams& P, const Cor
 // tracer.cu:282-310: `a*b*c*(cw>0) ? 1 : 0` == `(a*b*c*(cw>0)) ? 1 : 0`, i.e. the colour
 // is the plain mean of the corners that carry colour. A voxel whose colour weight is 0
 // has never had its colour written (every colour update increments the weight), so its
-// colour is the initial (0,0,0): the 12 colour bytes are only fetched when the weight is
-// positive, and when no corner of any lane has one (depth-only volumes) nothing is.
+// colour is the initial (0,0,0): the 12 colour bytes are only USED when the weight is positive.
 template <bool POOL32>
 __device__ __forceinline__ f3 corner_color(const PointParams& P, const Corners<POOL32>& C)
 {
+  // (one load per corner: until round 4 the weights were read first and the 12 colour bytes only where the weight was
+  // positive — two scattered loads per corner where colour exists, and a sampled trip is bound by the number of those)
+  vf4u tail[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) tail[c] = C.tail(P, c);
   int cw[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) cw[c] = (int)(int16_t)(__float_as_uint(C.word(P, c, 4)) >> 16);
+  for (int c = 0; c < 8; ++c) cw[c] = (int)(int16_t)(__float_as_uint(tail[c].w) >> 16);
 #pragma unroll
   for (int c = 0; c < 8; ++c) cw[c] = ((C.absent >> c) & 1u) ? 0 : cw[c];
 
-  int any_weight = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) any_weight |= (cw[c] > 0) ? 1 : 0;
   f3 acc = make3(0.0f, 0.0f, 0.0f);
-  if (!__any(any_weight)) return acc;
-
   const float w1x = C.fx, w1y = C.fy, w1z = C.fz;
   const float w0x = 1.0f - w1x, w0y = 1.0f - w1y, w0z = 1.0f - w1z;
   float total = 0.0f;
@@ -384,7 +393,7 @@ __device__ __forceinline__ f3 corner_color(const PointParams& P, const Corners<P
   for (int c = 0; c < 8; ++c)
   {
     rgb[c] = vf3{0.0f, 0.0f, 0.0f};
-    if (cw[c] > 0) rgb[c] = C.rgb(P, c);
+    if (cw[c] > 0) rgb[c] = vf3{tail[c].x, tail[c].y, tail[c].z};
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c)
