@@ -233,6 +233,9 @@ constexpr int kNormalRowStride = 16;      // words: a 64-byte line per counter (
                                           // hundred waiting groups held up the increments they were waiting for)
 constexpr int kNormalWaitPolls = 1 << 16; // x s_sleep(32): some 60 ms
 
+#ifndef VK_TR_WAVES
+#define VK_TR_WAVES 5
+#endif
 #ifndef VK_TRACE_NORMALS_RIDE
 #define VK_TRACE_NORMALS_RIDE 1
 #endif
@@ -373,7 +376,7 @@ __device__ __forceinline__ void normals_group(const PointParams& P, float* __res
 // the raycast reads the table, the voxels and its bounds; the request pass reads the table and the visibility bytes and
 // writes visibility bytes, request flags and the light preparation's buffers.
 template <bool POOL32, int PREP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void trace_and_request_kernel(PointParams P,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES))) void trace_and_request_kernel(PointParams P,
     RequestParams R, Retry retry, int trace_groups, int request_groups_x, int request_groups, float* normals)
 {
   __shared__ int4 directories[4][kDirWords];
