@@ -62,6 +62,28 @@ def test_pod_layouts_match_header():
     assert C.sizeof(T.Integrator) == 16 and C.sizeof(T.IcpView) == 2 * 8 + 2 * 4 + 16
 
 
+def test_every_mirrored_struct_has_the_size_the_c_compiler_gives_it(tmp_path):
+    """sizeof() of every struct of vk.h that vk_types.py mirrors, asked of gcc, against ctypes: a field added on one side only
+    (vk_view_bounds and vk_requests_ahead both grew in round 4) fails here, on the CPU, not as a corrupted launch on the GPU."""
+    from vulcan_amd import vk_types as T
+    pairs = [("vk_projection", T.Projection), ("vk_transform", T.Transform), ("vk_light", T.Light), ("vk_volume", T.Volume),
+             ("vk_frame", T.Frame), ("vk_integrator", T.Integrator), ("vk_view_bounds", T.ViewBounds), ("vk_color_view", T.ColorView),
+             ("vk_light_terms", T.LightTerms), ("vk_track_poll", T.TrackPoll), ("vk_light_prep", T.LightPrep),
+             ("vk_rig_exchange", T.RigExchange), ("vk_requests_ahead", T.RequestsAhead), ("vk_test_hooks", T.TestHooks),
+             ("vk_color_pose", T.ColorPose), ("vk_detector", T.Detector), ("vk_detect_state", T.DetectState), ("vk_icp_view", T.IcpView)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "vk.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{name} %zu\\n", sizeof({name}));\n' for name, _ in pairs) +
+                   f'  printf("abi %d ctr %d\\n", VK_ABI_VERSION, VK_CTR_COUNT);\n  return 0;\n}}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split(None, 1) for line in subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines())
+    for name, mirror in pairs:
+        assert int(out[name]) == C.sizeof(mirror), (name, out[name], C.sizeof(mirror))
+    abi, _, ctr = out["abi"].split()
+    assert int(abi) == T.VK_ABI_VERSION and int(ctr) == T.VK_CTR_COUNT
+
+
 def test_product_does_not_use_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
     bad = []
