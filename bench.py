@@ -273,7 +273,7 @@ class FrameLoop:
         # the request pass of the NEXT frame behind this frame's raycast (REQUESTS_AHEAD): a second frame descriptor
         # (frame i + 1: the same resident images, the next pose, the next content id) and the record SetView checks
         self.ahead = None
-        if ((REQUESTS_AHEAD if requests_ahead is None else requests_ahead) and self.split is None and not stream_input and workload != "rgbd-icp" and volumes == 1
+        if ((REQUESTS_AHEAD if requests_ahead is None else requests_ahead) and self.split is None and workload != "rgbd-icp" and volumes == 1
                 and (workload == "depth" or NORMALS_IN_SET_VIEW)):
             self.ahead = T.RequestsAhead()
             self.ndesc = T.Frame.from_buffer_copy(bytes(self.fdesc))
@@ -443,6 +443,12 @@ class FrameLoop:
         if self.ahead is not None and i + 1 < len(self.poses):
             # Trace(i) + the request pass of SetView(i + 1), one launch
             self.ndesc.depth, self.ndesc.color = self.fdesc.depth, self.fdesc.color
+            if self.upload is not None:
+                # the next frame's images: submitted at the top of this step, on the device by now or soon (the launch waits)
+                images = self.upload.acquire(n + 1)
+                self.ndesc.depth = images[0].data_ptr()
+                if len(images) > 1:
+                    self.ndesc.color = images[1].data_ptr()
             self.ndesc.depth_to_world = self.poses[i + 1]
             self.ndesc.content_id = self.fdesc.content_id + 2
             if normals_in_set_view:
