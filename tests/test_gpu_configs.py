@@ -160,6 +160,46 @@ def test_requests_ahead_record_for_another_frame_is_refused(api):
     assert rc == 0
 
 
+@pytest.mark.parametrize("size", [(1280, 960), (96, 1040), (200, 150)])
+def test_requests_ahead_at_other_image_sizes(api, size):
+    """Tracer.trace(frame, next_frame=) + set_view against trace() + set_view on a second, identical volume: the same images and
+    the same volume, bit for bit — at 1280x960 (120 rows of tiles for the normals' counters), at a height beyond the 1024 rows the
+    counters cover (the normals are then a launch of their own again) and at a size that is no multiple of the tiles."""
+    import torch
+    w, h = size
+    s = w / 640.0
+    k = T.Projection.make(547.0 * s, 547.0 * s, 0.5 * w, 0.5 * h)
+    depth = curved_depth(w, h)
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+    poses = [scenes.yaw(1.0 * i) for i in range(3)]
+    results = []
+    for ahead in (False, True):
+        vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+        integ, tracer = api.LightIntegrator(vol), api.Tracer(vol)
+        integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+        fs = [api.Frame(depth, k, p, color=color) for p in poses]
+        outs = []
+        for i, f in enumerate(fs):
+            if not (ahead and i > 0):
+                f.compute_normals()
+            vol.set_view(f, rounds=3)
+            integ.integrate(f)
+            out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, poses[i])
+            if ahead and i + 1 < len(fs):
+                tracer.trace(out, next_frame=fs[i + 1], next_needs_normals=True)
+                assert vol.requests_ahead.valid == 1
+            else:
+                tracer.trace(out)
+            sync()
+            outs.append((out.depth.cpu().numpy(), out.color.cpu().numpy(), out.normals.cpu().numpy(), f.normals.cpu().numpy()))
+        results.append((outs, vol.host_voxels().tobytes(), vol.host_entries().tobytes(), vol.visible_count))
+    (plain, pv, pe, pc), (made, mv, me, mc) = results
+    assert pc == mc > 100 and pv == mv and pe == me
+    for a, b in zip(plain, made):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+
+
 # ------------------------------------------------------------------ configs[3] --
 
 def curved_depth(w, h):
