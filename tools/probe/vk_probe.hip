@@ -221,7 +221,7 @@ int vk_probe_trace_log(const vk_hash_entry* entries, const vk_voxel* voxels, con
   P.inv_voxel_length = 1.0 / (double)voxel_length;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);
-  P.k = *projection;
+  P.k = make_projection(*projection);
   P.depths = depths;
   P.colors = colors;
   P.image_width = image_width;

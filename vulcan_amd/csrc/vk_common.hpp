@@ -164,14 +164,36 @@ __device__ __forceinline__ void project(const vk_projection& k, f3 X, float& u, 
   v = inv_w * k.fy * X.y + k.cy;
 }
 // projection.h:78-88
-__device__ __forceinline__ f3 unproject(const vk_projection& k, float u, float v)
+// A projection that carries 1 / fx and 1 / fy (projection.h:79-86 divides per call): the two quotients are launch constants,
+// but a GPU lane has no cheaper way to a correctly rounded uniform quotient than the ten-instruction division, twice per
+// thread of every kernel that unprojects; the host's float division gives the same bits (make_projection).
+struct Projection : vk_projection
 {
-  const float ifx = 1.0f / k.fx;
-  const float ify = 1.0f / k.fy;
+  float ifx, ify;
+};
+inline Projection make_projection(const vk_projection& k)
+{
+  Projection p;
+  p.fx = k.fx;  p.fy = k.fy;  p.cx = k.cx;  p.cy = k.cy;
+  p.ifx = 1.0f / k.fx;
+  p.ify = 1.0f / k.fy;
+  return p;
+}
+__device__ __forceinline__ float inverse_fx(const vk_projection& k) { return 1.0f / k.fx; }
+__device__ __forceinline__ float inverse_fy(const vk_projection& k) { return 1.0f / k.fy; }
+__device__ __forceinline__ float inverse_fx(const Projection& k) { return k.ifx; }
+__device__ __forceinline__ float inverse_fy(const Projection& k) { return k.ify; }
+
+template <typename K>
+__device__ __forceinline__ f3 unproject(const K& k, float u, float v)
+{
+  const float ifx = inverse_fx(k);
+  const float ify = inverse_fy(k);
   return f3{ifx * u - k.cx * ifx, ify * v - k.cy * ify, 1.0f};
 }
 // projection.h:96-100: d * Unproject(uv)
-__device__ __forceinline__ f3 unproject_d(const vk_projection& k, float u, float v, float d)
+template <typename K>
+__device__ __forceinline__ f3 unproject_d(const K& k, float u, float v, float d)
 {
   return scale3(unproject(k, u, v), d);
 }
@@ -227,7 +249,8 @@ __device__ __forceinline__ void wave_lds_fence()
 // ---- Frame::ComputeNormals for one pixel (ref: frame.cu:9-122): `depth` at (x, y) and the four taps
 // two pixels away (0 = no measurement, or outside the image). Shared by compute_normals_kernel and
 // by the request pass of vk_volume_set_view_prepare when it computes the frame's normals on the way.
-__device__ __forceinline__ f3 normal_from_taps(const vk_projection& k, int x, int y, float depth,
+template <typename K>
+__device__ __forceinline__ f3 normal_from_taps(const K& k, int x, int y, float depth,
     float left, float right, float up, float down)
 {
   const int pad = 2;

@@ -36,7 +36,7 @@ struct PointParams
   float block_length, voxel_length, trunc_length;
   double inv_block_length, inv_voxel_length;   // RN64(1 / length), see div_uniform
   Rt Twc, Tcw;
-  vk_projection k;
+  Projection k;          // with 1 / fx, 1 / fy (vk_common.hpp)
   float* depths;
   float* colors;
   int image_width, image_height, bounds_width, bounds_height;

@@ -231,7 +231,7 @@ struct RequestParams
   vk_volume v;
   const float* depth;
   int width, height;
-  vk_projection k;
+  Projection k;            // with 1 / fx, 1 / fy (vk_common.hpp)
   Rt Twd;
   // PREP only: LightIntegrator's per-pixel preparation rides along (vk_volume_set_view_prepare)
   const float* colors;
@@ -593,7 +593,7 @@ inline int build_request_pass(RequestParams& P, Retry& retry, const vk_volume* v
   P.depth = depth;
   P.width = width;
   P.height = height;
-  P.k = *projection;
+  P.k = make_projection(*projection);
   P.Twd = make_rt(Twd->m);
   P.colors = P.normals = nullptr;
   P.Tcd = P.Twd;

@@ -518,7 +518,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.rows_target = rows_target;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
-  P.k = *projection;
+  P.k = make_projection(*projection);
   P.depths = depths;
   P.colors = colors;
   P.image_width = image_width;
