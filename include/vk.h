@@ -430,7 +430,9 @@ VK_API int vk_frame_filter_depths(int image_width, int image_height,
 
 /* Floats the `bounds` scratch of vk_trace must hold: the bounds grid itself
  * (tracer.cpp:140: 80*60 float2) followed by the per-workgroup private copies
- * the fused bounds pass reduces into. */
+ * the fused bounds pass reduces into and, since VK_ABI_VERSION 5, 2 048 words of
+ * row counters for the raycast's normals (vk_trace_ahead_requests; one scratch
+ * belongs to one vk_view_bounds record). */
 VK_API size_t vk_trace_bounds_floats(int bounds_width, int bounds_height);
 
 /* ref: src/tracer.cpp:41-47 Tracer::Trace — bounds (fused), points, normals.
