@@ -128,17 +128,21 @@ def spawn_ranks(args, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
     deadline = None
+    ranks = {p.pid: r for r, p in enumerate(procs)}
     while procs:
         for p in list(procs):
             code = p.poll()
             if code is None:
                 continue
             procs.remove(p)
+            if code != 0:
+                print(f"bench.py: rank {ranks[p.pid]} exited {code}", file=sys.stderr)
             if code != 0 and rc == 0:
                 rc = code
                 deadline = time.time() + 30          # one rank died: the others cannot finish
         if deadline is not None and time.time() > deadline:
             for p in procs:
+                print(f"bench.py: rank {ranks[p.pid]} killed (still running 30 s after another rank failed)", file=sys.stderr)
                 p.kill()                              # exact children, by handle
             break
         time.sleep(0.05)
@@ -162,13 +166,28 @@ def launch_selftest(args):
     vd.allreduce_system(system)
     slowest = vd.max_over_ranks(1.0 + rank)
     frames = vd.sum_over_ranks(args.steps)
+    per_rank = vd.gather_over_ranks(1.0 + rank)
     vd.barrier()
+    result = {"launch_selftest": True, "n_gpus": world, "system_sum": float(system[0]),
+              "max_over_ranks": slowest, "frames_all_ranks": frames, "per_rank_ms_per_step": per_rank,
+              "local_rank_env": int(os.environ.get("LOCAL_RANK", "-1"))}
+    # the rig step's failure protocol, rehearsed with the functions the GPU run uses (vd.agreed_step, rig_failed, the
+    # exit code): a step that raises on ONE rank must end EVERY rank non-zero, with the line printed
+    collective = {"ok": True, "vk_comm": {"ok": True, "vk_comm_count": world}, "vk_comm_count": world,
+                  "update_identical_on_all_ranks": True}
+    try:
+        def rig_step():
+            if rank == args.selftest_rig_fail_rank:
+                raise RuntimeError("rehearsed failure inside the rig step")
+            return world
+        vd.agreed_step("the rehearsed rig step", rig_step)
+    except vd.StepFailed as e:
+        collective["vk_comm"] = {"ok": False, "error": str(e)}
+    result["collective"] = collective
     if rank == 0:
-        emit({"launch_selftest": True, "n_gpus": world, "system_sum": float(system[0]),
-              "max_over_ranks": slowest, "frames_all_ranks": frames,
-              "local_rank_env": int(os.environ.get("LOCAL_RANK", "-1"))})
+        emit(result)
     vd.shutdown()
-    return 0
+    return RIG_FAILED_EXIT if rig_failed(collective) else 0
 
 
 # ------------------------------------------------------------------- frame loops ----
@@ -263,7 +282,7 @@ class FrameLoop:
         if SPLIT_STREAMS and workload != "rgbd-icp" and volumes == 1 and (workload == "depth" or NORMALS_IN_SET_VIEW):
             side, requested, integrated = C.c_void_p(), C.c_void_p(), C.c_void_p()
             api.check(self.lib.vk_stream_create(C.byref(side)), "vk_stream_create")
-            api.check(self.lib.vk_event_create_ordering(C.byref(requested), 0), "vk_event_create_ordering")
+            api.check(self.lib.vk_event_create_ordering(C.byref(requested), 1), "vk_event_create_ordering")   # the pass writes what the waiter reads
             api.check(self.lib.vk_event_create_ordering(C.byref(integrated), 0), "vk_event_create_ordering")
             self.split = {"stream": side, "requested": requested, "integrated": integrated, "frames": 0}
         self.upload = None
@@ -517,8 +536,10 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
         loop.step(warmup + i)
     torch.cuda.synchronize()
     vd.barrier()
-    elapsed = vd.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    local = time.perf_counter() - t0
+    elapsed = vd.max_over_ranks(local, device="cuda")
     frames_all = vd.sum_over_ranks(steps, device="cuda")
+    per_rank_ms = vd.gather_over_ranks(1e3 * local / steps, device="cuda")      # value uses the max; these say who was slow
 
     # The roofline sample: ROOFLINE_SAMPLE_FRAMES more frames of the same sequence, AFTER the timed region, with HIP
     # events (created without the system-scope fence, vk_event_create) around the integrate launch of every frame and
@@ -541,7 +562,8 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
     if with_roofline:
         pair_us = float(np.mean([loop.elapsed_ms(e0, e1) for e0, e1 in pairs]) * 1e3)
 
-    out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup}
+    out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+           "per_rank_ms_per_step": per_rank_ms}
     if with_roofline:
         integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled]
         trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled if i in traced]
@@ -549,7 +571,8 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
         out["_event_pair_us"] = pair_us
     ctr = loop.vols[0]["vol"].read_counters()
     out["_counters"] = ctr
-    out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps)
+    # VK_CTR_ROUNDS counts every frame this volume has seen: warm-up, timed AND the roofline sample's
+    out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps + len(sampled))
     if loop.tracker is not None:
         # the closed loop, scored against the ground truth it never saw
         errors = [pose_error(p, sequence.truth[i]) for i, p in enumerate(loop.tracked_poses)]
@@ -628,8 +651,8 @@ def probes(loop, nvis_last):
     read = timed(lambda: pl.vk_probe_stream_read(ap, n, C.c_void_p(sink.data_ptr()), s), n)
     del a, b
     vref = loop.vols[0]["vref"]
+    nhit = touched_blocks(pl, loop)          # first: it compares against the last raycast of the loop, volume untouched since
     rmw = timed(lambda: pl.vk_probe_block_rmw(vref, 0, s), float(nvis_last) * 2 * 10240, reps=10)
-    nhit = touched_blocks(pl, loop)
     return {"raycast_blocks_touched": nhit,"measured_copy_GBps": max(shapes.values()), "copy_shapes_GBps": shapes, "measured_read_GBps": read,
             "measured_block_rmw_GBps": rmw, "copy_buffer_bytes": n}
 
@@ -646,14 +669,22 @@ def touched_blocks(pl, loop):
     pl.vk_probe_trace_touched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, F, F, F, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+    # the pose of the LAST raycast: step() moves kdesc.depth_to_world, never the key frame's own field (which keeps the pose
+    # the frame object was created with — rounds 3 and 4 passed that one here, the images differed and the figures went missing)
     rc = pl.vk_probe_trace_touched(vol.hash_entries.data_ptr(), vol.voxels.data_ptr(), tracer.bounds.data_ptr(), vol.main,
-                                   F(np.float32(8) * np.float32(VOXEL)), F(VOXEL), F(TRUNC), C.byref(loop.key.depth_to_world),
+                                   F(np.float32(8) * np.float32(VOXEL)), F(VOXEL), F(TRUNC), C.byref(loop.kdesc.depth_to_world),
                                    C.byref(loop.k), d2.data_ptr(), c2.data_ptr(), W, H, tracer.BOUNDS_W, tracer.BOUNDS_H,
                                    touched.data_ptr(), None, loop.stream)
     torch.cuda.synchronize()
-    if rc != 0 or not torch.equal(d2, loop.key.depth):
-        return None                      # the counting kernel must reproduce the product's image
-    return int(touched.sum())
+    # the counting kernel must reproduce the product's image; when it does not, the line says so instead of dropping the figures
+    if rc != 0:
+        return {"error": f"vk_probe_trace_touched returned {rc}"}
+    if not torch.equal(d2, loop.key.depth):
+        differing = int((d2 != loop.key.depth).sum())
+        return {"error": f"the counting raycast's depth image differs from the product's in {differing} of {W * H} pixels"}
+    if not torch.equal(c2, loop.key.color):
+        return {"error": "the counting raycast's colour image differs from the product's"}
+    return {"blocks_touched": int(touched.sum())}
 
 
 # ----------------------------------------------------------------- multi-GPU rig ----
@@ -708,108 +739,126 @@ def rig_collective(rank, world, vd):
     torch.cuda.synchronize()
     allreduce_us = vd.max_over_ranks((time.perf_counter() - t0) / reps * 1e6, device="cuda")
 
-    # every rank solved the same system: the last update vector must be identical everywhere
-    upd = tracker.update.clone()
-    gathered = [torch.empty_like(upd) for _ in range(world)]
-    dist.all_gather(gathered, upd)
-    identical = all(torch.equal(g, gathered[0]) for g in gathered)
+    identical = updates_identical(tracker, world)
     residual = float(np.abs((got.matrix() @ rig_pose.inverse_matrix()) - np.eye(4)).max())
     out = {"pattern": "all-reduce(sum) of the packed ICP system, 48 x f32, once per Gauss-Newton iteration",
            "backend": dist.get_backend(), "ranks": dist.get_world_size(), "allreduce_us": allreduce_us,
            "iterations_per_frame": iterations, "track_ms_per_frame": track_ms,
-           "update_identical_on_all_ranks": bool(identical), "pose_error_after_track": residual}
+           "update_identical_on_all_ranks": bool(identical), "pose_error_after_track": residual, "ok": True}
     out["vk_comm"] = vk_comm_rig(rank, world, vd, tracker, key, frame, error * rig_pose)
+    out["vk_comm_count"] = out["vk_comm"].get("vk_comm_count")      # did RCCL itself see `world` ranks (ncclCommCount)
     return out
 
 
 def vk_comm_rig(rank, world, vd, tracker, key, frame, start):
-    """The same rig step through the shipped C binding (libvk_comm.so: vk_comm_* over RCCL,
-    no Python between the Gauss-Newton iterations). Failure here is reported, not fatal: the
-    torch.distributed numbers above stand on their own. Every step that can fail on ONE rank alone
-    (creating the communicator, RCCL's own rank count, attaching the exchange) is followed by
-    vd.all_ok: the ranks agree on the outcome before any of them enters the next collective, so
-    all of them take the same branch and none waits in a collective another rank never reaches."""
+    """The same rig step through the shipped C binding (libvk_comm.so: vk_comm_* over RCCL, no Python between the
+    Gauss-Newton iterations). Every step that can fail on ONE rank alone (creating the communicator, RCCL's own rank
+    count, attaching the exchange, a Track that raises) goes through vd.agreed_step: the ranks agree on its outcome before
+    any of them enters the next collective, so all of them take the same branch and none waits in a collective another
+    rank never reaches. A failure is reported in the line AND ends the run with a non-zero exit code on every rank
+    (main: rig_failed), after the headline — measured before the rig step — has been printed."""
     import torch
     import torch.distributed as dist
     from vulcan_amd import api, comm
 
-    def local(step):
-        """run a rank-local step; (value, error text or None)"""
-        try:
-            return step(), None
-        except Exception as e:     # noqa: BLE001  (reported in the JSON line)
-            return None, f"{type(e).__name__}: {e}"[:300]
+    def step(what, fn):
+        return vd.agreed_step(what, fn, device="cuda")
 
-    def agreed(error, what):
-        if vd.all_ok(error is None, device="cuda"):
-            return None
-        return {"ok": False, "error": error or f"another rank failed in: {what}"}
+    c = None
+    out = {"ok": False}
+    try:
+        c = step("vk_comm_init", lambda: comm.Communicator.from_torch_group(rank, world))
 
-    c, error = local(lambda: comm.Communicator.from_torch_group(rank, world))
-    failed = agreed(error, "vk_comm_init")
-    if failed:
-        return failed
-    seen, error = local(c.rccl_count)              # what RCCL itself says, not the launcher's environment
-    if error is None and seen != world:
-        error = f"ncclCommCount says {seen} ranks, WORLD_SIZE is {world}"
-    failed = agreed(error, "vk_comm_count")
-    if failed:
-        c.close()
-        return failed
+        def count():
+            seen = c.rccl_count()              # what RCCL itself says, not the launcher's environment
+            if seen != world:
+                raise RuntimeError(f"ncclCommCount says {seen} ranks, WORLD_SIZE is {world}")
+            return seen
+        out["vk_comm_count"] = out["ranks_rccl"] = step("vk_comm_count", count)
 
-    tracker.reduce_hook = None
-    frame.depth_to_world = start
-    c.track(tracker, frame)
-    torch.cuda.synchronize()
-    vd.barrier()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        frame.depth_to_world = start
-        c.track(tracker, frame)
-    torch.cuda.synchronize()
-    ms = vd.max_over_ranks((time.perf_counter() - t0) / 20 * 1e3, device="cuda")
-    us = vd.max_over_ranks(c.time_allreduce(200), device="cuda")
-    out = {"ok": True, "ranks_rccl": seen, "allreduce_us": us, "track_ms_per_frame": ms,
-           "iterations_per_frame": int(tracker.state.cpu()[0])}
+        tracker.reduce_hook = None
 
-    # the same Track with the ranks' sums exchanged INSIDE the one-launch loop (peer-mapped areas,
-    # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
-    # on a multi-GPU node the path is unmeasured on hardware over xGMI (DESIGN.md section 6; two processes on
-    # one GPU: tests/test_gpu_rig_two_ranks.py)
-    if not RIG_IN_LAUNCH_EXCHANGE:
-        out["in_launch_exchange"] = {"ok": False, "error": "not run: set VK_BENCH_RIG_EXCHANGE=1 (never run on more than "
-                                     "one GPU; DESIGN.md section 6)"}
-    else:
-        tracker.comm = None
-        c.agree = comm.agree_over_torch_group()
-        _, error = local(c.attach_exchange)        # collective, and so is its outcome (vk_comm.h); agreed once more anyway
-        failed = agreed(error, "vk_comm_exchange_attach")
-        if failed:
-            out["in_launch_exchange"] = failed
-        else:
-            def timed():
+        def tracked(what, call, frames=20):
+            """ms per Track; the warm-up and the timed loop are steps of their own, with the barrier BETWEEN them (a
+            rank that raised inside a step must not leave its peers in a barrier the step contained)"""
+            def once():
                 frame.depth_to_world = start
-                c.track_rig(tracker, frame)        # raises TrackAborted on EVERY rank if any rank gave up (c.agree)
+                call(tracker, frame)
                 torch.cuda.synchronize()
-                vd.barrier()
-                t1 = time.perf_counter()
-                for _ in range(20):
+
+            def timed():
+                t0 = time.perf_counter()
+                for _ in range(frames):
                     frame.depth_to_world = start
-                    c.track_rig(tracker, frame)
+                    call(tracker, frame)
                 torch.cuda.synchronize()
-                return vd.max_over_ranks((time.perf_counter() - t1) / 20 * 1e3, device="cuda")
-            xms, error = local(timed)
-            failed = agreed(error, "vk_icp_track_rig")
-            if failed:
-                out["in_launch_exchange"] = failed
-            else:
-                upd = tracker.update.clone()
-                gathered = [torch.empty_like(upd) for _ in range(world)]
-                dist.all_gather(gathered, upd)
-                out["in_launch_exchange"] = {"ok": True, "track_ms_per_frame": xms, "iterations_per_frame": int(tracker.state.cpu()[0]),
-                                             "update_identical_on_all_ranks": bool(all(torch.equal(g, gathered[0]) for g in gathered))}
-    c.close()
+                return (time.perf_counter() - t0) / frames * 1e3
+            step(what + " (first Track)", once)
+            vd.barrier()
+            return vd.max_over_ranks(step(what, timed), device="cuda")
+
+        out["track_ms_per_frame"] = tracked("vk_icp_track with vk_comm_reduce_hook", c.track)
+        out["allreduce_us"] = vd.max_over_ranks(step("vk_comm_allreduce_system", lambda: c.time_allreduce(200)), device="cuda")
+        out["iterations_per_frame"] = int(tracker.state.cpu()[0])
+        out["update_identical_on_all_ranks"] = updates_identical(tracker, world)
+        out["ok"] = True
+
+        # the same Track with the ranks' sums exchanged INSIDE the one-launch loop (peer-mapped areas,
+        # vk_comm_exchange_attach + vk_icp_track_rig); reported, not required: until this line has run
+        # on a multi-GPU node the path is unmeasured on hardware over xGMI (DESIGN.md section 6; two processes on
+        # one GPU: tests/test_gpu_rig_two_ranks.py)
+        if not RIG_IN_LAUNCH_EXCHANGE:
+            out["in_launch_exchange"] = {"ok": False, "not_run": True, "error": "not run: set VK_BENCH_RIG_EXCHANGE=1 (never run on "
+                                         "more than one GPU; DESIGN.md section 6)"}
+        else:
+            x = {"ok": False}
+            out["in_launch_exchange"] = x
+            tracker.comm = None
+            c.agree = comm.agree_over_torch_group()
+            step("vk_comm_exchange_attach", c.attach_exchange)     # collective, and so is its outcome (vk_comm.h); agreed once more
+            # (raises TrackAborted on EVERY rank if any rank gave up, c.agree; any other exception reaches the peers the same way)
+            x["track_ms_per_frame"] = tracked("vk_icp_track_rig", c.track_rig)
+            x["iterations_per_frame"] = int(tracker.state.cpu()[0])
+            x["update_identical_on_all_ranks"] = updates_identical(tracker, world)
+            x["ok"] = True
+    except vd.StepFailed as e:
+        failed = {"ok": False, "error": str(e)}
+        if out.get("ok") and "in_launch_exchange" in out:
+            out["in_launch_exchange"] = failed       # the RCCL path above stands; the in-launch exchange failed
+        else:
+            out.update(failed)
+    if c is not None:
+        try:
+            c.close()
+        except Exception as e:     # noqa: BLE001
+            out.setdefault("close_error", f"{type(e).__name__}: {e}"[:200])
     return out
+
+
+def updates_identical(tracker, world):
+    """every rank solved the same system: the last update vector must be the same bits everywhere"""
+    import torch
+    import torch.distributed as dist
+    upd = tracker.update.clone()
+    gathered = [torch.empty_like(upd) for _ in range(world)]
+    dist.all_gather(gathered, upd)
+    return bool(all(torch.equal(g, gathered[0]) for g in gathered))
+
+
+def rig_failed(collective):
+    """did the rig step FAIL (as opposed to: ran, or was not asked to run)? Then the run ends non-zero on every rank."""
+    if not isinstance(collective, dict):
+        return False
+    if collective.get("ok") is False:
+        return True
+    vk = collective.get("vk_comm", {})
+    if vk.get("ok") is False:
+        return True
+    x = vk.get("in_launch_exchange", {})
+    return x.get("ok") is False and not x.get("not_run")
+
+
+RIG_FAILED_EXIT = 4
 
 
 # --------------------------------------------------------------------------- main ----
@@ -829,6 +878,7 @@ def main():
                     help="CPU rehearsal of the N>1 launch path: ranks rendezvous over gloo, all-reduce one "
                          "48-float buffer and exit without touching a GPU (tests/test_bench_launch.py)")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-rig-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -894,6 +944,7 @@ def main():
     result = {
         "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "per_rank_ms_per_step": res["per_rank_ms_per_step"],     # rank order; ms_per_step is their max (barrier to barrier)
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
@@ -948,8 +999,11 @@ def main():
         result["roofline"].update(pr)
         if pr.get("measured_copy_GBps"):
             result["roofline"]["frac_of_measured_copy_here"] = achieved / pr["measured_copy_GBps"]
-        nhit = result["roofline"].pop("raycast_blocks_touched", None)
-        if nhit:
+        counted = result["roofline"].pop("raycast_blocks_touched", None) or {"error": "libvk_probe.so is not built"}
+        nhit = counted.get("blocks_touched")
+        if nhit is None:
+            result["roofline"]["raycast"]["error"] = counted["error"]      # loud: SURVEY 8(d)'s raycast figures are missing, and why
+        else:
             # outputs W*H*(4+12) + bounds 4800*8 + compulsory voxel traffic Nhit * 10240
             ray = result["roofline"]["raycast"]
             ray["blocks_touched"] = nhit
@@ -963,6 +1017,11 @@ def main():
                 # + the request pass: depth image read, normals + mask + records written; + the raycast's normals written
                 ray["algorithmic_bytes_of_the_launch"] = ray["algorithmic_bytes"] + W * H * (4 + 12 + 4 + 16) + W * H * 12
                 ray["algorithmic_GBps"] = ray["algorithmic_bytes_of_the_launch"] / (ray["avg_us"] * 1e-6) / 1e9
+            ray["frac_of_8TBps"] = ray["algorithmic_GBps"] / HBM_PEAK_GBS
+            # SURVEY §8d "report gather amplification = measured bytes / compulsory bytes": below 1 when a ray reads a few of
+            # a block's 512 voxels and the lines it needs are shared between neighbouring rays
+            if ray["traffic"]:
+                ray["gather_amplification"] = ray["traffic"] / ray.get("algorithmic_bytes_of_the_launch", ray["algorithmic_bytes"])
     del loop
     torch.cuda.empty_cache()
 
@@ -1065,6 +1124,10 @@ def main():
     if rank == 0:
         emit(result)
     vd.shutdown()
+    if rig_failed(result.get("collective")):
+        # the line above carries the headline (measured before the rig step) and the error; the run still FAILS, on every
+        # rank: the ranks agreed on the failure (vd.agreed_step), so all of them come through here
+        sys.exit(RIG_FAILED_EXIT)
 
 
 def pmc_traffic(workload):

@@ -147,7 +147,9 @@ enum {
   VK_OK              =  0,
   VK_ERR_ARGUMENT    = -1,  /* null pointer / non-positive size */
   VK_ERR_UNSUPPORTED = -2,
-  VK_ERR_NO_DEVICE   = -3
+  VK_ERR_NO_DEVICE   = -3,
+  VK_ERR_TIMEOUT     = -6   /* a bounded wait INSIDE a launch expired (vk_trace_normals_settle); what it says was not
+                               written has been recomputed, or the call must be repeated. (-4, -5: vk_comm.h) */
 };
 
 /* Device-memory view of a Volume (ref: include/vulcan/volume.h:89-116).
@@ -215,6 +217,9 @@ typedef struct vk_test_hooks {
   int32_t loop_grid_cap;      /* > 0: at most this many workgroups per loop kernel (a device with fewer CUs) */
   int32_t loop_cooperative;   /* 1: loop kernels go through hipLaunchCooperativeKernel (the runtime then refuses a
                                  grid that cannot be resident; +4..6.5 us per Track) */
+  int32_t force_normals_expiry; /* 1: the normals workgroups of the NEXT vk_trace_ahead_requests launch find their wait
+                                 expired at once (a target no counter reaches, no polls) — then back to 0 by itself: the
+                                 error path of vk_trace_normals_settle under test */
 } vk_test_hooks;
 
 VK_API int vk_test_hooks_set(const vk_test_hooks* hooks);   /* NULL: everything back to its default */
@@ -232,7 +237,7 @@ VK_API int vk_version(void);                       /* 100*major + minor */
  *   vk_abi_check(VK_ABI_VERSION, sizeof(vk_volume), sizeof(vk_frame), VK_CTR_COUNT)
  * and refuse to go on unless it returns VK_OK (VK_ERR_UNSUPPORTED otherwise). The class layer (vulcan_amd/host) and the
  * Python binding do. New struct fields are appended; a change of VK_CTR_COUNT bumps the version. No reference counterpart. */
-#define VK_ABI_VERSION 5
+#define VK_ABI_VERSION 6
 VK_API int vk_abi_version(void);
 VK_API int vk_abi_check(int header_abi_version, size_t sizeof_vk_volume, size_t sizeof_vk_frame, int ctr_count);
 VK_API int vk_device_count(int* count);
@@ -517,7 +522,10 @@ VK_API int vk_volume_set_view_rounds(const vk_volume* v, const vk_frame* frame, 
  *   vk_stream_wait_event(request_stream, integrated);   // the previous frame's vk_integrate_* has read the lists, mask, records
  *   vk_volume_set_view_rounds_split(&v, &f, &prep, 3, request_stream, ordering, stream);
  *   vk_integrate_ahead(.., stream);  vk_event_record(integrated, stream);  vk_trace_ahead(.., stream);
- * `ordering_event` (vk_event_create_ordering(&e, 0)) is recorded behind the request pass on request_stream, and `stream` waits
+ * `ordering_event` (vk_event_create_ordering(&e, 1): the request pass WRITES what the waiter reads — visibility bytes, request
+ * flags, the posted list, the preparation's buffers, the normals — so the event is one that publishes; `integrated` above is
+ * vk_event_create_ordering(&e, 0): the integrate launch only read what the request pass overwrites) is recorded behind the
+ * request pass on request_stream, and `stream` waits
  * for it before the handle + visibility pass, which must follow the previous raycast anyway (it writes table entries).
  * Same state as vk_volume_set_view_rounds, bit for bit (tests/test_gpu_configs.py runs bench.py's step, which uses this). */
 VK_API int vk_volume_set_view_rounds_split(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
@@ -562,6 +570,21 @@ typedef struct vk_view_bounds {
   int32_t       counted_width, counted_height;
   uint32_t      trace_launches;
   int32_t       pad_;
+  /* (ABI 6) The waiting normals workgroups' wait is BOUNDED (a launch whose counters were left behind by an aborted
+   * one must not hang the device). A group whose wait expires stores nothing, sets a word behind the counters in
+   * `scratch` and — when the caller gave one — `*late_host`: one int32 of pinned host memory (vk_malloc_host), zeroed by
+   * the caller once. The library looks at it, without synchronising anything, at the start of every vk_trace_ahead* call
+   * with this record, and vk_trace_normals_settle does after synchronising; see there for what happens then. The
+   * `last_*` fields say which images the riding normals of the last launch belong to (set by the library).
+   * ONE stream at a time per record: the counters' target counts the launches in stream order, so two traces in
+   * flight on two streams through one record would wait for the wrong count. A call that names another stream than the
+   * last one re-zeroes the counters on the new stream — the caller makes sure the old stream's launch has completed. */
+  int32_t*      late_host;
+  const float*  last_depths;
+  float*        last_normals;
+  int32_t       last_width, last_height;
+  vk_projection last_projection;
+  const void*   counted_stream;
 } vk_view_bounds;
 
 /* vk_integrate_depth / _depth_color / _depth_light (color_mode 0 / 1 / 2; `light`
@@ -615,6 +638,30 @@ VK_API int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_
     vk_requests_ahead* requests, void* stream);
 VK_API int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
     vk_requests_ahead* requests, void* stream);
+
+/* A record that is still valid when vk_trace_ahead_requests is called again names a frame whose requests are in the volume
+ * and whose SetView has not run: a second pass on top would mix two frames' requests, retry keys, posted list and touched
+ * bits — the state vk_volume_set_view_rounds_ahead refuses. vk_trace_ahead_requests therefore returns VK_ERR_ARGUMENT for a
+ * record with valid == 1 and launches nothing (round 5), and the staged SetView stages of the class layers refuse to run
+ * while their volume's record is valid. The way out of such a record — one a SetView refused, or a frame the caller no
+ * longer wants to fuse — is this call: it completes the ANNOUNCED frame's SetView (the handle + visibility pass with the
+ * record's own size, intrinsics and pose: everything that pass needs; `max_rounds` as there) and marks the record used. The
+ * volume is then exactly where `max_rounds` upstream SetView calls with the announced frame leave it — a state upstream can
+ * reach — and any frame may follow. A record that is not valid: VK_OK, nothing launched. A record of another volume:
+ * VK_ERR_ARGUMENT. ref: src/volume.cu:430-437 (the SetView it completes), :520-535, :473-495. */
+VK_API int vk_requests_ahead_cancel(const vk_volume* v, vk_requests_ahead* requests, int max_rounds, void* stream);
+
+/* The outcome of the bounded wait of the raycast's riding normals (vk_view_bounds.late_host; round 5; no reference
+ * counterpart; ref: include/vulcan/device.h:14-17 CUDA_ASSERT — the contract it keeps is upstream's "a failed device step
+ * always surfaces" — and src/frame.cu:9-122 for the normals it recomputes). Synchronises `stream`, then looks at the expiry word (the pinned one,
+ * or — without one — the word behind the counters, by a blocking copy). Nothing expired: VK_OK. Otherwise the riding
+ * normals of the last launch are incomplete: the counters and both words are re-zeroed, the launch count starts over,
+ * Frame::ComputeNormals of the last traced image is enqueued on `stream` as a launch of its own (ahead->last_*), and the
+ * call returns VK_ERR_TIMEOUT: the normals are right once `stream` has drained, and the caller knows its counters had been
+ * left in a bad state. Every vk_trace_ahead / vk_trace_ahead_requests call makes the same check first, on the pinned word
+ * only and without synchronising; when it finds the word set it repairs in the same way, launches NOTHING of its own and
+ * returns VK_ERR_TIMEOUT — the caller repeats the call. */
+VK_API int vk_trace_normals_settle(vk_view_bounds* ahead, void* stream);
 
 /* ------------------------------------------------------------------- image -- */
 

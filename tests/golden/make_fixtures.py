@@ -4,6 +4,7 @@ scenes of SURVEY.md §8(d), produced by the CPU oracle (oracle/, the restated re
 kernels — the reference itself cannot be built or run here: CUDA + OpenCV).
 
   python tests/golden/make_fixtures.py            # regenerate (needs liboracle.so)
+  python tests/golden/make_fixtures.py --step-cap-only   # only tests/golden/step_cap_64x48.npz (round 5)
 
 Inputs are closed-form (tests/scenes.py) and are not stored. Per scene the file holds the
 raycast depth / colour / normal images and bounds grid, the visible count and pool pointers,
@@ -85,16 +86,33 @@ def oracle_backend(depth, color, k, pose):
                 icp_residuals=residuals)
 
 
+# ---- the march's 500-step cap (tracer.cu:437-442; tests/scenes.py STEP_CAP_*, tests/step_cap.py): a file of its own
+STEP_CAP_FILE = os.path.join(HERE, "step_cap_64x48.npz")
+
+
+def step_cap_oracle():
+    from oracle import oracle as orc
+    import step_cap
+    hv, hf = step_cap.build_host(orc)
+    depth, color, normals, bounds = orc.trace(hv, hf)
+    return dict(depth=depth, color=color, normals=normals, bounds=bounds, visible=np.sort(hv.visible()),
+                entries_sha256=digest(hv.hash_entries), voxels_sha256=digest(hv.voxels))
+
+
 def main():
     from oracle import oracle as orc
     orc.build()
     orc.set_threads(8)
-    out = {}
-    for name in SCENES:
-        for key, value in run_scene(oracle_backend, name).items():
-            out[f"{name}/{key}"] = np.asarray(value)
-    np.savez_compressed(FILE, **out)
-    print(f"{FILE}: {os.path.getsize(FILE) / 1e6:.2f} MB, {len(out)} arrays")
+    if "--step-cap-only" not in sys.argv:
+        out = {}
+        for name in SCENES:
+            for key, value in run_scene(oracle_backend, name).items():
+                out[f"{name}/{key}"] = np.asarray(value)
+        np.savez_compressed(FILE, **out)
+        print(f"{FILE}: {os.path.getsize(FILE) / 1e6:.2f} MB, {len(out)} arrays")
+    out = {f"step_cap/{key}": np.asarray(value) for key, value in step_cap_oracle().items()}
+    np.savez_compressed(STEP_CAP_FILE, **out)
+    print(f"{STEP_CAP_FILE}: {os.path.getsize(STEP_CAP_FILE) / 1e3:.1f} kB, {len(out)} arrays")
 
 
 if __name__ == "__main__":

@@ -197,3 +197,46 @@ def room_frame(k, pose, w, h, light=None):
     color = np.empty((h, w, 3), dtype=np.float32)
     color[...] = value[..., None]
     return s.astype(np.float32), color
+
+
+# ---- the march's step cap (tracer.cu:437-442): a hand-built volume whose rays take 500 steps -------------------
+# A ray's step through an allocated block is max(voxel_length, trunc * sdf) (tracer.cu:425): a slab of blocks whose
+# voxels all hold the small positive distance STEP_CAP_SDF (trunc * sdf < voxel_length) is marched one voxel length at
+# a time, and a slab deeper than 500 voxel lengths along the ray ends the march at the cap: colour (1, 0, 0), depth 0.
+# The slab is ALLOCATED by SetView itself with a truncation length of half its depth (the DDA of volume.cu:87-301
+# requests every block within +-truncation of the depth pixel), then filled by step_cap_fill and raycast with the
+# reference's truncation length. Camera-frame left half (x < 0): the deep slab, every ray capped. Right half: at
+# STEP_CAP_SURFACE the distances turn negative, so those rays hit a surface after ~250 steps — both exits in one image.
+STEP_CAP_SIZE = (64, 48)
+STEP_CAP_INTRINSICS = (800.0, 800.0, 32.0, 24.0)
+STEP_CAP_VOLUME = (8192, 2048)                    # main, excess
+STEP_CAP_VOXEL, STEP_CAP_TRUNC = 0.002, 0.04      # 2 mm voxels (16 mm blocks), the reference's truncation (volume.cu:375)
+STEP_CAP_ALLOC_DEPTH, STEP_CAP_ALLOC_TRUNC = 0.85, 0.55     # blocks from 0.30 to 1.40 m along every ray
+STEP_CAP_SDF, STEP_CAP_BEHIND, STEP_CAP_SURFACE = 0.04, -0.1, 0.8
+
+
+def step_cap_pose():
+    from vulcan_amd import vk_types as T
+    return T.Transform.translate(0.53, -0.31, 0.22) * T.Transform.rotate(0.9961947, 0.0, 0.0871557, 0.0)   # 10 degrees about y
+
+
+def step_cap_fill(entries, voxels, pose):
+    """Fills every ALLOCATED block of a volume (numpy views of the hash table and the pool, vk_types dtypes) in place:
+    distance STEP_CAP_SDF with weight 1 and colour (.2, .4, .6) with weight 1 everywhere, STEP_CAP_BEHIND where the
+    voxel centre lies in the camera's right half (x >= 0) deeper than STEP_CAP_SURFACE. Returns the allocated count."""
+    alloc = np.nonzero(entries["data"] >= 0)[0]
+    slots = entries["data"][alloc].astype(np.int64)
+    origin = entries["block"]["origin"][alloc].astype(np.float64)            # (n, 3) block coordinates
+    idx = np.arange(8, dtype=np.float64) + 0.5
+    zz, yy, xx = np.meshgrid(idx, idx, idx, indexing="ij")                   # voxel index z*64 + y*8 + x
+    local = np.stack([xx, yy, zz], axis=-1).reshape(512, 3)
+    world = (origin[:, None, :] * 8.0 + local[None, :, :]) * STEP_CAP_VOXEL  # (n, 512, 3) voxel centres
+    Tcw = pose.inverse_matrix().astype(np.float64)
+    cam = world @ Tcw[:3, :3].T + Tcw[:3, 3]
+    behind = (cam[..., 0] >= 0.0) & (cam[..., 2] > STEP_CAP_SURFACE)
+    v = voxels.reshape(-1, 512)
+    v["distance"][slots] = np.where(behind, np.float32(STEP_CAP_BEHIND), np.float32(STEP_CAP_SDF))
+    v["distance_weight"][slots] = 1
+    v["color"][slots] = np.array([0.2, 0.4, 0.6], dtype=np.float32)
+    v["color_weight"][slots] = 1
+    return len(alloc)

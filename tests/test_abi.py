@@ -52,9 +52,12 @@ def test_version_and_errors_without_gpu():
     assert lib.vk_trace_ahead_requests(None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.vk_volume_set_view_rounds_ahead(None, None, None, 3, None, None) == -1
     assert lib.vk_icp_pyramid_track_frame(None, None, None, None, None, 1, None, None, None, None, None, None, None, None, None) == -1
-    assert lib.vk_abi_version() == 5 and lib.vk_abi_check(4, 0, 0, 0) == -2      # VK_ERR_UNSUPPORTED
-    # scratch of a tracer: merged grid + 32 private grids + the normals' row counters (128 lines of 16 words)
-    assert lib.vk_trace_bounds_floats(80, 60) == 2 * 4800 * 33 + 128 * 16
+    assert lib.vk_abi_version() == 6 and lib.vk_abi_check(5, 0, 0, 0) == -2      # VK_ERR_UNSUPPORTED
+    # round 5: the cancel of an announced frame, the outcome of the normals' bounded wait
+    assert lib.vk_requests_ahead_cancel(None, None, 1, None) == -1 and lib.vk_trace_normals_settle(None, None) == -1
+    assert b"bounded wait" in lib.vk_error_string(-6)
+    # scratch of a tracer: merged grid + 32 private grids + the normals' row counters (128 lines of 16 words) + the expiry line
+    assert lib.vk_trace_bounds_floats(80, 60) == 2 * 4800 * 33 + 128 * 16 + 16
     assert lib.vk_icp_workspace_floats(640, 480) == 4 * 1200 * 32 + 32     # two parities of 1200 slots (256-pixel groups) x 32 {tag, value} words + a pose
     n = C.c_int(-5)
     lib.vk_device_count(C.byref(n))

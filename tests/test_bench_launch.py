@@ -29,6 +29,9 @@ def test_self_launch_two_ranks():
     assert out["n_gpus"] == 2 and out["system_sum"] == 3.0       # 1 + 2: the collective ran over both ranks
     assert out["max_over_ranks"] == 2.0 and out["frames_all_ranks"] == 10.0
     assert out["local_rank_env"] == 0
+    # the line says what every rank took, and whether RCCL (here: the rehearsal) saw all ranks
+    assert out["per_rank_ms_per_step"] == [1.0, 2.0]
+    assert out["collective"]["vk_comm_count"] == 2 and out["collective"]["update_identical_on_all_ranks"] is True
 
 
 def test_self_launch_reports_a_dying_rank():
@@ -48,3 +51,44 @@ def test_joins_an_external_launcher():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--selftest-launch"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, env=env, timeout=300)
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_a_rank_failing_inside_the_rig_step_ends_every_rank_non_zero():
+    """A step of the rig that raises on ONE rank (bench.vk_comm_rig's steps all go through vd.agreed_step; rehearsed here
+    over gloo with the same functions and the same exit path): every rank learns of it, the line is still printed — the
+    headline is measured before the rig step — with the error in it, and EVERY rank exits non-zero, well within the
+    rig's timeout."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--selftest-launch", "--selftest-rig-fail-rank", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_clean_env(), timeout=300)
+    assert time.time() - t0 < 120
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    assert "rank 0 exited 4" in p.stderr and "rank 1 exited 4" in p.stderr, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["system_sum"] == 3.0                          # what was measured before the failure is in the line
+    vk = out["collective"]["vk_comm"]
+    assert vk["ok"] is False and "rig step" in vk["error"]
+    # rank 0 did not fail itself: it reports the peer's failure
+    assert "another rank failed" in vk["error"]
+
+
+def test_recorded_bench_line_carries_the_raycast_figures():
+    """SURVEY 8(d)'s raycast figures were silently missing from two rounds of driver records, and
+    rounds_run_per_frame read 6.0 of at most 3. The newest bench line on file (profiles/r05_*_bench.json, written by
+    tools/round_run.sh on the GPU box) must carry them."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_*_bench.json")))
+    assert files, "no round-5 bench line recorded under profiles/"
+    d = json.load(open(files[-1]))
+    ray = d["roofline"]["raycast"]
+    assert "error" not in ray, ray.get("error")
+    for key in ("blocks_touched", "algorithmic_bytes", "algorithmic_GBps", "traffic", "gather_amplification", "avg_us"):
+        assert key in ray and ray[key], key
+    assert 1000 < ray["blocks_touched"] < 73216
+    assert 0.0 < ray["algorithmic_GBps"] < 8000.0
+    rounds = d["config"]["set_view"]["rounds_run_per_frame"]
+    assert 1.0 <= rounds <= d["config"]["set_view"]["max_rounds"] == 3
+    assert len(d["per_rank_ms_per_step"]) == d["n_gpus"]

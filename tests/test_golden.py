@@ -44,3 +44,16 @@ def test_fixture_is_small_and_complete(golden):
             assert f"{name}/{key}" in golden.files
         assert golden[f"{name}/depth"].shape == (mf.H, mf.W)
         assert (golden[f"{name}/depth"] > 0).sum() > 1000           # the scene was really raycast
+
+
+def test_oracle_reproduces_the_step_cap_vectors(orc):
+    """tests/golden/step_cap_64x48.npz: the hand-built slab whose rays reach the march's 500-step cap (tracer.cu:437-442)"""
+    assert os.path.exists(mf.STEP_CAP_FILE), "run python tests/golden/make_fixtures.py --step-cap-only"
+    golden = np.load(mf.STEP_CAP_FILE)
+    orc.set_threads(8)
+    compare(mf.step_cap_oracle(), golden, "step_cap")
+    orc.set_threads(1)
+    color, depth = golden["step_cap/color"], golden["step_cap/depth"]
+    capped = (color[..., 0] == 1) & (color[..., 1] == 0) & (color[..., 2] == 0)
+    assert capped.sum() > 1200 and np.all(depth[capped] == 0) and (depth > 0).sum() > 1200
+    assert os.path.getsize(mf.STEP_CAP_FILE) < 200 << 10

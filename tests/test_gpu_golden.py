@@ -64,6 +64,27 @@ def test_device_reproduces_the_golden_vectors(api, name):
     compare(got, golden, name)
 
 
+def test_device_reproduces_the_step_cap_vectors(api):
+    """The march's 500-step cap (tracer.cu:437-442) against tests/golden/step_cap_64x48.npz, without the oracle: the
+    device's own SetView allocates the slab (its table must have the golden digest), the voxels are the closed form of
+    tests/scenes.py, the raycast must paint the capped half (1, 0, 0) at depth 0 and hit the surface in the other."""
+    import torch
+    import step_cap
+    golden = np.load(mf.STEP_CAP_FILE)
+    dv, df = step_cap.build_device(api)
+    tracer = api.Tracer(dv)
+    w, h = df.width, df.height
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), df.depth_projection, df.depth_to_world)
+    tracer.trace(out)
+    sync()
+    got = dict(depth=out.depth.cpu().numpy(), color=out.color.cpu().numpy(), normals=out.normals.cpu().numpy(),
+               bounds=tracer.bounds.cpu().numpy(), visible=np.sort(dv.visible()),
+               entries_sha256=mf.digest(dv.host_entries()), voxels_sha256=mf.digest(dv.host_voxels()))
+    compare(got, golden, "step_cap")
+    capped, hit = step_cap.classify(got["depth"], got["color"])
+    assert capped.sum() > 1200 and hit.sum() > 1200
+
+
 def test_debug_build_reproduces_the_golden_vectors():
     """libvk_hip_debug.so (VK_DEBUG_SYNC: device synchronisation + error check after every
     launch, ref: device.h:48-52) is the same ABI and must give the same bits. Run in a child

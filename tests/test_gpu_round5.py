@@ -1,0 +1,303 @@
+"""Round 5: the parity holes and error paths VERDICT r4 / ADVICE r4 named.
+
+  * the march's 500-step cap (tracer.cu:437-442) against the oracle, through both raycast launches;
+  * configs[1]'s exact timed step — bench.FrameLoop("depth").step, request pass made ahead and not — at 640x480,
+    every image of every frame and every voxel byte (the RGB-D step has had this since round 4);
+  * the bounded wait of the raycast's riding normals has an OUTCOME: VK_ERR_TIMEOUT, and the normals recomputed;
+  * a second announce on a record that is still valid is refused, and vk_requests_ahead_cancel is the way out.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import api, assert_volume_equal, sync  # noqa: F401
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ the step cap --
+
+@pytest.mark.parametrize("launch", ["trace", "trace + next frame's requests"])
+def test_step_cap_matches_oracle(api, orc, launch):
+    """tracer.cu:437-442 on the device: depth 0 and colour (1, 0, 0) where the oracle says so, every other pixel bit for bit
+    — in compute_points_kernel (vk_trace_ahead) and in trace_and_request_kernel (vk_trace_ahead_requests), which compile
+    the march separately."""
+    import torch
+    import step_cap
+    orc.set_threads(8)
+    hv, hf = step_cap.build_host(orc)
+    odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+    orc.set_threads(1)
+    dv, df = step_cap.build_device(api)
+    assert np.array_equal(dv.host_entries(), hv.hash_entries)
+    assert dv.host_voxels().tobytes() == hv.voxels.tobytes()
+    tracer = api.Tracer(dv)
+    out = api.Frame(torch.zeros((df.height, df.width), dtype=torch.float32, device="cuda"), df.depth_projection, df.depth_to_world)
+    if launch == "trace":
+        tracer.trace(out)
+    else:
+        nxt = api.Frame(df.depth, df.depth_projection, scenes.yaw(0.5) * df.depth_to_world)
+        tracer.trace(out, next_frame=nxt)
+        assert dv.requests_ahead.valid == 1
+    sync()
+    got_d, got_c = out.depth.cpu().numpy(), out.color.cpu().numpy()
+    capped, hit = step_cap.classify(odepth, ocolor)
+    assert capped.sum() > 1200 and hit.sum() > 1200
+    assert np.array_equal(got_d, odepth) and np.array_equal(got_c, ocolor)
+    assert np.array_equal(tracer.bounds.cpu().numpy(), obounds)
+    assert np.array_equal(out.normals.cpu().numpy(), onormals, equal_nan=True)
+    assert np.all(got_d[capped] == 0) and np.all(got_c[capped] == np.array([1, 0, 0], np.float32))
+
+
+# ------------------------------------------------------------------ configs[1] --
+
+@pytest.mark.parametrize("ahead", [True, False], ids=["requests ahead", "requests inside SetView"])
+def test_depth_bench_step_matches_oracle(api, orc, ahead, monkeypatch):
+    """The exact step `bench.py --workload depth` times — bench.FrameLoop("depth", poses).step: ONE
+    vk_volume_set_view_rounds[_ahead](.., 3), vk_integrate_ahead with the raycast bounds riding along, vk_trace_ahead or —
+    bench.py's default — vk_trace_ahead_requests (trace_and_request_kernel<.., 0>: the raycast, the next frame's request
+    pass without a preparation, the raycast's normals) — six frames from the empty volume at 640x480, 5 mm,
+    Volume(65024, 8192), against three oracle SetView calls + integrate + trace per frame (vulcan.cu:316-325): every image
+    of every frame, the table after every frame and every voxel byte at the end; then once more with all six frames
+    enqueued back to back."""
+    sys.path.insert(0, ROOT)
+    import bench
+    count = 6
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    poses = [scenes.orbit_pose(i, bench.YAW_STEP) for i in range(count)]
+    monkeypatch.setattr(bench, "SPLIT_STREAMS", False)
+    monkeypatch.setattr(bench, "REQUESTS_AHEAD", ahead)
+
+    orc.set_threads(16)
+    hv = orc.HostVolume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    hf = orc.HostFrame(depth, k, T.Transform.identity())
+    want = []
+    for i in range(count):
+        hf.depth_to_world = poses[i]
+        for _ in range(3):                                    # vulcan.cu:316-318
+            hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        odepth, ocolor, onormals, obounds = orc.trace(hv, hf)
+        want.append(dict(depth=odepth, color=ocolor, normals=onormals, bounds=obounds, visible=hv.visible_count,
+                         table=hv.hash_entries.copy()))
+    orc.set_threads(1)
+
+    def compare_images(loop, w):
+        tracer = loop.vols[0]["tracer"]
+        assert tracer.view_bounds.valid == 1                  # the bounds came with the integrate launch
+        assert np.array_equal(tracer.bounds.cpu().numpy(), w["bounds"])
+        assert np.array_equal(loop.key.depth.cpu().numpy(), w["depth"])
+        assert np.array_equal(loop.key.color.cpu().numpy(), w["color"])
+        assert np.array_equal(loop.key.normals.cpu().numpy(), w["normals"], equal_nan=True)
+
+    loop = bench.FrameLoop("depth", poses)
+    assert (loop.ahead is not None) == ahead and loop.split is None
+    dv = loop.vols[0]["vol"]
+    for i in range(count):
+        loop.key.normals.fill_(-7.0)
+        sync()
+        loop.step(i)
+        sync()
+        if ahead:
+            assert loop.ahead.valid == (1 if i + 1 < count else 0)
+        assert dv.visible_count == want[i]["visible"] > 5000
+        assert np.array_equal(dv.host_entries(), want[i]["table"])
+        compare_images(loop, want[i])
+    assert_volume_equal(dv, hv)
+    assert loop.vols[0]["tracer"].view_bounds.late_host and C.c_int32.from_address(loop.vols[0]["tracer"].view_bounds.late_host).value == 0
+
+    del loop, dv
+    loop = bench.FrameLoop("depth", poses)
+    for i in range(count):
+        loop.step(i)
+    sync()
+    compare_images(loop, want[-1])
+    assert_volume_equal(loop.vols[0]["vol"], hv)
+
+
+# ------------------------------------------------- the riding normals' bounded wait --
+
+def _small_scene(api, frames=3):
+    import torch
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160.0, 120.0)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.4 + 0.1 * np.cos(5.0 * x / w) * np.sin(4.0 * y / h + 0.3)).astype(np.float32)
+    vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    integ, tracer = api.DepthIntegrator(vol), api.Tracer(vol)
+    fs = [api.Frame(depth, k, scenes.yaw(1.0 * i)) for i in range(frames)]
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, T.Transform.identity())
+    return vol, integ, tracer, fs, out
+
+
+def test_expired_normals_wait_surfaces_and_is_repaired(api, orc):
+    """vk_test_hooks.force_normals_expiry: the normals workgroups of ONE vk_trace_ahead_requests launch find their wait expired.
+    They must store nothing (the normal image keeps its -7 fill), the pinned word must be set, vk_trace_normals_settle must
+    return VK_ERR_TIMEOUT (upstream: a failed device step always throws, device.h:14-17) after enqueuing
+    Frame::ComputeNormals of the traced image — which then equals the oracle's normals of that image — and the next
+    launch with the same record works again, counters re-zeroed."""
+    vol, integ, tracer, fs, out = _small_scene(api)
+    vb = tracer.view_bounds
+    late = C.c_int32.from_address(vb.late_host)
+    vol.set_view(fs[0], rounds=3)
+    integ.integrate(fs[0])
+    # a healthy launch first: the counters stand at one launch
+    out.depth_to_world = fs[0].depth_to_world
+    tracer.trace(out, next_frame=fs[1])
+    sync()
+    assert late.value == 0 and vb.trace_launches == 1
+    tracer.settle_normals()                                   # nothing expired: no error
+    healthy = out.normals.cpu().numpy().copy()
+    assert np.array_equal(healthy, orc.compute_normals(out.depth.cpu().numpy(), out.depth_projection), equal_nan=True)
+
+    vol.set_view(fs[1], rounds=3)
+    integ.integrate(fs[1])
+    out.depth_to_world = fs[1].depth_to_world
+    out.normals.fill_(-7.0)
+    with api.test_hooks(force_normals_expiry=1):
+        tracer.trace(out, next_frame=fs[2])
+        hooks = T.TestHooks()
+        api.lib().vk_test_hooks_get(C.byref(hooks))
+        assert hooks.force_normals_expiry == 0                # it fires once
+    sync()
+    assert late.value == 1
+    assert np.all(out.normals.cpu().numpy() == -7.0)          # an expired group stores nothing
+    traced = out.depth.cpu().numpy()
+    with pytest.raises(api.VkError, match=r"\[-6\]"):
+        tracer.settle_normals()
+    sync()
+    assert late.value == 0 and vb.trace_launches == 0
+    assert np.array_equal(out.normals.cpu().numpy(), orc.compute_normals(traced, out.depth_projection), equal_nan=True)
+    tracer.settle_normals()                                   # repaired: quiet again
+
+    # the raycast itself and the next frame's request pass were not touched by the expiry
+    assert vol.requests_ahead.valid == 1
+    vol.set_view(fs[2], rounds=3)
+    integ.integrate(fs[2])
+    out.depth_to_world = fs[2].depth_to_world
+    out.normals.fill_(-7.0)
+    tracer.trace(out, next_frame=fs[0])
+    sync()
+    assert late.value == 0 and vb.trace_launches == 1
+    assert np.array_equal(out.normals.cpu().numpy(), orc.compute_normals(out.depth.cpu().numpy(), out.depth_projection), equal_nan=True)
+    vol.cancel_requests_ahead(rounds=3)
+
+
+def test_next_trace_reports_an_expired_wait_without_being_asked(api, orc):
+    """The same expiry found by the NEXT vk_trace_ahead* call (the pinned word, no synchronisation unless it is set): that
+    call repairs, launches nothing of its own, returns VK_ERR_TIMEOUT; repeated, it runs."""
+    vol, integ, tracer, fs, out = _small_scene(api)
+    late = C.c_int32.from_address(tracer.view_bounds.late_host)
+    vol.set_view(fs[0], rounds=3)
+    integ.integrate(fs[0])
+    out.depth_to_world = fs[0].depth_to_world
+    with api.test_hooks(force_normals_expiry=1):
+        tracer.trace(out, next_frame=fs[1])
+    sync()
+    assert late.value == 1
+    first = out.depth.cpu().numpy().copy()
+    vol.set_view(fs[1], rounds=3)
+    integ.integrate(fs[1])
+    out2 = api.Frame(out.depth.clone(), out.depth_projection, fs[1].depth_to_world)
+    with pytest.raises(api.VkError, match=r"\[-6\]"):
+        tracer.trace(out2, next_frame=fs[2])
+    sync()
+    assert late.value == 0 and vol.requests_ahead.valid == 0          # nothing of that call was launched
+    assert np.array_equal(out.normals.cpu().numpy(), orc.compute_normals(first, out.depth_projection), equal_nan=True)
+    tracer.trace(out2, next_frame=fs[2])                                # the repeat
+    sync()
+    assert late.value == 0 and vol.requests_ahead.valid == 1
+    assert np.array_equal(out2.normals.cpu().numpy(), orc.compute_normals(out2.depth.cpu().numpy(), out2.depth_projection), equal_nan=True)
+    vol.cancel_requests_ahead()
+
+
+# ---------------------------------------------------- announce twice / cancel --
+
+def test_second_announce_is_refused_and_cancel_completes_the_announced_set_view(api, orc):
+    """vk_trace_ahead_requests on a record that still announces a frame must launch nothing (VK_ERR_ARGUMENT); the
+    staged stages refuse while it is valid; SetView of another frame is refused with the record kept; and
+    vk_requests_ahead_cancel completes the ANNOUNCED frame's SetView — the oracle's state after SetView(announced) — after
+    which any frame goes through."""
+    import torch
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160.0, 120.0)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.4 + 0.1 * np.cos(5.0 * x / w) * np.sin(4.0 * y / h + 0.3)).astype(np.float32)
+    poses = [scenes.yaw(2.0 * i) for i in range(3)]
+    hv = orc.HostVolume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    dv = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    hfs = [orc.HostFrame(depth, k, p) for p in poses]
+    dfs = [api.Frame(depth, k, p) for p in poses]
+    integ, tracer = api.DepthIntegrator(dv), api.Tracer(dv)
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, poses[0])
+
+    hv.set_view(hfs[0], orc.POLICY_MAXKEY)
+    orc.integrate_depth(hv, hfs[0])
+    dv.set_view(dfs[0])
+    integ.integrate(dfs[0])
+    tracer.trace(out, next_frame=dfs[1])                                # announces frame 1
+    sync()
+    assert dv.requests_ahead.valid == 1
+    before = {n: getattr(dv, n).clone() for n in ("block_visibility", "allocation_types", "allocation_blocks", "counters")}
+    with pytest.raises(api.VkError, match=r"\[-1\]"):
+        tracer.trace(out, next_frame=dfs[2])                            # a second announce: refused, nothing launched
+    sync()
+    assert dv.requests_ahead.valid == 1
+    for n, t in before.items():
+        assert torch.equal(getattr(dv, n), t), n
+    for stage in (dv.reset_block_visibility, lambda: dv.create_allocation_requests(dfs[2]), dv.handle_allocation_requests):
+        with pytest.raises(api.VkError, match="announced"):
+            stage()
+    with pytest.raises(api.VkError):
+        dv.set_view(dfs[2])                                             # another frame than the announced one
+    assert dv.requests_ahead.valid == 1                                 # the record is kept: not wedged, cancel is the way out
+    dv.cancel_requests_ahead()
+    hv.set_view(hfs[1], orc.POLICY_MAXKEY)                              # = SetView(announced frame)
+    assert dv.requests_ahead.valid == 0
+    assert_volume_equal(dv, hv)
+    # any frame may follow
+    hv.set_view(hfs[2], orc.POLICY_MAXKEY)
+    orc.integrate_depth(hv, hfs[2])
+    dv.set_view(dfs[2])
+    integ.integrate(dfs[2])
+    assert_volume_equal(dv, hv)
+
+
+def test_set_view_with_compute_normals_takes_the_announced_frame(api):
+    """Tracer.trace(.., next_frame=f, next_needs_normals=True) followed by
+    Volume.set_view(f, compute_normals=True) must go through (the normals came with the pass) instead of touching the frame
+    and being refused for it."""
+    import torch
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160.0, 120.0)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.4 + 0.1 * np.cos(5.0 * x / w) * np.sin(4.0 * y / h + 0.3)).astype(np.float32)
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+    results = []
+    for announce in (False, True):
+        vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+        integ, tracer = api.LightIntegrator(vol), api.Tracer(vol)
+        integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+        f0, f1 = api.Frame(depth, k, scenes.yaw(0.0), color=color), api.Frame(depth, k, scenes.yaw(1.0), color=color)
+        out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, scenes.yaw(0.0))
+        vol.set_view(f0, rounds=3, compute_normals=True)
+        integ.integrate(f0)
+        if announce:
+            tracer.trace(out, next_frame=f1, next_needs_normals=True)
+            assert vol.requests_ahead.valid == 1
+        else:
+            tracer.trace(out)
+        vol.set_view(f1, rounds=3, compute_normals=True)
+        assert vol.requests_ahead is None or vol.requests_ahead.valid == 0
+        integ.integrate(f1)
+        sync()
+        results.append((vol.host_voxels().tobytes(), vol.host_entries().tobytes(), f1.normals.cpu().numpy()))
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    assert np.array_equal(results[0][2], results[1][2], equal_nan=True)

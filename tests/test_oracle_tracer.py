@@ -158,3 +158,71 @@ def test_compute_normals_sphere(orc):
     nn = np.linalg.norm(normals, axis=-1)
     assert np.all((np.abs(nn - 1) < 1e-4)[hit & (r < 170)])
     assert np.all(nn[~hit] == 0)
+
+
+# ---- the march's 500-step cap (tracer.cu:437-442) ---------------------------------------------------------------
+
+def test_step_cap_is_reached_and_paints_the_pixel_red(orc):
+    """tracer.cu:437-442: `if (++iters >= 500) { color = Vector3f(1, 0, 0); break; }` — the loop is left with final_depth
+    still 0. No scene a depth camera produces gets there (test_compute_points_plane asserts that for the plane); the
+    hand-built slab of tests/scenes.py STEP_CAP_* does: the left half of the image is capped, the right half hits the
+    surface behind the slab after some 250 steps."""
+    import step_cap
+    orc.set_threads(8)
+    hv, hf = step_cap.build_host(orc)
+    depth, color, normals, bounds, steps = orc.trace(hv, hf, want_steps=True)
+    orc.set_threads(1)
+    capped, hit = step_cap.classify(depth, color)
+    assert capped.sum() > 1200 and hit.sum() > 1200 and (capped | hit).all() and not (capped & hit).any()
+    assert np.all(steps[capped] == 500) and np.all(depth[capped] == 0.0)           # :437-442, and final_depth untouched
+    assert steps[hit].max() < 500 and steps[hit].min() > 200
+    # the hits are the plane z = STEP_CAP_SURFACE in the camera frame, to a voxel
+    assert np.abs(depth[hit] - scenes.STEP_CAP_SURFACE).max() < 4 * scenes.STEP_CAP_VOXEL
+    # their colour is the mean of the corners' colours (tracer.cu:282-310): the slab's constant colour
+    assert np.abs(color[hit] - np.array([0.2, 0.4, 0.6], np.float32)).max() < 1e-6
+    w, h = scenes.STEP_CAP_SIZE
+    xs = np.nonzero(capped.any(axis=0))[0]
+    assert xs.max() < w // 2 and np.nonzero(hit.any(axis=0))[0].min() >= w // 2 - 1   # left half / right half
+
+
+def test_step_cap_by_hand(orc):
+    """The same cap re-derived without the oracle's march, for four capped pixels: replay tracer.cu:358-444 in plain Python
+    with what the slab makes of it — outside an allocated block the step is one block length (:431), inside the slab the
+    nearest voxel holds STEP_CAP_SDF <= 0.1, the trilinear sample of eight equal corners is that value again (to rounding,
+    and far from the branch points 0 and voxel_length / trunc), so the step is max(voxel_length, trunc * sdf) =
+    voxel_length (:425) — and count the trips: the 500th comes while the ray is still inside the slab and in front of
+    the far bound, so the reference leaves the loop through :437-442."""
+    import step_cap
+    hv, hf = step_cap.build_host(orc)
+    depth, color, normals, bounds, steps = orc.trace(hv, hf, want_steps=True)
+    capped, _ = step_cap.classify(depth, color)
+    allocated = {tuple(int(c) for c in e["block"]["origin"]) for e in hv.hash_entries if e["data"] >= 0}
+    w, h = scenes.STEP_CAP_SIZE
+    fx, fy, cx, cy = scenes.STEP_CAP_INTRINSICS
+    Twc = hf.depth_to_world.matrix().astype(np.float64)
+    Tcw = hf.depth_to_world.inverse_matrix().astype(np.float64)
+    block, voxel = 8 * scenes.STEP_CAP_VOXEL, scenes.STEP_CAP_VOXEL
+    assert scenes.STEP_CAP_TRUNC * scenes.STEP_CAP_SDF < voxel and scenes.STEP_CAP_SDF <= 0.1
+    ys, xs = np.nonzero(capped)
+    for i in np.linspace(0, len(ys) - 1, 4).astype(int):
+        x, y = int(xs[i]), int(ys[i])
+        near, far = bounds[(60 * y) // h, (80 * x) // w]          # tracer.cu:329-331 (80 x 60 grid)
+        assert near < far
+        cam = np.array([(x + 0.5 - cx) / fx * near, (y + 0.5 - cy) / fy * near, near])
+        p = Twc[:3, :3] @ cam + Twc[:3, 3]
+        d = Twc[:3, :3] @ cam
+        d /= np.linalg.norm(d)
+        iters, inside = 0, 0
+        while True:
+            b = tuple(int(c) for c in np.floor(p / block))
+            if b in allocated:
+                p = p + voxel * d
+                inside += 1
+            else:
+                p = p + block * d
+            z = (Tcw[:3, :3] @ p + Tcw[:3, 3])[2]
+            iters += 1
+            if iters >= 500:
+                break
+            assert z < far, "the ray left its bound before the cap"
+        assert inside > 400 and steps[y, x] == 500

@@ -234,6 +234,9 @@ int vk_probe_trace_log(const vk_hash_entry* entries, const vk_voxel* voxels, con
   P.trip_log_passes = trip_log_passes;
   P.rows_done = nullptr;
   P.rows_target = 0;
+  P.late_dev = nullptr;
+  P.late_host = nullptr;
+  P.normal_polls = 0;
   const int tiles = ((image_width + 15) / 16) * ((image_height + 15) / 16);
   hipLaunchKernelGGL(count_points_kernel, dim3(tiles), dim3(256), 0, vk_s(stream), P, wave_clocks);
   VK_LAUNCH_CHECK();

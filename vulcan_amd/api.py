@@ -95,6 +95,8 @@ _SIGNATURES = {
     "vk_volume_set_view_rounds_split": ([_P, _P, _P, _I, _P, _P, _P], _I),
     "vk_trace_ahead_requests": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_volume_set_view_rounds_ahead": ([_P, _P, _P, _I, _P, _P], _I),
+    "vk_requests_ahead_cancel": ([_P, _P, _I, _P], _I),
+    "vk_trace_normals_settle": ([_P, _P], _I),
     "vk_light_prepared": ([_P, _P, C.c_float], _I),
     "vk_color_image_convert": ([_I, _P, _P, _P], _I),
     "vk_image_gradients": ([_I, _I, _P, _P, _P, _P], _I),
@@ -382,6 +384,17 @@ class Volume:
         request pass when a LightIntegrator's preparation rides along (vk_light_prep.normals_out)."""
         import torch
         self._view_changed()
+        announced = self.requests_ahead is not None and self.requests_ahead.valid == 1
+        if announced and compute_normals:
+            # Tracer.trace(.., next_frame=frame, next_needs_normals=True) has computed this frame's normals with the pass
+            # (or, without a riding preparation, as a launch of their own): nothing is due any more. Touching the frame
+            # now would give it a content id the record does not name, and the library would refuse the very frame that
+            # was announced (ADVICE r4). Any OTHER frame is refused below, by the library, with the record kept.
+            r = self.requests_ahead
+            if not (r.depth == (frame.depth.data_ptr() if frame.depth is not None else None) and r.content_id == frame.desc().content_id):
+                raise VkError("set_view(compute_normals=True): another frame was announced by Tracer.trace(next_frame=...); "
+                              "fuse that frame first, or Volume.cancel_requests_ahead()")
+            compute_normals = False
         if compute_normals:
             if self.light_prep is None:
                 frame.compute_normals()
@@ -391,7 +404,7 @@ class Volume:
                 frame.touch()                                  # the normal image's content is new
                 self.light_prep.normals_out = frame.normals.data_ptr()
         prep = _ref(self.light_prep) if self.light_prep is not None else None
-        if self.requests_ahead is not None and self.requests_ahead.valid == 1:
+        if announced:
             # Tracer.trace(frame, next_frame=...) announced a frame: its request pass is made, this must be its SetView
             # (vk_volume_set_view_rounds_ahead refuses any other frame)
             check(lib().vk_volume_set_view_rounds_ahead(_ref(self.desc()), _ref(frame.desc()), prep, int(rounds),
@@ -408,15 +421,33 @@ class Volume:
         else:
             check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
 
+    def cancel_requests_ahead(self, rounds=1):
+        """vk_requests_ahead_cancel: the way out of an announced frame that will not be fused as announced — its SetView is
+        completed from the record (handle + visibility pass), after which any frame may follow."""
+        if self.requests_ahead is None:
+            return
+        self._view_changed()
+        check(lib().vk_requests_ahead_cancel(_ref(self.desc()), _ref(self.requests_ahead), int(rounds), stream()),
+              "vk_requests_ahead_cancel")
+
+    def _no_requests_pending(self, stage):
+        # the staged SetView stages on top of an announced frame's requests would mix two frames' state (vk.h)
+        if self.requests_ahead is not None and self.requests_ahead.valid == 1:
+            raise VkError(f"{stage}: a frame announced by Tracer.trace(next_frame=...) has its requests in the volume; "
+                          "set_view(that frame) or cancel_requests_ahead() first")
+
     def reset_block_visibility(self):
+        self._no_requests_pending("reset_block_visibility")
         check(lib().vk_volume_reset_block_visibility(_ref(self.desc()), stream()), "reset_block_visibility")
 
     def create_allocation_requests(self, frame):
+        self._no_requests_pending("create_allocation_requests")
         check(lib().vk_volume_create_allocation_requests(
             _ref(self.desc()), _ptr(frame.depth), frame.width, frame.height,
             _ref(frame.depth_projection), _ref(frame.depth_to_world), stream()), "create_allocation_requests")
 
     def handle_allocation_requests(self):
+        self._no_requests_pending("handle_allocation_requests")
         check(lib().vk_volume_handle_allocation_requests(_ref(self.desc()), stream()), "handle_allocation_requests")
 
     def update_block_visibility(self, frame):
@@ -578,8 +609,25 @@ class Tracer:
         vb.scratch = self.bounds_scratch.data_ptr()
         vb.bounds_width, vb.bounds_height = self.BOUNDS_W, self.BOUNDS_H
         vb.min_depth, vb.max_depth = self.depth_range
+        # the pinned word a normals workgroup sets when its bounded wait expires (vk.h vk_view_bounds.late_host)
+        self._late = C.c_void_p()
+        check(lib().vk_malloc_host(C.byref(self._late), 4), "vk_malloc_host")
+        C.memset(self._late, 0, 4)
+        vb.late_host = self._late.value
         self.view_bounds = vb
         volume.attach_view_bounds(vb)
+
+    def __del__(self):
+        late = getattr(self, "_late", None)
+        if late is not None and late.value and _LIB is not None:
+            self.view_bounds.late_host = None
+            _LIB.vk_free_host(late)
+            self._late = None
+
+    def settle_normals(self):
+        """vk_trace_normals_settle: synchronises, and raises VkError (VK_ERR_TIMEOUT) when a normals workgroup of the last
+        trace(next_frame=...) gave up its wait — the normals have then been recomputed by a launch of their own."""
+        check(lib().vk_trace_normals_settle(_ref(self.view_bounds), stream()), "vk_trace_normals_settle")
 
     def trace(self, frame, next_frame=None, next_needs_normals=False):
         """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals. `next_frame` (not upstream): the frame the

@@ -181,15 +181,26 @@ class Communicator:
         from . import api
         if self.exchange is None:
             self.attach_exchange()
-        aborted, out = False, None
+        aborted, out, failure = False, None, None
         try:
             out = api.track_rig(tracker, frame, self.exchange)
         except api.TrackAborted:
             aborted = True
+        except BaseException as e:     # noqa: BLE001  a VkError, a HIP error, a KeyboardInterrupt: anything that is not a pose
+            # this rank takes no further part in the Track, and its peers must learn that the same way they learn of an
+            # abort — otherwise they wait in agree(), or in their next in-launch exchange, for a rank that has left
+            # (ADVICE r4). The exception travels on, after the collective.
+            aborted, failure = True, e
         finally:
             self.exchange.sequence = lib().vk_comm_exchange_next_sequence(self.exchange.sequence)
         if self.agree is not None:
-            aborted = bool(self.agree(aborted))              # collective: everybody learns of anybody's abort
+            try:
+                aborted = bool(self.agree(aborted))          # collective: everybody learns of anybody's abort
+            except BaseException:     # noqa: BLE001
+                if failure is None:
+                    raise
+        if failure is not None:
+            raise failure
         if aborted:
             raise api.TrackAborted("a rank of the rig gave up waiting for a peer's sums (VK_TRACK_ABORTED)")
         return out

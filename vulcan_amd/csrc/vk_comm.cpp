@@ -67,6 +67,11 @@ struct Communicator
 {
   Comm comm;     // null for the single-rank loopback
   int rank, world;
+  // Device buffers of vk_comm_exchange_attach's collectives (handle all-gather + verdict all-reduce), allocated by
+  // vk_comm_init: a rank that ran out of memory INSIDE the attach could not take part in the collective that tells
+  // its peers so — here the attach has nothing left to allocate but the area itself, whose failure travels
+  // in the verdict. Null for the loopback.
+  void* staging;
 };
 
 // ---- the part of the HIP runtime the rig exchange needs (hip_runtime_api.h), bound like RCCL ----
@@ -165,6 +170,9 @@ int map_peers(const Hip* h, RigExchange* x, const IpcHandle* all)
 
 inline int from_nccl(Result r) { return r == 0 ? VK_OK_ : 1000 + r; }
 
+// send handle | world received handles | {my verdict, everybody's}
+constexpr size_t kStagingBytes = (size_t)kIpcHandleBytes * (size_t)(kRigMaxRanks + 1) + 2 * sizeof(float);
+
 }  // namespace
 
 extern "C" {
@@ -186,7 +194,7 @@ int vk_comm_init(void** comm, const void* id, int rank, int world)
   if (!comm) return VK_ERR_ARGUMENT_;
   *comm = nullptr;
   if (world < 1 || rank < 0 || rank >= world) return VK_ERR_ARGUMENT_;
-  Communicator* c = new Communicator{nullptr, rank, world};
+  Communicator* c = new Communicator{nullptr, rank, world, nullptr};
   if (world > 1 && !id) { delete c; return VK_ERR_ARGUMENT_; }
   if (id)   // world == 1 with an id: a real one-rank RCCL communicator; without: a loopback
   {
@@ -196,6 +204,14 @@ int vk_comm_init(void** comm, const void* id, int rank, int world)
     memcpy(u.internal, id, VK_COMM_ID_BYTES);
     const Result rc = r->CommInitRank(&c->comm, world, u, rank);
     if (rc != 0) { delete c; return from_nccl(rc); }
+    // the attach's device buffers, now (a rank-local failure: the caller agrees on the outcome of vk_comm_init over its
+    // own channel before anybody enters a collective of this communicator, bench.py vk_comm_rig). Without a HIP runtime
+    // the communicator still sums; vk_comm_exchange_attach then returns VK_COMM_ERR_NO_RCCL on every rank alike.
+    if (const Hip* h = hip())
+    {
+      const int mrc = h->Malloc(&c->staging, kStagingBytes);
+      if (mrc != 0) { (void)r->CommDestroy(c->comm); delete c; return mrc; }
+    }
   }
   *comm = c;
   return VK_OK_;
@@ -252,16 +268,9 @@ int vk_comm_exchange_attach(void* comm, void* exchange)
   IpcHandle mine;
   memset(&mine, 0, sizeof(mine));
   if (rc == 0) rc = h->IpcGetMemHandle(&mine, x->areas[c->rank]);
-  void* staging = nullptr;
-  const size_t staging_bytes = (size_t)kIpcHandleBytes * (size_t)(c->world + 1) + 2 * sizeof(float);
-  const int staging_rc = h->Malloc(&staging, staging_bytes);
-  if (staging_rc != 0)
-  {
-    // no device memory for the collective's buffers at all: this rank cannot even take part (its peers' calls
-    // then fail or time out inside RCCL, which reports it); nothing better can be done from here
-    vk_comm_exchange_detach(comm, exchange);
-    return staging_rc;
-  }
+  // the collectives' buffers were allocated by vk_comm_init: nothing on this path can keep a rank out of them
+  void* staging = c->staging;
+  if (!staging) { vk_comm_exchange_detach(comm, exchange); return VK_ERR_ARGUMENT_; }   // (a communicator not made by vk_comm_init)
   char* send = static_cast<char*>(staging);
   char* recv = send + kIpcHandleBytes;
   float* verdict = reinterpret_cast<float*>(recv + (size_t)kIpcHandleBytes * (size_t)c->world);
@@ -284,7 +293,6 @@ int vk_comm_exchange_attach(void* comm, void* exchange)
     step = nr == 0 ? h->DeviceSynchronize() : 1000 + nr;
   }
   if (step == 0) step = h->Memcpy(&everyone, verdict + 1, sizeof(float), kCopyDefault);
-  h->Free(staging);
   if (rc == 0 && step != 0) rc = step;
   if (rc == 0 && everyone != 1.0f) rc = VK_COMM_ERR_PEER;
   if (rc != 0) vk_comm_exchange_detach(comm, exchange);
@@ -348,6 +356,7 @@ int vk_comm_destroy(void* comm)
   Communicator* c = static_cast<Communicator*>(comm);
   int rc = VK_OK_;
   if (c->comm) rc = from_nccl(g_rccl.CommDestroy(c->comm));
+  if (c->staging) { if (const Hip* h = hip()) (void)h->Free(c->staging); }
   delete c;
   return rc;
 }

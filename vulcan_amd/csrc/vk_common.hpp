@@ -41,8 +41,9 @@ static inline hipStream_t vk_s(void* stream) { return reinterpret_cast<hipStream
 
 // a field of vk_test_hooks (vk.h), by position; defined in vk_runtime.hip
 enum { VK_HOOK_POSTED_CAPACITY = 0, VK_HOOK_RETRY_CAPACITY, VK_HOOK_SET_VIEW_UNFUSED, VK_HOOK_FORCE_LOOP_ABORT,
-       VK_HOOK_LOOP_GRID_CAP, VK_HOOK_LOOP_COOPERATIVE };
+       VK_HOOK_LOOP_GRID_CAP, VK_HOOK_LOOP_COOPERATIVE, VK_HOOK_FORCE_NORMALS_EXPIRY };
 int vk_hook(int field);
+int vk_hook_take(int field);   // the value, and 0 from then on
 
 namespace vk
 {

@@ -51,6 +51,11 @@ struct PointParams
   // 8-pixel row of tiles, bumped by every wave that has written its tile's depths; nullptr = nobody waits for them.
   uint32_t* rows_done;
   uint32_t rows_target;        // a row is complete once (int)(rows_done[row] - rows_target) >= 0
+  // the outcome of that wait when it expires (vk.h vk_view_bounds.late_host): a word behind the counters, and the
+  // caller's pinned word or nullptr; normal_polls: how often a group looks before it gives up
+  uint32_t* late_dev;
+  int32_t* late_host;
+  int normal_polls;
 };
 
 // a / b, correctly rounded, for a divisor known on the host: inv_b = RN64(1 / b).

@@ -33,18 +33,20 @@ uint32_t vk_next_loop_epoch()
 // vk_test_hooks (vk.h): one copy per library image, every field an atomic of its own
 namespace
 {
-std::atomic<int32_t> g_hooks[6] = {{-1}, {0}, {0}, {0}, {0}, {0}};
+std::atomic<int32_t> g_hooks[7] = {{-1}, {0}, {0}, {0}, {0}, {0}, {0}};
 }
 int vk_hook(int field) { return g_hooks[field].load(std::memory_order_relaxed); }
+// a hook that fires once: its value, and 0 from then on
+int vk_hook_take(int field) { return g_hooks[field].exchange(0, std::memory_order_relaxed); }
 
 extern "C" {
 int vk_test_hooks_set(const vk_test_hooks* h)
 {
-  const vk_test_hooks defaults = {-1, 0, 0, 0, 0, 0};
+  const vk_test_hooks defaults = {-1, 0, 0, 0, 0, 0, 0};
   if (!h) h = &defaults;
-  const int32_t v[6] = {h->posted_capacity, h->retry_capacity, h->set_view_unfused, h->force_loop_abort,
-                        h->loop_grid_cap, h->loop_cooperative};
-  for (int i = 0; i < 6; ++i) g_hooks[i].store(v[i], std::memory_order_relaxed);
+  const int32_t v[7] = {h->posted_capacity, h->retry_capacity, h->set_view_unfused, h->force_loop_abort,
+                        h->loop_grid_cap, h->loop_cooperative, h->force_normals_expiry};
+  for (int i = 0; i < 7; ++i) g_hooks[i].store(v[i], std::memory_order_relaxed);
   return VK_OK;
 }
 int vk_test_hooks_get(vk_test_hooks* out)
@@ -56,6 +58,7 @@ int vk_test_hooks_get(vk_test_hooks* out)
   out->force_loop_abort = vk_hook(3);
   out->loop_grid_cap = vk_hook(4);
   out->loop_cooperative = vk_hook(5);
+  out->force_normals_expiry = vk_hook(6);
   return VK_OK;
 }
 }
@@ -119,6 +122,7 @@ const char* vk_error_string(int code)
     case VK_ERR_ARGUMENT: return "invalid argument [vk error -1]";
     case VK_ERR_UNSUPPORTED: return "unsupported [vk error -2]";
     case VK_ERR_NO_DEVICE: return "no HIP device [vk error -3]";
+    case VK_ERR_TIMEOUT: return "a bounded wait inside a launch expired [vk error -6]";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -232,6 +232,7 @@ constexpr int kNormalRowStride = 16;      // words: a 64-byte line per counter (
                                           // polls of ONE row meet on a line; with 16 counters to a line the polls of a few
                                           // hundred waiting groups held up the increments they were waiting for)
 constexpr int kNormalWaitPolls = 1 << 16; // x s_sleep(32): some 60 ms
+constexpr int kNormalLateWords = 16;      // one more line behind the counters: word 0 = a group's wait has expired
 
 #ifndef VK_TR_WAVES
 #define VK_TR_WAVES 5
@@ -339,18 +340,31 @@ __device__ __forceinline__ float depth_through(const float* depths, int w, int h
   return (x >= 0 && x < w && y >= 0 && y < h) ? __hip_atomic_load(&depths[y * w + x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
 }
 
-__device__ __forceinline__ void normals_group(const PointParams& P, float* __restrict__ normals, int group_x, int group_y)
+// The wait is bounded, and its expiry has an OUTCOME (round 5): the group stores nothing — normals from depths that are
+// not all there would be wrong without anyone knowing — and says so in the word behind the counters and in the caller's
+// pinned word; the host side repairs and reports it (vk_trace_normals_settle, and the check at the start of trace_ahead).
+__device__ __forceinline__ void normals_group(const PointParams& P, float* __restrict__ normals, int group_x, int group_y, int* expired)
 {
   if (threadIdx.x == 0)
   {
     const int first = vmaxi(group_y * 4 - 2, 0) >> 3, last = vmini(group_y * 4 + 5, P.image_height - 1) >> 3;
     int polls = 0;
-    for (int row = first; row <= last; ++row)
-      while ((int)(__hip_atomic_load(&P.rows_done[row * kNormalRowStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.rows_target) < 0 &&
-             ++polls < kNormalWaitPolls)
+    bool late = false;
+    for (int row = first; row <= last && !late; ++row)
+      while ((int)(__hip_atomic_load(&P.rows_done[row * kNormalRowStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.rows_target) < 0)
+      {
+        if (++polls > P.normal_polls) { late = true; break; }
         __builtin_amdgcn_s_sleep(32);
+      }
+    *expired = late ? 1 : 0;
+    if (late)
+    {
+      __hip_atomic_store(P.late_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.late_host) __hip_atomic_store(P.late_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
+  if (*expired) return;
   const int x = group_x * 64 + (threadIdx.x & 63);
   const int y = group_y * 4 + (threadIdx.x >> 6);
   if (x >= P.image_width || y >= P.image_height) return;
@@ -380,6 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES
     RequestParams R, Retry retry, int trace_groups, int request_groups_x, int request_groups, float* normals)
 {
   __shared__ int4 directories[4][kDirWords];
+  __shared__ int normals_expired;
   if ((int)blockIdx.x < trace_groups)
   {
     points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES
     return;
   }
   const int n = g - request_groups, normal_groups_x = (P.image_width + 63) / 64;
-  normals_group(P, normals, n % normal_groups_x, n / normal_groups_x);
+  normals_group(P, normals, n % normal_groups_x, n / normal_groups_x, &normals_expired);
 }
 
 // ------------------------------------------------------------------ normals ----
@@ -496,7 +511,8 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
     const vk_transform* Twc, const vk_projection* projection, float* depths, float* colors,
     int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
     hipStream_t s, float* normals = nullptr, uint32_t* rows_done = nullptr, uint32_t rows_target = 0,
-    const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr, int next_prep = 0)
+    const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr, int next_prep = 0,
+    int32_t* late_host = nullptr, int normal_polls = kNormalWaitPolls)
 {
   PointParams P;
   P.entries = entries;
@@ -516,6 +532,9 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.trip_log_passes = 0;
   P.rows_done = (normals && rows_done && next_requests) ? rows_done : nullptr;
   P.rows_target = rows_target;
+  P.late_dev = P.rows_done ? P.rows_done + kNormalRows * kNormalRowStride : nullptr;
+  P.late_host = late_host;
+  P.normal_polls = normal_polls;
   P.Twc = make_rt(Twc->m);
   P.Tcw = make_rt(Twc->inv);  // tracer.cu:350 Twc.Inverse()
   P.k = make_projection(*projection);
@@ -658,7 +677,8 @@ size_t vk_trace_bounds_floats(int bounds_width, int bounds_height)
   if (bounds_width <= 0 || bounds_height <= 0) return 0;
   const size_t cells = (size_t)bounds_width * bounds_height;
   // the merged grid, the private grids of the fused bounds pass, and the row counters of the raycast's normals (normals_group)
-  return 2 * cells * (cells <= (size_t)kBoundsMaxCells ? 1 + kBoundsGroups : 1) + kNormalRows * kNormalRowStride;
+  // ... and the line that says a normals workgroup's wait has expired
+  return 2 * cells * (cells <= (size_t)kBoundsMaxCells ? 1 + kBoundsGroups : 1) + kNormalRows * kNormalRowStride + kNormalLateWords;
 }
 
 int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float max_depth,
@@ -695,6 +715,31 @@ int vk_trace(const vk_volume* v, const vk_frame* frame, float min_depth, float m
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 
+// the row counters and the expiry line behind the grids of a tracer's scratch (nullptr: a grid too large for private copies)
+static uint32_t* normals_counters(const vk_view_bounds* ahead)
+{
+  const int cells = ahead->bounds_width * ahead->bounds_height;
+  if (cells > kBoundsMaxCells) return nullptr;
+  return reinterpret_cast<uint32_t*>(ahead->scratch + 2 * (size_t)cells * (1 + kBoundsGroups));
+}
+
+// A normals workgroup's wait has expired (the stream has been synchronised by the caller): counters, expiry words and
+// launch count start over, and the normals of the last traced image are made by a launch of their own.
+static int normals_repair(vk_view_bounds* ahead, hipStream_t s)
+{
+  uint32_t* counters = normals_counters(ahead);
+  if (counters) VK_CHECK(hipMemsetAsync(counters, 0, (kNormalRows * kNormalRowStride + kNormalLateWords) * sizeof(uint32_t), s));
+  if (ahead->late_host) __atomic_store_n(ahead->late_host, 0, __ATOMIC_RELAXED);
+  ahead->trace_launches = 0;
+  if (ahead->last_depths && ahead->last_normals && ahead->last_width > 0 && ahead->last_height > 0)
+  {
+    const int rc = launch_normals(ahead->last_depths, &ahead->last_projection, ahead->last_normals, ahead->last_width,
+        ahead->last_height, s);
+    if (rc != VK_OK) return rc;
+  }
+  return VK_ERR_TIMEOUT;
+}
+
 static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
     float* out_color, float* out_normals, void* stream, const RequestParams* next_requests, const Retry* next_retry, int next_prep)
 {
@@ -702,6 +747,12 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
   VK_REQUIRE(v->hash_entries && v->voxels && v->visible_blocks && v->counters);
   VK_REQUIRE(ahead->bounds_width > 0 && ahead->bounds_height > 0);
   hipStream_t s = vk_s(stream);
+  // the last launch's riding normals: did a group give up? (the pinned word, no synchronisation unless it is set)
+  if (ahead->late_host && __atomic_load_n(ahead->late_host, __ATOMIC_RELAXED) != 0)
+  {
+    VK_CHECK(hipStreamSynchronize(s));
+    return normals_repair(ahead, s);      // VK_ERR_TIMEOUT, nothing of this call launched: the caller repeats it
+  }
   const float block_length = VK_BLOCK_RESOLUTION * v->voxel_length;
   const int cells = ahead->bounds_width * ahead->bounds_height;
   float* bounds = ahead->scratch;
@@ -729,27 +780,47 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
   if (normals_ride)
   {
     rows_done = reinterpret_cast<uint32_t*>(bounds + 2 * (size_t)cells * (1 + kBoundsGroups));
-    if (ahead->counted_scratch != bounds || ahead->counted_width != frame->width || ahead->counted_height != frame->height)
+    // (another stream than the last launch's: the counters count launches in STREAM order — they start over on the new
+    // one; vk.h says the caller has let the old stream's launch complete)
+    if (ahead->counted_scratch != bounds || ahead->counted_width != frame->width || ahead->counted_height != frame->height ||
+        ahead->counted_stream != stream)
     {
-      VK_CHECK(hipMemsetAsync(rows_done, 0, kNormalRows * kNormalRowStride * sizeof(uint32_t), s));
+      VK_CHECK(hipMemsetAsync(rows_done, 0, (kNormalRows * kNormalRowStride + kNormalLateWords) * sizeof(uint32_t), s));
       ahead->counted_scratch = bounds;
       ahead->counted_width = frame->width;
       ahead->counted_height = frame->height;
+      ahead->counted_stream = stream;
       ahead->trace_launches = 0;
     }
     rows_target = (ahead->trace_launches + 1u) * (uint32_t)waves_per_row;   // (wraps with the counters)
+  }
+  // vk_test_hooks.force_normals_expiry, once: a target no counter reaches and no patience
+  int normal_polls = kNormalWaitPolls;
+  if (normals_ride && vk_hook_take(VK_HOOK_FORCE_NORMALS_EXPIRY) == 1)
+  {
+    rows_target += 0x40000000u;
+    normal_polls = 0;
   }
   if ((rc = launch_points(v->hash_entries, v->voxels, bounds, partials, v->main_block_count, block_length,
            v->voxel_length, v->truncation_length, &frame->depth_to_world, &frame->depth_projection,
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
            (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s,
-           normals_ride ? out_normals : nullptr, rows_done, rows_target, next_requests, next_retry, next_prep)) != VK_OK)
+           normals_ride ? out_normals : nullptr, rows_done, rows_target, next_requests, next_retry, next_prep,
+           ahead->late_host, normal_polls)) != VK_OK)
     return rc;
   if (normals_ride)
   {
     ++ahead->trace_launches;
+    // which images the riding normals belong to: what a repair recomputes
+    ahead->last_depths = out_depth;
+    ahead->last_normals = out_normals;
+    ahead->last_width = frame->width;
+    ahead->last_height = frame->height;
+    ahead->last_projection = frame->depth_projection;
     return VK_OK;
   }
+  ahead->last_depths = nullptr;             // the normals were a launch of their own: nothing rides, nothing to repair
+  ahead->last_normals = nullptr;
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 
@@ -764,6 +835,9 @@ int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bo
     void* stream)
 {
   VK_REQUIRE(v && next && requests);
+  // a record that still announces a frame: that frame's requests are in the volume and its SetView has not run — a second
+  // pass on top would mix two frames' requests (vk.h vk_requests_ahead_cancel is the way out). Nothing is launched.
+  if (requests->valid == 1) return VK_ERR_ARGUMENT;
   requests->valid = 0;
   // the pass is made ahead only in the form SetView itself would give it without further launches: a frame that names
   // its content, and — when its normals are still to be computed — a preparation that rides (the normals come with it)
@@ -790,6 +864,22 @@ int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bo
   requests->content_id = next->content_id;
   requests->valid = 1;
   return VK_OK;
+}
+
+int vk_trace_normals_settle(vk_view_bounds* ahead, void* stream)
+{
+  VK_REQUIRE(ahead && ahead->scratch && ahead->bounds_width > 0 && ahead->bounds_height > 0);
+  hipStream_t s = vk_s(stream);
+  VK_CHECK(hipStreamSynchronize(s));
+  bool late = false;
+  if (ahead->late_host) late = __atomic_load_n(ahead->late_host, __ATOMIC_RELAXED) != 0;
+  else if (ahead->counted_scratch == ahead->scratch && normals_counters(ahead))
+  {
+    uint32_t word = 0;
+    VK_CHECK(hipMemcpy(&word, normals_counters(ahead) + kNormalRows * kNormalRowStride, sizeof(word), hipMemcpyDeviceToHost));
+    late = word != 0;
+  }
+  return late ? normals_repair(ahead, s) : VK_OK;
 }
 
 }  // extern "C"

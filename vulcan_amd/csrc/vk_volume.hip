@@ -924,6 +924,9 @@ __device__ __forceinline__ unsigned long long arrival(int visible, int excess, i
 // locations has been consumed by then (the arrival's addend and the slots it reserves are computed from them, so the
 // loads have returned), and a CU issues a wave's memory operations in order. A port to a part that lets a load
 // complete after a younger atomic of another lane of its workgroup would have to arrive with release semantics.
+#ifndef VK_HANDLE_ALWAYS_FENCED
+#define VK_HANDLE_ALWAYS_FENCED 0
+#endif
 __device__ __forceinline__ unsigned long long arrive(const vk_volume& v, unsigned long long add, bool fenced)
 {
   unsigned long long* word = reinterpret_cast<unsigned long long*>(v.counters + VK_CTR_ARRIVALS);
@@ -1106,7 +1109,9 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   const bool contest = contended != 0 || (origin_seen != 0 && v.allocation_types[origin_bucket] != VK_ALLOC_NONE);
   // (the flag-scan form also arrives with release / acquire: its last workgroup reads VK_CTR_DROPPED_NOW, which the
   // others wrote, and clears the flags all of them read; it is the rare form, the fences cost it nothing that matters)
-  const bool fenced = contest || !listed;
+  // (-DVK_HANDLE_ALWAYS_FENCED=1: every arrival ordered, for the A/B ADVICE r3 / VERDICT r4 asked for; the numbers are
+  // beside arrive())
+  const bool fenced = VK_HANDLE_ALWAYS_FENCED || contest || !listed;
   const bool losers = P.max_rounds > 1 && contest;
   const uint32_t* list = reinterpret_cast<const uint32_t*>(posted_list(v.counters));
 
@@ -1431,6 +1436,39 @@ int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float de
   return (frame && prep_is_for(prep, frame) && prep->prepared_threshold == depth_threshold) ? 1 : 0;
 }
 
+// SetView's second launch — the handle pass, the visibility pass and the later rounds (volume.cu:520-535, :473-495): what
+// follows a request pass, whoever made it and when. `Tdw`: the 16 floats of depth_to_world's cached inverse.
+static int launch_handle_visibility(const vk_volume* v, int width, int height, const vk_projection& k, const float* Tdw,
+    int max_rounds, hipStream_t s)
+{
+  const int handle_groups = (v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
+  const int vis_groups = (v->main_block_count + v->excess_block_count + kVisPerGroup - 1) / kVisPerGroup;
+  if (!set_view_unfused(v))
+  {
+    // two launches: requests, then handle + visibility (+ the later rounds, if a request lost)
+    FusedParams F;
+    F.vis.v = *v;
+    F.vis.finish_handle = 0;
+    F.vis.deferred_reset = 1;
+    F.vis.width = width;
+    F.vis.height = height;
+    F.vis.k = k;
+    F.vis.Tdw = make_rt(Tdw);
+    F.handle_wgs = handle_groups < VK_POSTED_SLOTS / kHandleThreads ? handle_groups : VK_POSTED_SLOTS / kHandleThreads;
+    F.max_rounds = max_rounds;
+    F.retry_capacity = retry_capacity();
+    F.posted_capacity = posted_capacity();
+    hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
+  // the three-launch form (vk_test_hooks.set_view_unfused: kept for comparison and as the reference for the fused one)
+  hipLaunchKernelGGL(handle_rounds_kernel, dim3(handle_groups), dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
+  VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
+  return launch_update_visibility(v, width, height, &k,
+      Tdw, max_rounds, true, s);
+}
+
 // `request_stream` / `ordering` (vk_volume_set_view_rounds_split): the request pass — and the normals launch, when the
 // call has to make it — go to request_stream; `ordering` is recorded behind them there and `stream` waits for it before
 // the handle + visibility pass.
@@ -1493,32 +1531,7 @@ static int set_view(const vk_volume* v, const vk_frame* frame, vk_light_prep* pr
     VK_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(ordering), vk_s(first_stream)));
     VK_CHECK(hipStreamWaitEvent(s, reinterpret_cast<hipEvent_t>(ordering), 0));
   }
-  const int handle_groups = (v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
-  const int vis_groups = (v->main_block_count + v->excess_block_count + kVisPerGroup - 1) / kVisPerGroup;
-  if (!set_view_unfused(v))
-  {
-    // two launches: requests, then handle + visibility (+ the later rounds, if a request lost)
-    FusedParams F;
-    F.vis.v = *v;
-    F.vis.finish_handle = 0;
-    F.vis.deferred_reset = 1;
-    F.vis.width = frame->width;
-    F.vis.height = frame->height;
-    F.vis.k = frame->depth_projection;
-    F.vis.Tdw = make_rt(frame->depth_to_world.inv);
-    F.handle_wgs = handle_groups < VK_POSTED_SLOTS / kHandleThreads ? handle_groups : VK_POSTED_SLOTS / kHandleThreads;
-    F.max_rounds = max_rounds;
-    F.retry_capacity = retry_capacity();
-    F.posted_capacity = posted_capacity();
-    hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
-    VK_LAUNCH_CHECK();
-    return VK_OK;
-  }
-  // the three-launch form (vk_test_hooks.set_view_unfused: kept for comparison and as the reference for the fused one)
-  hipLaunchKernelGGL(handle_rounds_kernel, dim3(handle_groups), dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
-  VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
-  return launch_update_visibility(v, frame->width, frame->height, &frame->depth_projection,
-      frame->depth_to_world.inv, max_rounds, true, s);
+  return launch_handle_visibility(v, frame->width, frame->height, frame->depth_projection, frame->depth_to_world.inv, max_rounds, s);
 }
 
 int vk_volume_set_view(const vk_volume* v, const vk_frame* frame, void* stream)
@@ -1548,6 +1561,19 @@ int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* frame, v
     vk_requests_ahead* requests, void* stream)
 {
   return set_view(v, frame, prep, max_rounds, stream, nullptr, nullptr, requests);
+}
+
+int vk_requests_ahead_cancel(const vk_volume* v, vk_requests_ahead* requests, int max_rounds, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(requests && max_rounds >= 1);
+  if (requests->valid != 1) return VK_OK;                       // nothing announced, nothing pending
+  VK_REQUIRE(requests->counters == v->counters && requests->width > 0 && requests->height > 0);
+  requests->valid = 0;
+  // the announced frame's SetView, completed: its requests are handled, its visible list made — a state upstream reaches
+  return launch_handle_visibility(v, requests->width, requests->height, requests->depth_projection,
+      requests->depth_to_world.inv, max_rounds, vk_s(stream));
 }
 
 int vk_volume_read_counters_sync(const vk_volume* v, int32_t* host_out, void* stream)

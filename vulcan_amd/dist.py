@@ -86,3 +86,33 @@ def all_ok(ok, device="cpu"):
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(int(t.item()))
+
+
+def gather_over_ranks(value, device="cpu"):
+    """The python float of every rank, in rank order (bench.py: per-rank ms_per_step next to the max)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+class StepFailed(RuntimeError):
+    """Raised by agreed_step on EVERY rank when the step failed on ANY rank."""
+
+
+def agreed_step(what, step, device="cpu"):
+    """Runs a rank-local step that may fail on one rank alone (creating a communicator, mapping a peer's memory, a
+    check of what RCCL reports) and makes its OUTCOME collective: every rank learns whether all ranks passed before any of
+    them enters the next collective. Returns the step's value; raises StepFailed — on every rank, with this rank's own
+    error text or "another rank failed" — if any rank failed. A rank that raised on its own would leave the others
+    inside the next collective until a timeout."""
+    value, error = None, None
+    try:
+        value = step()
+    except Exception as e:     # noqa: BLE001  (the text travels in the JSON line)
+        error = f"{type(e).__name__}: {e}"[:300]
+    if not all_ok(error is None, device=device):
+        raise StepFailed(f"{what}: {error}" if error else f"another rank failed in: {what}")
+    return value

@@ -57,6 +57,12 @@ class Tracer
     // The results are those of Trace(frame); ...; SetView(next_frame), bit for bit (vk_trace_ahead_requests).
     void Trace(Frame& frame, Frame& next_frame, bool next_needs_normals = false);
 
+    // Not upstream: the normals of Trace(frame, next_frame) are computed by workgroups of the raycast's own launch that
+    // WAIT for the depths they need — a bounded wait. SettleNormals synchronises the stream and throws (upstream: a failed
+    // device step always throws, device.h:14-17) if a wait expired; the normal image has then been recomputed by a launch
+    // of its own. The next Trace makes the same check without synchronising (vk_trace_normals_settle).
+    void SettleNormals();
+
   protected:
     void ComputePatches(const Frame& frame);
     void ComputeBounds(const Frame& frame);

@@ -110,6 +110,9 @@ class Volume
     // handle + visibility pass; any other SetView while the record is valid throws (the announced frame's requests
     // are in the volume and have to be handled first).
     vk_requests_ahead* GetRequestsAhead() const { return &requests_ahead_; }
+    // The way out of an announced frame that will not be fused as announced (vk_requests_ahead_cancel): its SetView is
+    // completed from the record — `rounds` as in SetView — and any frame may follow. No-op without a valid record.
+    void CancelRequestsAhead(int rounds = 1);
 
   protected:
     // the four stages of SetView, in call order
@@ -145,6 +148,7 @@ class Volume
     void* requested_;                   // event behind the request pass
     void* integrated_;                  // event behind the last Integrate
     mutable bool integrated_recorded_;
+    mutable int32_t* normals_late_;     // pinned: vk_view_bounds.late_host of the attached tracer's record
 
   private:
     void Initialize();

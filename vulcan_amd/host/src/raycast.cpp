@@ -90,6 +90,14 @@ void Tracer::Trace(Frame& frame)
   TraceWith(frame, nullptr, false);
 }
 
+void Tracer::SettleNormals()
+{
+  vk_view_bounds* ahead = volume_->GetViewBounds();
+  if (!ahead) return;
+  // VK_ERR_TIMEOUT -> vulcan::Exception: upstream's contract is that a failed device step always throws (device.h:14-17)
+  VK_ASSERT(vk_trace_normals_settle(ahead, Device::GetStream()));
+}
+
 void Tracer::Trace(Frame& frame, Frame& next_frame, bool next_needs_normals)
 {
   TraceWith(frame, &next_frame, next_needs_normals);

@@ -22,7 +22,8 @@ Volume::Volume(int main_block_count, int excess_block_count) :
   request_stream_(nullptr),
   requested_(nullptr),
   integrated_(nullptr),
-  integrated_recorded_(false)
+  integrated_recorded_(false),
+  normals_late_(nullptr)
 {
   std::memset(&view_bounds_, 0, sizeof(view_bounds_));
   std::memset(&light_prep_, 0, sizeof(light_prep_));
@@ -32,6 +33,7 @@ Volume::Volume(int main_block_count, int excess_block_count) :
 
 Volume::~Volume()
 {
+  if (normals_late_) (void)vk_free_host(normals_late_);
   if (request_stream_)
   {
     (void)vk_stream_synchronize(request_stream_);
@@ -96,6 +98,16 @@ vk_view_bounds* Volume::GetViewBounds() const { return view_bounds_.scratch ? &v
 void Volume::AttachViewBounds(float* scratch, int bounds_width, int bounds_height, const Vector2f& depth_range) const
 {
   std::memset(&view_bounds_, 0, sizeof(view_bounds_));
+  // the pinned word a normals workgroup of Tracer::Trace(keyframe, next_frame) sets when its bounded wait expires
+  // (vk.h vk_view_bounds.late_host): the next Trace, or Tracer::SettleNormals, then throws instead of leaving wrong normals
+  if (!normals_late_)
+  {
+    void* word = nullptr;
+    VK_ASSERT(vk_malloc_host(&word, sizeof(int32_t)));
+    normals_late_ = static_cast<int32_t*>(word);
+  }
+  *normals_late_ = 0;
+  view_bounds_.late_host = normals_late_;
   view_bounds_.scratch = scratch;
   view_bounds_.bounds_width = bounds_width;
   view_bounds_.bounds_height = bounds_height;
@@ -106,6 +118,16 @@ void Volume::AttachViewBounds(float* scratch, int bounds_width, int bounds_heigh
 void Volume::DetachViewBounds(const float* scratch) const
 {
   if (view_bounds_.scratch == scratch) std::memset(&view_bounds_, 0, sizeof(view_bounds_));
+}
+
+void Volume::CancelRequestsAhead(int rounds)
+{
+  if (requests_ahead_.valid != 1) return;
+  view_bounds_.valid = 0;
+  const vk_volume v = ToVk();
+  VK_ASSERT(vk_requests_ahead_cancel(&v, &requests_ahead_, rounds, Device::GetStream()));
+  visible_count_stale_ = true;
+  empty_ = false;
 }
 
 vk_light_prep* Volume::GetLightPreparation() const { return light_prep_.mask ? &light_prep_ : nullptr; }
@@ -155,7 +177,7 @@ void Volume::EnableRequestStream()
 {
   if (request_stream_) return;
   VK_ASSERT(vk_stream_create(&request_stream_));
-  VK_ASSERT(vk_event_create_ordering(&requested_, 0));
+  VK_ASSERT(vk_event_create_ordering(&requested_, 1));    // behind a pass that WRITES what the waiting stream reads (vk.h)
   VK_ASSERT(vk_event_create_ordering(&integrated_, 0));
   integrated_recorded_ = false;
 }
@@ -169,6 +191,14 @@ void Volume::NoteIntegrated() const
 
 void Volume::ComputeNormalsAndSetView(Frame& frame, int rounds)
 {
+  if (requests_ahead_.valid == 1)
+  {
+    // Tracer::Trace(keyframe, frame, true) announced this frame and its normals came with the pass: nothing is due.
+    // (Stamping the normal image again would give the frame a content id the record does not name; another frame
+    // than the announced one is refused by SetView.)
+    SetView(frame, rounds);
+    return;
+  }
   vk_light_prep* prep = GetLightPreparation();
   if (!prep)
   {
@@ -212,6 +242,7 @@ void Volume::GetCounters(int32_t* counters) const
 
 void Volume::ResetBlockVisibility()
 {
+  VULCAN_ASSERT_MSG(requests_ahead_.valid != 1, "a frame announced by Tracer::Trace(keyframe, next_frame) has its requests in the volume: SetView(that frame) or CancelRequestsAhead() first");
   const vk_volume v = ToVk();
   VK_ASSERT(vk_volume_reset_block_visibility(&v, Device::GetStream()));
 }
@@ -230,6 +261,7 @@ void Volume::UpdateBlockVisibility(const Frame& frame)
 
 void Volume::CreateAllocationRequests(const Frame& frame)
 {
+  VULCAN_ASSERT_MSG(requests_ahead_.valid != 1, "a frame announced by Tracer::Trace(keyframe, next_frame) has its requests in the volume: SetView(that frame) or CancelRequestsAhead() first");
   const vk_volume v = ToVk();
   const vk_projection k = frame.depth_projection.ToVk();
   const vk_transform Twd = frame.depth_to_world_transform.ToVk();
@@ -239,6 +271,7 @@ void Volume::CreateAllocationRequests(const Frame& frame)
 
 void Volume::HandleAllocationRequests()
 {
+  VULCAN_ASSERT_MSG(requests_ahead_.valid != 1, "a frame announced by Tracer::Trace(keyframe, next_frame) has its requests in the volume: SetView(that frame) or CancelRequestsAhead() first");
   const vk_volume v = ToVk();
   VK_ASSERT(vk_volume_handle_allocation_requests(&v, Device::GetStream()));
 }

@@ -14,7 +14,7 @@ VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 
 VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_PUBLIC = 8, 9, 10, 24
 VK_RETRY_SLOTS, VK_RETRY_KEYS, VK_POSTED_SLOTS = 65536, 8192, 2048
 # counters, two key sets, two slot lists, the posted buckets and their chains' last entries
-VK_ABI_VERSION = 5                       # include/vk.h
+VK_ABI_VERSION = 6                       # include/vk.h
 VK_CTR_BANDED, VK_BANDS, VK_BAND_SLOTS = 20, 8, 16384
 VK_CTR_COUNT = (VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
                 + VK_BANDS + VK_BANDS * VK_BAND_SLOTS)
@@ -157,7 +157,10 @@ class ViewBounds(C.Structure):
                 ("block_length", C.c_float), ("visible_blocks", C.c_void_p),
                 ("projection", Projection), ("depth_to_world", Transform),
                 ("counted_scratch", C.c_void_p), ("counted_width", C.c_int32), ("counted_height", C.c_int32),
-                ("trace_launches", C.c_uint32), ("pad_", C.c_int32)]
+                ("trace_launches", C.c_uint32), ("pad_", C.c_int32),
+                ("late_host", C.c_void_p), ("last_depths", C.c_void_p), ("last_normals", C.c_void_p),
+                ("last_width", C.c_int32), ("last_height", C.c_int32), ("last_projection", Projection),
+                ("counted_stream", C.c_void_p)]
 
 
 class ColorView(C.Structure):
@@ -197,7 +200,8 @@ class RequestsAhead(C.Structure):
 class TestHooks(C.Structure):
     """vk_test_hooks (vk.h)"""
     _fields_ = [("posted_capacity", C.c_int32), ("retry_capacity", C.c_int32), ("set_view_unfused", C.c_int32),
-                ("force_loop_abort", C.c_int32), ("loop_grid_cap", C.c_int32), ("loop_cooperative", C.c_int32)]
+                ("force_loop_abort", C.c_int32), ("loop_grid_cap", C.c_int32), ("loop_cooperative", C.c_int32),
+                ("force_normals_expiry", C.c_int32)]
 
 
 class ColorPose(C.Structure):
