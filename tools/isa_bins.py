@@ -2,39 +2,64 @@
 """Instruction histogram of a kernel's ISA by what the instructions are FOR ("the histogram first").
 
   hipcc ... --cuda-device-only -gline-tables-only -S vk_trace.hip -o /tmp/vk_trace_g.s        (tools/isa_bins.sh does it)
-  python tools/isa_bins.py /tmp/vk_trace_g.s compute_points_kernelILb1E [--blocks] [--path L1,L2,...]
+  python tools/isa_bins.py /tmp/vk_trace_g.s compute_points_kernelILb1E [--blocks] [--path L1,L2,...] [--source old_vk_raycast.hpp]
 
 Every instruction is attributed to the source line its .loc names; helper lines (vk_common.hpp: add3, f2i, xform_point
 ...; the HIP headers) inherit the last vk_raycast.hpp / vk_trace.hip line seen before them in the same basic block, or
-the next one. Lines are mapped to bins by the table BINS below (vk_raycast.hpp line ranges). --blocks lists the basic
+the next one. Lines are mapped to bins by the ANCHORS below (regular expressions on vk_raycast.hpp's own text). --blocks lists the basic
 blocks (label, instructions, bins, terminator) so that the blocks of ONE path through the march loop can be named;
 --path sums the histogram over exactly those blocks."""
 import collections
 import re
 import sys
 
-# (file, first line, last line) -> bin. vk_raycast.hpp as of this commit; tools/isa_bins.py --check verifies the anchors.
-BINS = [
-    ("vk_raycast.hpp", 99, 121, "table probe (global hash walk: directory miss only)"),
-    ("vk_raycast.hpp", 135, 160, "file_blocks (directory miss only)"),
-    ("vk_raycast.hpp", 165, 191, "directory lookup: march block (find_block / lookup_block)"),
-    ("vk_raycast.hpp", 211, 232, "corner loads (Corners::word / tail)"),
-    ("vk_raycast.hpp", 249, 258, "corner index arithmetic (floor, & 7, crossing flags)"),
-    ("vk_raycast.hpp", 268, 296, "directory lookup: neighbour blocks (8 guarded LDS reads + compares)"),
-    ("vk_raycast.hpp", 297, 308, "neighbour miss loop"),
-    ("vk_raycast.hpp", 310, 322, "slot selection network (cndmask tree)"),
-    ("vk_raycast.hpp", 324, 345, "corner address arithmetic (slot * 10240 + voxel * 20, absent bits, fractions)"),
-    ("vk_raycast.hpp", 350, 366, "corner distance: loads, absent override, trilinear"),
-    ("vk_raycast.hpp", 373, 413, "corner colour (after the march)"),
-    ("vk_raycast.hpp", 429, 450, "ray set-up"),
-    ("vk_raycast.hpp", 454, 456, "block coordinates of p (3 x double mul + floor + cvt)"),
-    ("vk_raycast.hpp", 457, 473, "loop head / find_block call"),
-    ("vk_raycast.hpp", 474, 499, "voxel coordinates + nearest-voxel load"),
-    ("vk_raycast.hpp", 518, 532, "sample decision + bookkeeping of the last sample"),
-    ("vk_raycast.hpp", 534, 557, "step (p += dir * ...)"),
-    ("vk_raycast.hpp", 559, 574, "depth of p, exit tests"),
-    ("vk_raycast.hpp", 579, 597, "colour of last sample + stores"),
+# Bins by ANCHOR: a source line of vulcan_amd/csrc/vk_raycast.hpp belongs to the bin of the last anchor (a regular expression
+# matched against the file's own text, so that the table follows the source) at or above it.
+SOURCE = "vulcan_amd/csrc/vk_raycast.hpp"
+ANCHORS = [
+    (r"^struct PointParams", "outside the march"),
+    (r"^// a / b, correctly rounded, for a divisor known on the host", None),       # div_uniform: a helper, inherits its caller's bin
+    (r"^struct BlockCache", "outside the march"),
+    (r"^__device__ __forceinline__ Entry load_whole_entry", "table probe (global hash walk: directory miss only)"),
+    (r"^__device__ __forceinline__ void file_blocks", "file_blocks (directory miss only)"),
+    (r"^__device__ __forceinline__ int lookup_block", "block coordinates of p (3 x double mul, floor, cvt) + directory lookup of that block (find_block)"),
+    (r"^struct Corners", "corner loads (Corners::word / tail)"),
+    (r"^__device__ __forceinline__ uint32_t lds_address", "directory lookup: the corners' blocks (reads, wait, tag test)"),
+    (r"^\s+const int ix = f2i\(floorf\(wx", "corner index arithmetic (floor, & 7, crossing flags, base block)"),
+    (r"^\s+// Pool slots of the", "directory lookup: the corners' blocks (reads, wait, tag test)"),
+    (r"^\s+if \(__any\(moved\)\)", "directory lookup: the corners' blocks (reads, wait, tag test)"),
+    (r"^\s+while \(__any\(missing != 0\)\)", "corner-block miss loop (rare)"),
+    (r"^\s+// corner c is in block", "slot selection network (cndmask tree)"),
+    (r"^\s+Corners<POOL32> C;", "corner address arithmetic (slot * 10240 + voxel * 20, absent bits, fractions)"),
+    (r"^__device__ __forceinline__ float corner_distance", "corner distance: absent override, trilinear"),
+    (r"^__device__ __forceinline__ f3 corner_color", "corner colour (after the march)"),
+    (r"^__device__ __forceinline__ void march_ray_nested", "ray set-up"),
+    (r"^\s+for \(;;\)", "block coordinates of p (3 x double mul + floor + cvt) + loop head"),
+    (r"^\s+const int data = find_block", "block coordinates of p (3 x double mul, floor, cvt) + directory lookup of that block (find_block)"),
+    (r"^\s+if \(data >= 0\)", "voxel coordinates + nearest-voxel load"),
+    (r"^\s+if \(!refine\) sample = ", "sample decision + bookkeeping of the last sample"),
+    (r"^\s+if \(refine\)$", "step (p += dir * ...)"),
+    (r"^\s+const float depth = xform_point", "depth of p, exit tests"),
+    (r"^\s+if \(__any\(sampled\)\)", "colour of last sample + stores"),
 ]
+
+
+def load_bins(root):
+    import os
+    path = sys.argv[sys.argv.index("--source") + 1] if "--source" in sys.argv else os.path.join(root, SOURCE)
+    lines = open(path).read().split("\n")
+    table, current, used = {}, "outside the march", set()
+    for number, text in enumerate(lines, 1):
+        for rx, name in ANCHORS:
+            if re.search(rx, text):
+                current = name
+                used.add(rx)
+        table[number] = current
+    return table
+
+
+LINE_BINS = None
+
 
 CLASSES = [
     (re.compile(r"^s_waitcnt"), "s_waitcnt"),
@@ -93,9 +118,12 @@ def parse(path, kernel):
 
 
 def bin_of(f, l):
-    for bf, lo, hi, name in BINS:
-        if f.endswith(bf) and lo <= l <= hi:
-            return name
+    global LINE_BINS
+    if LINE_BINS is None:
+        import os
+        LINE_BINS = load_bins(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if f.endswith("vk_raycast.hpp") and l in LINE_BINS:
+        return LINE_BINS[l]          # (None for a helper's lines)
     return None
 
 
@@ -120,7 +148,7 @@ def attribute(instrs):
                 nxt = i["bin"]
         for i in block:
             if i["bin"] is None:
-                i["bin"] = "outside the march (tile set-up, bounds merge, normals, request pass)" if not i["file"].endswith("vk_raycast.hpp") else f"{i['file']}:{i['line']}"
+                i["bin"] = "outside the march"
     return by_block
 
 
@@ -157,6 +185,28 @@ def main():
         names = sys.argv[sys.argv.index("--path") + 1].split(",")
         chosen = [i for label in names for i in blocks[label]]
         histogram(chosen, f"{kernel}: blocks {','.join(names)}")
+        return
+    if "--trip" in sys.argv:
+        # the march loop's body: from the first instruction of its head to the last of its exit tests (the second, inlined
+        # copy of resolve_corners — the colour of the last sample — lies behind it and is left out)
+        flat = [i for block in blocks.values() for i in block]
+        head = next(n for n, i in enumerate(flat) if i["bin"].startswith("block coordinates of p") and i["block"] != "entry")
+        # ... up to the basic block in which the code behind the loop (the colour of the last sample) begins
+        after = next(n for n, i in enumerate(flat) if n > head and i["bin"].startswith("colour of last sample"))
+        while after > head and flat[after - 1]["block"] == flat[after]["block"]:
+            after -= 1
+        body = flat[head:after]
+        rare = ("table probe", "file_blocks", "corner-block miss loop", "slot selection network", "outside the march", "ray set-up",
+                "corner colour", "colour of last sample")
+        absent_bins = ("block coordinates of p", "step (p +=", "depth of p")
+        histogram([i for i in body if not i["bin"].startswith(rare)],
+                  f"{kernel}: ONE SAMPLED TRIP through the march loop, every block of the directory met before (static upper bound: "
+                  "all instructions of the loop body outside the miss handling)")
+        print()
+        histogram([i for i in body if i["bin"].startswith(absent_bins)],
+                  f"{kernel}: ONE PASS THROUGH A BLOCK THAT IS NOT THERE (loop head, block lookup in the directory, step, exit tests)")
+        print()
+        histogram([i for i in body if i["bin"].startswith(rare[:4])], f"{kernel}: miss handling inside the loop (not on the two paths above)")
         return
     histogram(instrs, f"{kernel}: whole kernel (static)")
 

@@ -237,6 +237,37 @@ struct Corners
   }
 };
 
+// ---- the directory reads of a sample (resolve_corners) ------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+// the LDS byte address of a __shared__ object (what ds_* instructions take)
+__device__ __forceinline__ uint32_t lds_address(const void* shared)
+{
+  return (uint32_t)(uintptr_t)(lds_char*)(char*)const_cast<void*>(shared);
+}
+
+// One 16-byte LDS read the compiler can neither split into two nor wait for on the spot: hipcc's own bookkeeping does not
+// see it, so its data must not be touched before lds_wait8 has named the destination.
+__device__ __forceinline__ v4i lds_read16_async(uint32_t byte_address)
+{
+  v4i r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(byte_address));
+  return r;
+}
+
+// waits for every LDS operation of the wave; the eight destinations are operands so that no use of them moves above it
+__device__ __forceinline__ void lds_wait8(v4i& a, v4i& b, v4i& c, v4i& d, v4i& e, v4i& f, v4i& g, v4i& h)
+{
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+
+// zero exactly when directory entry `e` holds block (bx, by, bz)
+__device__ __forceinline__ uint32_t tag_difference(const v4i& e, int bx, int by, int bz)
+{
+  return (uint32_t)(e.x ^ bx) | (uint32_t)(e.y ^ by) | (uint32_t)(e.z ^ bz);
+}
+
 // (wx, wy, wz): the sample position in voxel units relative to block (bx, by, bz), i.e.
 // (p - b * block_length) / voxel_length as computed by the caller (tracer.cu:193-195);
 // `data`: that block's pool slot.
@@ -262,69 +293,85 @@ __device__ __forceinline__ Corners<POOL32> resolve_corners(const PointParams& P,
   const bool cx = l0x == 7, cy = l0y == 7, cz = l0z == 7;
   const bool moved = ((ix | iy | iz) >> 3) != 0;     // the base block is not (bx, by, bz)
 
-  // Pool slots of the up-to-eight blocks base + (m & 1, m >> 1 & 1, m >> 2); only the
-  // combinations some lane of the wave needs are looked up: one LDS read each, with the
-  // coordinates and the directory index of neighbour m put together from per-axis halves.
-  // Misses (a block the wave has not met yet: rare once the march is under way) are
-  // collected in a bit mask and resolved against the global table afterwards, in one place.
-  // (Measured and rejected, r02: looking up all eight once per base block and keeping
-  // them per lane from sample to sample — 40.6 us against 31.3: the eager lookups resolve
-  // blocks beyond the band that no sample ever reads.)
-  const int nx[2] = {base_x, base_x + 1}, ny[2] = {base_y, base_y + 1}, nz[2] = {base_z, base_z + 1};
-  const int dx[2] = {(nx[0] & 3) << 4, (nx[1] & 3) << 4};          // byte offsets into the int4 directory
-  const int dy[2] = {(ny[0] & 3) << 6, (ny[1] & 3) << 6};
-  const int dz[2] = {(nz[0] & 3) << 8, (nz[1] & 3) << 8};
-  const char* dir_bytes = reinterpret_cast<const char*>(dir);
+  // Pool slots of the eight blocks the corners live in. Corner (dx, dy, dz) lives in block base + (dx & cx, dy & cy,
+  // dz & cz): with the HIGH coordinate of an axis defined as base + (crossing ? 1 : 0), block m = (nx[m & 1], ny[m >> 1
+  // & 1], nz[m >> 2]) IS corner m's block, whatever crosses — a lane that crosses nothing asks for its base block eight
+  // times (one LDS broadcast each) and no selection network is needed afterwards.
+  //
+  // Round 5, from the ISA (profiles/r05_raycast_trip_isa.txt): until round 4 the lookups were guarded one by one
+  // (`if (__any(need))`), and the compiler had turned `e.x == nx && e.y == ny && e.z == nz` into control flow — read {x,
+  // slot}, wait, compare, branch, read {y, z}, wait, compare: SIXTEEN dependent LDS round trips and ~175 instructions per
+  // sample, most of a lone wave's 2 us per sampled trip. Now: eight 16-byte reads leave together (lds_read16_async: the
+  // compiler can neither split them nor put a wait between them), ONE wait, four instructions per block for the tag
+  // test (three xor, one or3), and the rare miss — a block this wave has not met — is found by OR-ing the eight.
+  const int nx[2] = {base_x, base_x + (cx ? 1 : 0)}, ny[2] = {base_y, base_y + (cy ? 1 : 0)}, nz[2] = {base_z, base_z + (cz ? 1 : 0)};
+  const uint32_t dx[2] = {(uint32_t)(nx[0] & 3) << 4, (uint32_t)(nx[1] & 3) << 4};          // byte offsets into the int4 directory
+  const uint32_t dy[2] = {(uint32_t)(ny[0] & 3) << 6, (uint32_t)(ny[1] & 3) << 6};
+  const uint32_t dz[2] = {(uint32_t)(nz[0] & 3) << 8, (uint32_t)(nz[1] & 3) << 8};
+  const uint32_t dir_lds = lds_address(dir);
 
-  int n[8];
-  uint32_t missing = 0;
-  n[0] = data;
-  if (__any(moved))
+  v4i e0 = lds_read16_async(dir_lds + (dx[0] | dy[0] | dz[0]));
+  v4i e1 = lds_read16_async(dir_lds + (dx[1] | dy[0] | dz[0]));
+  v4i e2 = lds_read16_async(dir_lds + (dx[0] | dy[1] | dz[0]));
+  v4i e3 = lds_read16_async(dir_lds + (dx[1] | dy[1] | dz[0]));
+  v4i e4 = lds_read16_async(dir_lds + (dx[0] | dy[0] | dz[1]));
+  v4i e5 = lds_read16_async(dir_lds + (dx[1] | dy[0] | dz[1]));
+  v4i e6 = lds_read16_async(dir_lds + (dx[0] | dy[1] | dz[1]));
+  v4i e7 = lds_read16_async(dir_lds + (dx[1] | dy[1] | dz[1]));
+  lds_wait8(e0, e1, e2, e3, e4, e5, e6, e7);
+
+  int n[8] = {e0.w, e1.w, e2.w, e3.w, e4.w, e5.w, e6.w, e7.w};
+  // tag test: zero where the entry holds exactly this block
+  uint32_t t[8];
+  t[0] = tag_difference(e0, nx[0], ny[0], nz[0]);
+  t[1] = tag_difference(e1, nx[1], ny[0], nz[0]);
+  t[2] = tag_difference(e2, nx[0], ny[1], nz[0]);
+  t[3] = tag_difference(e3, nx[1], ny[1], nz[0]);
+  t[4] = tag_difference(e4, nx[0], ny[0], nz[1]);
+  t[5] = tag_difference(e5, nx[1], ny[0], nz[1]);
+  t[6] = tag_difference(e6, nx[0], ny[1], nz[1]);
+  t[7] = tag_difference(e7, nx[1], ny[1], nz[1]);
+  // the block the march stands in is known without the directory (its entry may have gone to another lane's block since)
+  n[0] = moved ? n[0] : data;
+  t[0] = moved ? t[0] : 0u;
+
+  if (__any((t[0] | t[1] | t[2] | t[3] | t[4] | t[5] | t[6] | t[7]) != 0u))
   {
-    const int4 e = *reinterpret_cast<const int4*>(dir_bytes + (dx[0] | dy[0] | dz[0]));
-    const bool hit = e.x == nx[0] && e.y == ny[0] && e.z == nz[0];
-    n[0] = moved ? e.w : data;
-    missing |= (moved && !hit) ? 1u : 0u;
-  }
+    // A block the wave has not met yet (rare once the march is under way): the DISTINCT missing blocks of a lane —
+    // neighbour m is a block of its own only along the axes that cross — are resolved against the global table, all
+    // lanes in parallel, filed, and handed on to the corners that share them.
+    uint32_t missing = 0;
 #pragma unroll
-  for (int m = 1; m < 8; ++m)
-  {
-    const bool need = ((m & 1) ? cx : true) && ((m & 2) ? cy : true) && ((m & 4) ? cz : true);
-    n[m] = -1;
-    if (__any(need))   // (unguarded, all seven reads issued back to back: 32.0 us against 30.8)
+    for (int m = 0; m < 8; ++m)
     {
-      const int4 e = *reinterpret_cast<const int4*>(dir_bytes + (dx[m & 1] | dy[(m >> 1) & 1] | dz[m >> 2]));
-      const bool hit = e.x == nx[m & 1] && e.y == ny[(m >> 1) & 1] && e.z == nz[m >> 2];
-      n[m] = e.w;
-      missing |= (need && !hit) ? (1u << m) : 0u;
+      const bool own = ((m & 1) ? cx : true) && ((m & 2) ? cy : true) && ((m & 4) ? cz : true);
+      missing |= (own && t[m] != 0u) ? (1u << m) : 0u;
     }
-  }
-  while (__any(missing != 0))
-  {
-    const bool mine = missing != 0;
-    const int m = __ffs((int)missing) - 1;           // this lane's next missing neighbour
-    const int qx = base_x + (m & 1), qy = base_y + ((m >> 1) & 1), qz = base_z + ((m >> 2) & 1);
-    int found = -1;
-    if (mine) found = probe_table(P, qx, qy, qz);
-    file_blocks(dir, mine, qx, qy, qz, found);
+    while (__any(missing != 0))
+    {
+      const bool mine = missing != 0;
+      const int m = __ffs((int)missing) - 1;           // this lane's next missing neighbour
+      const int qx = base_x + (m & 1), qy = base_y + ((m >> 1) & 1), qz = base_z + ((m >> 2) & 1);
+      int found = -1;
+      if (mine) found = probe_table(P, qx, qy, qz);
+      file_blocks(dir, mine, qx, qy, qz, found);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) n[k] = (mine && m == k) ? found : n[k];
-    missing &= missing - 1;
+      for (int k = 0; k < 8; ++k) n[k] = (mine && m == k) ? found : n[k];
+      missing &= missing - 1;
+    }
+    // corner c is in block (c & crossing mask)
+    const int a1 = cx ? n[1] : n[0];
+    const int a2 = cy ? n[2] : n[0];
+    const int n13 = cy ? n[3] : n[1];
+    const int a3 = cx ? n13 : a2;
+    const int z0 = cz ? n[4] : n[0], z1 = cz ? n[5] : n[1], z2 = cz ? n[6] : n[2], z3 = cz ? n[7] : n[3];
+    const int a5 = cx ? z1 : z0;
+    const int a6 = cy ? z2 : z0;
+    const int z13 = cy ? z3 : z1;
+    const int a7 = cx ? z13 : a6;
+    n[1] = a1; n[2] = a2; n[3] = a3; n[4] = z0; n[5] = a5; n[6] = a6; n[7] = a7;
   }
-
-  // corner c is in block (c & crossing mask)
-  int slot[8];
-  slot[0] = n[0];
-  slot[1] = cx ? n[1] : n[0];
-  slot[2] = cy ? n[2] : n[0];
-  const int n13 = cy ? n[3] : n[1];
-  slot[3] = cx ? n13 : slot[2];
-  const int z0 = cz ? n[4] : n[0], z1 = cz ? n[5] : n[1], z2 = cz ? n[6] : n[2], z3 = cz ? n[7] : n[3];
-  slot[4] = z0;
-  slot[5] = cx ? z1 : z0;
-  slot[6] = cy ? z2 : z0;
-  const int z13 = cy ? z3 : z1;
-  slot[7] = cx ? z13 : slot[6];
+  const int (&slot)[8] = n;
 
   Corners<POOL32> C;
   const global_floats pool = (global_floats)reinterpret_cast<const float*>(P.voxels);
