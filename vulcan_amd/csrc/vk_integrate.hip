@@ -23,8 +23,14 @@
 #ifndef VK_INTEGRATE_PLAIN_LIST
 #define VK_INTEGRATE_PLAIN_LIST 0   // 1: never use the banded visible lists (A/B measurements, tools/build_variant.sh)
 #endif
+#ifndef VK_LIGHT_PACKED
+// 1: the light model of two voxels in hand-packed f32 (divide2 below; VERDICT r4 #4's experiment). Bit-exact (the whole GPU
+// suite passes with it) and SLOWER: profiles/r05_light_packed_f32.txt — 36.7 us against 34.8 (35.7 at the same number of
+// gathers ahead). The product is the scalar form.
+#define VK_LIGHT_PACKED 0
+#endif
 #ifndef VK_INTEGRATE_GATHER_AHEAD
-#define VK_INTEGRATE_GATHER_AHEAD 4
+#define VK_INTEGRATE_GATHER_AHEAD (VK_LIGHT_PACKED ? 2 : 4)   // packed: three / four voxels' gathers ahead cost 12 / 28 bytes of scratch
 #endif
 #ifndef VK_INTEGRATE_WAVES_PER_EU
 #define VK_INTEGRATE_WAVES_PER_EU 4
@@ -96,6 +102,63 @@ __device__ __forceinline__ float light_shading(const vk_light& l, f3 point, f3 n
   const float distance_squared = sqnorm3(delta);
   const float cos_theta = dot3(normal, direction);
   return l.intensity * cos_theta / distance_squared;
+}
+
+// ---- the light model for TWO voxels at a time, in packed f32 (round 5; an experiment that lost: VK_LIGHT_PACKED) -----
+// The RGB-D kernel issues 817 vector instructions per half block and wave, and most of them are the light model's: per
+// voxel four correctly rounded divisions, a square root, and some sixty multiplies and adds. gfx950 issues v_pk_mul_f32 /
+// v_pk_add_f32 / v_pk_fma_f32 — two binary32 operations per lane — in the slot of one: the two voxels a lane updates side
+// by side (kLightGroup) become the two halves of 64-bit register pairs. It removes 8 % of the loop's vector instructions
+// (1881 -> 1733 static, 260 of them packed) and adds 60 v_mov (pairs put together from separately loaded registers), 100
+// scalar instructions and 88 s_nop (more VALU-writes-SGPR hazards), and the aligned pairs cost registers: with all four
+// voxels' gathers ahead 28 bytes of scratch, with three 12, none with two. Measured: slower in every form. Every operation
+// is the same IEEE operation on the same operands in the same order as in the scalar form (contraction stays off: a packed
+// multiply followed by a packed add is two roundings), so the bits are the scalar form's — tests/test_gpu_*.py compare
+// them with the oracle as before. The division is written out: it is hipcc's own expansion of `a / b` (LowerFDIV32:
+// v_div_scale x2, v_rcp, FMA x3 + MUL + FMA x2, v_div_fmas, v_div_fixup — correctly rounded, so ANY correct sequence gives
+// these bits) with its six multiply-adds done for both quotients at once.
+typedef float f2v __attribute__((ext_vector_type(2)));
+struct p3 { f2v x, y, z; };          // three coordinates of a PAIR of points / vectors
+
+__device__ __forceinline__ f2v splat2(float a) { return f2v{a, a}; }
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f2v divide2(f2v n, f2v d)
+{
+  bool unused, flag0, flag1;
+  const f2v ds = {__builtin_amdgcn_div_scalef(n.x, d.x, false, &unused), __builtin_amdgcn_div_scalef(n.y, d.y, false, &unused)};
+  const f2v ns = {__builtin_amdgcn_div_scalef(n.x, d.x, true, &flag0), __builtin_amdgcn_div_scalef(n.y, d.y, true, &flag1)};
+  const f2v r = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y)};
+  const f2v nd = -ds;
+  const f2v e0 = fma2(nd, r, splat2(1.0f));
+  const f2v r1 = fma2(e0, r, r);
+  const f2v q = ns * r1;
+  const f2v e1 = fma2(nd, q, ns);
+  const f2v q1 = fma2(e1, r1, q);
+  const f2v e2 = fma2(nd, q1, ns);
+  return f2v{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.x, r1.x, q1.x, flag0), d.x, n.x),
+             __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.y, r1.y, q1.y, flag1), d.y, n.y)};
+}
+
+// matrix.h:157-169 Dot for a pair: starts from 0, adds in index order
+__device__ __forceinline__ f2v dot3(const p3& a, const p3& b)
+{
+  f2v r = splat2(0.0f);
+  r += a.x * b.x;
+  r += a.y * b.y;
+  r += a.z * b.z;
+  return r;
+}
+
+// light.h:53-60 for two points and their normals
+__device__ __forceinline__ f2v light_shading(const vk_light& l, const p3& point, const p3& normal)
+{
+  const p3 delta = {splat2(l.position[0]) - point.x, splat2(l.position[1]) - point.y, splat2(l.position[2]) - point.z};
+  const f2v squared = dot3(delta, delta);                                     // sqnorm3, also distance_squared below
+  const f2v inv = divide2(splat2(1.0f), f2v{sqrtf(squared.x), sqrtf(squared.y)});   // normalized3: 1 / sqrt(dot)
+  const p3 direction = {delta.x * inv, delta.y * inv, delta.z * inv};
+  const f2v cos_theta = dot3(normal, direction);
+  return divide2(splat2(l.intensity) * cos_theta, squared);
 }
 
 // ---------------------------------------------------------------------------
@@ -364,11 +427,9 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
       {
         if (RECORDS)
         {
-          if (g0 >= AHEAD)
-          {
 #pragma unroll
-            for (int i = 0; i < G; ++i) rec[g0 + i] = reinterpret_cast<const float4*>(P.records)[depth_index[g0 + i]];
-          }
+          for (int i = 0; i < G; ++i)
+            if (g0 + i >= AHEAD) rec[g0 + i] = reinterpret_cast<const float4*>(P.records)[depth_index[g0 + i]];
 #pragma unroll
           for (int i = 0; i < G; ++i)
           {
@@ -388,13 +449,80 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
           }
         }
       }
-      if (g0 >= AHEAD)
-      {
 #pragma unroll
-        for (int i = 0; i < G; ++i)
+      for (int i = 0; i < G; ++i)
+        if (g0 + i >= AHEAD)
           pixel_color[g0 + i] = *reinterpret_cast<const vf3*>(P.color + 3 * (want[g0 + i] ? color_index[g0 + i] : 0u));
-      }
 
+      if (COLOR == COLOR_LIGHT && VK_LIGHT_PACKED && G == 2)
+      {
+        // ---- both voxels of the group in packed f32 (see divide2): light_integrator.cu:197-248, twice at once -----------
+        const int k0 = g0, k1 = g0 + 1;
+        float* vox0 = tile + (k0 * 64 + lane) * 5;
+        float* vox1 = tile + (k1 * 64 + lane) * 5;
+        // the voxels' positions in the colour camera: x and y of the two voxel offsets are the same numbers, so the part
+        // of xform_point's sum that they make up — (r0 * px + r1 * py), the first two terms in its order — is the same
+        // for both and computed once
+        const Rt& T = SAME_CAM ? P.Tdw : P.Tcw;
+        const f3 offset_xy = scale3(make3(vx + 0.5f, vy + 0.5f, 0.0f), P.voxel_length);
+        const float px = off.x + offset_xy.x, py = off.y + offset_xy.y;
+        const f2v pz = splat2(off.z) + f2v{(half * 4 + k0) + 0.5f, (half * 4 + k1) + 0.5f} * splat2(P.voxel_length);
+        p3 Xcp;
+        Xcp.x = splat2(T.r[0] * px + T.r[1] * py) + splat2(T.r[2]) * pz + splat2(T.r[3] * 1.0f);
+        Xcp.y = splat2(T.r[4] * px + T.r[5] * py) + splat2(T.r[6]) * pz + splat2(T.r[7] * 1.0f);
+        Xcp.z = splat2(T.r[8] * px + T.r[9] * py) + splat2(T.r[10]) * pz + splat2(T.r[11] * 1.0f);
+        const p3 normal = {f2v{pixel_normal[0].x, pixel_normal[1].x}, f2v{pixel_normal[0].y, pixel_normal[1].y},
+                           f2v{pixel_normal[0].z, pixel_normal[1].z}};
+        const f2v shading = light_shading(P.light, Xcp, normal);
+        const bool ok0 = want[k0] && shading.x > 0.05f, ok1 = want[k1] && shading.y > 0.05f;
+        if (ok0 || ok1)
+        {
+          const f2v inv_shading = divide2(splat2(1.0f), shading);                   // div3: multiply by 1.0f / s
+          const p3 curr = {f2v{pixel_color[k0].x, pixel_color[k1].x} * inv_shading, f2v{pixel_color[k0].y, pixel_color[k1].y} * inv_shading,
+                           f2v{pixel_color[k0].z, pixel_color[k1].z} * inv_shading};
+          // color_integrator.cu:100-134 / light_integrator.cu:233-246
+          // (the weights as the depth pass left them, from the tile: four registers less across the wait for the gathers)
+          const uint32_t w0 = __float_as_uint(vox0[4]), w1 = __float_as_uint(vox1[4]);
+          const int16_t cw0 = (int16_t)(w0 >> 16), cw1 = (int16_t)(w1 >> 16);
+          const f2v cwf = {(float)cw0, (float)cw1};
+          const p3 stored = {f2v{vox0[1], vox1[1]}, f2v{vox0[2], vox1[2]}, f2v{vox0[3], vox1[3]}};
+          const f2v color_weight = {(float)(cw0 + 1), (float)(cw1 + 1)};
+          const int16_t new_cw0 = (int16_t)vmin(P.max_color_weight, color_weight.x), new_cw1 = (int16_t)vmin(P.max_color_weight, color_weight.y);
+          // matrix.h:279-295: operator/ multiplies by 1.0f / s
+          const f2v inv_weight = small_weights ? f2v{(float)reciprocal[cw0 + 1], (float)reciprocal[cw1 + 1]}
+                                               : divide2(splat2(1.0f), color_weight);
+          const p3 c = {(stored.x * cwf + curr.x) * inv_weight, (stored.y * cwf + curr.y) * inv_weight, (stored.z * cwf + curr.z) * inv_weight};
+          const uint32_t nw0 = (w0 & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw0 << 16);
+          const uint32_t nw1 = (w1 & 0x0000ffffu) | ((uint32_t)(uint16_t)new_cw1 << 16);
+          if (ok0)
+          {
+            vox0[1] = c.x.x; vox0[2] = c.y.x; vox0[3] = c.z.x; vox0[4] = __uint_as_float(nw0);
+            const int dword = (k0 * 64 + lane) * 5;
+            if ((__float_as_uint(c.x.x) ^ __float_as_uint(stored.x.x)) | (__float_as_uint(c.y.x) ^ __float_as_uint(stored.y.x)) |
+                (__float_as_uint(c.z.x) ^ __float_as_uint(stored.z.x)))
+            {
+              changed[(dword + 1) >> 2] = 1;   // dwords 1..3 touch at most these two pieces
+              changed[(dword + 3) >> 2] = 1;
+              dirty = true;
+            }
+            if (nw0 != w0) { changed[(dword + 4) >> 2] = 1; dirty = true; }
+          }
+          if (ok1)
+          {
+            vox1[1] = c.x.y; vox1[2] = c.y.y; vox1[3] = c.z.y; vox1[4] = __uint_as_float(nw1);
+            const int dword = (k1 * 64 + lane) * 5;
+            if ((__float_as_uint(c.x.y) ^ __float_as_uint(stored.x.y)) | (__float_as_uint(c.y.y) ^ __float_as_uint(stored.y.y)) |
+                (__float_as_uint(c.z.y) ^ __float_as_uint(stored.z.y)))
+            {
+              changed[(dword + 1) >> 2] = 1;
+              changed[(dword + 3) >> 2] = 1;
+              dirty = true;
+            }
+            if (nw1 != w1) { changed[(dword + 4) >> 2] = 1; dirty = true; }
+          }
+        }
+      }
+      else
 #pragma unroll
       for (int i = 0; i < G; ++i)
       {
@@ -415,7 +543,7 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
         }
 
         // color_integrator.cu:100-134 / light_integrator.cu:233-246
-        const uint32_t weights = old_w[k];
+        const uint32_t weights = (COLOR == COLOR_LIGHT) ? __float_as_uint(vox[4]) : old_w[k];   // (light: from the tile, see the packed form)
         const int16_t cw = (int16_t)(weights >> 16);
         const float cwf = cw;
         const f3 stored = make3(vox[1], vox[2], vox[3]);
