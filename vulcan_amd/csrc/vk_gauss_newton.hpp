@@ -411,6 +411,87 @@ __device__ __forceinline__ bool gather_partials(const Exchange& E, int step, int
   return true;
 }
 
+// ---- the same exchange by float atomics (an A/B experiment, -DVK_LOOP_ATOMIC_EXCHANGE; VERDICT r4 #6a) -----------------
+// The reference itself sums with atomicAdd in arrival order (depth_tracker.cu:207-209,261-263). Here: three accumulators
+// of 32 floats (step % 3) and one arrival counter at the head of the exchange area, zeroed by the host before the launch.
+// A workgroup adds its 27 sums with returning atomics (their return is their completion), then — behind a workgroup
+// barrier — bumps the counter; a reader waits for count x (step + 1) arrivals and reads 27 words instead of 27 x count.
+// Buffer (step - 1) % 3 is zeroed by workgroup 0 once step `step` is complete (nobody reads it any more; it is added to
+// again at step + 2, after arrivals that follow workgroup 0's own). The order of the additions is the order of arrival:
+// the sums are no longer the same bits from run to run — the property the product's fixed-order exchange exists for.
+#ifdef VK_LOOP_ATOMIC_EXCHANGE
+template <int WAVES>
+__device__ __forceinline__ void publish_atomic(const float (&acc)[27], float (*lds)[kSysStride], const Exchange& E, int step)
+{
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 27; ++i)
+  {
+    const float v = wave_sum_lane63(acc[i]);
+    if (lane == 63) lds[wave][i] = v;
+  }
+  __syncthreads();
+  float* accumulators = reinterpret_cast<float*>(E.words) + 16;      // behind the counter's line
+  if (threadIdx.x < 27)
+  {
+    float v = 0.0f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += lds[w][threadIdx.x];
+    const float before = __hip_atomic_fetch_add(accumulators + (step % 3) * kSysStride + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" :: "v"(before));                                    // returned = performed
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(E.words, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool gather_atomic(const Exchange& E, int step, int translation_enabled, float* hessian,
+    float* gradient, float* sums, int* failed)
+{
+  float* accumulators = reinterpret_cast<float*>(E.words) + 16;
+  if (threadIdx.x == 0)
+  {
+    const unsigned long long target = (unsigned long long)E.count * (unsigned long long)(step + 1);
+    const unsigned long long deadline = (unsigned long long)wall_clock64() + kExchangeTimeout;
+    while (__hip_atomic_load(E.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+    {
+      if ((unsigned long long)wall_clock64() > deadline) { *failed = 1; break; }
+      __builtin_amdgcn_s_sleep(VK_POLL_GAP);
+    }
+  }
+  __syncthreads();
+  if (*failed) return false;
+  if (threadIdx.x < 27)
+  {
+    const float v = __hip_atomic_load(accumulators + (step % 3) * kSysStride + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = translation_enabled ? 6 : 3, nh = translation_enabled ? 21 : 6;
+    if (threadIdx.x < 6)
+    {
+      const float g = (int)threadIdx.x < n ? v : 0.0f;
+      if (gradient) gradient[threadIdx.x] = g;
+      sums[36 + threadIdx.x] = g;
+    }
+    else
+    {
+      const int out = (int)threadIdx.x - 6;
+      const float h = out < nh ? v : 0.0f;
+      if (hessian) hessian[out] = h;
+      sums[out] = h;
+    }
+    // the buffer of the step before has no reader left: ready for step + 2
+    if (blockIdx.x == 0 && step >= 1)
+      __hip_atomic_store(accumulators + ((step - 1) % 3) * kSysStride + threadIdx.x, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x >= 27 && threadIdx.x < 42)     // hessian[21 .. 36) as finish_sums leaves them
+  {
+    sums[threadIdx.x - 6] = 0.0f;
+    if (hessian) hessian[threadIdx.x - 6] = 0.0f;
+  }
+  __syncthreads();
+  return true;
+}
+#endif
+
 // LDL^T, no pivoting, float32 (the reference calls Eigen::LDLT — unpinned,
 // not vendored; agreement is to rounding). A zero pivot is handled the way
 // Eigen's LDLT handles it (the column of L is left at 0, and the solve sets

@@ -462,13 +462,22 @@ __global__ __launch_bounds__(kIcpThreads) void track_loop_kernel(IcpParams P, Lo
       if (resident) accumulate_pixels<TRANSLATION>(P, Twc, group, 0, px, acc);
       else accumulate_group<TRANSLATION>(P, Twc, group, acc);
       VK_STAMP(1);
+#ifdef VK_LOOP_ATOMIC_EXCHANGE
+      publish_atomic<kIcpThreads / 64>(acc, lds, L.exchange, it);
+#else
       publish_partial<kIcpThreads / 64>(acc, lds, L.exchange, it, group);
+#endif
     }
     VK_STAMP(2);
     VK_STAMP(3);
+#ifdef VK_LOOP_ATOMIC_EXCHANGE
+    if (!gather_atomic(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr, publisher ? L.gradient : nullptr, sums, &failed))
+      break;
+#else
     if (!gather_partials<kIcpThreads>(L.exchange, it, TRANSLATION, publisher ? L.hessian : nullptr,
             publisher ? L.gradient : nullptr, slices, sums, &failed))
       break;
+#endif
     if (L.rig.world > 0)
     {
       // a rigid rig: this view's sums go to every rank, every rank's come back (vk_rig_protocol.h);
@@ -854,6 +863,10 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
     L.force_abort = vk_forced_loop_abort();
     L.last_launch = (ends_track && done + kExchangeSteps >= iterations) ? 1 : 0;
     IcpParams Pk = P;
+#ifdef VK_LOOP_ATOMIC_EXCHANGE
+    // (the experiment's counter and accumulators start from zero; the product's tagged words need no such launch)
+    VK_CHECK(hipMemsetAsync(workspace, 0, (16 + 3 * kSysStride) * sizeof(float), s));
+#endif
     vk_loop_launch_begin(s);
     const hipError_t le = translation_enabled ? launch_loop_kernel(track_loop_kernel<true>, grid, kIcpThreads, s, Pk, L)
                                               : launch_loop_kernel(track_loop_kernel<false>, grid, kIcpThreads, s, Pk, L);
