@@ -84,6 +84,10 @@ SPLIT_STREAMS = os.environ.get("VK_BENCH_SPLIT_STREAMS", "0") == "1"
 # SetView(i + 1) is left with its handle + visibility launch. Same work, same results (tests/test_gpu_configs.py); one
 # launch boundary less per frame. Not for rgbd-icp: its next pose comes out of this raycast.
 REQUESTS_AHEAD = os.environ.get("VK_BENCH_REQUESTS_AHEAD", "1") != "0"
+# rgbd-icp: the raycast leaves its normal image to the NEXT frame's pyramid launch (vk_trace_ahead(.., normals = NULL) +
+# vk_icp_pyramid_track_frame(.., frame_normals_due = 1 | 2)): nobody reads the key frame's normals before that Track, the
+# bits are the same, and the frame has one launch less. "0": Tracer::Trace's own normals launch (A/B).
+KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "1") != "0"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
@@ -298,6 +302,7 @@ class FrameLoop:
             self.ndesc = T.Frame.from_buffer_copy(bytes(self.fdesc))
             self.nref, self.aref = C.byref(self.ndesc), C.byref(self.ahead)
         self.tracker = None
+        self.key_normals_pending = False
         self.tracked_poses, self.gn_steps = [], []
         if workload == "rgbd-icp":
             # PyramidTracker<DepthTracker>::Track through its one C entry point, descriptors built once
@@ -413,7 +418,9 @@ class FrameLoop:
                 self.frame_view.depths = self.fdesc.depth
                 # frame.ComputeNormals() + Tracker::BeginSolve's pose upload + PyramidTracker::Track (vulcan.cu:297-311), one call:
                 # the start pose and the frame's normal image travel with the pyramid's launch
-                rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), 1, *a[4:], s)
+                due = 1 | (2 if self.key_normals_pending else 0)       # the frame's normals, and the key frame's when the raycast left them out
+                self.key_normals_pending = False
+                rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
                 rc |= lib.vk_track_wait(a[-1], s)                   # Tracker::EndSolve: the pose, from pinned memory
                 if rc:
                     raise self.api.VkError(f"frame {i}: tracking returned {rc}")
@@ -474,6 +481,10 @@ class FrameLoop:
                 self.prep.normals_out = self.n_ptr.value
             rc |= lib.vk_trace_ahead_requests(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, self.nref, self.pprep,
                                               self.aref, s)
+        elif self.tracker is not None and KEY_NORMALS_WITH_PYRAMID and i + 1 < len(self.poses):
+            # tracer.cpp:41-95; its normals (:97-100) come with the next frame's pyramid launch
+            rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], self.out_ptrs[0], self.out_ptrs[1], None, s)
+            self.key_normals_pending = True
         else:
             rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, s)   # tracer.cpp:41-47
         if ev and len(ev) > 2:
@@ -950,7 +961,10 @@ def main():
             "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
             "set_view": set_view_policy,
             "input_normals": ("Frame::ComputeNormals of the input frame (vulcan.cu:297) is part of every timed step: "
-                              + ("by the launch that builds the tracker's pyramid (vk_icp_pyramid_track_frame)" if wl == "rgbd-icp" else
+                              + ("by the launch that builds the tracker's pyramid (vk_icp_pyramid_track_frame)"
+                                 + (", which also computes the PREVIOUS raycast's normal image (Tracer::Trace's last stage, "
+                                    "tracer.cpp:97-100, left out of vk_trace_ahead: one launch less per frame)" if KEY_NORMALS_WITH_PYRAMID else "")
+                                 if wl == "rgbd-icp" else
                                  "as a launch of its own" if not NORMALS_IN_SET_VIEW else
                                  "computed inside SetView's request pass (vk_light_prep.normals_out: same normal image, "
                                  "written to the frame; one launch less)"))

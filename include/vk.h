@@ -599,7 +599,8 @@ VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
 
 /* ref: src/tracer.cpp:41-47 Tracer::Trace, as vk_trace with the grid, depth range
  * and scratch taken from *ahead: when *ahead holds the bounds of this very view
- * the bounds pass is skipped, otherwise it runs and *ahead is updated. */
+ * the bounds pass is skipped, otherwise it runs and *ahead is updated. `normals` may be NULL (round 5): the normal image is
+ * then left to the caller — e.g. to the next frame's vk_icp_pyramid_track_frame(.., frame_normals_due = 2 | .., ..). */
 VK_API int vk_trace_ahead(const vk_volume* v, const vk_frame* frame,
     vk_view_bounds* ahead, float* depths, float* colors, float* normals, void* stream);
 
@@ -855,7 +856,11 @@ VK_API int vk_icp_pyramid_track(const vk_icp_view* keyframe, const vk_transform*
  * pyramid launch (instead of vk_transform_upload before the call), and with `frame_normals_due` the frame's normal image
  * frame->normals is COMPUTED by it (ref: src/frame.cu:9-122 Frame::ComputeNormals — vk_frame_compute_normals' bits; the
  * half-resolution normals are computed at the pixels they are sampled from, which is the same normal) instead of read.
- * Everything else as vk_icp_pyramid_track. */
+ * `frame_normals_due` is a set of bits: 1 = the frame's normal image as above; 2 (round 5) = the KEYFRAME's — the raycast's
+ * normal image, which Tracer::Trace otherwise computes with a launch of its own right behind the raycast (src/tracer.cpp:97-100)
+ * and which nobody reads before this Track: vk_trace_ahead(.., normals = NULL, ..) leaves it out, and this call writes
+ * keyframe->normals (the same bits) on the way. The caller that skips the raycast's normals owes them to whoever reads the
+ * key frame before the next Track. Everything else as vk_icp_pyramid_track. */
 VK_API int vk_icp_pyramid_track_frame(const vk_icp_view* keyframe, const vk_transform* Twm,
     const vk_icp_view* frame, vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due,
     float* pyramid, float* workspace, float* system, int32_t* state_dev, float* update_dev,

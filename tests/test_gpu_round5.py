@@ -301,3 +301,36 @@ def test_set_view_with_compute_normals_takes_the_announced_frame(api):
         results.append((vol.host_voxels().tobytes(), vol.host_entries().tobytes(), f1.normals.cpu().numpy()))
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert np.array_equal(results[0][2], results[1][2], equal_nan=True)
+
+
+# --------------------------------------- the raycast's normals with the next Track --
+
+def test_raycast_normals_made_by_the_next_tracks_pyramid_launch(api, orc):
+    """Tracer.trace(key, normals=False) + PyramidTracker.track(frame, compute_normals=True, keyframe_normals_due=True): the key
+    frame's normal image (Tracer::Trace's last stage, tracer.cpp:97-100) is written by the launch that builds the pyramid
+    (vk_icp_pyramid_track_frame, frame_normals_due = 1 | 2) — the oracle's normals of the raycast depth, the same half-resolution
+    level and the same pose as with the launch of its own, bit for bit."""
+    import torch
+    vol, integ, tracer, fs, out = _small_scene(api)
+    vol.set_view(fs[0], rounds=3)
+    integ.integrate(fs[0])
+    results = []
+    for fused in (False, True):
+        key = api.Frame(torch.zeros_like(out.depth), out.depth_projection, fs[0].depth_to_world)
+        key.normals = torch.full((key.height, key.width, 3), -7.0, dtype=torch.float32, device="cuda")
+        tracer.trace(key, normals=not fused)
+        sync()
+        if fused:
+            assert torch.all(key.normals == -7.0)                       # the raycast left them alone
+        nxt = api.Frame(fs[1].depth, fs[1].depth_projection, fs[0].depth_to_world)
+        tracker = api.PyramidTracker()
+        tracker.keyframe = key
+        pose = tracker.track(nxt, compute_normals=True, keyframe_normals_due=fused)
+        sync()
+        results.append((key.normals.cpu().numpy().copy(), nxt.normals.cpu().numpy().copy(), tracker._pyramid.cpu().numpy().copy(),
+                        bytes(pose), key.depth.cpu().numpy().copy()))
+    (kn0, fn0, py0, p0, d0), (kn1, fn1, py1, p1, d1) = results
+    assert np.array_equal(d0, d1) and np.array_equal(kn0, kn1, equal_nan=True) and np.array_equal(fn0, fn1, equal_nan=True)
+    assert np.array_equal(py0, py1, equal_nan=True) and p0 == p1
+    assert np.array_equal(kn1, orc.compute_normals(d1, out.depth_projection), equal_nan=True)
+    assert (np.abs(kn1).sum(axis=-1) > 0).sum() > 10000

@@ -629,8 +629,10 @@ class Tracer:
         trace(next_frame=...) gave up its wait — the normals have then been recomputed by a launch of their own."""
         check(lib().vk_trace_normals_settle(_ref(self.view_bounds), stream()), "vk_trace_normals_settle")
 
-    def trace(self, frame, next_frame=None, next_needs_normals=False):
-        """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals. `next_frame` (not upstream): the frame the
+    def trace(self, frame, next_frame=None, next_needs_normals=False, normals=True):
+        """Tracer::Trace (tracer.cpp:41-47): writes frame.depth / color / normals. `normals=False` (not upstream): the last
+        stage is left out — for the tracking loop, whose next PyramidTracker.track(.., keyframe_normals_due=True) computes the
+        key frame's normal image in its pyramid launch (one launch less per frame). `next_frame` (not upstream): the frame the
         volume's next set_view will be called with — its request pass (and, with `next_needs_normals` and a LightIntegrator's
         preparation attached, its normal image) is made behind the raycast's workgroups, in the same launch
         (vk_trace_ahead_requests)."""
@@ -645,7 +647,7 @@ class Tracer:
             vb.valid = 0
         if next_frame is None:
             check(lib().vk_trace_ahead(_ref(self.volume.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth),
-                                       _ptr(frame.color), _ptr(frame.normals), stream()), "vk_trace_ahead")
+                                       _ptr(frame.color), _ptr(frame.normals) if normals else None, stream()), "vk_trace_ahead")
             frame.touch()
             return
         v = self.volume
@@ -1095,10 +1097,15 @@ class PyramidTracker:
         self.tracker = tracker or DepthTracker(device)
         self.keyframe = None
 
-    def track(self, frame, compute_normals=False):
+    def track(self, frame, compute_normals=False, keyframe_normals_due=False):
         """`compute_normals` (not upstream): frame.compute_normals() is still due; with a DepthTracker it is done by the launch
-        that builds the pyramid (vk_icp_pyramid_track_frame)."""
+        that builds the pyramid (vk_icp_pyramid_track_frame). `keyframe_normals_due`: the key frame came from
+        Tracer.trace(.., normals=False); its normal image is computed by the same launch."""
         t = self.tracker
+        if keyframe_normals_due and not isinstance(t, DepthTracker):
+            self.keyframe.compute_normals()
+            keyframe_normals_due = False
+        self._key_normals_due = bool(keyframe_normals_due)
         if isinstance(t, DepthTracker):
             if compute_normals:
                 import torch
@@ -1135,8 +1142,8 @@ class PyramidTracker:
         if getattr(self, "_pyramid", None) is None or self._pyramid.numel() < n:
             self._pyramid = torch.empty(n, dtype=torch.float32, device=t.device)
         t.max_iterations, t.translation_enabled, t.keyframe = 20, True, key
-        due = 1 if getattr(self, "_normals_due", False) else 0
-        self._normals_due = False                  # (a second attempt after an aborted loop finds them computed)
+        due = (1 if getattr(self, "_normals_due", False) else 0) | (2 if getattr(self, "_key_normals_due", False) else 0)
+        self._normals_due = self._key_normals_due = False       # (a second attempt after an aborted loop finds them computed)
         check(lib().vk_icp_pyramid_track_frame(_ref(t._view(key)), _ref(key.depth_to_world), _ref(t._view(frame)),
                                                _ptr(t.pose), _ref(frame.depth_to_world), due, _ptr(self._pyramid),
                                                _ptr(t._workspace(frame)), _ptr(t.system), _ptr(t.state), _ptr(t.update),

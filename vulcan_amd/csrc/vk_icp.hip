@@ -732,9 +732,12 @@ struct LevelParams
   // blockIdx.z == 2 writes it, and the frame's half-resolution normals are computed at the pixels they are sampled from
   // instead of copied (nearest sampling: the same pixel's normal, bit for bit) — and the pose the Track starts from is
   // stored by workgroup 0 (vk_transform_upload's launch)
-  float* frame_normals_out;        // nullptr: the frame's normals exist
-  int src_h_frame;
-  vk_projection frame_k;
+  // (round 5) the same for the KEYFRAME — the raycast's normal image, which Tracer::Trace otherwise computes with a launch
+  // of its own right behind the raycast (tracer.cpp:97-100) and which nobody reads before this Track: side 0
+  float* normals_out[2];           // [0] keyframe, [1] frame; nullptr: that side's normals exist
+  int src_h[2];
+  vk_projection k[2];
+  int due_side[2];                 // blockIdx.z == 2 + i computes the whole normal image of side due_side[i]
   vk_transform* pose_out;          // nullptr: the pose is on the device already
   vk_transform pose_start;
 };
@@ -765,12 +768,13 @@ __global__ __launch_bounds__(256) void pyramid_level_kernel(LevelParams L)
   }
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (blockIdx.z == 2)
+  if (blockIdx.z >= 2)
   {
-    // the frame's own normal image, every pixel
-    if (x >= L.src_w[1] || y >= L.src_h_frame) return;
-    const f3 n = level_normal(L.src_depth[1], L.frame_k, L.src_w[1], L.src_h_frame, x, y);
-    float* out = L.frame_normals_out + 3 * ((size_t)y * L.src_w[1] + x);
+    // a side's own normal image, every pixel
+    const int side = L.due_side[blockIdx.z - 2];
+    if (x >= L.src_w[side] || y >= L.src_h[side]) return;
+    const f3 n = level_normal(L.src_depth[side], L.k[side], L.src_w[side], L.src_h[side], x, y);
+    float* out = L.normals_out[side] + 3 * ((size_t)y * L.src_w[side] + x);
     out[0] = n.x;  out[1] = n.y;  out[2] = n.z;
     return;
   }
@@ -781,9 +785,9 @@ __global__ __launch_bounds__(256) void pyramid_level_kernel(LevelParams L)
   const int dst = dst_y * L.dst_w[side] + dst_x;
   L.dst_depth[side][dst] = L.src_depth[side][src];
   vf3 n;
-  if (side == 1 && L.frame_normals_out)
+  if (L.normals_out[side])
   {
-    const f3 computed = level_normal(L.src_depth[1], L.frame_k, L.src_w[1], L.src_h_frame, 2 * dst_x, 2 * dst_y);
+    const f3 computed = level_normal(L.src_depth[side], L.k[side], L.src_w[side], L.src_h[side], 2 * dst_x, 2 * dst_y);
     n = vf3{computed.x, computed.y, computed.z};
   }
   else n = *reinterpret_cast<const vf3*>(L.src_normals[side] + 3 * src);
@@ -1060,17 +1064,26 @@ static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
   }
   int gw = half[0].width > half[1].width ? half[0].width : half[1].width;
   int gh = half[0].height > half[1].height ? half[0].height : half[1].height;
-  L.frame_normals_out = frame_normals_due ? const_cast<float*>(frame->normals) : nullptr;
-  L.src_h_frame = frame->height;
-  L.frame_k = frame->projection;
+  // frame_normals_due: bit 0 the frame's normal image, bit 1 the keyframe's (vk.h)
+  VK_REQUIRE(frame_normals_due >= 0 && frame_normals_due <= 3);
+  int due = 0;
+  L.due_side[0] = L.due_side[1] = 0;
+  for (int side = 0; side < 2; ++side)
+  {
+    const bool wanted = (frame_normals_due >> (1 - side)) & 1;          // side 0 = keyframe = bit 1, side 1 = frame = bit 0
+    L.normals_out[side] = wanted ? const_cast<float*>(full[side]->normals) : nullptr;
+    L.src_h[side] = full[side]->height;
+    L.k[side] = full[side]->projection;
+    if (wanted)
+    {
+      L.due_side[due++] = side;
+      gw = gw > full[side]->width ? gw : full[side]->width;
+      gh = gh > full[side]->height ? gh : full[side]->height;
+    }
+  }
   L.pose_out = Twc_start ? Twc_dev : nullptr;
   if (Twc_start) L.pose_start = *Twc_start;
-  if (frame_normals_due)
-  {
-    gw = gw > frame->width ? gw : frame->width;
-    gh = gh > frame->height ? gh : frame->height;
-  }
-  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, frame_normals_due ? 3 : 2), dim3(256), 0, s, L);
+  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2 + due), dim3(256), 0, s, L);
   VK_LAUNCH_CHECK();
 
   // :79-83 half level, 15 steps; :85-89 full level, 20 steps, from the pose the half level left.

@@ -743,7 +743,8 @@ static int normals_repair(vk_view_bounds* ahead, hipStream_t s)
 static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
     float* out_color, float* out_normals, void* stream, const RequestParams* next_requests, const Retry* next_retry, int next_prep)
 {
-  VK_REQUIRE(v && frame && ahead && ahead->scratch && out_depth && out_color && out_normals);
+  // (out_normals == nullptr: the caller takes care of the normal image itself — vk_trace_ahead only)
+  VK_REQUIRE(v && frame && ahead && ahead->scratch && out_depth && out_color && (out_normals || !next_requests));
   VK_REQUIRE(v->hash_entries && v->voxels && v->visible_blocks && v->counters);
   VK_REQUIRE(ahead->bounds_width > 0 && ahead->bounds_height > 0);
   hipStream_t s = vk_s(stream);
@@ -821,6 +822,7 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
   }
   ahead->last_depths = nullptr;             // the normals were a launch of their own: nothing rides, nothing to repair
   ahead->last_normals = nullptr;
+  if (!out_normals) return VK_OK;
   return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, s);
 }
 

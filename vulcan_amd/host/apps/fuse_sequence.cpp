@@ -189,7 +189,8 @@ int main(int argc, char** argv)
       int run = 0;
       if (mode == 3) { app_tracker.SetKeyframe(keyframe); app_tracker.Track(frame); run = app_tracker.GetIterationsRun(); }
       else if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); run = light_tracker.GetTracker()->GetIterationsRun(); }
-      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.ComputeNormalsAndTrack(frame); run = depth_tracker.GetTracker()->GetIterationsRun(); }
+      // (mode 1: the raycast below leaves its normal image to this call — Tracer::TraceWithoutNormals — one launch less per frame)
+      else { depth_tracker.SetKeyframe(keyframe); depth_tracker.ComputeNormalsAndTrack(frame, true); run = depth_tracker.GetTracker()->GetIterationsRun(); }
       steps_run.push_back(run);
       if (run >= 0 && run < 64) ++steps_histogram[run];
       PoseError(frame.depth_to_world_transform, truth[i], last_translation, last_rotation);
@@ -211,6 +212,7 @@ int main(int argc, char** argv)
       next.depth_to_world_transform = truth[i + 1];
       tracer.Trace(*keyframe, next);   // :325, + the request pass of the next SetView
     }
+    else if (track && mode == 1 && i + 1 < frames) tracer.TraceWithoutNormals(*keyframe);   // :325; the normals: the next Track's launch
     else tracer.Trace(*keyframe);      // :325
   }
 

@@ -57,6 +57,13 @@ class Tracer
     // The results are those of Trace(frame); ...; SetView(next_frame), bit for bit (vk_trace_ahead_requests).
     void Trace(Frame& frame, Frame& next_frame, bool next_needs_normals = false);
 
+    // Not upstream: Trace(frame) without its last stage (tracer.cpp:97-100 ComputeNormals): depth and colour images only.
+    // For the tracking loop, where the raycast's normal image is read next by the tracker of the following frame:
+    // PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(frame, /*keyframe_normals_due*/ true) computes it — the same
+    // bits — in the launch that builds its pyramid, one launch less per frame. The normal image is allocated; whoever
+    // reads it before that Track calls frame.ComputeNormals().
+    void TraceWithoutNormals(Frame& frame);
+
     // Not upstream: the normals of Trace(frame, next_frame) are computed by workgroups of the raycast's own launch that
     // WAIT for the depths they need — a bounded wait. SettleNormals synchronises the stream and throws (upstream: a failed
     // device step always throws, device.h:14-17) if a wait expired; the normal image has then been recomputed by a launch
@@ -82,7 +89,7 @@ class Tracer
 
   private:
     void Initialize();
-    void TraceWith(Frame& frame, Frame* next, bool next_needs_normals);
+    void TraceWith(Frame& frame, Frame* next, bool next_needs_normals, bool with_normals = true);
 };
 
 // ---- stage functions (device pointers in, device pointers out) -----------------

@@ -113,7 +113,9 @@ class DepthTracker : public Tracker
 
     // PyramidTracker<DepthTracker>::Track as one call into the C ABI (vk_icp_pyramid_track)
     // `normals_due`: frame.normal_image is still to be computed (Frame::ComputeNormals) and is, by the pyramid's launch
-    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due = false);
+    // `keyframe_normals_due`: the KEYFRAME's normal image is still to be computed too (Tracer::TraceWithoutNormals left it
+    // out) and is, by the same launch
+    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due = false, bool keyframe_normals_due = false);
 
   protected:
     int GetResidualCount(const Frame& frame) const override;
@@ -222,7 +224,9 @@ class PyramidTracker
     void Track(Frame& frame);
     // frame.ComputeNormals(); Track(frame); (vulcan.cu:297-311) in one call — not upstream: with a DepthTracker the normal
     // image is computed by the launch that builds the pyramid (vk_icp_pyramid_track_frame), same bits
-    void ComputeNormalsAndTrack(Frame& frame);
+    // `keyframe_normals_due` (DepthTracker): the keyframe came from Tracer::TraceWithoutNormals — its normal image is computed by
+    // the same launch as well (other trackers: keyframe normals are computed first, by a launch of their own)
+    void ComputeNormalsAndTrack(Frame& frame, bool keyframe_normals_due = false);
 
   protected:
     void TrackLevels(Frame& frame);   // the generic two-level loop (pyramid_tracker.cpp:52-90)

@@ -90,6 +90,11 @@ void Tracer::Trace(Frame& frame)
   TraceWith(frame, nullptr, false);
 }
 
+void Tracer::TraceWithoutNormals(Frame& frame)
+{
+  TraceWith(frame, nullptr, false, false);
+}
+
 void Tracer::SettleNormals()
 {
   vk_view_bounds* ahead = volume_->GetViewBounds();
@@ -103,7 +108,7 @@ void Tracer::Trace(Frame& frame, Frame& next_frame, bool next_needs_normals)
   TraceWith(frame, &next_frame, next_needs_normals);
 }
 
-void Tracer::TraceWith(Frame& frame, Frame* next, bool next_needs_normals)
+void Tracer::TraceWith(Frame& frame, Frame* next, bool next_needs_normals, bool with_normals)
 {
   VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
   const int w = frame.depth_image->GetWidth();
@@ -129,7 +134,7 @@ void Tracer::TraceWith(Frame& frame, Frame* next, bool next_needs_normals)
   float* normals_out = reinterpret_cast<float*>(frame.normal_image->GetData());
   if (!next || volume_->GetRequestStream())
   {
-    VK_ASSERT(vk_trace_ahead(&v, &f, ahead, depth_out, color_out, normals_out, Device::GetStream()));
+    VK_ASSERT(vk_trace_ahead(&v, &f, ahead, depth_out, color_out, with_normals ? normals_out : nullptr, Device::GetStream()));
     if (next && next_needs_normals) next->ComputeNormals();
     return;
   }

@@ -242,7 +242,7 @@ void DepthTracker::TrackOnDevice(Frame& frame)
       DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
-void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due)
+void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due, bool keyframe_normals_due)
 {
   if (normals_due)
   {
@@ -269,7 +269,9 @@ void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& fr
     poll_.host_state[3] = 0;
     HookAdapter adapter = { reduce_hook_, reduce_user_ };
     // the start pose and (first attempt) the frame's normals travel with the pyramid's launch
-    VK_ASSERT(vk_icp_pyramid_track_frame(&key, &Twm, &frm, pose_.GetData(), &pose, normals_due && attempt == 0 ? 1 : 0,
+    // (bit 0: the frame's normal image, bit 1: the keyframe's — vk.h)
+    const int due = attempt == 0 ? ((normals_due ? 1 : 0) | (keyframe_normals_due ? 2 : 0)) : 0;
+    VK_ASSERT(vk_icp_pyramid_track_frame(&key, &Twm, &frm, pose_.GetData(), &pose, due,
         pyramid_.GetData(), workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(), DeviceHook(), &adapter,
         &poll_, Device::GetStream()));
     iteration_ = max_iterations_;
@@ -645,17 +647,23 @@ void PyramidTracker<DepthTracker>::Track(Frame& frame)
 }
 
 template <typename Tracker>
-void PyramidTracker<Tracker>::ComputeNormalsAndTrack(Frame& frame)
+void PyramidTracker<Tracker>::ComputeNormalsAndTrack(Frame& frame, bool keyframe_normals_due)
 {
+  // (the key frame is shared as const: its normal IMAGE is what is written, through the image's own pointer)
+  if (keyframe_normals_due && keyframe_ && keyframe_->normal_image && keyframe_->depth_image)
+  {
+    Frame key = *keyframe_;
+    key.ComputeNormals();
+  }
   frame.ComputeNormals();
   Track(frame);
 }
 
 template <>
-void PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(Frame& frame)
+void PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(Frame& frame, bool keyframe_normals_due)
 {
   VULCAN_DEBUG(keyframe_);
-  tracker_->TrackPyramid(keyframe_, frame, true);
+  tracker_->TrackPyramid(keyframe_, frame, true, keyframe_normals_due);
   ++iter_;
 }
 

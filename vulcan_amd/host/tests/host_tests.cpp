@@ -1545,6 +1545,50 @@ TEST(Tracer, TraceAnnouncingTheNextFrameEqualsTheTwoCalls)
   }
 }
 
+// Tracer::TraceWithoutNormals + PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(frame, true): the raycast's normal image
+// made by the launch that builds the next Track's pyramid (round 5) — the same key-frame normals, the same tracked pose, bit
+// for bit, as Tracer::Trace (tracer.cpp:41-47) followed by frame.ComputeNormals() and Track (vulcan.cu:297-311).
+TEST(Tracer, TraceWithoutNormalsLeavesThemToTheNextTrack)
+{
+  const int w = 160, h = 120;
+  std::vector<Vector3f> key_normals[2];
+  Transform tracked[2];
+  for (int variant = 0; variant < 2; ++variant)
+  {
+    Frame frame;
+    frame.depth_projection.SetFocalLength(136, 136);
+    frame.depth_projection.SetCenterPoint(80, 60);
+    frame.color_projection = frame.depth_projection;
+    frame.depth_image = MakeDepth(w, h, [&](int x, int y) { return float(1.4 + 0.08 * cos(5.0 * x / w) * sin(4.0 * y / h + 0.3)); });
+    frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+    auto volume = std::make_shared<Volume>(8192, 2048);
+    volume->SetVoxelLength(0.008f);
+    DepthIntegrator integrator(volume);
+    Tracer tracer(volume);
+    auto keyframe = std::make_shared<Frame>();
+    keyframe->depth_projection = keyframe->color_projection = frame.depth_projection;
+    keyframe->depth_image = std::make_shared<Image>(w, h);
+    FuseToFixedPoint(volume, frame);
+    integrator.Integrate(frame);
+    if (variant == 0) tracer.Trace(*keyframe); else tracer.TraceWithoutNormals(*keyframe);
+    Frame next = frame;
+    next.normal_image.reset();
+    next.depth_to_world_transform = Transform::Translate(0.002f, -0.001f, 0.0015f) * Transform::Rotate(0.999995f, 0.002f, -0.0015f, 0.001f);
+    PyramidTracker<DepthTracker> tracker;
+    tracker.SetKeyframe(keyframe);
+    tracker.ComputeNormalsAndTrack(next, variant == 1);
+    tracked[variant] = next.depth_to_world_transform;
+    key_normals[variant].resize(size_t(w) * h);
+    keyframe->normal_image->CopyToHost(key_normals[variant].data());
+  }
+  ASSERT_TRUE(std::memcmp(key_normals[0].data(), key_normals[1].data(), key_normals[0].size() * sizeof(Vector3f)) == 0);
+  const Matrix4f A = tracked[0].GetMatrix(), B = tracked[1].GetMatrix();
+  ASSERT_TRUE(std::memcmp(&A, &B, sizeof(A)) == 0);
+  size_t with_normal = 0;
+  for (const Vector3f& n : key_normals[1]) with_normal += (n[0] != 0 || n[1] != 0 || n[2] != 0) ? 1 : 0;
+  ASSERT_TRUE(with_normal > 10000);
+}
+
 // ---- FrameUploader (upload.h): no upstream test — upstream uploads with a blocking copy (image.h:100-123) ----
 
 TEST(FrameUploader, DeliversEveryFrameInOrderThroughTwoSlots)
