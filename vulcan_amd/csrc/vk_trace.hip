@@ -395,6 +395,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES
 {
   __shared__ int4 directories[4][kDirWords];
   __shared__ int normals_expired;
+#ifdef VK_TR_EXTRA_LDS
+  // experiment (profiles/r05_two_launch_frame.txt): the static LDS SetView's handle + visibility pass would bring into this
+  // launch if it rode here too (handle_listed 16 KiB, later_rounds 20 KiB) — what that does to the raycast's occupancy
+  __shared__ int extra_lds[VK_TR_EXTRA_LDS / 4];
+  asm volatile("" :: "v"(&extra_lds[threadIdx.x]));
+#endif
   if ((int)blockIdx.x < trace_groups)
   {
     points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
