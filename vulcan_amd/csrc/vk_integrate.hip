@@ -705,6 +705,11 @@ __global__ __launch_bounds__(kPipeWavesPerGroup * 64) VK_INTEGRATE_WAVES void in
   }
 }
 
+#ifndef VK_INTEGRATE_RING
+#define VK_INTEGRATE_RING 0     // 1: quarter-block units through a three-deep LDS-DMA ring (vk_integrate_ring.inc; an experiment)
+#endif
+#include "vk_integrate_ring.inc"
+
 int fill_params(IntegrateParams& P, const vk_volume* v, const vk_integrator* p, const vk_frame* f,
     const vk_light* light, const float* mask, bool need_depth, bool need_color, bool need_light,
     const float* records = nullptr)
@@ -796,6 +801,22 @@ int launch_as(const IntegrateParams& P, const vk_volume* v, const vk_frame* fram
     with_bounds = true;
   }
 
+#if VK_INTEGRATE_RING
+  // the experiment covers the two instantiations the bench times: depth only, and depth + light colour from one camera with records
+  if (DEPTH && (COLOR == COLOR_NONE || (COLOR == COLOR_LIGHT && SAME_CAM && RECORDS)))
+  {
+    constexpr int RING_COLOR = COLOR == COLOR_NONE ? COLOR_NONE : COLOR_LIGHT;
+    if (with_bounds)
+      hipLaunchKernelGGL((ring::integrate_ring_kernel<RING_COLOR, true>), dim3(pipe_grid_for(v, 4) + kBoundsGroups),
+          dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+    else
+      hipLaunchKernelGGL((ring::integrate_ring_kernel<RING_COLOR, false>), dim3(pipe_grid_for(v, 4)),
+          dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+    VK_LAUNCH_CHECK();
+    if (with_bounds) view_record(ahead, v, frame);
+    return VK_OK;
+  }
+#endif
   if (with_bounds)
   {
     // 37.5 KiB of LDS per workgroup: four per CU
