@@ -88,6 +88,9 @@ REQUESTS_AHEAD = os.environ.get("VK_BENCH_REQUESTS_AHEAD", "1") != "0"
 # vk_icp_pyramid_track_frame(.., frame_normals_due = 1 | 2)): nobody reads the key frame's normals before that Track, the
 # bits are the same, and the frame has one launch less. "0": Tracer::Trace's own normals launch (A/B).
 KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "1") != "0"
+# experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
+# makes them with launches of its own); never set in a reported run
+NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
@@ -457,7 +460,7 @@ class FrameLoop:
         if ev:
             lib.vk_event_record(ev[0], s)
         rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr, self.r_ptr,
-                                     vv["bref"], s)                                 # *_integrator.cu Integrate
+                                     None if NO_BOUNDS_AHEAD else vv["bref"], s)    # *_integrator.cu Integrate
         if ev:
             lib.vk_event_record(ev[1], s)
         if self.split is not None:
