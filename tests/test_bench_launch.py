@@ -92,3 +92,17 @@ def test_recorded_bench_line_carries_the_raycast_figures():
     rounds = d["config"]["set_view"]["rounds_run_per_frame"]
     assert 1.0 <= rounds <= d["config"]["set_view"]["max_rounds"] == 3
     assert len(d["per_rank_ms_per_step"]) == d["n_gpus"]
+
+
+def test_recorded_past_l3_trace_adds_up():
+    """roofline.past_l3.by_kernel_trace is read from profiles/r*_integrate_past_l3.json (rocprofv3 cannot run inside the
+    bench): what is on file must follow from its own numbers."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl in ("rgbd", "depth"):
+        d = bench.recorded_past_l3(wl)
+        assert d is not None and "NOT measured in this run" in d["source"]
+        assert abs(d["frac"] - d["achieved"] / bench.HBM_PEAK_GBS) < 1e-9
+        assert 20.0 < d["avg_launch_us"] < 80.0 and d["launches"] >= 48
+        assert d["frac"] < 1.0
+    assert bench.recorded_past_l3("rgbd-icp") is None
