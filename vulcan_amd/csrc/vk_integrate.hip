@@ -29,6 +29,16 @@
 // gathers ahead). The product is the scalar form.
 #define VK_LIGHT_PACKED 0
 #endif
+// Wave priority (s_setprio, round 5). The kernel is bound by instruction issue; which of a SIMD's four waves issues next is
+// the hardware's choice (oldest first) unless the waves say otherwise. A unit's update has one long stretch of pure
+// arithmetic — step 4, the light model — between two stretches that END IN MEMORY REQUESTS (steps 1-3: tile to LDS, depth
+// pass, the gathers and the next unit's tile; step 5: the write-back). With the arithmetic at priority 0 and the rest at 1
+// a wave whose data has just landed gets its next requests out before a neighbour's light model takes the issue slots:
+// 34.9 -> 34.0 us (two alternating pairs of runs; steps 1-3 alone 34.2, steps 2-3 alone 34.8, the light model ALONE raised
+// 34.6; levels 1, 2, 3 the same). Same instructions, same bits. -DVK_INTEGRATE_PRIO=0: without.
+#ifndef VK_INTEGRATE_PRIO
+#define VK_INTEGRATE_PRIO 1
+#endif
 #ifndef VK_INTEGRATE_GATHER_AHEAD
 #define VK_INTEGRATE_GATHER_AHEAD (VK_LIGHT_PACKED ? 2 : 4)   // packed: three / four voxels' gathers ahead cost 12 / 28 bytes of scratch
 #endif
@@ -271,6 +281,9 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
 {
   float* tile = reinterpret_cast<float*>(tile4);
   const int vx = lane & 7, vy = lane >> 3;
+#if VK_INTEGRATE_PRIO
+  __builtin_amdgcn_s_setprio(VK_INTEGRATE_PRIO);   // steps 1-3 end in memory requests: ahead of the other waves' arithmetic
+#endif
   // The never-allocated origin block (data == -1) has read slot 0 and goes through the update like
   // any other unit — one straight path keeps the wait counts of the steady state exact — but writes nothing back.
   const bool skip = u_skip;
@@ -410,6 +423,9 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
   if (NEXT) unit_issue<DEPTH, COLOR, SAME_CAM>(P, my_entry, next_s, lane, r0, r1, r2, r3, r4, u_depth, u_z, u_pix, u_valid,
       u_base, u_skip, u_off, u_half);
   __builtin_amdgcn_sched_barrier(0);
+#if VK_INTEGRATE_PRIO
+  __builtin_amdgcn_s_setprio(0);                   // the light model: pure arithmetic, behind the others' requests
+#endif
 
   // ---- step 4: the colour running averages -------------------------------------------------------------------------
   if (COLOR != COLOR_NONE)
@@ -571,6 +587,9 @@ __device__ __forceinline__ void unit_step(const IntegrateParams& P, int4 my_entr
     }
   }
 
+#if VK_INTEGRATE_PRIO
+  __builtin_amdgcn_s_setprio(VK_INTEGRATE_PRIO);   // the write-back
+#endif
   if (__any(dirty) && !skip)
   {
     // Write back only what differs from what was read: in steady state about a
