@@ -234,6 +234,12 @@ constexpr int kNormalRowStride = 16;      // words: a 64-byte line per counter (
 constexpr int kNormalWaitPolls = 1 << 16; // x s_sleep(32): some 60 ms
 constexpr int kNormalLateWords = 16;      // one more line behind the counters: word 0 = a group's wait has expired
 
+// The raycast's waves above the request pass's in the launch they share (s_setprio, round 5): the launch is as long as its
+// slowest raycast wave, the request pass fills in. 37.75 -> 37.53 us in two alternating pairs of runs (the request pass's waves
+// raised instead: 38.2; a march's waves raised after 8 / 16 / 32 passes through the loop: nothing, either scene). -DVK_TR_PRIO=0: without.
+#ifndef VK_TR_PRIO
+#define VK_TR_PRIO 1
+#endif
 #ifndef VK_TR_WAVES
 #define VK_TR_WAVES 5
 #endif
@@ -403,6 +409,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES
 #endif
   if ((int)blockIdx.x < trace_groups)
   {
+#if VK_TR_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
     points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
     return;
   }
