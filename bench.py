@@ -91,6 +91,11 @@ KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "
 # experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
 # makes them with launches of its own); never set in a reported run
 NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
+# How the roofline sample times an integrate launch. Default: the dispatch's own begin and end (vk_integrate_time_next ->
+# hipExtLaunchKernelGGL's start / stop events) — the duration rocprofv3's kernel trace reports. "0": two vk_event_record
+# around the call, as until round 5 — that bracket also holds the events' own processing and the launch latency behind
+# the first of them (1.7 - 3.5 us of a 34 us launch: 0.555 where the trace says 0.58)
+TIME_BY_DISPATCH = os.environ.get("VK_BENCH_TIME_BY_DISPATCH", "1") != "0"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 
 
@@ -458,10 +463,13 @@ class FrameLoop:
             else:
                 rc |= lib.vk_light_prepare(self.fref, self.depth_threshold, self.m_ptr, self.r_ptr, s)
         if ev:
-            lib.vk_event_record(ev[0], s)
+            if TIME_BY_DISPATCH:
+                rc |= lib.vk_integrate_time_next(ev[0], ev[1])      # the launch records them as its own begin and end
+            else:
+                lib.vk_event_record(ev[0], s)
         rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr, self.r_ptr,
                                      None if NO_BOUNDS_AHEAD else vv["bref"], s)    # *_integrator.cu Integrate
-        if ev:
+        if ev and not TIME_BY_DISPATCH:
             lib.vk_event_record(ev[1], s)
         if self.split is not None:
             lib.vk_event_record(self.split["integrated"], s)
@@ -990,9 +998,14 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_bytes, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": float(alg[sampled].mean()),
             "avg_launch_us": float(integ_ms.mean() * 1e3), "launches_timed": len(sampled),
-            "sample": f"HIP events around every integrate launch of {len(sampled)} further frames of the same sequence, "
-                      "right after the timed region (no event is recorded inside it)",
-            "event_pair_us": pair_us,      # two records with nothing between them; included in avg_launch_us, not subtracted
+            "sample": (f"HIP start / stop events OF every integrate dispatch (vk_integrate_time_next -> hipExtLaunchKernelGGL: the "
+                       f"launch's own begin and end, what rocprofv3's kernel trace reports) of {len(sampled)} further frames of the "
+                       "same sequence, right after the timed region (no event is recorded inside it)") if TIME_BY_DISPATCH else
+                      (f"HIP events recorded AROUND every integrate launch of {len(sampled)} further frames of the same sequence, "
+                       "right after the timed region (no event is recorded inside it); the bracket holds event_pair_us and the "
+                       "launch latency behind its first event as well"),
+            "timed_by": "dispatch" if TIME_BY_DISPATCH else "bracket",
+            "event_pair_us": pair_us,      # two vk_event_record with nothing between them: what a bracket would add (not in avg_launch_us when timed_by = dispatch)
             # where the bytes come from at this size: a frame's voxel working set is ~75 MB and
             # consecutive frames overlap almost entirely, so it lives in the 256 MiB Infinity Cache
             "memory_level": "infinity-cache assisted" if voxel_ws < L3_BYTES else "hbm",

@@ -597,6 +597,16 @@ VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
     const vk_frame* frame, int color_mode, const vk_light* light, const float* mask,
     const float* light_records, vk_view_bounds* ahead, void* stream);
 
+/* A measurement aid (round 5; no reference counterpart — upstream times nothing on the device; ref: src/depth_integrator.cu:
+ * 83-120, src/light_integrator.cu:296-340 for the launches it times): the NEXT pipelined integrate launch issued from this
+ * host thread (vk_integrate_depth / _depth_color / _depth_light / vk_integrate_ahead) records `start_event` and `stop_event`
+ * (vk_event_create) as the begin and the end OF THE DISPATCH ITSELF (hipExtLaunchKernelGGL) — the duration rocprofv3's kernel
+ * trace reports. A caller that brackets the call with two vk_event_record instead also times the events' own processing and
+ * the launch latency behind the first of them: 1.7 - 3.5 us on a 34 us launch, which is what separated bench.py's roofline
+ * fraction from the kernel trace's until round 5. One launch only; (NULL, NULL) cancels. Not a stream operation: nothing is
+ * enqueued by this call. */
+VK_API int vk_integrate_time_next(void* start_event, void* stop_event);
+
 /* ref: src/tracer.cpp:41-47 Tracer::Trace, as vk_trace with the grid, depth range
  * and scratch taken from *ahead: when *ahead holds the bounds of this very view
  * the bounds pass is skipped, otherwise it runs and *ahead is updated. `normals` may be NULL (round 5): the normal image is

@@ -56,6 +56,10 @@ def test_version_and_errors_without_gpu():
     # round 5: the cancel of an announced frame, the outcome of the normals' bounded wait
     assert lib.vk_requests_ahead_cancel(None, None, 1, None) == -1 and lib.vk_trace_normals_settle(None, None) == -1
     assert b"bounded wait" in lib.vk_error_string(-6)
+    # the launch that times itself takes both events or neither (host state only: nothing is enqueued, no device touched)
+    one = C.c_void_p(1)
+    assert lib.vk_integrate_time_next(one, None) == -1 and lib.vk_integrate_time_next(None, one) == -1
+    assert lib.vk_integrate_time_next(None, None) == 0
     # scratch of a tracer: merged grid + 32 private grids + the normals' row counters (128 lines of 16 words) + the expiry line
     assert lib.vk_trace_bounds_floats(80, 60) == 2 * 4800 * 33 + 128 * 16 + 16
     assert lib.vk_icp_workspace_floats(640, 480) == 4 * 1200 * 32 + 32     # two parities of 1200 slots (256-pixel groups) x 32 {tag, value} words + a pose

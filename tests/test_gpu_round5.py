@@ -334,3 +334,59 @@ def test_raycast_normals_made_by_the_next_tracks_pyramid_launch(api, orc):
     assert np.array_equal(py0, py1, equal_nan=True) and p0 == p1
     assert np.array_equal(kn1, orc.compute_normals(d1, out.depth_projection), equal_nan=True)
     assert (np.abs(kn1).sum(axis=-1) > 0).sum() > 10000
+
+
+# ------------------------------------------------ a launch that times itself --
+
+def test_integrate_launch_times_itself_and_changes_nothing(api):
+    """vk_integrate_time_next: the next pipelined integrate launch records the two events as its own begin and end
+    (bench.py's roofline sample). The duration is that of one launch — positive, and no longer than a bracket of two
+    vk_event_record around the same call on an otherwise idle stream —, the request is used up by that launch, and the
+    volume is the one an untimed launch leaves."""
+    lib = api.lib()
+    w, h = 320, 240
+    k = T.Projection.make(273.5, 273.5, 160.0, 120.0)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.4 + 0.1 * np.cos(5.0 * x / w) * np.sin(4.0 * y / h + 0.3)).astype(np.float32)
+    color = scenes.checker_color(w, h, 0.1, 0.9)
+
+    def events(n):
+        out = []
+        for _ in range(n):
+            e = C.c_void_p()
+            api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
+            out.append(e)
+        return out
+
+    def elapsed(e0, e1):
+        ms = C.c_float()
+        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(ms)), "vk_event_elapsed_ms")
+        return ms.value
+
+    states = []
+    for timed in (False, True):
+        vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+        integ = api.LightIntegrator(vol)
+        integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+        frames = [api.Frame(depth, k, scenes.yaw(0.5 * i), color=color) for i in range(3)]
+        own, around = events(2), events(2)
+        for i, f in enumerate(frames):
+            vol.set_view(f, rounds=3, compute_normals=True)
+            integ.prepare(f)
+            sync()
+            if timed and i == 1:
+                assert lib.vk_integrate_time_next(own[0], None) == -1      # VK_ERR_ARGUMENT: both or neither
+                api.check(lib.vk_integrate_time_next(own[0], own[1]), "vk_integrate_time_next")
+                lib.vk_event_record(around[0], api.stream())
+            integ.integrate(f)
+            if timed and i == 1:
+                lib.vk_event_record(around[1], api.stream())
+        sync()
+        if timed:
+            inner, outer = elapsed(own[0], own[1]), elapsed(around[0], around[1])
+            assert 0.001 < inner < 5.0, inner                 # one launch: microseconds to a few milliseconds
+            assert inner <= outer + 1e-3, (inner, outer)      # the dispatch lies inside the bracket
+            # used up: frame 2's launch did not record them again (the same elapsed time is still there)
+            assert elapsed(own[0], own[1]) == inner
+        states.append((vol.host_voxels().tobytes(), vol.host_entries().tobytes()))
+    assert states[0] == states[1]

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vk_trace": ([_P, _P, _F, _F, _P, _I, _I, _P, _P, _P, _P], _I),
     "vk_light_prepare": ([_P, _F, _P, _P, _P], _I),
     "vk_integrate_ahead": ([_P, _P, _P, _I, _P, _P, _P, _P, _P], _I),
+    "vk_integrate_time_next": ([_P, _P], _I),
     "vk_trace_ahead": ([_P, _P, _P, _P, _P, _P, _P], _I),
     "vk_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),
     "vk_color_image_downsample": ([_I, _I, _P, _P, _I, _P], _I),

@@ -16,6 +16,7 @@
 #include "vk_bounds.hpp"
 
 #include <cstring>
+#include <hip/hip_ext.h>
 
 #ifndef VK_INTEGRATE_NT_STORES
 #define VK_INTEGRATE_NT_STORES 0
@@ -804,6 +805,20 @@ int pipe_grid_for(const vk_volume* v, int groups_per_cu)
   return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
+// vk_integrate_time_next: the events the next pipelined launch of this host thread records as its own begin and end
+thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
+
+template <typename Kernel>
+void launch_pipelined(Kernel kernel, int grid, hipStream_t s, const IntegrateParams& P, const AheadParams& A)
+{
+  if (g_time_start && g_time_stop)
+  {
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kPipeWavesPerGroup * 64), 0, s, g_time_start, g_time_stop, 0, P, A);
+    g_time_start = g_time_stop = nullptr;
+  }
+  else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+}
+
 // `ahead` (optional): also compute the raycast bounds of the frame's own view
 template <bool DEPTH, int COLOR, bool SAME_CAM, bool RECORDS>
 int launch_as(const IntegrateParams& P, const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, hipStream_t s)
@@ -839,13 +854,10 @@ int launch_as(const IntegrateParams& P, const vk_volume* v, const vk_frame* fram
   if (with_bounds)
   {
     // 37.5 KiB of LDS per workgroup: four per CU
-    const int grid = pipe_grid_for(v, 4) + kBoundsGroups;
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, true, SAME_CAM, RECORDS>), dim3(grid),
-        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+    launch_pipelined(integrate_pipelined_kernel<DEPTH, COLOR, true, SAME_CAM, RECORDS>, pipe_grid_for(v, 4) + kBoundsGroups, s, P, A);
   }
   else
-    hipLaunchKernelGGL((integrate_pipelined_kernel<DEPTH, COLOR, false, SAME_CAM, RECORDS>), dim3(pipe_grid_for(v, 5)),
-        dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+    launch_pipelined(integrate_pipelined_kernel<DEPTH, COLOR, false, SAME_CAM, RECORDS>, pipe_grid_for(v, 5), s, P, A);
   VK_LAUNCH_CHECK();
   if (with_bounds) view_record(ahead, v, frame);
   return VK_OK;
@@ -988,6 +1000,14 @@ int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const v
   const int rc = fill_params(P, v, p, frame, light, mask, true, true, true);
   if (rc != VK_OK) return rc;
   return launch<true, COLOR_LIGHT>(P, v, frame, nullptr, vk_s(stream));
+}
+
+int vk_integrate_time_next(void* start_event, void* stop_event)
+{
+  VK_REQUIRE((start_event == nullptr) == (stop_event == nullptr));
+  g_time_start = static_cast<hipEvent_t>(start_event);
+  g_time_stop = static_cast<hipEvent_t>(stop_event);
+  return VK_OK;
 }
 
 int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int color_mode,
