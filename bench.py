@@ -923,8 +923,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank % torch.cuda.device_count())   # == local_rank on a full node
     api.lib()
-    if os.environ.get("VK_BENCH_STREAM") == "side":
-        # experiment: a created stream instead of the legacy default stream torch starts on
+    if os.environ.get("VK_BENCH_STREAM", "created") != "legacy":
+        # A created stream (what a C++ caller has, and vulcan_amd/host's classes) instead of the legacy default stream torch
+        # starts on: launches on the legacy stream follow one another about 1 us later on some boxes of this pool — 85.6 / 86.8 /
+        # 85.7 us per frame against 83.4 / 82.5 / 82.9 in three alternating pairs of runs (tools/debug/stream_ab.sh), the kernels
+        # alike. VK_BENCH_STREAM=legacy: the old behaviour. The timed region's torch.cuda.synchronize() waits for the device.
         torch.cuda.set_stream(torch.cuda.Stream())
 
     total = args.warmup + args.steps + ROOFLINE_SAMPLE_FRAMES
