@@ -928,7 +928,12 @@ def main():
         # starts on: launches on the legacy stream follow one another about 1 us later on some boxes of this pool — 85.6 / 86.8 /
         # 85.7 us per frame against 83.4 / 82.5 / 82.9 in three alternating pairs of runs (tools/debug/stream_ab.sh), the kernels
         # alike. VK_BENCH_STREAM=legacy: the old behaviour. The timed region's torch.cuda.synchronize() waits for the device.
-        torch.cuda.set_stream(torch.cuda.Stream())
+        if os.environ.get("VK_BENCH_STREAM") == "vk":      # experiment: the library's own vk_stream_create, as the C++ loop has
+            made = C.c_void_p()
+            api.check(api.lib().vk_stream_create(C.byref(made)), "vk_stream_create")
+            torch.cuda.set_stream(torch.cuda.ExternalStream(made.value))
+        else:
+            torch.cuda.set_stream(torch.cuda.Stream())
 
     total = args.warmup + args.steps + ROOFLINE_SAMPLE_FRAMES
     # every rank walks the same arc, offset so ranks do not share poses

@@ -2,7 +2,7 @@
 # bench.py's headline loop on torch's legacy default stream against a created one (VK_BENCH_STREAM=legacy | created, the
 # default since the end of round 5), alternating; then the C++ loop (which creates its own stream)
 for r in 1 2 3; do
-  for m in legacy created; do
+  for m in ${STREAMS:-legacy created}; do
     export VK_BENCH_STREAM=$m
     python bench.py --only --cpu-seconds 0 --steps 200 --warmup 20 2>/dev/null | python3 -c "
 import json,sys

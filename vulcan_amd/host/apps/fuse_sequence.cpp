@@ -71,6 +71,18 @@ int main(int argc, char** argv)
   VK_ASSERT(vk_device_count(&devices));
   if (devices == 0) { std::fprintf(stderr, "no HIP device\n"); return 2; }
 
+  // The classes submit to Device::GetStream(), which starts as the legacy default stream like upstream's stream 0
+  // (device.h:40-52). On some boxes of this pool consecutive launches on the legacy stream follow one another about 1 us
+  // later than on a created one (bench.py: 85.6-86.8 against 82.5-83.4 us per frame in alternating runs), so the app creates
+  // its stream; VK_APP_LEGACY_STREAM=1 keeps upstream's.
+  void* app_stream = nullptr;
+  const char* legacy = std::getenv("VK_APP_LEGACY_STREAM");
+  if (!(legacy && legacy[0] == '1'))
+  {
+    VK_ASSERT(vk_stream_create(&app_stream));
+    Device::SetStream(app_stream);
+  }
+
   // app defaults: vulcan.cu:12-13 (65024 + 8192 blocks), :283-287 intrinsics, 5 mm voxels
   auto volume = std::make_shared<Volume>(65024, 8192);
   volume->SetVoxelLength(0.005f);
