@@ -16,7 +16,7 @@ for m in 0 1 2 3; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 $m 
 timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 300 0 0 0 1 >> $out/fuse_sequence.txt 2>&1
 # the photometric loops once more over half a cycle of the camera's path: what they allocate then fits the app's pool
 for m in 2 3; do timeout -k 10 120 vulcan_amd/host/bin/fuse_sequence 120 $m >> $out/fuse_sequence.txt 2>&1; done
-grep "^frames" $out/fuse_sequence.txt
+grep "^frames\|^steady" $out/fuse_sequence.txt
 timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err || { tail -20 $out/bench.err; exit 1; }
 python3 -c "
 import json; d=json.load(open('$out/bench.json')); o=d['other_workloads']

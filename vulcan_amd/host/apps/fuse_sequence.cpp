@@ -173,8 +173,17 @@ int main(int argc, char** argv)
   Device::Synchronize();
   const auto t0 = std::chrono::steady_clock::now();
 
+  // the same loop without its cold start (frame 0 allocates the whole first view: a 200 us request pass, the table's first
+  // fill): an event behind frame `warm - 1` and one behind the last frame, on the classes' stream
+  const int warm = 20;
+  void* steady_from = nullptr;
+  void* steady_to = nullptr;
+  VK_ASSERT(vk_event_create(&steady_from));
+  VK_ASSERT(vk_event_create(&steady_to));
+
   for (int i = 0; i < frames; ++i)
   {
+    if (i == warm) VK_ASSERT(vk_event_record(steady_from, Device::GetStream()));
     if (track)
     {
       frame.depth_image = depth_images[i];
@@ -231,6 +240,7 @@ int main(int argc, char** argv)
   // how long the host needed to ENQUEUE the frames (mode 0 never waits for the device inside the loop): when this is
   // close to the total, the loop is bound by the host's launch calls, not by the kernels
   const double enqueue_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (frames > warm) VK_ASSERT(vk_event_record(steady_to, Device::GetStream()));
   Device::Synchronize();
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int32_t counters[VK_CTR_PUBLIC];
@@ -241,6 +251,15 @@ int main(int argc, char** argv)
           (split_streams ? "resident, requests on their own stream" : (requests_ahead ? "resident, requests made ahead" : "resident")), mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
   std::printf("host enqueue %.1f us per frame of %.1f\n", 1e6 * enqueue_seconds / frames, 1e6 * seconds / frames);
+  if (frames > warm)
+  {
+    float steady_ms = 0;
+    VK_ASSERT(vk_event_elapsed_ms(steady_from, steady_to, &steady_ms));
+    std::printf("steady %.1f us per frame = %.1f frames/s (frames %d..%d between two events on the stream: without the cold start)\n",
+        1e3 * steady_ms / (frames - warm), (frames - warm) / (1e-3 * steady_ms), warm, frames - 1);
+  }
+  (void)vk_event_destroy(steady_from);
+  (void)vk_event_destroy(steady_to);
   std::printf("final pose row0: %.5f %.5f %.5f %.5f\n", M(0, 0), M(0, 1), M(0, 2), M(0, 3));
 
   double motion_translation = 0, motion_rotation = 0;
