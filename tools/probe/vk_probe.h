@@ -60,6 +60,11 @@ VK_API int vk_probe_launch_floor(const int32_t* counters, float* sink, int workg
 /* the same chain captured once into a hipGraph on a stream of its own (the legacy default stream cannot be
  * captured) and replayed: *us_per_launch = time per kernel over `replays` graph launches. Returns the HIP
  * error code of the first call that fails (positive), 0 on success. */
+/* vk_probe.hip's rcp_rn_mid / sqrt_rn_mid (an experiment of round 5, not in the product) against the compiler's 1.0f / x and sqrtf(x) for EVERY float in [2^-60, 2^60] (both
+ * signs for the reciprocal): out[0..5] (device) = tested, differing (reciprocal); tested, differing (square root); first
+ * differing input of each as bit pattern + 1 (0: none). */
+VK_API int vk_probe_rounding(unsigned long long* out_dev6, void* stream);
+
 VK_API int vk_probe_launch_floor_graph(const int32_t* counters, float* sink, int workgroups, int launches, int replays,
     float* us_per_launch);
 

@@ -151,7 +151,86 @@ __global__ __launch_bounds__(256) void early_exit_kernel(const int32_t* __restri
 
 }  // namespace
 
+// ---- correctly rounded 1 / d and sqrt(x) for operands in the middle of the range: an experiment of round 5 ----------------
+// `1.0f / d` and `sqrtf(x)` are correctly rounded (IEEE-754 RN), so any sequence that is correctly rounded gives their bits.
+// hipcc's own expansions spend most of their instructions on the ends of the range: 1 / d = v_div_scale x2, v_rcp, five
+// multiply-adds, v_div_fmas, v_div_fixup (11 vector instructions); sqrt = scale by 2^32 below 2^-96 (3), v_sqrt, the two
+// neighbours tried by their residuals (8), unscale (2), class fix-up (3) (17). For |d|, x in [2^-60, 2^60] none of that is
+// needed: v_rcp + ONE Newton step (3), and v_sqrt + the neighbours' test (9), give the same bits — for EVERY float of the
+// range, which is what rounding_kernel checks (2.0e9 / 1.0e9 values, 0 differences; the bare v_rcp differs for 10.7 %).
+// In the integrate kernel (projection, light direction, shading: three reciprocals and a square root per shaded voxel, 32
+// of its ~200 vector instructions) the guarded form — fast path + hipcc's expansion behind a range test — measures 33.96 us
+// against 33.85, and even WITHOUT the guard only 33.4: since the wave priorities the light model's arithmetic runs in the
+// gaps of the memory phases, and fewer instructions there buy nothing. Not adopted; docs/rounds/r05.md section 8.
+__device__ __forceinline__ bool mid_range(float x)
+{
+  const float a = __builtin_fabsf(x);
+  return a >= 0x1p-60f && a <= 0x1p60f;      // (a NaN fails both)
+}
+#ifndef VK_RCP_STEPS
+#define VK_RCP_STEPS 1
+#endif
+__device__ __forceinline__ float rcp_rn_mid(float d)
+{
+  float r = __builtin_amdgcn_rcpf(d);
+#pragma unroll
+  for (int i = 0; i < VK_RCP_STEPS; ++i) r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  return r;
+}
+__device__ __forceinline__ float sqrt_rn_mid(float x)
+{
+  const float s = __builtin_amdgcn_sqrtf(x);
+  // the neighbours of s, as hipcc's expansion tries them: s - 1 ulp if its residual says s is too large, s + 1 ulp if too small
+  const float below = __int_as_float(__float_as_int(s) - 1), above = __int_as_float(__float_as_int(s) + 1);
+  const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+  float out = r_below <= 0.0f ? below : s;
+  out = r_above > 0.0f ? above : out;
+  return out;
+}
+
+// Every float: rcp_rn_mid / sqrt_rn_mid against the compiler's own 1.0f / x and sqrtf(x), bit for bit, over the range a
+// caller would use them in. out[0], out[1]: values tested, values that differ (reciprocal); out[2], out[3]: the same
+// for the square root; out[4], out[5]: the first differing input of each (bit pattern + 1; 0 = none).
+__global__ __launch_bounds__(256) void rounding_kernel(unsigned long long* out)
+{
+  unsigned long long tested_r = 0, bad_r = 0, tested_s = 0, bad_s = 0;
+  const unsigned long long threads = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += threads)
+  {
+    const float x = __uint_as_float((uint32_t)b);
+    if (!mid_range(x)) continue;
+    ++tested_r;
+    if (__float_as_uint(rcp_rn_mid(x)) != __float_as_uint(1.0f / x))
+    {
+      ++bad_r;
+      atomicCAS(&out[4], 0ull, b + 1);
+    }
+    if (x > 0.0f)
+    {
+      ++tested_s;
+      if (__float_as_uint(sqrt_rn_mid(x)) != __float_as_uint(sqrtf(x)))
+      {
+        ++bad_s;
+        atomicCAS(&out[5], 0ull, b + 1);
+      }
+    }
+  }
+  atomicAdd(&out[0], tested_r);
+  if (bad_r) atomicAdd(&out[1], bad_r);
+  atomicAdd(&out[2], tested_s);
+  if (bad_s) atomicAdd(&out[3], bad_s);
+}
+
 extern "C" {
+
+int vk_probe_rounding(unsigned long long* out_dev6, void* stream)
+{
+  VK_REQUIRE(out_dev6);
+  VK_CHECK(hipMemsetAsync(out_dev6, 0, 6 * sizeof(unsigned long long), vk_s(stream)));
+  hipLaunchKernelGGL(rounding_kernel, dim3(16384), dim3(256), 0, vk_s(stream), out_dev6);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
+}
 
 int vk_probe_stream_copy(void* dst, const void* src, size_t bytes, int shape, void* stream)
 {
