@@ -841,11 +841,9 @@ int launch_as(const IntegrateParams& P, const vk_volume* v, const vk_frame* fram
   {
     constexpr int RING_COLOR = COLOR == COLOR_NONE ? COLOR_NONE : COLOR_LIGHT;
     if (with_bounds)
-      hipLaunchKernelGGL((ring::integrate_ring_kernel<RING_COLOR, true>), dim3(pipe_grid_for(v, 4) + kBoundsGroups),
-          dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+      launch_pipelined(ring::integrate_ring_kernel<RING_COLOR, true>, pipe_grid_for(v, 4) + kBoundsGroups, s, P, A);
     else   // (without the bounds groups' 37.5 KiB the ring's 32.4 KiB fit five times into a CU: VK_INTEGRATE_WAVES_PER_EU=5)
-      hipLaunchKernelGGL((ring::integrate_ring_kernel<RING_COLOR, false>), dim3(pipe_grid_for(v, VK_INTEGRATE_WAVES_PER_EU)),
-          dim3(kPipeWavesPerGroup * 64), 0, s, P, A);
+      launch_pipelined(ring::integrate_ring_kernel<RING_COLOR, false>, pipe_grid_for(v, VK_INTEGRATE_WAVES_PER_EU), s, P, A);
     VK_LAUNCH_CHECK();
     if (with_bounds) view_record(ahead, v, frame);
     return VK_OK;
