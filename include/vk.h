@@ -225,6 +225,17 @@ typedef struct vk_test_hooks {
 VK_API int vk_test_hooks_set(const vk_test_hooks* hooks);   /* NULL: everything back to its default */
 VK_API int vk_test_hooks_get(vk_test_hooks* out);
 
+/* The library's count of one-launch Gauss-Newton loops (vk_icp_track & co.). Every such launch tags the words its
+ * workgroups exchange with 22 bits of this count (1 + count mod (2^22 - 1)), so the tags repeat every 2^22 - 1 launches —
+ * about ten minutes of tracking. The library keeps the repeat from ever being seen: a tracker's `workspace` is cleared
+ * in front of a launch whenever it is new to the library, was last cleared 2^21 or more launches ago, or was written by
+ * a launch-per-stage loop in between (vulcan_amd/csrc/vk_runtime.hip, vk_loop_epoch_begin). What the caller owes: nothing
+ * but the library writes a workspace between two calls that use it. This entry point lets a test put the count right
+ * in front of a repeat instead of tracking for ten minutes: `set_to` (may be NULL) replaces the count, `count_now` and
+ * `clears` (may be NULL) receive the count and the number of clears enqueued so far. No reference counterpart (upstream's
+ * loop, src/tracker.cpp:53-63, has no launch tags). */
+VK_API int vk_test_hooks_loop_count(const uint64_t* set_to, uint64_t* count_now, uint64_t* clears);
+
 /* ------------------------------------------------------ library / device -- */
 
 VK_API const char* vk_error_string(int code);
@@ -237,7 +248,7 @@ VK_API int vk_version(void);                       /* 100*major + minor */
  *   vk_abi_check(VK_ABI_VERSION, sizeof(vk_volume), sizeof(vk_frame), VK_CTR_COUNT)
  * and refuse to go on unless it returns VK_OK (VK_ERR_UNSUPPORTED otherwise). The class layer (vulcan_amd/host) and the
  * Python binding do. New struct fields are appended; a change of VK_CTR_COUNT bumps the version. No reference counterpart. */
-#define VK_ABI_VERSION 6
+#define VK_ABI_VERSION 7
 VK_API int vk_abi_version(void);
 VK_API int vk_abi_check(int header_abi_version, size_t sizeof_vk_volume, size_t sizeof_vk_frame, int ctr_count);
 VK_API int vk_device_count(int* count);
@@ -641,7 +652,10 @@ typedef struct vk_requests_ahead {
   vk_transform  depth_to_world;
   uint64_t      content_id;
   int32_t       valid;
-  int32_t       pad_;
+  int32_t       normals_made;      /* round 6 (was padding): 1 = the announced frame's normal image (next_frame->normals) was written
+                                      with the pass (next_prep->normals_out rode) — or, set by the class layer, by a launch of its
+                                      own in front of the announce; 0 = the announce left the normals as they were. A caller
+                                      whose next step is "ComputeNormals, then SetView" may skip the normals only on 1 */
 } vk_requests_ahead;
 
 VK_API int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bounds* ahead, float* out_depth,

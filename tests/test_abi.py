@@ -52,7 +52,7 @@ def test_version_and_errors_without_gpu():
     assert lib.vk_trace_ahead_requests(None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.vk_volume_set_view_rounds_ahead(None, None, None, 3, None, None) == -1
     assert lib.vk_icp_pyramid_track_frame(None, None, None, None, None, 1, None, None, None, None, None, None, None, None, None) == -1
-    assert lib.vk_abi_version() == 6 and lib.vk_abi_check(5, 0, 0, 0) == -2      # VK_ERR_UNSUPPORTED
+    assert lib.vk_abi_version() == 7 and lib.vk_abi_check(6, 0, 0, 0) == -2      # VK_ERR_UNSUPPORTED
     # round 5: the cancel of an announced frame, the outcome of the normals' bounded wait
     assert lib.vk_requests_ahead_cancel(None, None, 1, None) == -1 and lib.vk_trace_normals_settle(None, None) == -1
     assert b"bounded wait" in lib.vk_error_string(-6)

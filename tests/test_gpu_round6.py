@@ -1,0 +1,96 @@
+"""Round 6: what VERDICT r5 / ADVICE r5 named.
+
+  * an announce WITHOUT the next frame's normals (Tracer.trace(out, next_frame=f) — next_needs_normals defaults to False)
+    followed by Volume.set_view(f, compute_normals=True): the normals are still due and the light preparation that rode
+    with the pass (made from the OLD normal image) must not be used;
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_parity import api, assert_volume_equal, sync  # noqa: F401
+from vulcan_amd import vk_types as T
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rgbd_inputs(w=320, h=240):
+    k = T.Projection.make(273.5, 273.5, 160.0, 120.0)
+    y, x = np.mgrid[0:h, 0:w]
+    depth = (1.4 + 0.1 * np.cos(5.0 * x / w) * np.sin(4.0 * y / h + 0.3)).astype(np.float32)
+    return k, depth, scenes.checker_color(w, h, 0.1, 0.9)
+
+
+# --------------------------------------------------- announce without the normals --
+
+def test_announce_without_normals_then_set_view_computes_them(api, orc):
+    """Trace(key, next) with next_needs_normals = false, then ComputeNormalsAndSetView(next). Until round 5 the
+    normals were skipped on the record's validity alone and LightIntegrator shaded from whatever the normal image held.
+    Now vk_requests_ahead.normals_made says whether they came with the pass; when not, they are computed in place, the
+    announced SetView runs, and the preparation made from the old normals is void. The result is the unannounced
+    sequence's, bit for bit, and the normal image is the oracle's."""
+    import torch
+    w, h = 320, 240
+    k, depth, color = _rgbd_inputs(w, h)
+    results = []
+    for announce in (None, "without normals", "with normals"):
+        vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+        integ, tracer = api.LightIntegrator(vol), api.Tracer(vol)
+        integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+        f0, f1 = api.Frame(depth, k, scenes.yaw(0.0), color=color), api.Frame(depth, k, scenes.yaw(1.0), color=color)
+        # a normal image that holds something else (a recycled frame): what round 5's code shaded from
+        f1.normals = torch.full((h, w, 3), 0.57735, dtype=torch.float32, device="cuda")
+        out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, scenes.yaw(0.0))
+        vol.set_view(f0, rounds=3, compute_normals=True)
+        integ.integrate(f0)
+        if announce is None:
+            tracer.trace(out)
+        else:
+            tracer.trace(out, next_frame=f1, next_needs_normals=(announce == "with normals"))
+            assert vol.requests_ahead.valid == 1
+            assert vol.requests_ahead.normals_made == (1 if announce == "with normals" else 0)
+        vol.set_view(f1, rounds=3, compute_normals=True)
+        assert vol.requests_ahead is None or vol.requests_ahead.valid == 0
+        integ.integrate(f1)
+        sync()
+        results.append((vol.host_voxels().tobytes(), vol.host_entries().tobytes(), f1.normals.cpu().numpy()))
+    want_normals = orc.compute_normals(depth, k)
+    for voxels, entries, normals in results:
+        assert np.array_equal(normals, want_normals, equal_nan=True)
+        assert voxels == results[0][0] and entries == results[0][1]
+    # and the shading did depend on the normals: integrating from the stale image gives another volume
+    vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    integ = api.LightIntegrator(vol)
+    integ.light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    f0, f1 = api.Frame(depth, k, scenes.yaw(0.0), color=color), api.Frame(depth, k, scenes.yaw(1.0), color=color)
+    f1.normals = torch.full((h, w, 3), 0.57735, dtype=torch.float32, device="cuda")
+    vol.set_view(f0, rounds=3, compute_normals=True)
+    integ.integrate(f0)
+    vol.set_view(f1, rounds=3)
+    integ.integrate(f1)
+    sync()
+    assert vol.host_voxels().tobytes() != results[0][0], "the test's stale normal image does not change the shading"
+
+
+def test_class_layer_records_normals_made_by_its_own_launch(api):
+    """Without a LightIntegrator attached the announce cannot carry the normals; Tracer.trace(.., next_needs_normals=True) then
+    computes them with a launch of its own IN FRONT of the announce, and the record says so (the class layer's flag)."""
+    import torch
+    w, h = 320, 240
+    k, depth, _ = _rgbd_inputs(w, h)
+    vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    integ, tracer = api.DepthIntegrator(vol), api.Tracer(vol)
+    f0, f1 = api.Frame(depth, k, scenes.yaw(0.0)), api.Frame(depth, k, scenes.yaw(1.0))
+    out = api.Frame(torch.zeros((h, w), dtype=torch.float32, device="cuda"), k, scenes.yaw(0.0))
+    vol.set_view(f0)
+    integ.integrate(f0)
+    tracer.trace(out, next_frame=f1, next_needs_normals=True)
+    assert vol.requests_ahead.valid == 1 and vol.requests_ahead.normals_made == 1
+    made = f1.normals.clone()
+    vol.set_view(f1, compute_normals=True)                  # nothing is due: the frame is taken as announced
+    sync()
+    assert vol.requests_ahead.valid == 0 and torch.equal(f1.normals, made)

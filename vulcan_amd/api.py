@@ -119,6 +119,7 @@ _SIGNATURES = {
     "vk_detect": ([_P, _P, C.c_int32, _P, _P, _P, _P], _I),
     "vk_test_hooks_set": ([_P], _I),
     "vk_test_hooks_get": ([_P], _I),
+    "vk_test_hooks_loop_count": ([_P, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn
@@ -386,6 +387,7 @@ class Volume:
         import torch
         self._view_changed()
         announced = self.requests_ahead is not None and self.requests_ahead.valid == 1
+        stale_prep = False
         if announced and compute_normals:
             # Tracer.trace(.., next_frame=frame, next_needs_normals=True) has computed this frame's normals with the pass
             # (or, without a riding preparation, as a launch of their own): nothing is due any more. Touching the frame
@@ -395,6 +397,16 @@ class Volume:
             if not (r.depth == (frame.depth.data_ptr() if frame.depth is not None else None) and r.content_id == frame.desc().content_id):
                 raise VkError("set_view(compute_normals=True): another frame was announced by Tracer.trace(next_frame=...); "
                               "fuse that frame first, or Volume.cancel_requests_ahead()")
+            if not r.normals_made:
+                # announced WITHOUT its normals (trace(next_frame=frame), next_needs_normals left False): they are still due
+                # (skipped until round 5 on the record's validity alone). Written in place and without a new stamp
+                # — the record names the frame by its content id — and whatever the pass prepared from the old normals is
+                # void after this SetView: LightIntegrator.integrate prepares again from the new ones.
+                if frame.normals is None:
+                    raise VkError("set_view(compute_normals=True): the announced frame has no normal image to write to")
+                check(lib().vk_frame_compute_normals(_ptr(frame.depth), _ref(frame.depth_projection), _ptr(frame.normals),
+                                                     frame.width, frame.height, stream()), "vk_frame_compute_normals")
+                stale_prep = self.light_prep is not None
             compute_normals = False
         if compute_normals:
             if self.light_prep is None:
@@ -421,6 +433,8 @@ class Volume:
                   "vk_volume_set_view_prepare")
         else:
             check(lib().vk_volume_set_view(_ref(self.desc()), _ref(frame.desc()), stream()), "vk_volume_set_view")
+        if stale_prep:
+            self.light_prep.valid = 0
 
     def cancel_requests_ahead(self, rounds=1):
         """vk_requests_ahead_cancel: the way out of an announced frame that will not be fused as announced — its SetView is
@@ -666,6 +680,8 @@ class Tracer:
         check(lib().vk_trace_ahead_requests(_ref(v.desc()), _ref(frame.desc()), _ref(vb), _ptr(frame.depth), _ptr(frame.color),
                                             _ptr(frame.normals), _ref(next_frame.desc()), _ref(prep) if prep is not None else None,
                                             _ref(v.requests_ahead), stream()), "vk_trace_ahead_requests")
+        if next_needs_normals and prep is None and v.requests_ahead.valid == 1:
+            v.requests_ahead.normals_made = 1              # (the library knows of the riding normals only)
         if prep is not None and prep.normals_out and v.requests_ahead.valid != 1:
             prep.normals_out = None                        # the pass could not be made ahead: the normals as a launch of their own
             next_frame.compute_normals()

@@ -837,7 +837,7 @@ int launch_color_loop_of(const ColorParams& P, ColorLoopParams& L, int iteration
   {
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
     L.exchange.count = L.groups;
-    L.exchange.epoch = vk_next_loop_epoch();
+    { const int rc = vk_loop_epoch_begin(workspace, exchange_floats(L.groups) * sizeof(float), s, &L.exchange.epoch);  if (rc != VK_OK) return rc; }
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.last_launch = done + kExchangeSteps >= iterations ? 1 : 0;
@@ -898,6 +898,7 @@ void launch_partials_of(const ColorParams& P, int translation_enabled, int parti
 
 void launch_color_partials(const ColorParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
 {
+  vk_loop_area_written(workspace);      // float partials over the loop kernels' tagged words: the next loop launch clears them
   if (P.mask) launch_partials_of<true>(P, translation_enabled, partials, workspace, s);
   else launch_partials_of<false>(P, translation_enabled, partials, workspace, s);
 }

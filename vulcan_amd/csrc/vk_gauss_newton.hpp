@@ -212,9 +212,15 @@ inline unsigned long long* loop_timing_attach(hipStream_t s)
 // and L2-cached slots: one fabric trip more per step, 1 us slower). Nothing is ever
 // invalidated, so the images stay in L2 across steps.
 //
-// Tag = epoch (22 bits, unique per launch, never 0) << 10 | step + 1. Slots are double
-// buffered by step parity: a workgroup writes step i + 2 only after it has read every
-// workgroup's step i + 1, which they wrote after reading all of step i.
+// Tag = epoch (22 bits, never 0) << 10 | step + 1. Slots are double buffered by step
+// parity: a workgroup writes step i + 2 only after it has read every workgroup's step
+// i + 1, which they wrote after reading all of step i. The epoch names the launch among
+// the last 2^22 - 2 of the process, and no word older than 2^21 launches is ever left in
+// an area (vk_loop_epoch_begin, vk_runtime.hip, clears it first): what a reader of
+// {epoch, step} can find in a slot is cleared memory, a word of a younger launch with
+// another epoch, an earlier step of its own launch, or the word it waits for — the
+// counter's wrap (every ~10 minutes of tracking) is not an event
+// (tests/test_gpu_epoch_wrap.py crosses it with a tracker that sat idle for a whole period).
 //
 // Every workgroup of the launch must be resident at the same time (the host sizes the grid
 // from the occupancy query); should that ever not hold — or a workgroup die — the readers
@@ -240,8 +246,12 @@ struct Exchange
 
 }  // namespace vk
 
-// process-wide source of launch tags (vk_runtime.hip): 22 bits, never 0
-uint32_t vk_next_loop_epoch();
+// The tag of the next loop launch on the exchange area `area` (vk_runtime.hip: a process-wide count of loop
+// launches, 22 bits of it, never 0), and — enqueued on `s` in front of that launch — the area's clear when it is due
+// (first use, grown, written by a launch-per-stage loop, or 2^21 launches old). VK_OK or the runtime's error.
+int vk_loop_epoch_begin(void* area, size_t bytes, hipStream_t s, uint32_t* epoch);
+// something other than a loop launch is about to write `area` (the launch-per-stage loops' float partials)
+void vk_loop_area_written(const void* area);
 
 // test aid (vk_test_hooks.force_loop_abort): the next loop launches behave as if a workgroup's sums had
 // never arrived — they end with VK_TRACK_ABORTED at once — so that the hosts' way out of an

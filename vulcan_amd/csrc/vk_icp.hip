@@ -822,6 +822,7 @@ int fill_icp(IcpParams& P, const vk_icp_view* keyframe, const vk_transform* Twm,
 
 void launch_partials(const IcpParams& P, int translation_enabled, int partials, float* workspace, hipStream_t s)
 {
+  vk_loop_area_written(workspace);      // float partials over the loop kernels' tagged words: the next loop launch clears them
   if (translation_enabled)
     hipLaunchKernelGGL(system_partial_kernel<true>, dim3(partials), dim3(kIcpThreads), 0, s, P, workspace);
   else
@@ -860,7 +861,7 @@ int launch_loop(const IcpParams& P, vk_transform* Twc_dev, int iterations, int t
   {
     L.exchange.words = reinterpret_cast<unsigned long long*>(workspace);
     L.exchange.count = groups;
-    L.exchange.epoch = vk_next_loop_epoch();
+    { const int rc = vk_loop_epoch_begin(workspace, exchange_floats(groups) * sizeof(float), s, &L.exchange.epoch);  if (rc != VK_OK) return rc; }
     VK_LOOP_TIMING_ATTACH(L, s);
     L.iterations = iterations - done < kExchangeSteps ? iterations - done : kExchangeSteps;
     L.fresh_state = (fresh_state && done == 0) ? fresh_state : 0;

@@ -9,24 +9,93 @@
 
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
-// Launch tags of the loop kernels (vk_gauss_newton.hpp, "partials exchanged inside a
-// launch"): one counter for the whole library, so that two trackers that are handed the
-// same memory one after the other never use the same tag. It starts at a value taken from
-// the clock and the library's load address: a second copy of the library in the same
-// process (the debug build next to the release build) then counts from somewhere else.
-uint32_t vk_next_loop_epoch()
+// Launch tags of the loop kernels (vk_gauss_newton.hpp, "partials exchanged inside a launch").
+//
+// One 64-bit count of loop launches for the whole library image, so that two trackers that are handed the same memory
+// one after the other never use the same tag. The 22-bit epoch of launch n is 1 + n mod (2^22 - 1): never 0, and two
+// launches share an epoch only if their counts differ by a multiple of 2^22 - 1 (at the tracked loop's ~7 300 loop
+// launches per second: every ~9.6 minutes). A reader accepts a word whose tag is {its launch's epoch, its step}; a
+// word that an EARLIER launch with the same epoch left in the same slot would be taken for the step's — a silently
+// wrong pose. What excludes it:
+//
+//   every exchange area is cleared (hipMemsetAsync on the launch's stream, in front of the launch) when it is first
+//   seen, when a launch needs more of it than was cleared, when something that is not a loop launch wrote into it
+//   (the launch-per-stage loops keep float partials there: vk_loop_area_written), and whenever the count has moved
+//   2^21 or more since the area's last clear.
+//
+// So a tagged word found in an area was written by a loop launch m with cleared_at <= m < n and n - m < 2^21
+// < 2^22 - 1: its epoch differs from launch n's. (Tag 0 — cleared memory — names no launch: epochs start at 1 and the
+// step field at 1.) The registry is keyed by the area's address; an address that comes back after a free holds either
+// the words it held (same entry, same argument) or whatever its interim owner wrote (the caller's contract, vk.h:
+// nothing but the library writes a workspace between two calls that use it). The cost is one table lookup per loop
+// launch and one 0.6 MB memset per area every 2^21 launches. The count starts at a value taken from the clock and the
+// library's load address: a second copy of the library in the same process (the debug build next to the release
+// build) then counts from somewhere else. `VK_LOOP_EPOCH_UNGUARDED` (a build for the test's own proof that it bites:
+// tests/test_gpu_epoch_wrap.py, profiles/r06_epoch_wrap.txt) leaves the clears out.
+namespace
 {
-  static std::atomic<uint32_t> counter{[] {
+constexpr uint64_t kEpochPeriod = (1ull << 22) - 1;
+constexpr uint64_t kAreaMaxAge = 1ull << 21;
+struct LoopArea { uint64_t cleared_at; size_t cleared_bytes; bool foreign; };
+struct LoopAreas
+{
+  std::mutex lock;
+  uint64_t count;
+  std::unordered_map<const void*, LoopArea> areas;
+  uint64_t clears = 0;
+  LoopAreas()
+  {
     timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
-    uint64_t x = (uint64_t)t.tv_nsec ^ ((uint64_t)t.tv_sec << 20) ^ (uint64_t)reinterpret_cast<uintptr_t>(&vk_next_loop_epoch);
+    uint64_t x = (uint64_t)t.tv_nsec ^ ((uint64_t)t.tv_sec << 20) ^ (uint64_t)reinterpret_cast<uintptr_t>(&vk_hook);
     x ^= x >> 33;  x *= 0xff51afd7ed558ccdull;  x ^= x >> 33;
-    return (uint32_t)x;
-  }()};
-  uint32_t e;
-  do { e = (counter.fetch_add(1) + 1u) & 0x3fffffu; } while (e == 0);
-  return e;
+    count = x >> 8;          // 56 bits: never reaches 2^64 in a process's life
+  }
+};
+LoopAreas& loop_areas() { static LoopAreas a; return a; }
+}
+
+int vk_loop_epoch_begin(void* area, size_t bytes, hipStream_t s, uint32_t* epoch)
+{
+  LoopAreas& A = loop_areas();
+  bool clear = false;
+  {
+    std::lock_guard<std::mutex> hold(A.lock);
+    const uint64_t n = A.count++;
+    *epoch = (uint32_t)(1 + n % kEpochPeriod);
+    if (A.areas.size() > 8192) A.areas.clear();        // forgotten areas are cleared at their next launch
+    auto it = A.areas.find(area);
+    if (it == A.areas.end() || it->second.foreign || it->second.cleared_bytes < bytes || n - it->second.cleared_at >= kAreaMaxAge)
+    {
+      clear = true;
+      A.areas[area] = LoopArea{n, bytes, false};
+      ++A.clears;
+    }
+  }
+#ifndef VK_LOOP_EPOCH_UNGUARDED
+  if (clear) VK_CHECK(hipMemsetAsync(area, 0, bytes, s));
+#endif
+  return VK_OK;
+}
+
+void vk_loop_area_written(const void* area)
+{
+  LoopAreas& A = loop_areas();
+  std::lock_guard<std::mutex> hold(A.lock);
+  auto it = A.areas.find(area);
+  if (it != A.areas.end()) it->second.foreign = true;
+}
+
+extern "C" int vk_test_hooks_loop_count(const uint64_t* set_to, uint64_t* count_now, uint64_t* clears)
+{
+  LoopAreas& A = loop_areas();
+  std::lock_guard<std::mutex> hold(A.lock);
+  if (set_to) A.count = *set_to;
+  if (count_now) *count_now = A.count;
+  if (clears) *clears = A.clears;
+  return VK_OK;
 }
 
 

@@ -153,6 +153,8 @@ void Tracer::TraceWith(Frame& frame, Frame* next, bool next_needs_normals, bool 
   const vk_frame n = next->ToVk();
   VK_ASSERT(vk_trace_ahead_requests(&v, &f, ahead, depth_out, color_out, normals_out, &n, prep, volume_->GetRequestsAhead(),
       Device::GetStream()));
+  // the record says whether the announced frame's normals are made (the library knows of the riding ones only)
+  if (next_needs_normals && !prep && volume_->GetRequestsAhead()->valid == 1) volume_->GetRequestsAhead()->normals_made = 1;
   if (prep && prep->normals_out && volume_->GetRequestsAhead()->valid != 1)
   {
     // the pass could not be made ahead (vk.h): the normals are then the caller's launch, as in Frame::ComputeNormals

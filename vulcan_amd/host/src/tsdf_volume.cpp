@@ -191,12 +191,36 @@ void Volume::NoteIntegrated() const
 
 void Volume::ComputeNormalsAndSetView(Frame& frame, int rounds)
 {
-  if (requests_ahead_.valid == 1)
+  if (requests_ahead_.valid == 1 && requests_ahead_.normals_made == 1)
   {
     // Tracer::Trace(keyframe, frame, true) announced this frame and its normals came with the pass: nothing is due.
     // (Stamping the normal image again would give the frame a content id the record does not name; another frame
     // than the announced one is refused by SetView.)
     SetView(frame, rounds);
+    return;
+  }
+  if (requests_ahead_.valid == 1)
+  {
+    // Announced WITHOUT its normals (Tracer::Trace(keyframe, frame) — next_needs_normals defaults to false): they are
+    // still due (this used to be skipped on the record's validity alone, and LightIntegrator then shaded from
+    // a stale or uninitialised normal image, silently). The record names the frame by its images' stamps, so the normal
+    // image is written in place without a new stamp (a kernel launch, as Frame::ComputeNormals; ref: src/frame.cpp:21-36),
+    // the announced SetView runs, and whatever the pass prepared from the OLD normals is void: LightIntegrator::Integrate
+    // then prepares again (vk_light_prepare) from the new ones.
+    VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+    const int w = frame.depth_image->GetWidth(), h = frame.depth_image->GetHeight();
+    const bool sized = frame.normal_image && frame.normal_image->GetWidth() == w && frame.normal_image->GetHeight() == h;
+    // (a frame announced without a normal image of its size cannot have had a preparation riding: prep_rides needs one,
+    // and a new image is new content — SetView below then refuses the frame, as for any frame that was not announced)
+    if (!sized) { frame.ComputeNormals(); SetView(frame, rounds); return; }
+    const ColorImage& normals = *frame.normal_image;                  // const view: no new stamp
+    const vk_projection k = frame.depth_projection.ToVk();
+    const Image& depths = *frame.depth_image;
+    VK_ASSERT(vk_frame_compute_normals(depths.GetData(), &k,
+        const_cast<float*>(reinterpret_cast<const float*>(normals.GetData())), w, h, Device::GetStream()));
+    vk_light_prep* made = GetLightPreparation();
+    SetView(frame, rounds);
+    if (made) made->valid = 0;
     return;
   }
   vk_light_prep* prep = GetLightPreparation();

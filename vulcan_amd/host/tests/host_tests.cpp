@@ -1355,6 +1355,70 @@ TEST(Volume, ComputeNormalsAndSetViewEqualsTheTwoCalls)
   ASSERT_TRUE(coloured > 1000);
 }
 
+// Tracer::Trace(keyframe, next) — next_needs_normals defaults to false — followed by
+// Volume::ComputeNormalsAndSetView(next). The announce left the normal image as it was (vk_requests_ahead.normals_made = 0):
+// the normals are still due, and the preparation that rode with the pass was made from the OLD image. Same voxels and the
+// same normal image as the sequence without an announce.
+TEST(Volume, ComputeNormalsAndSetViewAfterAnAnnounceWithoutNormals)
+{
+  const int w = 160, h = 120;
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.025f, 0.08f, 0.0f);
+  std::vector<Voxel> voxels[3];
+  std::vector<Vector3f> normals[3];
+  for (int variant = 0; variant < 3; ++variant)       // 0: no announce; 1: announced without normals; 2: with
+  {
+    Frame frames[2];
+    for (int i = 0; i < 2; ++i)
+    {
+      Frame& f = frames[i];
+      f.depth_projection.SetFocalLength(136, 136);
+      f.depth_projection.SetCenterPoint(80, 60);
+      f.color_projection = f.depth_projection;
+      f.depth_image = MakeDepth(w, h, [](int x, int y) { return 1.5f + 0.001f * x + 0.0007f * y; });
+      f.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+      f.depth_to_world_transform = Transform::Translate(0.004f * i, 0.0f, 0.0f);
+    }
+    // the second frame arrives with a normal image that holds something else (a recycled frame object)
+    frames[1].normal_image = MakeColor(w, h, [](int, int) { return Vector3f(0.0f, 0.6f, -0.8f); });
+    auto volume = std::make_shared<Volume>(8192, 2048);
+    volume->SetVoxelLength(0.008f);
+    LightIntegrator integrator(volume);
+    integrator.SetLight(light);
+    Tracer tracer(volume);
+    volume->ComputeNormalsAndSetView(frames[0], 3);
+    integrator.Integrate(frames[0]);
+    Frame keyframe;
+    keyframe.depth_projection = frames[0].depth_projection;
+    keyframe.color_projection = frames[0].color_projection;
+    keyframe.depth_to_world_transform = frames[0].depth_to_world_transform;
+    keyframe.depth_image = MakeDepth(w, h, [](int, int) { return 0.0f; });
+    if (variant == 0) tracer.Trace(keyframe);
+    else
+    {
+      tracer.Trace(keyframe, frames[1], variant == 2);
+      ASSERT_EQ(1, volume->GetRequestsAhead()->valid);
+      ASSERT_EQ(variant == 2 ? 1 : 0, volume->GetRequestsAhead()->normals_made);
+    }
+    volume->ComputeNormalsAndSetView(frames[1], 3);
+    ASSERT_EQ(0, volume->GetRequestsAhead()->valid);
+    integrator.Integrate(frames[1]);
+    voxels[variant] = Download(volume->GetVoxels());
+    normals[variant].resize(size_t(w) * h);
+    frames[1].normal_image->CopyToHost(normals[variant].data());
+  }
+  for (int variant = 1; variant < 3; ++variant)
+  {
+    ASSERT_TRUE(std::memcmp(normals[0].data(), normals[variant].data(), normals[0].size() * sizeof(Vector3f)) == 0);
+    ASSERT_EQ(voxels[0].size(), voxels[variant].size());
+    ASSERT_TRUE(std::memcmp(voxels[0].data(), voxels[variant].data(), voxels[0].size() * sizeof(Voxel)) == 0);
+  }
+  size_t coloured = 0;
+  for (const Voxel& voxel : voxels[0]) coloured += voxel.color_weight > 1;
+  ASSERT_TRUE(coloured > 1000);
+}
+
 TEST(Extractor, Extract)   // extractor.h:116-134; faces are what upstream leaves unwritten (extractor.cu:392-430)
 {
   Frame frame;

@@ -14,7 +14,7 @@ VK_CTR_REQUESTS, VK_CTR_DROPPED, VK_CTR_PENDING_ALL, VK_CTR_PENDING_EXCESS = 4, 
 VK_CTR_ROUNDS, VK_CTR_UNSETTLED, VK_CTR_CONTENDED, VK_CTR_PUBLIC = 8, 9, 10, 24
 VK_RETRY_SLOTS, VK_RETRY_KEYS, VK_POSTED_SLOTS = 65536, 8192, 2048
 # counters, two key sets, two slot lists, the posted buckets and their chains' last entries
-VK_ABI_VERSION = 6                       # include/vk.h
+VK_ABI_VERSION = 7                       # include/vk.h
 VK_CTR_BANDED, VK_BANDS, VK_BAND_SLOTS = 20, 8, 16384
 VK_CTR_COUNT = (VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
                 + VK_BANDS + VK_BANDS * VK_BAND_SLOTS)
@@ -194,7 +194,7 @@ class RequestsAhead(C.Structure):
     """vk_requests_ahead (vk.h): the frame a request pass was made for ahead of its SetView"""
     _fields_ = [("counters", C.c_void_p), ("depth", C.c_void_p), ("prep", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
                 ("depth_projection", Projection), ("depth_to_world", Transform), ("content_id", C.c_uint64),
-                ("valid", C.c_int32), ("pad_", C.c_int32)]
+                ("valid", C.c_int32), ("normals_made", C.c_int32)]
 
 
 class TestHooks(C.Structure):
