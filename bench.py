@@ -97,6 +97,11 @@ NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
 # the first of them (1.7 - 3.5 us of a 34 us launch: 0.555 where the trace says 0.58)
 TIME_BY_DISPATCH = os.environ.get("VK_BENCH_TIME_BY_DISPATCH", "1") != "0"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
+# The headline's spread: WINDOWS consecutive windows of --steps frames (the sequence continues; `value` is the first window's).
+# The camera yaws 0.5 deg per frame and allocates new blocks every frame until it has turned once, so the windows stop short
+# of a full turn (SEQUENCE_FRAMES): a run with --steps 20 (the driver's) has all nine, the default --steps 200 has two.
+WINDOWS = int(os.environ.get("VK_BENCH_WINDOWS", "9"))
+SEQUENCE_FRAMES = 700
 
 
 def sphere_room_depth(k):
@@ -217,6 +222,14 @@ class RoomSequence:
             frames = list(pool.map(lambda p: scenes.room_frame(k, p, W, H, light=LIGHT), self.truth))
         self.depth = [torch.from_numpy(d).cuda() for d, _ in frames]
         self.color = [torch.from_numpy(c).cuda() for _, c in frames]
+
+    def view(self, start, count):
+        """frames start .. start + count - 1 as a sequence of its own (the same resident images): another camera's run through
+        the same room, a quarter of the swing later — what a second replica volume on the same GPU is fed (MultiLoop)"""
+        assert start + count <= len(self.truth)
+        other = RoomSequence.__new__(RoomSequence)
+        other.truth, other.depth, other.color = (lst[start:start + count] for lst in (self.truth, self.depth, self.color))
+        return other
 
 
 def pose_error(got, truth):
@@ -393,9 +406,17 @@ class FrameLoop:
             lib.vk_stream_synchronize(self.copy_stream)
             return reps * self.bytes_per_frame / (time.perf_counter() - t0) / 1e9
 
-    def step(self, i, ev=None, v=0):
-        lib, s, vv = self.lib, self.stream, self.vols[v]
+    def step(self, i, ev=None, v=0, by_dispatch=None):
+        """one frame: begin (the frame's inputs; a tracked frame: the Track, enqueued) + finish (a tracked frame: the pose,
+        waited for; then SetView, Integrate, Trace). Several sequences on one GPU (MultiLoop) call begin for all of them
+        before they call finish for any: the host then waits for one sequence's pose while the others' Tracks are queued."""
+        self.begin(i)
+        self.finish(i, ev, v, by_dispatch)
+
+    def begin(self, i):
+        lib, s = self.lib, self.stream
         seq = self.sequence
+        n = None
         if self.upload is not None:
             n = self.upload.count - 1                  # the frame this step fuses (its upload was submitted one step ago)
             self.upload.submit()                       # frame n + 1 crosses the bus while frame n is fused
@@ -429,7 +450,17 @@ class FrameLoop:
                 due = 1 | (2 if self.key_normals_pending else 0)       # the frame's normals, and the key frame's when the raycast left them out
                 self.key_normals_pending = False
                 rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
-                rc |= lib.vk_track_wait(a[-1], s)                   # Tracker::EndSolve: the pose, from pinned memory
+        self._begun = (i, n, rc, normals_in_set_view)
+
+    def finish(self, i, ev=None, v=0, by_dispatch=None):
+        lib, s, vv = self.lib, self.stream, self.vols[v]
+        by_dispatch = TIME_BY_DISPATCH if by_dispatch is None else by_dispatch
+        begun, n, rc, normals_in_set_view = self._begun
+        assert begun == i, "finish(i) follows begin(i)"
+        if self.tracker is not None:
+            pose = self.current
+            if i > 0:
+                rc |= lib.vk_track_wait(self.track_args[-1], s)     # Tracker::EndSolve: the pose, from pinned memory
                 if rc:
                     raise self.api.VkError(f"frame {i}: tracking returned {rc}")
                 pose = self.T.Transform.from_buffer_copy(C.string_at(self.tracker.tracker._pose_host, 128))
@@ -463,13 +494,13 @@ class FrameLoop:
             else:
                 rc |= lib.vk_light_prepare(self.fref, self.depth_threshold, self.m_ptr, self.r_ptr, s)
         if ev:
-            if TIME_BY_DISPATCH:
+            if by_dispatch:
                 rc |= lib.vk_integrate_time_next(ev[0], ev[1])      # the launch records them as its own begin and end
             else:
                 lib.vk_event_record(ev[0], s)
         rc |= lib.vk_integrate_ahead(vv["vref"], vv["pref"], self.fref, self.mode, vv["lref"], self.m_ptr, self.r_ptr,
                                      None if NO_BOUNDS_AHEAD else vv["bref"], s)    # *_integrator.cu Integrate
-        if ev and not TIME_BY_DISPATCH:
+        if ev and not by_dispatch:
             lib.vk_event_record(ev[1], s)
         if self.split is not None:
             lib.vk_event_record(self.split["integrated"], s)
@@ -516,6 +547,70 @@ class FrameLoop:
         return ms.value
 
 
+class MultiLoop:
+    """S independent sequences on ONE GPU (north_star: replica volumes, sharded by frame / camera): S
+    replica volumes — 750 MB each of 288 GB —, S FrameLoops, each on a stream of its own, issued by one host thread in lock
+    step: begin(i) for every sequence (a tracked frame: its Track enqueued), then finish(i) for every sequence (the pose
+    waited for; SetView, Integrate, Trace enqueued). A tracked frame is a strict chain with the device idle in every tail
+    (Gauss-Newton steps with 2 us of pixels in 9.4, a raycast whose last third idles, a launch-floor visibility pass): this
+    offers the idle device another sequence's INDEPENDENT work. Loop launches stay chained across streams by the library
+    (vk_loop_launch_begin / _end: a loop kernel needs all its workgroups resident). Each sequence's volume, images and
+    poses are bit-equal to the same sequence run alone (tests/test_gpu_round6.py)."""
+
+    def __init__(self, workload, pose_lists, sequences=None):
+        import torch
+        self.streams = [torch.cuda.Stream() for _ in pose_lists]
+        self.loops = []
+        for j, (st, poses) in enumerate(zip(self.streams, pose_lists)):
+            with torch.cuda.stream(st):
+                self.loops.append(FrameLoop(workload, poses, sequence=None if sequences is None else sequences[j]))
+            st.synchronize()
+
+    def step(self, i):
+        for loop in self.loops:
+            loop.begin(i)
+        for loop in self.loops:
+            loop.finish(i)
+
+
+def run_sequences(workload, count, warmup, steps, room=None, stride=60):
+    """`count` sequences of `workload` on this GPU (MultiLoop): aggregate frames/s over `steps` frames of every sequence."""
+    import torch
+    import scenes
+    if workload == "rgbd-icp":
+        sequences = [room.view(j * stride, warmup + steps) for j in range(count)]
+        pose_lists = [seq.truth for seq in sequences]
+    else:
+        sequences = None
+        pose_lists = [[scenes.orbit_pose(i + 7 * j, YAW_STEP) for i in range(warmup + steps)] for j in range(count)]
+    torch.cuda.synchronize()             # (the resident input images were written on another stream)
+    multi = MultiLoop(workload, pose_lists, sequences)
+    for i in range(warmup):
+        multi.step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        multi.step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    from vulcan_amd import vk_types as T
+    out = {"sequences": count, "value": count * steps / dt, "unit": "frames/s (all sequences)", "steps": steps, "warmup": warmup,
+           "ms_per_frame_of_one_sequence": 1e3 * dt / steps, "frames_per_s_per_sequence": steps / dt,
+           "how": f"{count} replica volumes on one GPU, each with its own frames and its own stream; one host thread issues them in "
+                  "lock step (begin for all, then finish for all)"}
+    dropped = [int(loop.vols[0]["vol"].read_counters()[T.VK_CTR_DROPPED]) for loop in multi.loops]
+    out["dropped_requests"] = dropped
+    if any(dropped):
+        out["error"] = f"allocation requests were dropped ({dropped}): a pool ran dry, the figure is not the configured workload's"
+    if workload == "rgbd-icp":
+        errs = []
+        for loop, seq in zip(multi.loops, sequences):
+            e = [pose_error(p, seq.truth[i]) for i, p in enumerate(loop.tracked_poses)][warmup:]
+            errs.append({"translation_m": max(x[0] for x in e), "rotation_deg": max(x[1] for x in e)})
+        out["pose_error_max_per_sequence"] = errs
+    return out, multi
+
+
 def visible_counts(poses, depths=None):
     """Allocation depends only on the depth image and the pose and is deterministic, so an
     untimed replay of SetView over the same poses gives the visible-block count every
@@ -538,15 +633,18 @@ def visible_counts(poses, depths=None):
     return np.array(out, dtype=np.float64), per_frame
 
 
-def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frames=0, stream_input=False, requests_ahead=None):
-    """W untimed + K timed frames (+ `sample_frames` untimed frames with event brackets: the roofline sample);
+def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frames=0, stream_input=False, requests_ahead=None,
+                 windows=1, room=None):
+    """W untimed + K timed frames (+ `windows` - 1 further windows of K frames of the same sequence, each bracketed like the
+    first: the spread of the headline) (+ `sample_frames` untimed frames with event brackets: the roofline sample);
     returns the JSON fields of that workload."""
     import torch
     from vulcan_amd import vk_types as T
     import scenes
     sequence = None
     if workload == "rgbd-icp":
-        sequence = RoomSequence(warmup + steps + sample_frames, T.Projection.make(*scenes.APP_INTRINSICS))
+        need = warmup + steps * windows + sample_frames
+        sequence = room.view(0, need) if room is not None else RoomSequence(need, T.Projection.make(*scenes.APP_INTRINSICS))
     loop = FrameLoop(workload, poses, sequence=sequence, stream_input=stream_input, requests_ahead=requests_ahead)
 
     for i in range(warmup):
@@ -563,16 +661,34 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
     frames_all = vd.sum_over_ranks(steps, device="cuda")
     per_rank_ms = vd.gather_over_ranks(1e3 * local / steps, device="cuda")      # value uses the max; these say who was slow
 
+    # The spread (a 20-step headline rests on 1.6 ms of wall time): the sequence simply continues for
+    # `windows` - 1 further windows of K frames, each between its own barrier + synchronise pair and each the max over
+    # ranks, exactly like the first. `value` stays the FIRST window's (steps / ms_per_step match the command line).
+    window_s = [elapsed]
+    for wnd in range(1, windows):
+        vd.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loop.step(warmup + wnd * steps + i)
+        torch.cuda.synchronize()
+        vd.barrier()
+        window_s.append(vd.max_over_ranks(time.perf_counter() - t0, device="cuda"))
+    steps_run = steps * windows
+
     # The roofline sample: ROOFLINE_SAMPLE_FRAMES more frames of the same sequence, AFTER the timed region, with HIP
     # events (created without the system-scope fence, vk_event_create) around the integrate launch of every frame and
     # around the raycast of every second one. A pair of records costs the stream ~2.7 us, so inside the timed region
     # they cost frames/s (round 3 sampled five frames of the driver's K = 20 run there: 0.48 against rocprofv3's 0.52
     # for the same kernel); out here they cost nothing that is reported, and 120 launches are averaged whatever K is.
-    sampled = list(range(steps, steps + sample_frames)) if with_roofline else []
+    sampled = list(range(steps_run, steps_run + sample_frames)) if with_roofline else []
     traced = set(sampled[::2])
+    # every third launch of the sample is timed the old way as well — two event records AROUND the call — so that the line
+    # carries both figures from the same run (r04's 0.555 and r05's 0.58 were the same kernels, timed differently)
+    bracketed = set(sampled[2::3]) if TIME_BY_DISPATCH else set()
     events = {i: tuple(loop.make_event() for _ in range(4 if i in traced else 2)) for i in sampled}
     for i in sampled:
-        loop.step(warmup + i, events[i])
+        loop.step(warmup + i, events[i], by_dispatch=(i not in bracketed) and TIME_BY_DISPATCH)
     # what a pair of event records reads with nothing between them (stated next to the sample, never subtracted)
     pair_us = None
     if with_roofline:
@@ -586,25 +702,38 @@ def run_workload(workload, poses, warmup, steps, vd, with_roofline, sample_frame
 
     out = {"value": frames_all / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
            "per_rank_ms_per_step": per_rank_ms}
+    if windows > 1:
+        fps = [frames_all / w for w in window_s]
+        out["windows"] = {"count": windows, "frames_each": steps, "median": float(np.median(fps)), "min": float(min(fps)),
+                          "max": float(max(fps)), "frames_per_s": fps,
+                          "what": f"{windows} consecutive windows of {steps} frames of the same sequence, each between its own "
+                                  "barrier + synchronise pair (max over ranks); `value` is the first"}
     if with_roofline:
-        integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled]
+        integ_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled if i not in bracketed]
+        bracket_ms = [loop.elapsed_ms(events[i][0], events[i][1]) for i in sampled if i in bracketed]
         trace_ms = [loop.elapsed_ms(events[i][2], events[i][3]) for i in sampled if i in traced]
-        out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, sampled
+        out["_integrate_ms"], out["_trace_ms"], out["_sampled"] = integ_ms, trace_ms, [i for i in sampled if i not in bracketed]
+        out["_bracket_ms"], out["_bracketed"] = bracket_ms, sorted(bracketed)
         out["_event_pair_us"] = pair_us
     ctr = loop.vols[0]["vol"].read_counters()
     out["_counters"] = ctr
     # VK_CTR_ROUNDS counts every frame this volume has seen: warm-up, timed AND the roofline sample's
-    out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps + len(sampled))
+    out["set_view_rounds_run_per_frame"] = float(ctr[T.VK_CTR_ROUNDS]) / (warmup + steps_run + sample_frames * bool(with_roofline))
+    # a frame rate measured on a pool that ran dry is not the configured workload: every entry says so
+    out["dropped_requests"] = int(ctr[T.VK_CTR_DROPPED])
+    if out["dropped_requests"]:
+        out["error"] = (f"{out['dropped_requests']} allocation requests were dropped: the pool of {MAIN + EXCESS} blocks ran dry "
+                        "during this run, the figure is not the configured workload's")
     if loop.tracker is not None:
         # the closed loop, scored against the ground truth it never saw
         errors = [pose_error(p, sequence.truth[i]) for i, p in enumerate(loop.tracked_poses)]
-        timed = errors[warmup:warmup + steps]
-        steps_timed = np.array(loop.gn_steps[max(0, warmup - 1):warmup + steps - 1], dtype=np.int64)
+        timed = errors[warmup:warmup + steps_run]
+        steps_timed = np.array(loop.gn_steps[max(0, warmup - 1):warmup + steps_run - 1], dtype=np.int64)
         hist = np.bincount(steps_timed, minlength=21)
         out["tracked_pose_drives_fusion"] = True
         out["pose_error_max"] = {"translation_m": max(e[0] for e in timed), "rotation_deg": max(e[1] for e in timed)}
         out["pose_error_last_frame"] = {"translation_m": timed[-1][0], "rotation_deg": timed[-1][1]}
-        motion = pose_error(sequence.truth[warmup + steps - 1], sequence.truth[0])
+        motion = pose_error(sequence.truth[warmup + steps_run - 1], sequence.truth[0])
         out["camera_motion_over_run"] = {"translation_m": motion[0], "rotation_deg": motion[1]}
         out["gn_steps_median"] = float(np.median(steps_timed))
         out["gn_steps_histogram_full_resolution_level"] = {str(n): int(c) for n, c in enumerate(hist) if c}
@@ -708,6 +837,146 @@ def touched_blocks(pl, loop):
         return {"error": "the counting raycast's colour image differs from the product's"}
     return {"blocks_touched": int(touched.sum())}
 
+
+
+# -------------------------------------------------- configs[0] and configs[3] ----
+
+DENSE_ORIGIN = [[x, y, z] for z in range(42, 58) for y in range(-8, 8) for x in range(-8, 8)]
+
+
+def dense_128_gpu(reps=60):
+    """BASELINE configs[0] (SURVEY 8d Config 1) ON THE DEVICE: the same unit of work cpu_baseline.configs0_dense_128 times on
+    the host — one 640x480 depth frame into a dense 128^3 voxel region = 4096 hand-placed blocks (tests/integrator_test.cu:
+    141-199 is the arithmetic; tests/test_gpu_configs.py::test_configs0_dense_128_on_the_device holds the device to the
+    oracle's bytes for exactly this volume) — through vk_integrate_depth, every launch timed by its own begin / end events."""
+    import torch
+    from vulcan_amd import api, vk_types as T
+    import scenes
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth_np = sphere_room_depth(k)
+    vol = api.Volume(8192, 1024, voxel_length=VOXEL, truncation_length=TRUNC)
+    n = len(DENSE_ORIGIN)
+    entries = vol.host_entries().copy()
+    entries["block"]["origin"][:n] = np.array(DENSE_ORIGIN, dtype=np.int16)
+    entries["data"][:n] = np.arange(n)
+    entries["next"][:n] = -1
+    vol.hash_entries.copy_(torch.from_numpy(np.frombuffer(entries.tobytes(), dtype=np.uint8).copy()).cuda())
+    vol.visible_blocks[:n] = torch.arange(n, dtype=torch.int32, device="cuda")
+    vol.counters[T.VK_CTR_VISIBLE] = n
+    frame = api.Frame(depth_np, k, T.Transform.identity())
+    lib, s = api.lib(), api.stream()
+    vdesc, fdesc, params = vol.desc(), frame.desc(), T.Integrator.default()
+    vref, fref, pref = C.byref(vdesc), C.byref(fdesc), C.byref(params)
+
+    def event():
+        e = C.c_void_p()
+        api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
+        return e
+
+    api.check(lib.vk_integrate_depth(vref, pref, fref, s), "vk_integrate_depth")
+    torch.cuda.synchronize()
+    updated = int((vol.host_voxels()["distance_weight"][:n * 512] > 0).sum())
+    pairs = [(event(), event()) for _ in range(reps)]
+    rc = 0
+    for e0, e1 in pairs:
+        rc |= lib.vk_integrate_time_next(e0, e1)
+        rc |= lib.vk_integrate_depth(vref, pref, fref, s)
+    torch.cuda.synchronize()
+    api.check(rc, "vk_integrate_depth (timed)")
+    ms = []
+    for e0, e1 in pairs:
+        t = C.c_float()
+        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(t)), "vk_event_elapsed_ms")
+        ms.append(t.value)
+    # back to back, no events: what a caller sees per call when it does nothing but integrate
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rc |= lib.vk_integrate_depth(vref, pref, fref, s)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    api.check(rc, "vk_integrate_depth")
+    dt = float(np.mean(ms)) * 1e-3
+    bytes_per_launch = n * BYTES_PER_BLOCK + IMAGE_BYTES["depth"]
+    return {"ms": dt * 1e3, "ms_median": float(np.median(ms)), "ms_back_to_back": wall_ms, "voxels": n * 512, "blocks": n,
+            "voxels_per_s": n * 512 / dt, "voxels_updated": updated, "launches_timed": reps,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_GBps": bytes_per_launch / dt / 1e9,
+            "frac_of_8TBps": bytes_per_launch / dt / 1e9 / HBM_PEAK_GBS,
+            "memory_level": "infinity-cache assisted (42 MB of voxels, relaunched on the same volume)",
+            "timed_by": "the dispatch's own begin / end events (vk_integrate_time_next); ms_back_to_back = wall time per call of "
+                        f"{reps} calls enqueued back to back",
+            "kernel": "integrate_pipelined_kernel<depth> (vk_integrate_depth)"}
+
+
+def pyramid_icp(reps=30):
+    """BASELINE configs[3]: PyramidTracker<DepthTracker>::Track (src/pyramid_tracker.cpp:52-90: the half-resolution level
+    built by Frame::Downsample, src/image.cu:101-165; 15 Gauss-Newton steps on it, then 20 at full resolution, each loop
+    ending early at |update| < 1e-6) at base sizes 320x240, 640x480 and 1280x960, through the one C entry point and
+    Tracker::EndSolve's pose readback (vk_icp_pyramid_track_frame + vk_track_wait), descriptors built once as FrameLoop does.
+    The scene is tests/test_gpu_configs.py::test_pyramid_tracker_matches_oracle's (a curved surface, the frame started 3.7 mm /
+    0.3 deg off) — the case whose poses are held to the oracle's at all three sizes. Per size: us per Track (median and
+    min of `reps`, host wall clock around the blocking call), the steps each level ran, and SURVEY 8(d)'s bytes — 2 * W * H *
+    (4 + 12) per iteration at that level's size — as GB/s over the Track."""
+    import torch
+    from vulcan_amd import api, vk_types as T
+    lib, s = api.lib(), api.stream()
+    out = {}
+    for (w, h) in ((320, 240), (640, 480), (1280, 960)):
+        scale = w / 640.0
+        k = T.Projection.make(547.0 * scale, 547.0 * scale, 320.0 * scale, 240.0 * scale)
+        y, x = np.mgrid[0:h, 0:w]
+        depth = (1.0 + 0.05 * np.cos(3.0 * x / w) * np.sin(2.0 * y / h)).astype(np.float32)
+        key = api.Frame(depth, k, T.Transform.identity())
+        key.compute_normals()
+        start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+        frame = api.Frame(key.depth, k, start, normals=key.normals)
+        tracker = api.PyramidTracker()
+        tracker.keyframe = key
+        t = tracker.tracker
+        # the half-resolution level alone, once, for its step count (the pyramid call leaves the full level's in its state)
+        half_key, half_frame = key.downsample(), frame.downsample()
+        t.max_iterations, t.keyframe = 15, half_key
+        t.track(half_frame)
+        steps_half = int(t.state.cpu()[0])
+        t.max_iterations, t.keyframe = 20, key
+        key_view, frame_view = t._view(key), t._view(frame)
+        n = int(lib.vk_icp_pyramid_floats(w, h, w, h))
+        pyramid = torch.empty(n, dtype=torch.float32, device="cuda")
+        poll = t._poll()
+        args = (C.byref(key_view), C.byref(key.depth_to_world), C.byref(frame_view), C.c_void_p(t.pose.data_ptr()), C.byref(start), 0,
+                C.c_void_p(pyramid.data_ptr()), C.c_void_p(t._workspace(frame).data_ptr()), C.c_void_p(t.system.data_ptr()),
+                C.c_void_p(t.state.data_ptr()), C.c_void_p(t.update.data_ptr()), None, None, poll, s)
+        words = (C.c_int32 * 4).from_address(t._poll_host.value)
+        times, rc = [], 0
+        for i in range(reps + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rc |= lib.vk_icp_pyramid_track_frame(*args)
+            rc |= lib.vk_track_wait(poll, s)                     # Tracker::EndSolve: the pose, from pinned memory
+            if i >= 3:
+                times.append(time.perf_counter() - t0)
+        api.check(rc, f"vk_icp_pyramid_track_frame at {w}x{h}")
+        steps_full = int(words[0])
+        aborted = int(t.state.cpu()[1]) < 0
+        pose = T.Transform.from_buffer_copy(C.string_at(t._pose_host, 128))
+        us = float(np.median(times) * 1e6)
+        steps = steps_half + steps_full
+        level_bytes = steps_half * 2 * (w // 2) * (h // 2) * 16 + steps_full * 2 * w * h * 16
+        entry = {"us_per_track": us, "us_per_track_min": float(min(times) * 1e6), "tracks_timed": reps,
+                 "steps_run": {"half_resolution": steps_half, "full_resolution": steps_full, "enqueued": {"half_resolution": 15, "full_resolution": 20}},
+                 "us_per_step": us / max(1, steps),
+                 "algorithmic_bytes_per_track": level_bytes, "algorithmic_GBps": level_bytes / (us * 1e-6) / 1e9,
+                 "frac_of_8TBps": level_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "pose_recovered_max_abs_error": float(np.abs(pose.matrix() - np.eye(4)).max())}
+        if aborted:
+            entry["error"] = "the loop kernel ended with VK_TRACK_ABORTED"
+        out[f"{w}x{h}"] = entry
+        del tracker, pyramid, key, frame
+        torch.cuda.empty_cache()
+    return {"workload": "BASELINE configs[3]: PyramidTracker<DepthTracker>::Track, half-resolution level (15 steps enqueued) then full "
+                        "resolution (20), at base sizes 320x240 / 640x480 / 1280x960; one C call + the pose readback per Track",
+            "unit": "us per Track", "bound": "latency: a strict chain of Gauss-Newton steps (exchange + solve, ~9.4 us each), not bandwidth",
+            "sizes": out}
 
 # ----------------------------------------------------------------- multi-GPU rig ----
 
@@ -896,6 +1165,10 @@ def main():
     ap.add_argument("--stream-input", action="store_true",
                     help="also run the headline workload with the frame's depth + colour images uploaded over PCIe every frame "
                          "(reported under other_workloads, never instead of the headline)")
+    ap.add_argument("--sequences", type=int, default=1,
+                    help="N > 1: ONLY time that many independent sequences of --workload on one GPU (a replica volume and a "
+                         "stream each, MultiLoop) and print their aggregate frames/s; the default run reports x2 / x4 under "
+                         "other_workloads")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU rehearsal of the N>1 launch path: ranks rendezvous over gloo, all-reduce one "
                          "48-float buffer and exit without touching a GPU (tests/test_bench_launch.py)")
@@ -935,20 +1208,35 @@ def main():
         else:
             torch.cuda.set_stream(torch.cuda.Stream())
 
-    total = args.warmup + args.steps + ROOFLINE_SAMPLE_FRAMES
+    if args.sequences > 1:
+        assert world == 1, "--sequences is a single-GPU measurement"
+        room = RoomSequence(args.warmup + args.steps + 60 * (args.sequences - 1), T.Projection.make(*scenes.APP_INTRINSICS)) \
+            if args.workload == "rgbd-icp" else None
+        o, _ = run_sequences(args.workload, args.sequences, args.warmup, args.steps, room=room)
+        o.update(metric=METRIC + f", {args.sequences} independent sequences on one GPU", n_gpus=1, higher_is_better=True, dtype="f32",
+                 data="synthetic", ms_per_step=o["ms_per_frame_of_one_sequence"])
+        emit(o)
+        vd.shutdown()
+        return
+    windows = max(1, min(WINDOWS, (SEQUENCE_FRAMES - args.warmup - ROOFLINE_SAMPLE_FRAMES) // max(1, args.steps)))
+    timed_frames = args.steps * windows
+    total = args.warmup + timed_frames + ROOFLINE_SAMPLE_FRAMES
     # every rank walks the same arc, offset so ranks do not share poses
     poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
     wl = args.workload
-    res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True, sample_frames=ROOFLINE_SAMPLE_FRAMES)
+    res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True, sample_frames=ROOFLINE_SAMPLE_FRAMES,
+                             windows=windows)
 
     tracked, depths = res.pop("_tracked", None), res.pop("_depths", None)
     nvis, rounds_per_frame = visible_counts(tracked or poses, depths)
-    nvis_timed = nvis[args.warmup:]                   # the timed frames, then the roofline sample's
+    nvis_timed = nvis[args.warmup:]                   # the timed frames (every window), then the roofline sample's
     image_bytes = IMAGE_BYTES["depth" if wl == "depth" else "rgbd"]
     alg = nvis_timed * BYTES_PER_BLOCK + image_bytes
     sampled = res.pop("_sampled")
     integ_ms, trace_ms = np.array(res.pop("_integrate_ms")), np.array(res.pop("_trace_ms"))
     achieved = float(alg[sampled].sum() / (integ_ms.sum() * 1e-3) / 1e9)
+    bracket_ms, bracketed = np.array(res.pop("_bracket_ms")), res.pop("_bracketed")
+    by_bracket = float(alg[bracketed].sum() / (bracket_ms.sum() * 1e-3) / 1e9) if len(bracketed) else None
     ctr = res.pop("_counters")
     pair_us = res.pop("_event_pair_us")
     frame_bytes = float(alg[:args.steps].mean())
@@ -975,6 +1263,8 @@ def main():
         "metric": METRIC, "value": res["value"], "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "per_rank_ms_per_step": res["per_rank_ms_per_step"],     # rank order; ms_per_step is their max (barrier to barrier)
+        "windows": res.get("windows", {"count": 1, "frames_each": args.steps, "median": res["value"], "min": res["value"],
+                                       "max": res["value"], "frames_per_s": [res["value"]]}),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
             "workload": names[wl] + ", 5 mm voxels, Volume(65024,8192)",
@@ -1013,10 +1303,21 @@ def main():
                        "right after the timed region (no event is recorded inside it); the bracket holds event_pair_us and the "
                        "launch latency behind its first event as well"),
             "timed_by": "dispatch" if TIME_BY_DISPATCH else "bracket",
+            # the same kernels timed the way the lines up to round 4 timed them (two event records AROUND the call), on every
+            # third launch of the same sample: round-over-round comparisons of `frac` must use like with like
+            "by_bracket": None if by_bracket is None else {
+                "achieved": by_bracket, "frac": by_bracket / HBM_PEAK_GBS, "avg_launch_us": float(bracket_ms.mean() * 1e3),
+                "launches_timed": len(bracketed)},
             "event_pair_us": pair_us,      # two vk_event_record with nothing between them: what a bracket would add (not in avg_launch_us when timed_by = dispatch)
             # where the bytes come from at this size: a frame's voxel working set is ~75 MB and
             # consecutive frames overlap almost entirely, so it lives in the 256 MiB Infinity Cache
             "memory_level": "infinity-cache assisted" if voxel_ws < L3_BYTES else "hbm",
+            # `frac` above is the kernel as the headline runs it; at this size that is "cache-assisted". `frac_hbm` (filled in below, next
+            # to it) is the same kernel with its voxels coming from HBM: eight replica volumes in lock step push the working
+            # set past the 256 MiB L3. A reader of ONE key should take frac_hbm for "fraction of the HBM roofline"
+            "frac_is": ("cache-assisted: the ~75 MB voxel working set of consecutive frames lives in the 256 MiB Infinity Cache; "
+                        "frac_hbm is the figure past it") if voxel_ws < L3_BYTES else "hbm: the working set exceeds the Infinity Cache",
+            "frac_hbm": None if voxel_ws < L3_BYTES else achieved / HBM_PEAK_GBS,
             "voxel_working_set_bytes": voxel_ws,
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
             "frame_level_GBps": frame_bytes / (res["ms_per_step"] * 1e-3) / 1e9,     # per GPU: integrate bytes / frame wall time
@@ -1026,6 +1327,8 @@ def main():
                         "avg_us": float(trace_ms.mean() * 1e3)},
         },
     }
+    if res.get("error"):
+        result["error"] = res["error"]           # e.g. the pool ran dry: the headline is not the configured workload's
     for key_ in ("tracked_pose_drives_fusion", "pose_error_max", "pose_error_last_frame", "camera_motion_over_run",
                  "gn_steps_median", "gn_steps_histogram_full_resolution_level"):
         if key_ in res:
@@ -1073,15 +1376,20 @@ def main():
             result["roofline"]["past_l3"] = pl3
             # next to `frac`: the same kernel when its voxels come from HBM, not from the Infinity Cache
             result["roofline"]["frac_past_l3"] = pl3["frac"]
+            result["roofline"]["frac_hbm"] = pl3["frac"]
             torch.cuda.empty_cache()
 
         others = {}
+        k_steps, k_warm = min(args.steps, 100), min(args.warmup, 10)
+        # the room sequence (tracking workloads): generated once, long enough for four cameras a quarter of the swing apart
+        room = RoomSequence(k_warm + k_steps + 40 + 3 * 60, T.Projection.make(*scenes.APP_INTRINSICS))
         for other in ("depth", "rgbd", "rgbd-icp"):
             if other == wl:
                 continue
-            k_steps, k_warm = min(args.steps, 100), min(args.warmup, 10)
-            o, oloop = run_workload(other, poses[:k_warm + k_steps + 40], k_warm, k_steps, vd, with_roofline=True, sample_frames=40)
+            o, oloop = run_workload(other, poses[:k_warm + k_steps + 40], k_warm, k_steps, vd, with_roofline=True, sample_frames=40,
+                                    room=room)
             o.pop("_event_pair_us", None)
+            o.pop("_bracket_ms", None), o.pop("_bracketed", None)
             ims, tms, smp = np.array(o.pop("_integrate_ms")), np.array(o.pop("_trace_ms")), o.pop("_sampled")
             o.pop("_counters")
             onvis = nvis
@@ -1112,7 +1420,37 @@ def main():
             others[wl + "-requests-inside-set-view"] = o
             del oloop
             torch.cuda.empty_cache()
+        # Several sequences per GPU: replica volumes are 750 MB of 288 GB, and a tracked frame is a strict
+        # chain that leaves the device idle in every tail. Aggregate frames/s of 2 and 4 independent sequences, beside the
+        # single sequence measured the same way (MultiLoop with one sequence: the same host loop, one stream)
+        for name, count in (("rgbd-icp", 1), ("rgbd-icp", 2), ("rgbd-icp", 4), (wl if wl != "rgbd-icp" else "rgbd", 1),
+                            (wl if wl != "rgbd-icp" else "rgbd", 2)):
+            try:
+                o, multi = run_sequences(name, count, k_warm, k_steps, room=room)
+                del multi
+            except Exception as e:     # noqa: BLE001  (reported next to the headline, never instead of it)
+                o = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+            o["workload"] = names[name] + f" — {count} independent sequence(s) on one GPU, a replica volume and a stream each"
+            others[f"{name} x{count}"] = o
+        for name in ("rgbd-icp", wl if wl != "rgbd-icp" else "rgbd"):
+            one = others.get(f"{name} x1", {}).get("value")
+            for count in (2, 4):
+                o = others.get(f"{name} x{count}")
+                if o and one and "value" in o:
+                    o["single_sequence_value"] = one
+                    o["aggregate_over_single"] = o["value"] / one
+        del room
+        torch.cuda.empty_cache()
+        try:
+            others["pyramid-icp"] = pyramid_icp()
+        except Exception as e:     # noqa: BLE001  (reported next to the headline, never instead of it)
+            others["pyramid-icp"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         result["other_workloads"] = others
+        try:
+            result["configs0_dense_128_gpu"] = dense_128_gpu()
+        except Exception as e:     # noqa: BLE001
+            result["configs0_dense_128_gpu"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if args.stream_input and world == 1 and wl != "rgbd-icp":
         # The input side (VERDICT r3 missing #3): the same step with the frame's images arriving from the host — pinned
@@ -1159,6 +1497,18 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:   # the CPU leg is reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(wl, poses, args.cpu_seconds)
+    gpu_dense = result.pop("configs0_dense_128_gpu", None)
+    if gpu_dense is not None:
+        # beside the CPU's figure for the IDENTICAL unit of work (VERDICT r5 missing #3)
+        if "cpu_baseline" in result:
+            dense = result["cpu_baseline"]["configs0_dense_128"]
+            dense["gpu"] = gpu_dense
+            if "ms" in gpu_dense:
+                cpu_keys = [key_ for key_ in dense if key_.endswith(("_core", "_cores"))]
+                dense["gpu_over_cpu"] = {key_: dense[key_]["ms"] / gpu_dense["ms"] for key_ in cpu_keys}
+                dense["same_voxels_updated"] = bool(dense.get("voxels_updated") == gpu_dense.get("voxels_updated"))
+        else:
+            result["configs0_dense_128_gpu"] = gpu_dense
 
     if rank == 0:
         emit(result)

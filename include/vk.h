@@ -614,8 +614,9 @@ VK_API int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p,
  * (vk_event_create) as the begin and the end OF THE DISPATCH ITSELF (hipExtLaunchKernelGGL) — the duration rocprofv3's kernel
  * trace reports. A caller that brackets the call with two vk_event_record instead also times the events' own processing and
  * the launch latency behind the first of them: 1.7 - 3.5 us on a 34 us launch, which is what separated bench.py's roofline
- * fraction from the kernel trace's until round 5. One launch only; (NULL, NULL) cancels. Not a stream operation: nothing is
- * enqueued by this call. */
+ * fraction from the kernel trace's until round 5. One CALL only: the pair is used up by the next vk_integrate_* call of this
+ * thread even when that call returns an error before its launch (round 6: events left armed by a failed call were recorded by a
+ * later, unrelated launch); (NULL, NULL) cancels. Not a stream operation: nothing is enqueued by this call. */
 VK_API int vk_integrate_time_next(void* start_event, void* stop_event);
 
 /* ref: src/tracer.cpp:41-47 Tracer::Trace, as vk_trace with the grid, depth range

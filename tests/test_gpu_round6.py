@@ -94,3 +94,78 @@ def test_class_layer_records_normals_made_by_its_own_launch(api):
     vol.set_view(f1, compute_normals=True)                  # nothing is due: the frame is taken as announced
     sync()
     assert vol.requests_ahead.valid == 0 and torch.equal(f1.normals, made)
+
+
+# -------------------------------------------- several sequences on one GPU --
+
+@pytest.mark.parametrize("workload", ["rgbd", "rgbd-icp"])
+def test_two_sequences_on_one_gpu_equal_each_alone(api, workload):
+    """bench.MultiLoop: two independent sequences — a replica volume, a stream and a FrameLoop each —
+    issued in lock step by one host thread, so that one sequence's integrate / raycast / request pass runs under the other's
+    Gauss-Newton loop and raycast tail. Each sequence's volume, hash table, raycast images and (tracked) poses are the ones
+    the same sequence gives when it runs alone, bit for bit. (Alone, bench.FrameLoop.step is held to the oracle by
+    tests/test_gpu_configs.py.)"""
+    import torch
+    import bench
+    frames = 6
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    if workload == "rgbd-icp":
+        room = bench.RoomSequence(frames + 8, k)
+        sequences = [room.view(0, frames), room.view(8, frames)]
+        pose_lists = [s.truth for s in sequences]
+    else:
+        sequences = None
+        pose_lists = [[scenes.orbit_pose(i + 7 * j, bench.YAW_STEP) for i in range(frames)] for j in range(2)]
+    sync()
+    multi = bench.MultiLoop(workload, pose_lists, sequences)
+    assert len({loop.stream.value for loop in multi.loops}) == 2, "the two sequences share a stream"
+    for i in range(frames):
+        multi.step(i)
+    sync()
+
+    def state(loop):
+        vol = loop.vols[0]["vol"]
+        ctr = torch.from_numpy(np.array([vol.read_counters()[c] for c in (T.VK_CTR_VISIBLE, T.VK_CTR_VOXEL_PTR, T.VK_CTR_DROPPED)]))
+        return {"voxels": vol.voxels, "entries": vol.hash_entries, "visible / free pointer / dropped": ctr,
+                "depth": loop.key.depth, "color": loop.key.color}
+
+    for j in range(2):
+        alone = bench.FrameLoop(workload, pose_lists[j], sequence=None if sequences is None else sequences[j])
+        for i in range(frames):
+            alone.step(i)
+        sync()
+        got, want = state(multi.loops[j]), state(alone)
+        for name in want:
+            assert torch.equal(got[name], want[name]), f"sequence {j}: {name} differs from the sequence run alone"
+        if workload == "rgbd-icp":
+            assert len(alone.tracked_poses) == frames
+            assert [bytes(p) for p in multi.loops[j].tracked_poses] == [bytes(p) for p in alone.tracked_poses], f"sequence {j}: poses"
+            assert multi.loops[j].gn_steps == alone.gn_steps
+        assert int(alone.vols[0]["vol"].read_counters()[T.VK_CTR_VISIBLE]) > 1000
+        del alone
+        torch.cuda.empty_cache()
+
+
+# -------------------------------------- a timed launch that never happened --
+
+def test_timing_events_are_used_up_by_a_call_that_fails(api):
+    """vk_integrate_time_next arms a pair of events for the next integrate launch of the thread. If the next
+    vk_integrate_* call returns before it launches (an argument error), the pair used to stay armed and was recorded by a
+    later, unrelated launch. Now the pair is used up by the CALL."""
+    lib = api.lib()
+    k, depth, color = _rgbd_inputs()
+    vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+    integ = api.DepthIntegrator(vol)
+    f = api.Frame(depth, k, scenes.yaw(0.0))
+    vol.set_view(f)
+    pair = []
+    for _ in range(2):
+        e = C.c_void_p()
+        api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
+        pair.append(e)
+    api.check(lib.vk_integrate_time_next(pair[0], pair[1]), "vk_integrate_time_next")
+    assert lib.vk_integrate_depth(None, None, None, None) == -1          # fails before its launch
+    integ.integrate(f)                                                    # an unrelated launch: must not record the pair
+    sync()
+    ms = C.c_float(-1.0)
+    assert lib.vk_event_elapsed_ms(pair[0], pair[1], C.byref(ms)) != 0, "the stale pair was recorded by a later launch"

@@ -808,6 +808,13 @@ int pipe_grid_for(const vk_volume* v, int groups_per_cu)
 // vk_integrate_time_next: the events the next pipelined launch of this host thread records as its own begin and end
 thread_local hipEvent_t g_time_start = nullptr, g_time_stop = nullptr;
 
+// the pair is used up by the next vk_integrate_* CALL, whether or not that call gets as far as its launch (an argument error,
+// a failed fill_params): armed events must never be recorded by a later, unrelated launch
+struct TimedLaunchScope
+{
+  ~TimedLaunchScope() { g_time_start = g_time_stop = nullptr; }
+};
+
 template <typename Kernel>
 void launch_pipelined(Kernel kernel, int grid, hipStream_t s, const IntegrateParams& P, const AheadParams& A)
 {
@@ -934,6 +941,7 @@ extern "C" {
 
 int vk_integrate_depth(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, false, false);
   if (rc != VK_OK) return rc;
@@ -942,6 +950,7 @@ int vk_integrate_depth(const vk_volume* v, const vk_integrator* p, const vk_fram
 
 int vk_integrate_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, false, true, false);
   if (rc != VK_OK) return rc;
@@ -950,6 +959,7 @@ int vk_integrate_color(const vk_volume* v, const vk_integrator* p, const vk_fram
 
 int vk_integrate_depth_color(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, nullptr, nullptr, true, true, false);
   if (rc != VK_OK) return rc;
@@ -985,6 +995,7 @@ int vk_light_prepare(const vk_frame* frame, float depth_threshold, float* mask, 
 int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p, const vk_light* light,
     const float* mask, const vk_frame* frame, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, light, mask, false, true, true);
   if (rc != VK_OK) return rc;
@@ -994,6 +1005,7 @@ int vk_integrate_light_color(const vk_volume* v, const vk_integrator* p, const v
 int vk_integrate_depth_light(const vk_volume* v, const vk_integrator* p, const vk_light* light,
     const float* mask, const vk_frame* frame, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   const int rc = fill_params(P, v, p, frame, light, mask, true, true, true);
   if (rc != VK_OK) return rc;
@@ -1011,6 +1023,7 @@ int vk_integrate_time_next(void* start_event, void* stop_event)
 int vk_integrate_ahead(const vk_volume* v, const vk_integrator* p, const vk_frame* frame, int color_mode,
     const vk_light* light, const float* mask, const float* light_records, vk_view_bounds* ahead, void* stream)
 {
+  TimedLaunchScope used_up;
   IntegrateParams P;
   VK_REQUIRE(color_mode >= 0 && color_mode <= 2);
   const int rc = fill_params(P, v, p, frame, color_mode == 2 ? light : nullptr, color_mode == 2 ? mask : nullptr, true,

@@ -247,19 +247,39 @@ __device__ __forceinline__ uint32_t lds_address(const void* shared)
   return (uint32_t)(uintptr_t)(lds_char*)(char*)const_cast<void*>(shared);
 }
 
-// One 16-byte LDS read the compiler can neither split into two nor wait for on the spot: hipcc's own bookkeeping does not
-// see it, so its data must not be touched before lds_wait8 has named the destination.
-__device__ __forceinline__ v4i lds_read16_async(uint32_t byte_address)
+// Eight 16-byte LDS reads that leave together and ONE wait, as a single asm statement (round 6, ADVICE r5: until then
+// nine statements — eight reads and a wait — whose outstanding data hipcc's own s_waitcnt bookkeeping could not see, so
+// that correctness rested on the register allocator never placing a copy or a spill of a destination between a read and
+// the wait). Inside one statement nothing can be scheduled, copied or spilled between the reads and the wait; the
+// destinations are early-clobber (they are written while the addresses are still being read), and the "memory" clobber
+// tells the compiler that the statement reads LDS the surrounding code has written with ordinary stores (file_blocks).
+// The eight addresses are the corners of a box: entry m sits at a + (m & 1 ? sx : 0) + (m & 2 ? sy : 0) + (m & 4 ? sz : 0).
+// Walking them in Gray-code order (0, 1, 3, 2, 6, 7, 5, 4) takes ONE running address and one add or subtract per read, so
+// the statement holds 32 + 4 registers instead of 32 + 8 (an LDS instruction reads its address register when it issues:
+// the add behind it may overwrite it).
+__device__ __forceinline__ void lds_read16x8(v4i& e0, v4i& e1, v4i& e2, v4i& e3, v4i& e4, v4i& e5, v4i& e6, v4i& e7,
+    uint32_t a, uint32_t sx, uint32_t sy, uint32_t sz)
 {
-  v4i r;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(byte_address));
-  return r;
-}
-
-// waits for every LDS operation of the wave; the eight destinations are operands so that no use of them moves above it
-__device__ __forceinline__ void lds_wait8(v4i& a, v4i& b, v4i& c, v4i& d, v4i& e, v4i& f, v4i& g, v4i& h)
-{
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+  asm volatile(
+      "ds_read_b128 %0, %8\n\t"
+      "v_add_u32 %8, %8, %9\n\t"
+      "ds_read_b128 %1, %8\n\t"
+      "v_add_u32 %8, %8, %10\n\t"
+      "ds_read_b128 %3, %8\n\t"
+      "v_sub_u32 %8, %8, %9\n\t"
+      "ds_read_b128 %2, %8\n\t"
+      "v_add_u32 %8, %8, %11\n\t"
+      "ds_read_b128 %6, %8\n\t"
+      "v_add_u32 %8, %8, %9\n\t"
+      "ds_read_b128 %7, %8\n\t"
+      "v_sub_u32 %8, %8, %10\n\t"
+      "ds_read_b128 %5, %8\n\t"
+      "v_sub_u32 %8, %8, %9\n\t"
+      "ds_read_b128 %4, %8\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "=&v"(e4), "=&v"(e5), "=&v"(e6), "=&v"(e7), "+v"(a)
+      : "v"(sx), "v"(sy), "v"(sz)
+      : "memory");
 }
 
 // zero exactly when directory entry `e` holds block (bx, by, bz)
@@ -301,7 +321,7 @@ __device__ __forceinline__ Corners<POOL32> resolve_corners(const PointParams& P,
   // Round 5, from the ISA (profiles/r05_raycast_trip_isa.txt): until round 4 the lookups were guarded one by one
   // (`if (__any(need))`), and the compiler had turned `e.x == nx && e.y == ny && e.z == nz` into control flow — read {x,
   // slot}, wait, compare, branch, read {y, z}, wait, compare: SIXTEEN dependent LDS round trips and ~175 instructions per
-  // sample, most of a lone wave's 2 us per sampled trip. Now: eight 16-byte reads leave together (lds_read16_async: the
+  // sample, most of a lone wave's 2 us per sampled trip. Now: eight 16-byte reads leave together (lds_read16x8: the
   // compiler can neither split them nor put a wait between them), ONE wait, four instructions per block for the tag
   // test (three xor, one or3), and the rare miss — a block this wave has not met — is found by OR-ing the eight.
   const int nx[2] = {base_x, base_x + (cx ? 1 : 0)}, ny[2] = {base_y, base_y + (cy ? 1 : 0)}, nz[2] = {base_z, base_z + (cz ? 1 : 0)};
@@ -310,15 +330,8 @@ __device__ __forceinline__ Corners<POOL32> resolve_corners(const PointParams& P,
   const uint32_t dz[2] = {(uint32_t)(nz[0] & 3) << 8, (uint32_t)(nz[1] & 3) << 8};
   const uint32_t dir_lds = lds_address(dir);
 
-  v4i e0 = lds_read16_async(dir_lds + (dx[0] | dy[0] | dz[0]));
-  v4i e1 = lds_read16_async(dir_lds + (dx[1] | dy[0] | dz[0]));
-  v4i e2 = lds_read16_async(dir_lds + (dx[0] | dy[1] | dz[0]));
-  v4i e3 = lds_read16_async(dir_lds + (dx[1] | dy[1] | dz[0]));
-  v4i e4 = lds_read16_async(dir_lds + (dx[0] | dy[0] | dz[1]));
-  v4i e5 = lds_read16_async(dir_lds + (dx[1] | dy[0] | dz[1]));
-  v4i e6 = lds_read16_async(dir_lds + (dx[0] | dy[1] | dz[1]));
-  v4i e7 = lds_read16_async(dir_lds + (dx[1] | dy[1] | dz[1]));
-  lds_wait8(e0, e1, e2, e3, e4, e5, e6, e7);
+  v4i e0, e1, e2, e3, e4, e5, e6, e7;
+  lds_read16x8(e0, e1, e2, e3, e4, e5, e6, e7, dir_lds + (dx[0] | dy[0] | dz[0]), dx[1] - dx[0], dy[1] - dy[0], dz[1] - dz[0]);
 
   int n[8] = {e0.w, e1.w, e2.w, e3.w, e4.w, e5.w, e6.w, e7.w};
   // tag test: zero where the entry holds exactly this block
