@@ -511,6 +511,8 @@ class FrameLoop:
         if self.ahead is not None and i + 1 < len(self.poses):
             # Trace(i) + the request pass of SetView(i + 1), one launch
             self.ndesc.depth, self.ndesc.color = self.fdesc.depth, self.fdesc.color
+            if self.sequence is not None:          # a sequence of resident camera frames: the NEXT frame's own images
+                self.ndesc.depth, self.ndesc.color = self.sequence.depth[i + 1].data_ptr(), self.sequence.color[i + 1].data_ptr()
             if self.upload is not None:
                 # the next frame's images: submitted at the top of this step, on the device by now or soon (the launch waits)
                 images = self.upload.acquire(n + 1)
@@ -844,68 +846,114 @@ def touched_blocks(pl, loop):
 DENSE_ORIGIN = [[x, y, z] for z in range(42, 58) for y in range(-8, 8) for x in range(-8, 8)]
 
 
-def dense_128_gpu(reps=60):
+def dense_128_gpu(reps=64, replicas=8):
     """BASELINE configs[0] (SURVEY 8d Config 1) ON THE DEVICE: the same unit of work cpu_baseline.configs0_dense_128 times on
     the host — one 640x480 depth frame into a dense 128^3 voxel region = 4096 hand-placed blocks (tests/integrator_test.cu:
     141-199 is the arithmetic; tests/test_gpu_configs.py::test_configs0_dense_128_on_the_device holds the device to the
-    oracle's bytes for exactly this volume) — through vk_integrate_depth, every launch timed by its own begin / end events."""
+    oracle's bytes for exactly this volume) — through vk_integrate_depth, every launch timed by its own begin / end events.
+    Twice: relaunched on ONE volume (its 42 MB of voxels stay in the 256 MiB Infinity Cache, as the CPU's stay in its caches:
+    the figure beside the CPU's), and rotating over `replicas` such volumes (336 MB between two launches on the same voxels:
+    they come from HBM — the figure that may be called a fraction of the HBM roofline)."""
     import torch
     from vulcan_amd import api, vk_types as T
     import scenes
     k = T.Projection.make(*scenes.APP_INTRINSICS)
     depth_np = sphere_room_depth(k)
-    vol = api.Volume(8192, 1024, voxel_length=VOXEL, truncation_length=TRUNC)
     n = len(DENSE_ORIGIN)
-    entries = vol.host_entries().copy()
-    entries["block"]["origin"][:n] = np.array(DENSE_ORIGIN, dtype=np.int16)
-    entries["data"][:n] = np.arange(n)
-    entries["next"][:n] = -1
-    vol.hash_entries.copy_(torch.from_numpy(np.frombuffer(entries.tobytes(), dtype=np.uint8).copy()).cuda())
-    vol.visible_blocks[:n] = torch.arange(n, dtype=torch.int32, device="cuda")
-    vol.counters[T.VK_CTR_VISIBLE] = n
     frame = api.Frame(depth_np, k, T.Transform.identity())
     lib, s = api.lib(), api.stream()
-    vdesc, fdesc, params = vol.desc(), frame.desc(), T.Integrator.default()
-    vref, fref, pref = C.byref(vdesc), C.byref(fdesc), C.byref(params)
+    fdesc, params = frame.desc(), T.Integrator.default()
+    fref, pref = C.byref(fdesc), C.byref(params)
+
+    def dense_volume():
+        vol = api.Volume(8192, 1024, voxel_length=VOXEL, truncation_length=TRUNC)
+        entries = vol.host_entries().copy()
+        entries["block"]["origin"][:n] = np.array(DENSE_ORIGIN, dtype=np.int16)
+        entries["data"][:n] = np.arange(n)
+        entries["next"][:n] = -1
+        vol.hash_entries.copy_(torch.from_numpy(np.frombuffer(entries.tobytes(), dtype=np.uint8).copy()).cuda())
+        vol.visible_blocks[:n] = torch.arange(n, dtype=torch.int32, device="cuda")
+        vol.counters[T.VK_CTR_VISIBLE] = n
+        desc = vol.desc()
+        return vol, desc, C.byref(desc)
 
     def event():
         e = C.c_void_p()
         api.check(lib.vk_event_create(C.byref(e)), "vk_event_create")
         return e
 
-    api.check(lib.vk_integrate_depth(vref, pref, fref, s), "vk_integrate_depth")
-    torch.cuda.synchronize()
-    updated = int((vol.host_voxels()["distance_weight"][:n * 512] > 0).sum())
-    pairs = [(event(), event()) for _ in range(reps)]
+    def timed(vrefs, count):
+        pairs, rc = [(event(), event()) for _ in range(count)], 0
+        for i, (e0, e1) in enumerate(pairs):
+            rc |= lib.vk_integrate_time_next(e0, e1)
+            rc |= lib.vk_integrate_depth(vrefs[i % len(vrefs)], pref, fref, s)
+        torch.cuda.synchronize()
+        api.check(rc, "vk_integrate_depth (timed)")
+        ms = []
+        for e0, e1 in pairs:
+            t = C.c_float()
+            api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(t)), "vk_event_elapsed_ms")
+            ms.append(t.value)
+        return np.array(ms)
+
+    volumes = [dense_volume() for _ in range(replicas)]
+    vrefs = [v[2] for v in volumes]
     rc = 0
-    for e0, e1 in pairs:
-        rc |= lib.vk_integrate_time_next(e0, e1)
+    for vref in vrefs:
         rc |= lib.vk_integrate_depth(vref, pref, fref, s)
     torch.cuda.synchronize()
-    api.check(rc, "vk_integrate_depth (timed)")
-    ms = []
-    for e0, e1 in pairs:
-        t = C.c_float()
-        api.check(lib.vk_event_elapsed_ms(e0, e1, C.byref(t)), "vk_event_elapsed_ms")
-        ms.append(t.value)
-    # back to back, no events: what a caller sees per call when it does nothing but integrate
+    api.check(rc, "vk_integrate_depth")
+    updated = int((volumes[0][0].host_voxels()["distance_weight"][:n * 512] > 0).sum())
+    ms_cached = timed(vrefs[:1], reps)
+    ms_hbm = timed(vrefs, reps)
+    # back to back on one volume, no events: what a caller sees per call when it does nothing but integrate
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        rc |= lib.vk_integrate_depth(vref, pref, fref, s)
+        rc |= lib.vk_integrate_depth(vrefs[0], pref, fref, s)
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) / reps * 1e3
     api.check(rc, "vk_integrate_depth")
-    dt = float(np.mean(ms)) * 1e-3
+    dt, dt_hbm = float(ms_cached.mean()) * 1e-3, float(ms_hbm.mean()) * 1e-3
     bytes_per_launch = n * BYTES_PER_BLOCK + IMAGE_BYTES["depth"]
-    return {"ms": dt * 1e3, "ms_median": float(np.median(ms)), "ms_back_to_back": wall_ms, "voxels": n * 512, "blocks": n,
+    return {"ms": dt * 1e3, "ms_median": float(np.median(ms_cached)), "ms_back_to_back": wall_ms, "voxels": n * 512, "blocks": n,
             "voxels_per_s": n * 512 / dt, "voxels_updated": updated, "launches_timed": reps,
             "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_GBps": bytes_per_launch / dt / 1e9,
-            "frac_of_8TBps": bytes_per_launch / dt / 1e9 / HBM_PEAK_GBS,
-            "memory_level": "infinity-cache assisted (42 MB of voxels, relaunched on the same volume)",
+            "memory_level": "infinity-cache assisted (one volume relaunched: its 42 MB of voxels never leave the 256 MiB cache, so the "
+                            "rate is the cache's and is NOT a fraction of the HBM roofline; past_l3 is)",
+            "past_l3": {"ms": dt_hbm * 1e3, "ms_median": float(np.median(ms_hbm)), "replica_volumes": replicas,
+                        "voxel_bytes_between_reuse": replicas * n * 10240, "voxels_per_s": n * 512 / dt_hbm,
+                        "algorithmic_GBps": bytes_per_launch / dt_hbm / 1e9,
+                        "frac_of_8TBps": bytes_per_launch / dt_hbm / 1e9 / HBM_PEAK_GBS, "launches_timed": reps},
             "timed_by": "the dispatch's own begin / end events (vk_integrate_time_next); ms_back_to_back = wall time per call of "
-                        f"{reps} calls enqueued back to back",
+                        f"{reps} calls enqueued back to back on one volume",
             "kernel": "integrate_pipelined_kernel<depth> (vk_integrate_depth)"}
+
+
+def pyramid_case(name, w, h):
+    """(intrinsics, key depth, key pose, frame depth, start pose, true pose) of a configs[3] case at base size w x h.
+    "same surface": tests/test_gpu_configs.py::test_pyramid_tracker_matches_oracle's — a curved surface seen twice, the frame
+    started 3.7 mm / 0.3 deg off (three steps at half resolution, one at full). "two views": the room scene (tests/scenes.py)
+    rendered from two poses of the room sequence five frames apart (33 mm, 2.6 deg), the frame started at the key frame's
+    pose as a live loop would — different images, projective association: eight steps and two to four
+    (test_pyramid_tracker_two_views_matches_oracle)."""
+    from vulcan_amd import vk_types as T
+    import scenes
+    scale = w / 640.0
+    if name == "same surface":
+        k = T.Projection.make(547.0 * scale, 547.0 * scale, 320.0 * scale, 240.0 * scale)
+        y, x = np.mgrid[0:h, 0:w]
+        depth = (1.0 + 0.05 * np.cos(3.0 * x / w) * np.sin(2.0 * y / h)).astype(np.float32)
+        start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
+        return k, depth, T.Transform.identity(), depth, start, T.Transform.identity()
+    k = T.Projection.make(*(v * scale for v in scenes.APP_INTRINSICS))
+    key_pose, true_pose = scenes.room_pose(20), scenes.room_pose(25)
+    key_depth, _ = scenes.room_frame(k, key_pose, w, h)
+    frame_depth, _ = scenes.room_frame(k, true_pose, w, h)
+    return k, key_depth, key_pose, frame_depth, key_pose, true_pose
+
+
+PYRAMID_CASES = ("same surface", "two views")
 
 
 def pyramid_icp(reps=30):
@@ -913,70 +961,74 @@ def pyramid_icp(reps=30):
     built by Frame::Downsample, src/image.cu:101-165; 15 Gauss-Newton steps on it, then 20 at full resolution, each loop
     ending early at |update| < 1e-6) at base sizes 320x240, 640x480 and 1280x960, through the one C entry point and
     Tracker::EndSolve's pose readback (vk_icp_pyramid_track_frame + vk_track_wait), descriptors built once as FrameLoop does.
-    The scene is tests/test_gpu_configs.py::test_pyramid_tracker_matches_oracle's (a curved surface, the frame started 3.7 mm /
-    0.3 deg off) — the case whose poses are held to the oracle's at all three sizes. Per size: us per Track (median and
-    min of `reps`, host wall clock around the blocking call), the steps each level ran, and SURVEY 8(d)'s bytes — 2 * W * H *
-    (4 + 12) per iteration at that level's size — as GB/s over the Track."""
+    Two cases per size (pyramid_case): the same surface started a few millimetres off, and two views of the room scene — both
+    held to the oracle's pose at all three sizes (tests/test_gpu_configs.py). Per size and case: us per Track (median and min of `reps`, host wall clock around the blocking call),
+    the steps each level ran, and SURVEY 8(d)'s bytes — 2 * W * H * (4 + 12) per iteration at that level's size — as GB/s
+    over the Track."""
     import torch
     from vulcan_amd import api, vk_types as T
     lib, s = api.lib(), api.stream()
     out = {}
     for (w, h) in ((320, 240), (640, 480), (1280, 960)):
-        scale = w / 640.0
-        k = T.Projection.make(547.0 * scale, 547.0 * scale, 320.0 * scale, 240.0 * scale)
-        y, x = np.mgrid[0:h, 0:w]
-        depth = (1.0 + 0.05 * np.cos(3.0 * x / w) * np.sin(2.0 * y / h)).astype(np.float32)
-        key = api.Frame(depth, k, T.Transform.identity())
-        key.compute_normals()
-        start = T.Transform.translate(0.002, -0.001, 0.003) * T.Transform.rotate(0.999995, 0.002, -0.0015, 0.001)
-        frame = api.Frame(key.depth, k, start, normals=key.normals)
-        tracker = api.PyramidTracker()
-        tracker.keyframe = key
-        t = tracker.tracker
-        # the half-resolution level alone, once, for its step count (the pyramid call leaves the full level's in its state)
-        half_key, half_frame = key.downsample(), frame.downsample()
-        t.max_iterations, t.keyframe = 15, half_key
-        t.track(half_frame)
-        steps_half = int(t.state.cpu()[0])
-        t.max_iterations, t.keyframe = 20, key
-        key_view, frame_view = t._view(key), t._view(frame)
-        n = int(lib.vk_icp_pyramid_floats(w, h, w, h))
-        pyramid = torch.empty(n, dtype=torch.float32, device="cuda")
-        poll = t._poll()
-        args = (C.byref(key_view), C.byref(key.depth_to_world), C.byref(frame_view), C.c_void_p(t.pose.data_ptr()), C.byref(start), 0,
-                C.c_void_p(pyramid.data_ptr()), C.c_void_p(t._workspace(frame).data_ptr()), C.c_void_p(t.system.data_ptr()),
-                C.c_void_p(t.state.data_ptr()), C.c_void_p(t.update.data_ptr()), None, None, poll, s)
-        words = (C.c_int32 * 4).from_address(t._poll_host.value)
-        times, rc = [], 0
-        for i in range(reps + 3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rc |= lib.vk_icp_pyramid_track_frame(*args)
-            rc |= lib.vk_track_wait(poll, s)                     # Tracker::EndSolve: the pose, from pinned memory
-            if i >= 3:
-                times.append(time.perf_counter() - t0)
-        api.check(rc, f"vk_icp_pyramid_track_frame at {w}x{h}")
-        steps_full = int(words[0])
-        aborted = int(t.state.cpu()[1]) < 0
-        pose = T.Transform.from_buffer_copy(C.string_at(t._pose_host, 128))
-        us = float(np.median(times) * 1e6)
-        steps = steps_half + steps_full
-        level_bytes = steps_half * 2 * (w // 2) * (h // 2) * 16 + steps_full * 2 * w * h * 16
-        entry = {"us_per_track": us, "us_per_track_min": float(min(times) * 1e6), "tracks_timed": reps,
-                 "steps_run": {"half_resolution": steps_half, "full_resolution": steps_full, "enqueued": {"half_resolution": 15, "full_resolution": 20}},
-                 "us_per_step": us / max(1, steps),
-                 "algorithmic_bytes_per_track": level_bytes, "algorithmic_GBps": level_bytes / (us * 1e-6) / 1e9,
-                 "frac_of_8TBps": level_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                 "pose_recovered_max_abs_error": float(np.abs(pose.matrix() - np.eye(4)).max())}
-        if aborted:
-            entry["error"] = "the loop kernel ended with VK_TRACK_ABORTED"
-        out[f"{w}x{h}"] = entry
-        del tracker, pyramid, key, frame
-        torch.cuda.empty_cache()
-    return {"workload": "BASELINE configs[3]: PyramidTracker<DepthTracker>::Track, half-resolution level (15 steps enqueued) then full "
-                        "resolution (20), at base sizes 320x240 / 640x480 / 1280x960; one C call + the pose readback per Track",
+        per_start = {}
+        for name in PYRAMID_CASES:
+            k, key_depth, key_pose, frame_depth, start, truth = pyramid_case(name, w, h)
+            key = api.Frame(key_depth, k, key_pose)
+            key.compute_normals()
+            frame = api.Frame(frame_depth, k, start)
+            frame.compute_normals()
+            tracker = api.PyramidTracker()
+            tracker.keyframe = key
+            t = tracker.tracker
+            # the half-resolution level alone, once, for its step count (the pyramid call leaves the full level's in its state)
+            half_key, half_frame = key.downsample(), frame.downsample()
+            t.max_iterations, t.keyframe = 15, half_key
+            t.track(half_frame)
+            steps_half = int(t.state.cpu()[0])
+            t.max_iterations, t.keyframe = 20, key
+            key_view, frame_view = t._view(key), t._view(frame)
+            n = int(lib.vk_icp_pyramid_floats(w, h, w, h))
+            pyramid = torch.empty(n, dtype=torch.float32, device="cuda")
+            poll = t._poll()
+            args = (C.byref(key_view), C.byref(key.depth_to_world), C.byref(frame_view), C.c_void_p(t.pose.data_ptr()), C.byref(start), 0,
+                    C.c_void_p(pyramid.data_ptr()), C.c_void_p(t._workspace(frame).data_ptr()), C.c_void_p(t.system.data_ptr()),
+                    C.c_void_p(t.state.data_ptr()), C.c_void_p(t.update.data_ptr()), None, None, poll, s)
+            words = (C.c_int32 * 4).from_address(t._poll_host.value)
+            times, rc = [], 0
+            for i in range(reps + 3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                rc |= lib.vk_icp_pyramid_track_frame(*args)
+                rc |= lib.vk_track_wait(poll, s)                     # Tracker::EndSolve: the pose, from pinned memory
+                if i >= 3:
+                    times.append(time.perf_counter() - t0)
+            api.check(rc, f"vk_icp_pyramid_track_frame at {w}x{h}")
+            steps_full = int(words[0])
+            aborted = int(t.state.cpu()[1]) < 0
+            pose = T.Transform.from_buffer_copy(C.string_at(t._pose_host, 128))
+            us = float(np.median(times) * 1e6)
+            steps = steps_half + steps_full
+            level_bytes = steps_half * 2 * (w // 2) * (h // 2) * 16 + steps_full * 2 * w * h * 16
+            entry = {"us_per_track": us, "us_per_track_min": float(min(times) * 1e6), "tracks_timed": reps,
+                     "steps_run": {"half_resolution": steps_half, "full_resolution": steps_full},
+                     "us_per_step": us / max(1, steps),
+                     "algorithmic_bytes_per_track": level_bytes, "algorithmic_GBps": level_bytes / (us * 1e-6) / 1e9,
+                     "frac_of_8TBps": level_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "start_off_by": dict(zip(("translation_m", "rotation_deg"), pose_error(start, truth))),
+                     "pose_error_after_track": dict(zip(("translation_m", "rotation_deg"), pose_error(pose, truth)))}
+            if aborted:
+                entry["error"] = "the loop kernel ended with VK_TRACK_ABORTED"
+            per_start[name] = entry
+            del tracker, pyramid, frame, key
+            torch.cuda.empty_cache()
+        out[f"{w}x{h}"] = per_start
+    return {"workload": "BASELINE configs[3]: PyramidTracker<DepthTracker>::Track, half-resolution level (15 steps enqueued, fewer run "
+                        "once |update| < 1e-6) then full resolution (20), at base sizes 320x240 / 640x480 / 1280x960; one C call + "
+                        "the pose readback per Track",
             "unit": "us per Track", "bound": "latency: a strict chain of Gauss-Newton steps (exchange + solve, ~9.4 us each), not bandwidth",
+            "steps_enqueued": {"half_resolution": 15, "full_resolution": 20},
             "sizes": out}
+
 
 # ----------------------------------------------------------------- multi-GPU rig ----
 
@@ -1287,7 +1339,7 @@ def main():
                                                                           if wl == "rgbd-icp" else ""),
             "frames_per_rank": args.steps, "image": [W, H], "voxel_length": VOXEL, "truncation_length": TRUNC,
             "visible_blocks_mean": float(nvis_timed[:args.steps].mean()),
-            "allocated_blocks_end": int(MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR]),
+            "allocated_blocks_end": int(min(MAIN + EXCESS, MAIN + EXCESS - 1 - ctr[T.VK_CTR_VOXEL_PTR])),
             "dropped_requests": int(ctr[T.VK_CTR_DROPPED]), "parallelism": f"replica volume per GPU x{world}",
         },
         "roofline": {

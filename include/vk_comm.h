@@ -17,6 +17,26 @@
  *
  * Conventions as in vk.h: plain C, 0 on success, negative VK_ERR_* on bad
  * arguments, positive = 1000 + ncclResult_t on an RCCL failure (vk_comm_error_string).
+ *
+ * Two PROCESSES on one GPU (a shared node; `bench.py --gpus 2` on a one-GPU box; round 6: stated here, it used to live
+ * in a round-2 note). One rank per GPU is the supported layout. What a shared device gets:
+ *   - RCCL itself refuses two ranks on one device (ncclCommInitRank fails): vk_comm_init returns 1000 + ncclResult_t on
+ *     every rank; the exchange can still be set up with vk_comm_exchange_create / _attach_handles over the host's own
+ *     channel (tests/test_gpu_rig_two_ranks.py does exactly that).
+ *   - The one-launch Gauss-Newton loops (vk_icp_track & co., vk_icp_track_rig) need ALL their workgroups on the device
+ *     at once, and one such launch fills it. The library chains the loop launches of ONE process across its streams
+ *     (vk_runtime.hip vk_loop_launch_begin / _end); it cannot chain two processes. When two processes' loop launches
+ *     meet, each may hold a part of the device and wait for the rest: the waits inside the launch are bounded (two
+ *     seconds), both launches then end with state[1] = VK_TRACK_ABORTED, no pose is published (vk_track_wait returns
+ *     VK_ERR_UNSUPPORTED), and the hosts' documented way out runs: the same Track again from the start pose as the
+ *     launch-per-stage loop (`reduce` = vk_reduce_nothing, or the all-reduce hook on a rig), which waits for nobody.
+ *     The class layer and vulcan_amd/api.py do this by themselves (Tracker::Track, _with_fallback); on a rig
+ *     Communicator.track_rig makes the ranks agree on the abort first. The result is the same pose (the staged loop is
+ *     held to the same oracle, tests/test_gpu_loop_abort.py); the cost is up to two seconds per collision. Nothing is
+ *     wrong silently; nothing hangs.
+ *   - The raycast's riding normals (vk_trace_ahead_requests) wait for workgroups of their OWN launch only; a second
+ *     process slows them down but cannot starve them; should the bounded wait still expire, VK_ERR_TIMEOUT and
+ *     vk_trace_normals_settle (vk.h) apply.
  */
 #ifndef VK_COMM_H_
 #define VK_COMM_H_

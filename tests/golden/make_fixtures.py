@@ -99,10 +99,69 @@ def step_cap_oracle():
                 entries_sha256=digest(hv.hash_entries), voxels_sha256=digest(hv.voxels))
 
 
+# ---- the soak run's parity leg (round 6; tools/soak.py): 2 000 frames of fusion + raycast at GIVEN poses on the room
+# sequence, looped (240 distinct frames), at the bench's size — Volume(65024, 8192), 640x480, 5 mm. The file holds SHA-256
+# digests of the hash table, the voxel pool and the raycast images at a few frame counts: long enough for the free list,
+# the visibility churn of revisited blocks and the saturated weights to matter, and still a parity statement.
+SOAK_FILE = os.path.join(HERE, "soak_room_640x480.json")
+SOAK_CHECKPOINTS = (20, 240, 480, 2000)
+SOAK_CYCLE = 240          # tests/scenes.py room_pose: frames per swing
+
+
+def soak_inputs(count=SOAK_CYCLE):
+    """[(depth, colour, pose)] of the first `count` frames of the room sequence at the bench's size"""
+    import scenes
+    from concurrent.futures import ThreadPoolExecutor
+    from vulcan_amd import vk_types as T
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    poses = [scenes.room_pose(i) for i in range(count)]
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        images = list(pool.map(lambda p: scenes.room_frame(k, p, 640, 480, light=(2.0, (0.025, 0.08, 0.0))), poses))
+    return k, [(d, c, p) for (d, c), p in zip(images, poses)]
+
+
+def soak_oracle(frames, checkpoints=SOAK_CHECKPOINTS, progress=None):
+    """the oracle's loop: Frame::ComputeNormals, SetView x3, depth + frame mask + shaded colour, Trace (vulcan.cu:297,316-325)"""
+    from oracle import oracle as orc
+    from vulcan_amd import vk_types as T
+    k, inputs = soak_inputs(min(frames, SOAK_CYCLE))
+    light = T.Light.make(2.0, (0.025, 0.08, 0.0))
+    hv = orc.HostVolume(65024, 8192, voxel_length=0.005, truncation_length=0.04)
+    out = {}
+    for i in range(frames):
+        depth, color, pose = inputs[i % SOAK_CYCLE]
+        hf = orc.HostFrame(depth, k, pose, color=color)
+        hf.compute_normals()
+        for _ in range(3):
+            hv.set_view(hf, orc.POLICY_MAXKEY)
+        orc.integrate_depth(hv, hf)
+        orc.integrate_light_color(hv, hf, light, orc.light_frame_mask(hf, 0.2))
+        if i + 1 in checkpoints:
+            odepth, ocolor, onormals, _ = orc.trace(hv, hf)
+            out[str(i + 1)] = {"entries_sha256": digest(hv.hash_entries), "voxels_sha256": digest(hv.voxels),
+                               "depth_sha256": digest(odepth), "color_sha256": digest(ocolor), "normals_sha256": digest(onormals),
+                               "visible": int(hv.visible_count), "voxel_pointer": int(hv.counters[T.VK_CTR_VOXEL_PTR]),
+                               "dropped": int(hv.counters[T.VK_CTR_DROPPED])}
+            if progress:
+                progress(i + 1, out[str(i + 1)])
+    return out
+
+
 def main():
     from oracle import oracle as orc
     orc.build()
     orc.set_threads(8)
+    if "--soak" in sys.argv:
+        import json
+        import time
+        t0 = time.time()
+        out = soak_oracle(max(SOAK_CHECKPOINTS), progress=lambda n, d: print(f"frame {n}: {time.time() - t0:.0f} s {d}", flush=True))
+        with open(SOAK_FILE, "w") as f:
+            json.dump({"what": "tests/golden/make_fixtures.py --soak: the CPU oracle over the looped room sequence, digests at "
+                               "the named frame counts (the raycast is made only there: it changes nothing)",
+                       "checkpoints": out}, f, indent=1)
+        print(f"{SOAK_FILE}: written")
+        return
     if "--step-cap-only" not in sys.argv:
         out = {}
         for name in SCENES:

@@ -34,6 +34,21 @@ def test_self_launch_two_ranks():
     assert out["collective"]["vk_comm_count"] == 2 and out["collective"]["update_identical_on_all_ranks"] is True
 
 
+def test_self_launch_eight_ranks():
+    """north_star's machine is 8 ranks; the launch path had only ever seen 2. `--gpus 8` over gloo:
+    eight fresh children rendezvous, the rig's collective sees eight ranks, rank 0 prints ONE line that says what each took."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "5", "--selftest-launch"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_clean_env(), timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["system_sum"] == 36.0      # 1 + 2 + ... + 8
+    assert out["max_over_ranks"] == 8.0 and out["frames_all_ranks"] == 40.0
+    assert out["per_rank_ms_per_step"] == [float(r + 1) for r in range(8)]
+    assert out["collective"]["vk_comm_count"] == 8 and out["collective"]["update_identical_on_all_ranks"] is True
+
+
 def test_self_launch_reports_a_dying_rank():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launch", "--selftest-fail-rank", "1"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_clean_env(), timeout=300)

@@ -208,6 +208,38 @@ def curved_depth(w, h):
 
 
 @pytest.mark.parametrize("size", [(320, 240), (640, 480), (1280, 960)])
+def test_pyramid_tracker_two_views_matches_oracle(api, orc, size):
+    """The second case bench.py's pyramid-icp leg times (configs[3], round 6; bench.pyramid_case "two views"): the room scene
+    rendered from two poses 33 mm / 2.6 deg apart, the frame started at the key frame's pose — different images, so both
+    levels run several Gauss-Newton steps. Same bar as the same-surface case: the oracle's pose within 2e-5 per matrix
+    entry, run-to-run identical bits; and the true pose is found to a tenth of a millimetre."""
+    sys.path.insert(0, ROOT)
+    import bench
+    w, h = size
+    k, key_depth, key_pose, frame_depth, start, truth = bench.pyramid_case("two views", w, h)
+    hk, dk = frames(api, orc, key_depth, k, key_pose)
+    hf, df = frames(api, orc, frame_depth, k, start)
+    orc.set_threads(8)
+    for f in (hk, hf):
+        f.compute_normals()
+    for f in (dk, df):
+        f.compute_normals()
+    want, iters = orc.pyramid_track(hk, hf)
+    orc.set_threads(1)
+    tracker = api.PyramidTracker()
+    tracker.keyframe = dk
+    got = tracker.track(df)
+    sync()
+    assert int(tracker.tracker.state.cpu()[1]) == 1 and int(tracker.tracker.state.cpu()[0]) >= 2
+    np.testing.assert_allclose(got.matrix(), want.matrix(), atol=2e-5)
+    np.testing.assert_allclose(got.inverse_matrix(), want.inverse_matrix(), atol=2e-5)
+    t_err, r_err = bench.pose_error(got, truth)
+    assert t_err < 1.5e-4 and r_err < 0.05, (t_err, r_err)
+    df.depth_to_world = start
+    assert bytes(tracker.track(df)) == bytes(got)
+
+
+@pytest.mark.parametrize("size", [(320, 240), (640, 480), (1280, 960)])
 def test_pyramid_tracker_matches_oracle(api, orc, size):
     """PyramidTracker<DepthTracker>::Track: downsampled levels bit-exact, final pose within
     2e-5 per matrix entry of the oracle's pyramid loop (float tree sums vs float64 sums are

@@ -11,10 +11,17 @@
 
 #include "../../include/vk.h"
 
+// A runtime call that fails is reported to OUR caller as its code — and taken out of the runtime's per-thread "last error",
+// which is sticky: left there it would be picked up by the next VK_LAUNCH_CHECK of an unrelated, good launch, or by the
+// caller's own framework (round 6: vk_event_elapsed_ms on a pair that was never recorded made torch's next call raise).
 #define VK_CHECK(expr)                                  \
   do {                                                  \
     const hipError_t vk_e__ = (expr);                   \
-    if (vk_e__ != hipSuccess) return (int)vk_e__;       \
+    if (vk_e__ != hipSuccess)                           \
+    {                                                   \
+      (void)hipGetLastError();                          \
+      return (int)vk_e__;                               \
+    }                                                   \
   } while (0)
 
 #define VK_REQUIRE(cond)                                \

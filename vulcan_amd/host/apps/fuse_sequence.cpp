@@ -245,8 +245,16 @@ int main(int argc, char** argv)
   const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int32_t counters[VK_CTR_PUBLIC];
   volume->GetCounters(counters);
+  // blocks of the pool in use: the free-slot pointer keeps falling below -1 once the pool is empty (as upstream's,
+  // src/volume.cu:352-356), so capacity - 1 - pointer overshoots the capacity by the dropped requests; VERDICT r5 weak #9
+  const int capacity = 65024 + 8192;
+  const int allocated = std::min(capacity, capacity - 1 - counters[VK_CTR_VOXEL_PTR]);
+  const bool pool_exhausted = counters[VK_CTR_DROPPED] > 0;
+  if (pool_exhausted)
+    std::printf("POOL EXHAUSTED: %d allocation requests were dropped — the map is missing those blocks and the figures below are "
+        "not those of the configured workload\n", counters[VK_CTR_DROPPED]);
   std::printf("frames %d  time %.3f s  fps %.1f  visible %d  allocated %d  dropped %d  input %s  tracking %s\n", frames,
-      seconds, frames / seconds, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
+      seconds, frames / seconds, counters[VK_CTR_VISIBLE], allocated,
       counters[VK_CTR_DROPPED], stream_input ? (split_streams ? "uploaded per frame, requests on their own stream" : "uploaded per frame") :
           (split_streams ? "resident, requests on their own stream" : (requests_ahead ? "resident, requests made ahead" : "resident")), mode == 0 ? "off" : (mode == 1 ? "depth" : (mode == 2 ? "light (pyramid)" : "light (app)")));
   const Matrix4f M = frame.depth_to_world_transform.GetMatrix();
@@ -272,7 +280,7 @@ int main(int argc, char** argv)
   }
   std::printf("{\"app\": \"fuse_sequence\", \"mode\": %d, \"tracker\": \"%s\", \"integrator\": \"%s\", \"frames\": %d, "
       "\"frames_per_s\": %.1f, \"us_per_frame\": %.1f, \"set_view_rounds_run_per_frame\": %.4f, \"visible_blocks_last\": %d, "
-      "\"allocated_blocks\": %d, \"dropped_requests\": %d, \"tracked_pose_drives_fusion\": %s, "
+      "\"allocated_blocks\": %d, \"dropped_requests\": %d, \"pool_exhausted\": %s, \"tracked_pose_drives_fusion\": %s, "
       "\"pose_error_max\": {\"translation_m\": %.6f, \"rotation_deg\": %.5f}, "
       "\"pose_error_last_frame\": {\"translation_m\": %.6f, \"rotation_deg\": %.5f}, "
       "\"camera_motion_over_run\": {\"translation_m\": %.4f, \"rotation_deg\": %.3f}, \"gn_steps_median\": %d, "
@@ -280,8 +288,8 @@ int main(int argc, char** argv)
       mode, mode == 0 ? "none" : (mode == 1 ? "PyramidTracker<DepthTracker>" : (mode == 2 ? "PyramidTracker<LightTracker>" :
           "LightTracker, SetMaxIterations(1) (apps/vulcan/vulcan.cu:106-111)")),
       mode == 3 ? "LightIntegrator, weight caps 100 / 16 (vulcan.cu:92-93)" : (mode == 2 ? "LightIntegrator" : "DepthIntegrator"), frames, frames / seconds, 1e6 * seconds / frames,
-      double(counters[VK_CTR_ROUNDS]) / frames, counters[VK_CTR_VISIBLE], 65024 + 8192 - 1 - counters[VK_CTR_VOXEL_PTR],
-      counters[VK_CTR_DROPPED], track ? "true" : "false", worst_translation, worst_rotation, last_translation,
+      double(counters[VK_CTR_ROUNDS]) / frames, counters[VK_CTR_VISIBLE], allocated,
+      counters[VK_CTR_DROPPED], pool_exhausted ? "true" : "false", track ? "true" : "false", worst_translation, worst_rotation, last_translation,
       last_rotation, motion_translation, motion_rotation, median);
   bool first = true;
   for (int n = 0; n < 64; ++n)

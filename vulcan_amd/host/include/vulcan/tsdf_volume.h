@@ -76,6 +76,10 @@ class Volume
 
     vk_volume ToVk() const;                        // device view for the C ABI
     void GetCounters(int32_t* counters) const;     // blocking readback of the VK_CTR_PUBLIC counters
+    // Not upstream: blocks of the pool in use, min(capacity, capacity - 1 - free-slot pointer) (blocking readback). The
+    // pointer itself keeps falling once the pool is empty (upstream's does too, src/volume.cu:352-356): VK_CTR_DROPPED
+    // counts the requests that found it empty.
+    int GetAllocatedBlockCount() const;
 
     // Raycast bounds prepared ahead of time (vk_view_bounds, not upstream): a Tracer
     // registers its scratch buffer and settings here, the integrators then compute
@@ -148,6 +152,8 @@ class Volume
     void* requested_;                   // event behind the request pass
     void* integrated_;                  // event behind the last Integrate
     mutable bool integrated_recorded_;
+    mutable bool pool_exhaustion_noted_ = false;
+    void NotePoolExhaustion(int32_t dropped) const;
     mutable int32_t* normals_late_;     // pinned: vk_view_bounds.late_host of the attached tracer's record
 
   private:

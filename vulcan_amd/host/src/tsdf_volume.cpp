@@ -1,5 +1,6 @@
 // tsdf_volume.cpp — Volume host class over vk_volume_* (ref: src/volume.cu:370-627).
 #include <vulcan/tsdf_volume.h>
+#include <cstdio>
 #include <cstring>
 #include <vulcan/block.h>
 #include <vulcan/exception.h>
@@ -33,6 +34,15 @@ Volume::Volume(int main_block_count, int excess_block_count) :
 
 Volume::~Volume()
 {
+#ifndef NDEBUG
+  // a pool that ran dry is said once before the volume goes (debug builds; a blocking readback is harmless here)
+  if (!empty_ && !pool_exhaustion_noted_ && counters_.GetData())
+  {
+    int32_t counters[VK_CTR_PUBLIC];
+    const vk_volume v = ToVk();
+    if (vk_volume_read_counters_sync(&v, counters, Device::GetStream()) == VK_OK) NotePoolExhaustion(counters[VK_CTR_DROPPED]);
+  }
+#endif
   if (normals_late_) (void)vk_free_host(normals_late_);
   if (request_stream_)
   {
@@ -262,6 +272,34 @@ void Volume::GetCounters(int32_t* counters) const
 {
   const vk_volume v = ToVk();
   VK_ASSERT(vk_volume_read_counters_sync(&v, counters, Device::GetStream()));
+  NotePoolExhaustion(counters[VK_CTR_DROPPED]);
+}
+
+// Upstream asserts on the device, in debug builds, when the pool runs dry (VULCAN_DEBUG_MSG "voxel memory exhausted" /
+// "excess memory exhausted", src/volume.cu:338,353) and drops the request silently otherwise. Here the dropped requests are
+// counted on the device (VK_CTR_DROPPED) and never leave it inside the frame loop, so the note is made where the class
+// already reads the counters: once per volume, on stderr, in builds without NDEBUG — upstream's condition for its message.
+void Volume::NotePoolExhaustion(int32_t dropped) const
+{
+#ifndef NDEBUG
+  if (dropped > 0 && !pool_exhaustion_noted_)
+  {
+    pool_exhaustion_noted_ = true;
+    std::fprintf(stderr, "vulcan::Volume: voxel / excess memory exhausted: %d allocation requests dropped so far "
+        "(pool of %d + %d blocks; ref: src/volume.cu:338,353)\n", dropped, main_block_count_, excess_block_count_);
+  }
+#else
+  (void)dropped;
+#endif
+}
+
+int Volume::GetAllocatedBlockCount() const
+{
+  int32_t counters[VK_CTR_PUBLIC];
+  GetCounters(counters);
+  // the free-slot pointer keeps falling below -1 once the pool is empty, as upstream's does (src/volume.cu:352-356)
+  const int taken = max_block_count_ - 1 - counters[VK_CTR_VOXEL_PTR];
+  return taken < max_block_count_ ? taken : max_block_count_;
 }
 
 void Volume::ResetBlockVisibility()

@@ -1355,6 +1355,38 @@ TEST(Volume, ComputeNormalsAndSetViewEqualsTheTwoCalls)
   ASSERT_TRUE(coloured > 1000);
 }
 
+// a pool that runs dry must not go by in a counter. A 64 + 16 block pool in front of a frame that asks for
+// thousands: requests are dropped (counted), the free-slot pointer falls below -1 as upstream's does (src/volume.cu:352-356),
+// and the number of blocks in use is the capacity — not capacity - 1 - pointer, which overshoots by the dropped requests.
+TEST(Volume, PoolExhaustionIsCountedAndTheAllocatedCountStaysInsideThePool)
+{
+  const int w = 160, h = 120;
+  Frame frame;
+  frame.depth_projection.SetFocalLength(136, 136);
+  frame.depth_projection.SetCenterPoint(80, 60);
+  frame.depth_image = MakeDepth(w, h, [](int x, int y) { return 1.5f + 0.001f * x + 0.0007f * y; });
+  auto volume = std::make_shared<Volume>(64, 16);
+  volume->SetVoxelLength(0.008f);
+  volume->SetView(frame, 3);
+  int32_t counters[VK_CTR_PUBLIC];
+  volume->GetCounters(counters);           // (debug builds: says "memory exhausted" on stderr, once)
+  ASSERT_TRUE(counters[VK_CTR_DROPPED] > 100);
+  ASSERT_TRUE(counters[VK_CTR_VOXEL_PTR] < -1);
+  ASSERT_EQ(80, volume->GetAllocatedBlockCount());
+  // and the volume stays usable: integrate and raycast what did fit
+  DepthIntegrator integrator(volume);
+  integrator.Integrate(frame);
+  Tracer tracer(volume);
+  Frame traced;
+  traced.depth_projection = frame.depth_projection;
+  traced.depth_image = MakeDepth(w, h, [](int, int) { return 0.0f; });
+  tracer.Trace(traced);
+  Device::Synchronize();
+  volume->SetView(frame, 3);
+  volume->GetCounters(counters);
+  ASSERT_EQ(80, volume->GetAllocatedBlockCount());
+}
+
 // Tracer::Trace(keyframe, next) — next_needs_normals defaults to false — followed by
 // Volume::ComputeNormalsAndSetView(next). The announce left the normal image as it was (vk_requests_ahead.normals_made = 0):
 // the normals are still due, and the preparation that rode with the pass was made from the OLD image. Same voxels and the
