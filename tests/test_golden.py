@@ -57,3 +57,21 @@ def test_oracle_reproduces_the_step_cap_vectors(orc):
     capped = (color[..., 0] == 1) & (color[..., 1] == 0) & (color[..., 2] == 0)
     assert capped.sum() > 1200 and np.all(depth[capped] == 0) and (depth > 0).sum() > 1200
     assert os.path.getsize(mf.STEP_CAP_FILE) < 200 << 10
+
+
+def test_oracle_reproduces_the_soak_fixtures_first_checkpoint(orc):
+    """tests/golden/soak_room_640x480.json (make_fixtures.py --soak; tools/soak.py holds the device to it over 2 000 frames):
+    the oracle's first 20 frames of the looped room sequence at the bench's size still give the digests on file — the
+    2 000-frame file and the oracle cannot drift apart unnoticed (the whole run takes the oracle five minutes: made once)."""
+    import json
+    assert os.path.exists(mf.SOAK_FILE), "run python tests/golden/make_fixtures.py --soak"
+    golden = json.load(open(mf.SOAK_FILE))["checkpoints"]
+    assert sorted(int(n) for n in golden) == sorted(mf.SOAK_CHECKPOINTS)
+    orc.set_threads(8)
+    got = mf.soak_oracle(20, checkpoints=(20,))
+    orc.set_threads(1)
+    assert got["20"] == golden["20"]
+    # the later checkpoints: no request was ever dropped, and the table stops changing once the camera has seen the room
+    assert all(golden[n]["dropped"] == 0 for n in golden)
+    assert golden["240"]["entries_sha256"] == golden["2000"]["entries_sha256"] != golden["20"]["entries_sha256"]
+    assert golden["240"]["voxels_sha256"] != golden["2000"]["voxels_sha256"]

@@ -65,6 +65,19 @@ VK_API int vk_probe_launch_floor(const int32_t* counters, float* sink, int workg
  * differing input of each as bit pattern + 1 (0: none). */
 VK_API int vk_probe_rounding(unsigned long long* out_dev6, void* stream);
 
+/* FETCH_SIZE calibration for the raycast's access shape (round 6): one wave per 10 240-byte voxel block of
+ * `voxels` (block b of `blocks`, every block touched exactly once, so no line is read twice), 4- and 12-byte loads at the
+ * 20-byte voxel stride the raycast issues. The set of lines a launch touches is known on the host (tools/fetch_calibration.py
+ * enumerates the same addresses):
+ *   mode 0  dense:   every lane reads the 4-byte distance of 8 voxels — all 512 voxels, every line of the block
+ *   mode 1  sparse:  lanes 0..63 read the distance of voxel 8 * lane — one 4-byte word every 160 bytes
+ *   mode 2  corners: every lane reads distance (4 B) and rgb (12 B) of the 2 x 2 x 2 voxels at a position derived from
+ *                    (block, lane) by a fixed hash — the raycast's trilinear sample
+ *   mode 3  float4:  every lane reads ten aligned 16-byte words, the whole block as ten wave-wide 1 KiB loads (the guide's
+ *                    calibrated shape, x2: the control)
+ * The loaded values are folded into sink[wave] so that no load is dead. */
+VK_API int vk_probe_gather(const void* voxels, int blocks, int mode, float* sink, void* stream);
+
 VK_API int vk_probe_launch_floor_graph(const int32_t* counters, float* sink, int workgroups, int launches, int replays,
     float* us_per_launch);
 

@@ -221,6 +221,61 @@ __global__ __launch_bounds__(256) void rounding_kernel(unsigned long long* out)
   if (bad_s) atomicAdd(&out[3], bad_s);
 }
 
+
+// ---- FETCH_SIZE calibration: the raycast's gather shape over a known set of lines (vk_probe.h vk_probe_gather) ----
+__host__ __device__ inline uint32_t gather_hash(uint32_t block, uint32_t lane)
+{
+  uint32_t x = block * 0x9E3779B1u + lane * 0x85EBCA77u + 0x165667B1u;
+  x ^= x >> 15;  x *= 0x2C1B3C6Du;  x ^= x >> 12;  x *= 0x297A2D39u;  x ^= x >> 15;
+  return x;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_kernel(const char* __restrict__ voxels, int blocks, float* __restrict__ sink)
+{
+  const int wave = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  if (wave >= blocks) return;
+  const char* block = voxels + (size_t)wave * 10240;
+  float acc = 0.0f;
+  if (MODE == 0)
+  {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += *reinterpret_cast<const float*>(block + (size_t)(k * 64 + lane) * 20);
+  }
+  else if (MODE == 1)
+  {
+    acc = *reinterpret_cast<const float*>(block + (size_t)(8 * lane) * 20);
+  }
+  else if (MODE == 2)
+  {
+    const uint32_t h = gather_hash((uint32_t)wave, (uint32_t)lane);
+    const int x = (int)(h & 7) % 7, y = (int)((h >> 3) & 7) % 7, z = (int)((h >> 6) & 7) % 7;     // low corner in [0, 6]
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+      const int v = (z + (c >> 2)) * 64 + (y + ((c >> 1) & 1)) * 8 + x + (c & 1);
+      const char* p = block + (size_t)v * 20;
+      typedef float vf3 __attribute__((ext_vector_type(3)));
+      typedef vf3 __attribute__((aligned(4))) vf3u;
+      const vf3 rgb = *reinterpret_cast<const vf3u*>(p + 4);
+      acc += *reinterpret_cast<const float*>(p) + rgb.x + rgb.y + rgb.z;
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+    {
+      const float4 v = *reinterpret_cast<const float4*>(block + (size_t)(k * 64 + lane) * 16);
+      acc += v.x + v.y + v.z + v.w;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) sink[wave] = acc;
+}
+
 extern "C" {
 
 int vk_probe_rounding(unsigned long long* out_dev6, void* stream)
@@ -383,6 +438,20 @@ int vk_probe_launch_floor_graph(const int32_t* counters, float* sink, int workgr
   (void)hipStreamDestroy(s);
 #undef VK_PROBE_TRY
   return 0;
+}
+
+
+int vk_probe_gather(const void* voxels, int blocks, int mode, float* sink, void* stream)
+{
+  VK_REQUIRE(voxels && sink && blocks > 0 && mode >= 0 && mode <= 3);
+  const dim3 grid((blocks + 3) / 4);
+  const char* v = static_cast<const char*>(voxels);
+  if (mode == 0) hipLaunchKernelGGL(gather_kernel<0>, grid, dim3(256), 0, vk_s(stream), v, blocks, sink);
+  else if (mode == 1) hipLaunchKernelGGL(gather_kernel<1>, grid, dim3(256), 0, vk_s(stream), v, blocks, sink);
+  else if (mode == 2) hipLaunchKernelGGL(gather_kernel<2>, grid, dim3(256), 0, vk_s(stream), v, blocks, sink);
+  else hipLaunchKernelGGL(gather_kernel<3>, grid, dim3(256), 0, vk_s(stream), v, blocks, sink);
+  VK_LAUNCH_CHECK();
+  return VK_OK;
 }
 
 }  // extern "C"
