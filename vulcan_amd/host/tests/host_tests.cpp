@@ -1370,7 +1370,7 @@ TEST(Volume, PoolExhaustionIsCountedAndTheAllocatedCountStaysInsideThePool)
   volume->SetView(frame, 3);
   int32_t counters[VK_CTR_PUBLIC];
   volume->GetCounters(counters);           // (debug builds: says "memory exhausted" on stderr, once)
-  ASSERT_TRUE(counters[VK_CTR_DROPPED] > 100);
+  ASSERT_TRUE(counters[VK_CTR_DROPPED] > 10);      // (the rounds stop after a round that drops: counted once, not three times)
   ASSERT_TRUE(counters[VK_CTR_VOXEL_PTR] < -1);
   ASSERT_EQ(80, volume->GetAllocatedBlockCount());
   // and the volume stays usable: integrate and raycast what did fit
