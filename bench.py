@@ -587,14 +587,20 @@ def run_sequences(workload, count, warmup, steps, room=None, stride=60):
         pose_lists = [[scenes.orbit_pose(i + 7 * j, YAW_STEP) for i in range(warmup + steps)] for j in range(count)]
     torch.cuda.synchronize()             # (the resident input images were written on another stream)
     multi = MultiLoop(workload, pose_lists, sequences)
-    for i in range(warmup):
-        multi.step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        multi.step(warmup + i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # experiment (VK_BENCH_LOOP_GRID_CAP, docs/rounds/r06.md): a Gauss-Newton loop launch holds 4 800 waves on the device for
+    # its whole life and squeezes the other sequence's raycast out of its registers; a capped grid (vk_test_hooks.loop_grid_cap:
+    # every workgroup takes several pixel groups) leaves room — and makes every step longer. 0 in every reported run.
+    from vulcan_amd import api as _api
+    cap = int(os.environ.get("VK_BENCH_LOOP_GRID_CAP", "0"))
+    with _api.test_hooks(loop_grid_cap=cap):
+        for i in range(warmup):
+            multi.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            multi.step(warmup + i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     from vulcan_amd import vk_types as T
     out = {"sequences": count, "value": count * steps / dt, "unit": "frames/s (all sequences)", "steps": steps, "warmup": warmup,
            "ms_per_frame_of_one_sequence": 1e3 * dt / steps, "frames_per_s_per_sequence": steps / dt,
@@ -1260,7 +1266,7 @@ def main():
         else:
             torch.cuda.set_stream(torch.cuda.Stream())
 
-    if args.sequences > 1:
+    if args.sequences > 1 or os.environ.get("VK_BENCH_SEQUENCES_ONLY") == "1":
         assert world == 1, "--sequences is a single-GPU measurement"
         room = RoomSequence(args.warmup + args.steps + 60 * (args.sequences - 1), T.Projection.make(*scenes.APP_INTRINSICS)) \
             if args.workload == "rgbd-icp" else None
