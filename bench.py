@@ -88,6 +88,11 @@ REQUESTS_AHEAD = os.environ.get("VK_BENCH_REQUESTS_AHEAD", "1") != "0"
 # vk_icp_pyramid_track_frame(.., frame_normals_due = 1 | 2)): nobody reads the key frame's normals before that Track, the
 # bits are the same, and the frame has one launch less. "0": Tracer::Trace's own normals launch (A/B).
 KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "1") != "0"
+# rgbd-icp (round 6): the NEXT frame's pyramid — its normal image and half-resolution level, the raycast's normal image and half-
+# resolution level — made by trailing workgroups of THIS frame's raycast launch (vk_trace_ahead_pyramid), so that the next Track
+# is its two loop launches only (vk_icp_pyramid_track_built): the frame loses the 7 us pyramid launch from its chain. Same bits
+# (tests/test_gpu_round6.py). "0": the pyramid launch in front of the loops, as until round 5 (A/B).
+PYRAMID_AHEAD = os.environ.get("VK_BENCH_PYRAMID_AHEAD", "1") != "0"
 # experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
 # makes them with launches of its own); never set in a reported run
 NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
@@ -338,6 +343,9 @@ class FrameLoop:
                                C.c_void_p(t.update.data_ptr()), None, None, t._poll())
             self.pose_dev = C.c_void_p(t.pose.data_ptr())
             self.poll_words = (C.c_int32 * 4).from_address(t._poll_host.value)
+            self.built = T.PyramidAhead() if PYRAMID_AHEAD else None
+            self.next_view = t._view(self.frame)
+            self.pose_on_device = False
             self.current = T.Transform.from_buffer_copy(bytes(sequence.truth[0]))   # the first frame defines the map
 
     class Upload:
@@ -449,7 +457,14 @@ class FrameLoop:
                 # the start pose and the frame's normal image travel with the pyramid's launch
                 due = 1 | (2 if self.key_normals_pending else 0)       # the frame's normals, and the key frame's when the raycast left them out
                 self.key_normals_pending = False
-                rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
+                if self.built is not None:
+                    # (the level was built behind the previous raycast: no pyramid launch; the start pose is the one the last
+                    # Track left on the device — uploaded only in front of the first Track)
+                    start = None if (self.pose_on_device and self.built.valid == 1) else C.byref(pose)
+                    rc |= lib.vk_icp_pyramid_track_built(a[0], C.byref(pose), a[2], a[3], start, due, C.byref(self.built), *a[4:], s)
+                    self.pose_on_device = True
+                else:
+                    rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
         self._begun = (i, n, rc, normals_in_set_view)
 
     def finish(self, i, ev=None, v=0, by_dispatch=None):
@@ -525,6 +540,12 @@ class FrameLoop:
                 self.prep.normals_out = self.n_ptr.value
             rc |= lib.vk_trace_ahead_requests(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, self.nref, self.pprep,
                                               self.aref, s)
+        elif self.tracker is not None and self.built is not None and i + 1 < len(self.poses):
+            # tracer.cpp:41-100 + the next Track's pyramid (pyramid_tracker.cpp:58-62, frame.cpp:21-58) in the same launch
+            self.next_view.depths = self.sequence.depth[i + 1].data_ptr()
+            rc |= lib.vk_trace_ahead_pyramid(vv["vref"], self.kref, vv["bref"], *self.out_ptrs, C.byref(self.next_view),
+                                             self.track_args[4], C.byref(self.built), s)
+            self.key_normals_pending = False
         elif self.tracker is not None and KEY_NORMALS_WITH_PYRAMID and i + 1 < len(self.poses):
             # tracer.cpp:41-95; its normals (:97-100) come with the next frame's pyramid launch
             rc |= lib.vk_trace_ahead(vv["vref"], self.kref, vv["bref"], self.out_ptrs[0], self.out_ptrs[1], None, s)

@@ -891,6 +891,44 @@ VK_API int vk_icp_pyramid_track_frame(const vk_icp_view* keyframe, const vk_tran
     float* pyramid, float* workspace, float* system, int32_t* state_dev, float* update_dev,
     vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream);
 
+/* The NEXT Track's pyramid behind the raycast (round 6; no reference counterpart; ref: src/tracer.cpp:41-47,97-100 for the
+ * raycast it rides in, src/pyramid_tracker.cpp:52-62 + src/frame.cpp:21-58 for what it builds). In the tracking loop
+ * (apps/vulcan/vulcan.cu:297-325) the launch that builds a Track's pyramid — the input frame's normal image and half-resolution
+ * level, the key frame's normal image and half-resolution level — sits between the raycast and the Gauss-Newton loops, 7 us of
+ * launch-floor work in a strict chain; most of it needs only the INPUT frame, which a caller has while the previous frame is still
+ * being raycast. vk_trace_ahead_pyramid is vk_trace_ahead(v, frame, ahead, depths, colors, normals) with that work done by
+ * trailing workgroups of the raycast's own launch: next_frame->normals (written: Frame::ComputeNormals of next_frame->depths),
+ * the half-resolution level of next_frame and — behind the raycast's row counters, as the riding normals of
+ * vk_trace_ahead_requests — `normals` and the half-resolution level of the traced image, into `pyramid`
+ * (vk_icp_pyramid_floats(frame, next_frame) floats, vk_icp_pyramid_track's layout). *built (caller-owned, zeroed once) then names
+ * the images and the buffer; vk_icp_pyramid_track_built is vk_icp_pyramid_track_frame that skips its pyramid launch when *built
+ * is valid for exactly its keyframe (depths, normals = the traced images), frame and `pyramid` — and is the whole call, with
+ * `frame_normals_due` as given, otherwise. A record serves once. Same images, same level, same pose, bit for bit
+ * (tests/test_gpu_round6.py). All sizes even. When the launch cannot carry the work (a bounds grid too large for the row
+ * counters) it is vk_trace_ahead and *built stays invalid. The key side's wait is bounded like the riding normals': on expiry
+ * nothing is stored, ahead->late_host is set and the next vk_trace_ahead* / vk_trace_normals_settle returns VK_ERR_TIMEOUT after
+ * recomputing the normal image — and the Track that consumed the level in between is not to be trusted (its key level was
+ * incomplete): the caller repeats it from its start pose with vk_icp_pyramid_track_frame(.., frame_normals_due = 1 | 2, ..). */
+typedef struct vk_pyramid_ahead {
+  const float* key_depths;     /* the traced image: the next Track's keyframe */
+  const float* key_normals;
+  const float* frame_depths;   /* the next Track's frame */
+  const float* frame_normals;
+  const float* pyramid;
+  int32_t      key_width, key_height, frame_width, frame_height;
+  int32_t      valid;
+  int32_t      pad_;
+} vk_pyramid_ahead;
+
+/* ref: src/tracer.cpp:41-47,97-100 Tracer::Trace + what src/pyramid_tracker.cpp:58-62 builds next (see above) */
+VK_API int vk_trace_ahead_pyramid(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* depths, float* colors,
+    float* normals, const vk_icp_view* next_frame, float* pyramid, vk_pyramid_ahead* built, void* stream);
+/* ref: src/pyramid_tracker.cpp:52-90 PyramidTracker<DepthTracker>::Track, as vk_icp_pyramid_track_frame (see above) */
+VK_API int vk_icp_pyramid_track_built(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, vk_pyramid_ahead* built, float* pyramid,
+    float* workspace, float* system, int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
+    const vk_track_poll* poll, void* stream);
+
 /* ------------------------------------------------------------ colour tracker -- */
 
 /* ref: src/image.cu:10-19,235-247 ColorImage::ConvertTo — intensity = (r+g+b)/3.

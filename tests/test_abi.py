@@ -84,7 +84,7 @@ def test_every_mirrored_struct_has_the_size_the_c_compiler_gives_it(tmp_path):
              ("vk_frame", T.Frame), ("vk_integrator", T.Integrator), ("vk_view_bounds", T.ViewBounds), ("vk_color_view", T.ColorView),
              ("vk_light_terms", T.LightTerms), ("vk_track_poll", T.TrackPoll), ("vk_light_prep", T.LightPrep),
              ("vk_rig_exchange", T.RigExchange), ("vk_requests_ahead", T.RequestsAhead), ("vk_test_hooks", T.TestHooks),
-             ("vk_color_pose", T.ColorPose), ("vk_detector", T.Detector), ("vk_detect_state", T.DetectState), ("vk_icp_view", T.IcpView)]
+             ("vk_color_pose", T.ColorPose), ("vk_pyramid_ahead", T.PyramidAhead), ("vk_detector", T.Detector), ("vk_detect_state", T.DetectState), ("vk_icp_view", T.IcpView)]
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "vk.h"\nint main(void) {\n' +
                    "".join(f'  printf("{name} %zu\\n", sizeof({name}));\n' for name, _ in pairs) +

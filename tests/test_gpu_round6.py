@@ -169,3 +169,119 @@ def test_timing_events_are_used_up_by_a_call_that_fails(api):
     sync()
     ms = C.c_float(-1.0)
     assert lib.vk_event_elapsed_ms(pair[0], pair[1], C.byref(ms)) != 0, "the stale pair was recorded by a later launch"
+
+
+# --------------------------------- the next Track's pyramid behind the raycast --
+
+def test_pyramid_made_behind_the_raycast_equals_the_pyramid_launch(api, orc):
+    """vk_trace_ahead_pyramid: the raycast's launch also makes the NEXT Track's pyramid — the next input
+    frame's normal image and half-resolution level, the raycast's own normal image and half-resolution level (behind the
+    raycast's row counters) — and vk_icp_pyramid_track_built then launches the two loops only. Against Tracer.trace +
+    PyramidTracker.track (the pyramid launch): the same raycast, the same four images, the same pyramid buffer, the same pose,
+    bit for bit; the normal images are the oracle's; the record serves once and names its images."""
+    import torch
+    import bench
+    lib = api.lib()
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    poses = [scenes.room_pose(30 + i) for i in range(3)]
+    inputs = [scenes.room_frame(k, p, bench.W, bench.H, light=bench.LIGHT) for p in poses]
+    vol = api.Volume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+    integ, tracer = api.LightIntegrator(vol), api.Tracer(vol)
+    integ.light = T.Light.make(*bench.LIGHT)
+    f0 = api.Frame(inputs[0][0], k, poses[0], color=inputs[0][1])
+    vol.set_view(f0, rounds=3, compute_normals=True)
+    integ.integrate(f0)
+    sync()
+
+    def fresh(depth):
+        return api.Frame(depth, k, poses[0], normals=torch.full((bench.H, bench.W, 3), -7.0, dtype=torch.float32, device="cuda"))
+
+    # ---- the reference form: Trace, then Track (its pyramid launch computes the frame's normals)
+    key_a = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, poses[0])
+    tracer.trace(key_a)
+    next_a = fresh(inputs[1][0])
+    track_a = api.PyramidTracker()
+    track_a.keyframe = key_a
+    pose_a = track_a.track(next_a, compute_normals=True)
+    sync()
+
+    # ---- the riding form, through the C ABI
+    key_b = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, poses[0],
+                      color=torch.zeros((bench.H, bench.W, 3), dtype=torch.float32, device="cuda"),
+                      normals=torch.full((bench.H, bench.W, 3), -7.0, dtype=torch.float32, device="cuda"))
+    next_b = fresh(inputs[1][0])
+    track_b = api.PyramidTracker()
+    t = track_b.tracker
+    n = int(lib.vk_icp_pyramid_floats(bench.W, bench.H, bench.W, bench.H))
+    pyramid = torch.full((n,), -5.0, dtype=torch.float32, device="cuda")
+    built = T.PyramidAhead()
+    next_view, key_view = t._view(next_b), t._view(key_b)
+    vb = tracer.view_bounds
+    vb.valid = 0
+    api.check(lib.vk_trace_ahead_pyramid(C.byref(vol.desc()), C.byref(key_b.desc()), C.byref(vb), key_b.depth.data_ptr(),
+                                         key_b.color.data_ptr(), key_b.normals.data_ptr(), C.byref(next_view), pyramid.data_ptr(),
+                                         C.byref(built), api.stream()), "vk_trace_ahead_pyramid")
+    sync()
+    assert built.valid == 1 and built.key_depths == key_b.depth.data_ptr() and built.frame_normals == next_b.normals.data_ptr()
+    assert torch.equal(key_b.depth, key_a.depth) and torch.equal(key_b.color, key_a.color)
+    want_key_normals = orc.compute_normals(key_a.depth.cpu().numpy(), k)
+    assert np.array_equal(key_b.normals.cpu().numpy(), want_key_normals, equal_nan=True)
+    assert np.array_equal(next_b.normals.cpu().numpy(), orc.compute_normals(inputs[1][0], k), equal_nan=True)
+    assert torch.equal(next_b.normals, next_a.normals)
+    assert np.array_equal(pyramid.cpu().numpy(), track_a._pyramid.cpu().numpy()[:n], equal_nan=True), "the half-resolution level differs"
+    poll = t._poll()
+    t.state.zero_()
+    start = poses[0]
+    api.check(lib.vk_icp_pyramid_track_built(C.byref(key_view), C.byref(key_b.depth_to_world), C.byref(next_view), t.pose.data_ptr(),
+                                             C.byref(start), 1 | 2, C.byref(built), pyramid.data_ptr(),
+                                             t._workspace(next_b).data_ptr(), t.system.data_ptr(), t.state.data_ptr(),
+                                             t.update.data_ptr(), None, None, poll, api.stream()), "vk_icp_pyramid_track_built")
+    pose_b = t._wait_pose()
+    assert built.valid == 0                                                 # served once
+    assert bytes(pose_b) == bytes(pose_a)
+    # a record for OTHER images is not used: the call is then vk_icp_pyramid_track_frame, with its pyramid launch
+    built.valid = 1
+    built.frame_depths = key_b.depth.data_ptr()
+    pyramid.fill_(-5.0)
+    next_b.normals.fill_(-7.0)
+    t.state.zero_()
+    api.check(lib.vk_icp_pyramid_track_built(C.byref(key_view), C.byref(key_b.depth_to_world), C.byref(next_view), t.pose.data_ptr(),
+                                             C.byref(start), 1, C.byref(built), pyramid.data_ptr(),
+                                             t._workspace(next_b).data_ptr(), t.system.data_ptr(), t.state.data_ptr(),
+                                             t.update.data_ptr(), None, None, poll, api.stream()), "vk_icp_pyramid_track_built")
+    assert bytes(t._wait_pose()) == bytes(pose_a) and built.valid == 0
+    assert torch.equal(next_b.normals, next_a.normals)
+
+
+def test_tracked_loop_with_the_pyramid_behind_the_raycast_equals_the_loop_without(api, monkeypatch):
+    """bench.FrameLoop('rgbd-icp') — the step bench.py times — with the pyramid riding behind the raycast (the default) and with
+    the pyramid launch in front of the loops (VK_BENCH_PYRAMID_AHEAD=0): six frames, every tracked pose, the volume, the table
+    and the raycast images bit for bit."""
+    import torch
+    import bench
+    frames = 6
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    room = bench.RoomSequence(frames, k)
+    sync()
+    states = []
+    for ahead in (True, False):
+        monkeypatch.setattr(bench, "PYRAMID_AHEAD", ahead)
+        loop = bench.FrameLoop("rgbd-icp", room.truth, sequence=room)
+        assert (loop.built is not None) == ahead
+        for i in range(frames):
+            loop.step(i)
+            if ahead and 0 < i < frames - 1:
+                assert loop.built.valid == 1, "the raycast did not carry the next Track's pyramid"
+        sync()
+        vol = loop.vols[0]["vol"]
+        states.append(([bytes(p) for p in loop.tracked_poses], list(loop.gn_steps), vol.voxels.clone(), vol.hash_entries.clone(),
+                       loop.key.depth.clone(), loop.key.color.clone(), loop.key.normals.clone(), loop.frame.normals.clone()))
+        del loop
+    a, b = states
+    assert a[0] == b[0], "tracked poses differ"
+    assert a[1] == b[1]
+    for x, y, name in zip(a[2:], b[2:], ("voxels", "table", "key depth", "key colour", "key normals", "frame normals")):
+        if name in ("key normals", "frame normals"):
+            assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), name
+        else:
+            assert torch.equal(x, y), name

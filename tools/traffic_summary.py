@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise tools/traffic.sh: mean FETCH_SIZE / WRITE_SIZE per launch of the integrate and the
 raycast kernel, with the gfx950 correction from MI355X_MICROARCH.md (FETCH_SIZE counts the
-128-byte requests of 16 B/lane coalesced reads as 64 B: x2). Writes <outdir>/<name>_traffic.json
+128-byte requests of 16 B/lane coalesced reads as 64 B: x2) — which round 6 measured to hold for the
+raycast's scattered 4- and 12-byte loads as well (tools/fetch_calibration.sh). Writes <outdir>/<name>_traffic.json
 (committed under profiles/ as rNN_<name>_traffic.json)."""
 import csv, glob, json, os, sys
 
@@ -52,10 +53,13 @@ for k in KERNELS:
         if bench:
             doc["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
     else:
-        doc["FETCH_correction"] = ("none applied: the x2 of the guide is established for 16 B/lane coalesced streaming reads; this kernel "
-                                   "issues scattered 4- and 12-byte loads (one 64-B request per touched line). x2 would be the upper bound.")
-        doc["read_bytes_per_launch"] = fetch * 1024
-        doc["read_bytes_per_launch_if_x2"] = fetch * 1024 * 2
+        # Calibrated in round 6 (profiles/r06_fetch_calibration.json, tools/fetch_calibration.sh): on 4- and 12-byte loads at the
+        # 20-byte voxel stride — dense, sparse, and the raycast's own 2 x 2 x 2 corner shape alike — the L2 issues exactly ONE
+        # fabric request per touched 128-byte line (TCC_EA0_RDREQ = lines, no 32-byte requests) and FETCH_SIZE tallies it at
+        # 64 B, as for float4 streaming reads: the bytes MOVED are 2 x FETCH_SIZE for this kernel too.
+        doc["FETCH_correction"] = ("x2: one 128-byte fabric request per touched line, tallied at 64 B — measured on this kernel's own "
+                                   "access shape (4- and 12-byte loads at a 20-byte stride), profiles/r06_fetch_calibration.json")
+        doc["read_bytes_per_launch"] = fetch * 1024 * 2
     doc["write_bytes_per_launch"] = write * 1024
     doc["bytes_per_launch"] = doc["read_bytes_per_launch"] + doc["write_bytes_per_launch"]
     if doc.get("algorithmic_bytes_per_launch"):

@@ -120,6 +120,8 @@ _SIGNATURES = {
     "vk_test_hooks_set": ([_P], _I),
     "vk_test_hooks_get": ([_P], _I),
     "vk_test_hooks_loop_count": ([_P, _P, _P], _I),
+    "vk_trace_ahead_pyramid": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
+    "vk_icp_pyramid_track_built": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 _REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)   # vk_icp_reduce_fn

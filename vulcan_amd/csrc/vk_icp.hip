@@ -1027,9 +1027,12 @@ size_t vk_icp_pyramid_floats(int key_width, int key_height, int frame_width, int
   return 4 * ((size_t)(key_width / 2) * (key_height / 2) + (size_t)(frame_width / 2) * (frame_height / 2));
 }
 
+// `level_built`: the half-resolution level and both normal images were made behind the previous raycast
+// (vk_trace_ahead_pyramid): no pyramid launch
 static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
     vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, float* pyramid, float* workspace, float* system,
-    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream)
+    int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream,
+    bool level_built = false)
 {
   VK_REQUIRE(keyframe && Twm && frame && Twc_dev && pyramid && workspace && system && state_dev);
   VK_REQUIRE(keyframe->depths && keyframe->normals && frame->depths && frame->normals);
@@ -1084,8 +1087,16 @@ static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
   }
   L.pose_out = Twc_start ? Twc_dev : nullptr;
   if (Twc_start) L.pose_start = *Twc_start;
-  hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2 + due), dim3(256), 0, s, L);
-  VK_LAUNCH_CHECK();
+  if (!level_built)
+  {
+    hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2 + due), dim3(256), 0, s, L);
+    VK_LAUNCH_CHECK();
+  }
+  else if (Twc_start)
+  {
+    hipLaunchKernelGGL(store_transform_kernel, dim3(1), dim3(64), 0, s, Twc_dev, *Twc_start);
+    VK_LAUNCH_CHECK();
+  }
 
   // :79-83 half level, 15 steps; :85-89 full level, 20 steps, from the pose the half level left.
   // Tracker::CreateState (tracker.cpp:107-110) starts every Track at iteration 0.
@@ -1131,6 +1142,23 @@ int vk_icp_pyramid_track_frame(const vk_icp_view* keyframe, const vk_transform* 
 {
   return pyramid_track(keyframe, Twm, frame, Twc_dev, Twc_start, frame_normals_due, pyramid, workspace, system, state_dev,
       update_dev, reduce, reduce_user, poll, stream);
+}
+
+int vk_icp_pyramid_track_built(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
+    vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, vk_pyramid_ahead* built, float* pyramid,
+    float* workspace, float* system, int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user,
+    const vk_track_poll* poll, void* stream)
+{
+  VK_REQUIRE(keyframe && frame);
+  // the record names the images and the buffer the level was built from / into, and serves once
+  const bool level_built = built && built->valid == 1 && built->pyramid == pyramid &&
+      built->key_depths == keyframe->depths && built->key_normals == keyframe->normals &&
+      built->frame_depths == frame->depths && built->frame_normals == frame->normals &&
+      built->key_width == keyframe->width && built->key_height == keyframe->height &&
+      built->frame_width == frame->width && built->frame_height == frame->height;
+  if (built) built->valid = 0;
+  return pyramid_track(keyframe, Twm, frame, Twc_dev, Twc_start, level_built ? 0 : frame_normals_due, pyramid, workspace, system,
+      state_dev, update_dev, reduce, reduce_user, poll, stream, level_built);
 }
 
 int vk_reduce_nothing(float*, int, void*, void*) { return 0; }

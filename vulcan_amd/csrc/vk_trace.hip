@@ -243,6 +243,9 @@ constexpr int kNormalLateWords = 16;      // one more line behind the counters: 
 #ifndef VK_TR_WAVES
 #define VK_TR_WAVES 5
 #endif
+#ifndef VK_TP_WAVES
+#define VK_TP_WAVES 6        // trace_and_pyramid_kernel: the raycast alone (compute_points_kernel) runs six waves per SIMD
+#endif
 #ifndef VK_TRACE_NORMALS_RIDE
 #define VK_TRACE_NORMALS_RIDE 1
 #endif
@@ -425,6 +428,142 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TR_WAVES
   normals_group(P, normals, n % normal_groups_x, n / normal_groups_x, &normals_expired);
 }
 
+// ---- the NEXT Track's pyramid behind the raycast (round 6, vk_trace_ahead_pyramid) ------------------------------------------
+//
+// The tracking loop's frame is raycast(i) -> pyramid launch(i + 1) -> two Gauss-Newton loop launches -> ... The pyramid launch
+// (vk_icp.hip pyramid_level_kernel: the input frame's normal image and half-resolution level, the key frame's normal image and
+// half-resolution level) is 7 us of launch-floor work in a strict chain, and most of it needs nothing but the INPUT frame —
+// which is known while frame i is still being raycast. Here it rides behind the raycast's workgroups in the raycast's launch:
+//   [raycast: 16 x 16 pixel groups] [frame side: normals, then half level — plain loads, they wait for nobody]
+//   [key side: the raycast's normal image (normals_group) and its half level — per row of tiles behind the row counters]
+// The key side waits exactly as normals_group does, with the same bounded wait and the same outcome (VK_ERR_TIMEOUT through
+// the record's pinned word; the Track that consumed the level is then not to be trusted, vk.h). The bits are those of
+// pyramid_level_kernel: the same normal_from_taps on the same taps, nearest sampling at (2x, 2y).
+struct PyramidRide
+{
+  const float* frame_depths;       // the NEXT input frame
+  float* frame_normals;            // written: Frame::ComputeNormals
+  float* frame_half_depth;         // written: Frame::Downsample (nearest)
+  float* frame_half_normals;
+  int frame_w, frame_h;
+  vk_projection frame_k;
+  float* key_half_depth;           // written behind the row counters: the raycast image's half level
+  float* key_half_normals;
+  int groups_frame_full, groups_frame_half, groups_key_full, groups_key_half;    // workgroups of 64 x 4 pixels each
+};
+
+__device__ __forceinline__ float ride_depth_at(const float* depths, int w, int h, int x, int y)
+{
+  return (x >= 0 && x < w && y >= 0 && y < h) ? depths[y * w + x] : 0.0f;
+}
+
+// one side's normal at full-resolution pixel (x, y): compute_normals_kernel's expressions (ref: frame.cu:9-122)
+template <typename K>
+__device__ __forceinline__ f3 ride_normal(const float* depths, const K& k, int w, int h, int x, int y)
+{
+  const int pad = 2;
+  const float depth = depths[y * w + x];
+  f3 normal = make3(0, 0, 0);
+  if (depth > 0)
+    normal = normal_from_taps(k, x, y, depth, ride_depth_at(depths, w, h, x - pad, y), ride_depth_at(depths, w, h, x + pad, y),
+        ride_depth_at(depths, w, h, x, y - pad), ride_depth_at(depths, w, h, x, y + pad));
+  return normal;
+}
+
+__device__ __forceinline__ void ride_frame_group(const PyramidRide& Y, int g)
+{
+  if (g < Y.groups_frame_full)
+  {
+    const int gx = (Y.frame_w + 63) / 64;
+    const int x = (g % gx) * 64 + (threadIdx.x & 63), y = (g / gx) * 4 + (threadIdx.x >> 6);
+    if (x >= Y.frame_w || y >= Y.frame_h) return;
+    const f3 n = ride_normal(Y.frame_depths, Y.frame_k, Y.frame_w, Y.frame_h, x, y);
+    float* out = Y.frame_normals + 3 * ((size_t)y * Y.frame_w + x);
+    out[0] = n.x;  out[1] = n.y;  out[2] = n.z;
+    return;
+  }
+  g -= Y.groups_frame_full;
+  const int hw = Y.frame_w / 2, hh = Y.frame_h / 2, gx = (hw + 63) / 64;
+  const int x = (g % gx) * 64 + (threadIdx.x & 63), y = (g / gx) * 4 + (threadIdx.x >> 6);
+  if (x >= hw || y >= hh) return;
+  Y.frame_half_depth[y * hw + x] = Y.frame_depths[(2 * y) * Y.frame_w + 2 * x];
+  // (the half-resolution normal is computed at the pixel it is sampled from: the same normal, bit for bit — the full image is
+  // being written by other workgroups of this launch)
+  const f3 n = ride_normal(Y.frame_depths, Y.frame_k, Y.frame_w, Y.frame_h, 2 * x, 2 * y);
+  float* out = Y.frame_half_normals + 3 * ((size_t)y * hw + x);
+  out[0] = n.x;  out[1] = n.y;  out[2] = n.z;
+}
+
+// the wait of a key-side group for the 8-pixel rows of tiles [first, last] (normals_group's, factored out)
+__device__ __forceinline__ bool ride_rows_complete(const PointParams& P, int first, int last, int* expired)
+{
+  if (threadIdx.x == 0)
+  {
+    int polls = 0;
+    bool late = false;
+    for (int row = first; row <= last && !late; ++row)
+      while ((int)(__hip_atomic_load(&P.rows_done[row * kNormalRowStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - P.rows_target) < 0)
+      {
+        if (++polls > P.normal_polls) { late = true; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+    *expired = late ? 1 : 0;
+    if (late)
+    {
+      __hip_atomic_store(P.late_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.late_host) __hip_atomic_store(P.late_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  return *expired == 0;
+}
+
+__device__ __forceinline__ void ride_key_half_group(const PointParams& P, const PyramidRide& Y, int g, int* expired)
+{
+  const int hw = P.image_width / 2, hh = P.image_height / 2, gx = (hw + 63) / 64;
+  const int group_y = g / gx;
+  // half rows [4 gy, 4 gy + 3] sample full rows 8 gy .. 8 gy + 6, their normals' taps two rows further
+  const int first = vmaxi(group_y * 8 - 2, 0) >> 3, last = vmini(group_y * 8 + 8, P.image_height - 1) >> 3;
+  if (!ride_rows_complete(P, first, last, expired)) return;
+  const int x = (g % gx) * 64 + (threadIdx.x & 63), y = group_y * 4 + (threadIdx.x >> 6);
+  if (x >= hw || y >= hh) return;
+  const int w = P.image_width, h = P.image_height, sx = 2 * x, sy = 2 * y, pad = 2;
+  const float depth = depth_through(P.depths, w, h, sx, sy);
+  Y.key_half_depth[y * hw + x] = depth;
+  f3 normal = make3(0, 0, 0);
+  if (depth > 0)
+    normal = normal_from_taps(P.k, sx, sy, depth, depth_through(P.depths, w, h, sx - pad, sy), depth_through(P.depths, w, h, sx + pad, sy),
+        depth_through(P.depths, w, h, sx, sy - pad), depth_through(P.depths, w, h, sx, sy + pad));
+  float* out = Y.key_half_normals + 3 * ((size_t)y * hw + x);
+  out[0] = normal.x;  out[1] = normal.y;  out[2] = normal.z;
+}
+
+template <bool POOL32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VK_TP_WAVES))) void trace_and_pyramid_kernel(PointParams P,
+    PyramidRide Y, int trace_groups, float* normals)
+{
+  __shared__ int4 directories[4][kDirWords];
+  __shared__ int normals_expired;
+  if ((int)blockIdx.x < trace_groups)
+  {
+#if VK_TR_PRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    points_group<POOL32, 4>(P, (int)blockIdx.x, trace_groups, directories);
+    return;
+  }
+  int g = (int)blockIdx.x - trace_groups;
+  if (g < Y.groups_frame_full + Y.groups_frame_half) { ride_frame_group(Y, g);  return; }
+  g -= Y.groups_frame_full + Y.groups_frame_half;
+  if (g < Y.groups_key_full)
+  {
+    const int normal_groups_x = (P.image_width + 63) / 64;
+    normals_group(P, normals, g % normal_groups_x, g / normal_groups_x, &normals_expired);
+    return;
+  }
+  ride_key_half_group(P, Y, g - Y.groups_key_full, &normals_expired);
+}
+
 // ------------------------------------------------------------------ normals ----
 
 __device__ __forceinline__ float depth_at(const float* depths, int w, int h, int x, int y)
@@ -527,7 +666,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
     int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
     hipStream_t s, float* normals = nullptr, uint32_t* rows_done = nullptr, uint32_t rows_target = 0,
     const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr, int next_prep = 0,
-    int32_t* late_host = nullptr, int normal_polls = kNormalWaitPolls)
+    int32_t* late_host = nullptr, int normal_polls = kNormalWaitPolls, const PyramidRide* ride = nullptr)
 {
   PointParams P;
   P.entries = entries;
@@ -545,7 +684,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.march_steps = nullptr;
   P.trip_log = nullptr;
   P.trip_log_passes = 0;
-  P.rows_done = (normals && rows_done && next_requests) ? rows_done : nullptr;
+  P.rows_done = (normals && rows_done && (next_requests || ride)) ? rows_done : nullptr;
   P.rows_target = rows_target;
   P.late_dev = P.rows_done ? P.rows_done + kNormalRows * kNormalRowStride : nullptr;
   P.late_host = late_host;
@@ -560,6 +699,20 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.bounds_width = bounds_width;
   P.bounds_height = bounds_height;
   const bool pool32 = pool_bytes <= 0xffffffffull;   // a pool under 4 GiB is addressed with 32-bit offsets from a scalar base
+  if (ride)
+  {
+    // workgroups of 256: 16 x 16 pixel tiles of the raycast, then the next Track's pyramid (frame side, key side)
+    if (!P.rows_done) return VK_ERR_ARGUMENT;
+    const int tiles16 = ((image_width + 15) / 16) * ((image_height + 15) / 16);
+    int chunk16 = (tiles16 + 7) / 8;
+    if (VK_POINTS_ORDER == 1) chunk16 = 2 * ((chunk16 + 1) / 2);
+    const int trace_groups = 8 * chunk16;
+    const dim3 grid2(trace_groups + ride->groups_frame_full + ride->groups_frame_half + ride->groups_key_full + ride->groups_key_half);
+    if (pool32) hipLaunchKernelGGL(trace_and_pyramid_kernel<true>, grid2, dim3(256), 0, s, P, *ride, trace_groups, normals);
+    else hipLaunchKernelGGL(trace_and_pyramid_kernel<false>, grid2, dim3(256), 0, s, P, *ride, trace_groups, normals);
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
   if (next_requests)
   {
     // workgroups of 256: 16 x 16 pixel tiles of the raycast, then 64 x 4 pixel groups of the request pass and the normals
@@ -756,7 +909,8 @@ static int normals_repair(vk_view_bounds* ahead, hipStream_t s)
 }
 
 static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth,
-    float* out_color, float* out_normals, void* stream, const RequestParams* next_requests, const Retry* next_retry, int next_prep)
+    float* out_color, float* out_normals, void* stream, const RequestParams* next_requests, const Retry* next_retry, int next_prep,
+    const PyramidRide* ride = nullptr, bool* rode = nullptr)
 {
   // (out_normals == nullptr: the caller takes care of the normal image itself — vk_trace_ahead only)
   VK_REQUIRE(v && frame && ahead && ahead->scratch && out_depth && out_color && (out_normals || !next_requests));
@@ -790,7 +944,9 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
   const int rows = 2 * ((frame->height + 15) / 16), waves_per_row = 2 * ((frame->width + 15) / 16);
   // (only with the next frame's request pass between the raycast's workgroups and the normals': dispatched right behind
   // the raycast's, the waiting groups cost it 12 to 17 us — profiles/r04_trace_normals_ride.txt)
-  const bool normals_ride = VK_TRACE_NORMALS_RIDE && next_requests && partials && rows <= kNormalRows;
+  const bool normals_ride = VK_TRACE_NORMALS_RIDE && (next_requests || ride) && out_normals && partials && rows <= kNormalRows;
+  if (ride && !normals_ride) ride = nullptr;       // (a grid too large for the counters: the caller's pyramid launch stays)
+  if (rode) *rode = ride != nullptr;
   uint32_t* rows_done = nullptr;
   uint32_t rows_target = 0;
   if (normals_ride)
@@ -822,7 +978,7 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
            (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s,
            normals_ride ? out_normals : nullptr, rows_done, rows_target, next_requests, next_retry, next_prep,
-           ahead->late_host, normal_polls)) != VK_OK)
+           ahead->late_host, normal_polls, ride)) != VK_OK)
     return rc;
   if (normals_ride)
   {
@@ -881,6 +1037,45 @@ int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bo
   requests->content_id = next->content_id;
   requests->normals_made = with_prep == 2 ? 1 : 0;      // the pass wrote next->normals (prep->normals_out rode)
   requests->valid = 1;
+  return VK_OK;
+}
+
+int vk_trace_ahead_pyramid(const vk_volume* v, const vk_frame* frame, vk_view_bounds* ahead, float* out_depth, float* out_color,
+    float* out_normals, const vk_icp_view* next, float* pyramid, vk_pyramid_ahead* built, void* stream)
+{
+  VK_REQUIRE(v && frame && next && pyramid && built && out_normals);
+  built->valid = 0;
+  VK_REQUIRE(next->depths && next->normals && next->width > 0 && next->height > 0);
+  VK_REQUIRE(((frame->width | frame->height | next->width | next->height) & 1) == 0);
+  // vk_icp_pyramid_track*'s layout of `pyramid`: keyframe level (depth, normals), then the frame's
+  const int kw = frame->width / 2, kh = frame->height / 2, fw = next->width / 2, fh = next->height / 2;
+  PyramidRide Y;
+  Y.key_half_depth = pyramid;
+  Y.key_half_normals = pyramid + (size_t)kw * kh;
+  Y.frame_half_depth = pyramid + 4 * (size_t)kw * kh;
+  Y.frame_half_normals = Y.frame_half_depth + (size_t)fw * fh;
+  Y.frame_depths = next->depths;
+  Y.frame_normals = const_cast<float*>(next->normals);
+  Y.frame_w = next->width;
+  Y.frame_h = next->height;
+  Y.frame_k = next->projection;
+  Y.groups_frame_full = ((next->width + 63) / 64) * ((next->height + 3) / 4);
+  Y.groups_frame_half = ((fw + 63) / 64) * ((fh + 3) / 4);
+  Y.groups_key_full = ((frame->width + 63) / 64) * ((frame->height + 3) / 4);
+  Y.groups_key_half = ((kw + 63) / 64) * ((kh + 3) / 4);
+  bool rode = false;
+  const int rc = trace_ahead(v, frame, ahead, out_depth, out_color, out_normals, stream, nullptr, nullptr, 0, &Y, &rode);
+  if (rc != VK_OK || !rode) return rc;      // (not ridden: Tracer::Trace as vk_trace_ahead makes it; the record stays invalid)
+  built->key_depths = out_depth;
+  built->key_normals = out_normals;
+  built->frame_depths = next->depths;
+  built->frame_normals = next->normals;
+  built->pyramid = pyramid;
+  built->key_width = frame->width;
+  built->key_height = frame->height;
+  built->frame_width = next->width;
+  built->frame_height = next->height;
+  built->valid = 1;
   return VK_OK;
 }
 

@@ -197,6 +197,13 @@ class RequestsAhead(C.Structure):
                 ("valid", C.c_int32), ("normals_made", C.c_int32)]
 
 
+class PyramidAhead(C.Structure):
+    """vk_pyramid_ahead (vk.h): the images and the buffer a Track's pyramid was built from / into behind the raycast"""
+    _fields_ = [("key_depths", C.c_void_p), ("key_normals", C.c_void_p), ("frame_depths", C.c_void_p), ("frame_normals", C.c_void_p),
+                ("pyramid", C.c_void_p), ("key_width", C.c_int32), ("key_height", C.c_int32), ("frame_width", C.c_int32),
+                ("frame_height", C.c_int32), ("valid", C.c_int32), ("pad_", C.c_int32)]
+
+
 class TestHooks(C.Structure):
     """vk_test_hooks (vk.h)"""
     _fields_ = [("posted_capacity", C.c_int32), ("retry_capacity", C.c_int32), ("set_view_unfused", C.c_int32),
