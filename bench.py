@@ -88,11 +88,14 @@ REQUESTS_AHEAD = os.environ.get("VK_BENCH_REQUESTS_AHEAD", "1") != "0"
 # vk_icp_pyramid_track_frame(.., frame_normals_due = 1 | 2)): nobody reads the key frame's normals before that Track, the
 # bits are the same, and the frame has one launch less. "0": Tracer::Trace's own normals launch (A/B).
 KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "1") != "0"
-# rgbd-icp (round 6): the NEXT frame's pyramid — its normal image and half-resolution level, the raycast's normal image and half-
-# resolution level — made by trailing workgroups of THIS frame's raycast launch (vk_trace_ahead_pyramid), so that the next Track
-# is its two loop launches only (vk_icp_pyramid_track_built): the frame loses the 7 us pyramid launch from its chain. Same bits
-# (tests/test_gpu_round6.py). "0": the pyramid launch in front of the loops, as until round 5 (A/B).
-PYRAMID_AHEAD = os.environ.get("VK_BENCH_PYRAMID_AHEAD", "1") != "0"
+# rgbd-icp (round 6): the NEXT frame's pyramid — its normal image and half-resolution level, the raycast's
+# normal image and half-resolution level — made by trailing workgroups of THIS frame's raycast launch (vk_trace_ahead_pyramid),
+# so that the next Track is its two loop launches only (vk_icp_pyramid_track_built). Built, bit-exact (tests/test_gpu_round6.py),
+# and measured to LOSE (profiles/r06_pyramid_ahead.txt): the frame loses its 7.3 us pyramid launch and the raycast launch grows
+# by 9.9 us (65.0 -> 74.9: the key side's groups wait for the raycast's last rows, then do their work behind them) — 287.6
+# against 284.3 us per frame; with the frame side alone riding (nothing waits) the raycast launch still grows by 3.3 us and
+# the frame takes 286.2 against 282.3. Off in every reported run; "1": on (A/B).
+PYRAMID_AHEAD = os.environ.get("VK_BENCH_PYRAMID_AHEAD", "0") == "1"
 # experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
 # makes them with launches of its own); never set in a reported run
 NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"

@@ -1032,7 +1032,7 @@ size_t vk_icp_pyramid_floats(int key_width, int key_height, int frame_width, int
 static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, const vk_icp_view* frame,
     vk_transform* Twc_dev, const vk_transform* Twc_start, int frame_normals_due, float* pyramid, float* workspace, float* system,
     int32_t* state_dev, float* update_dev, vk_icp_reduce_fn reduce, void* reduce_user, const vk_track_poll* poll, void* stream,
-    bool level_built = false)
+    bool level_built = false, bool frame_side_only = false)
 {
   VK_REQUIRE(keyframe && Twm && frame && Twc_dev && pyramid && workspace && system && state_dev);
   VK_REQUIRE(keyframe->depths && keyframe->normals && frame->depths && frame->normals);
@@ -1087,8 +1087,10 @@ static int pyramid_track(const vk_icp_view* keyframe, const vk_transform* Twm, c
   }
   L.pose_out = Twc_start ? Twc_dev : nullptr;
   if (Twc_start) L.pose_start = *Twc_start;
-  if (!level_built)
+  if (!level_built || frame_side_only)
   {
+    // (frame_side_only — an experiment, -DVK_TP_KEY_SIDE=0 — : the frame's level exists, its workgroups leave at once)
+    if (level_built) L.dst_w[1] = L.dst_h[1] = 0;
     hipLaunchKernelGGL(pyramid_level_kernel, dim3((gw + 63) / 64, (gh + 3) / 4, 2 + due), dim3(256), 0, s, L);
     VK_LAUNCH_CHECK();
   }
@@ -1156,9 +1158,10 @@ int vk_icp_pyramid_track_built(const vk_icp_view* keyframe, const vk_transform* 
       built->frame_depths == frame->depths && built->frame_normals == frame->normals &&
       built->key_width == keyframe->width && built->key_height == keyframe->height &&
       built->frame_width == frame->width && built->frame_height == frame->height;
+  const bool frame_side_only = level_built && built->pad_ == 1;
   if (built) built->valid = 0;
-  return pyramid_track(keyframe, Twm, frame, Twc_dev, Twc_start, level_built ? 0 : frame_normals_due, pyramid, workspace, system,
-      state_dev, update_dev, reduce, reduce_user, poll, stream, level_built);
+  return pyramid_track(keyframe, Twm, frame, Twc_dev, Twc_start, level_built ? (frame_side_only ? 2 : 0) : frame_normals_due, pyramid,
+      workspace, system, state_dev, update_dev, reduce, reduce_user, poll, stream, level_built, frame_side_only);
 }
 
 int vk_reduce_nothing(float*, int, void*, void*) { return 0; }

@@ -243,6 +243,9 @@ constexpr int kNormalLateWords = 16;      // one more line behind the counters: 
 #ifndef VK_TR_WAVES
 #define VK_TR_WAVES 5
 #endif
+#ifndef VK_TP_KEY_SIDE
+#define VK_TP_KEY_SIDE 1     // 0 (experiment): only the FRAME side of the next pyramid rides behind the raycast — nothing waits
+#endif
 #ifndef VK_TP_WAVES
 #define VK_TP_WAVES 6        // trace_and_pyramid_kernel: the raycast alone (compute_points_kernel) runs six waves per SIMD
 #endif
@@ -684,7 +687,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   P.march_steps = nullptr;
   P.trip_log = nullptr;
   P.trip_log_passes = 0;
-  P.rows_done = (normals && rows_done && (next_requests || ride)) ? rows_done : nullptr;
+  P.rows_done = (normals && rows_done && (next_requests || ride)) ? rows_done : nullptr;   // (a ride of the frame side only: no counters)
   P.rows_target = rows_target;
   P.late_dev = P.rows_done ? P.rows_done + kNormalRows * kNormalRowStride : nullptr;
   P.late_host = late_host;
@@ -702,7 +705,7 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
   if (ride)
   {
     // workgroups of 256: 16 x 16 pixel tiles of the raycast, then the next Track's pyramid (frame side, key side)
-    if (!P.rows_done) return VK_ERR_ARGUMENT;
+    if (!P.rows_done && ride->groups_key_full + ride->groups_key_half > 0) return VK_ERR_ARGUMENT;
     const int tiles16 = ((image_width + 15) / 16) * ((image_height + 15) / 16);
     int chunk16 = (tiles16 + 7) / 8;
     if (VK_POINTS_ORDER == 1) chunk16 = 2 * ((chunk16 + 1) / 2);
@@ -944,8 +947,9 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
   const int rows = 2 * ((frame->height + 15) / 16), waves_per_row = 2 * ((frame->width + 15) / 16);
   // (only with the next frame's request pass between the raycast's workgroups and the normals': dispatched right behind
   // the raycast's, the waiting groups cost it 12 to 17 us — profiles/r04_trace_normals_ride.txt)
-  const bool normals_ride = VK_TRACE_NORMALS_RIDE && (next_requests || ride) && out_normals && partials && rows <= kNormalRows;
-  if (ride && !normals_ride) ride = nullptr;       // (a grid too large for the counters: the caller's pyramid launch stays)
+  const bool ride_waits = ride && ride->groups_key_full + ride->groups_key_half > 0;
+  const bool normals_ride = VK_TRACE_NORMALS_RIDE && (next_requests || ride_waits) && out_normals && partials && rows <= kNormalRows;
+  if (ride_waits && !normals_ride) ride = nullptr;       // (a grid too large for the counters: the caller's pyramid launch stays)
   if (rode) *rode = ride != nullptr;
   uint32_t* rows_done = nullptr;
   uint32_t rows_target = 0;
@@ -1064,8 +1068,22 @@ int vk_trace_ahead_pyramid(const vk_volume* v, const vk_frame* frame, vk_view_bo
   Y.groups_key_full = ((frame->width + 63) / 64) * ((frame->height + 3) / 4);
   Y.groups_key_half = ((kw + 63) / 64) * ((kh + 3) / 4);
   bool rode = false;
+#if !VK_TP_KEY_SIDE
+  // experiment: the frame side only; the raycast's normal image and half level stay with the next Track's pyramid launch
+  Y.groups_key_full = Y.groups_key_half = 0;
+  const int rc = trace_ahead(v, frame, ahead, out_depth, out_color, nullptr, stream, nullptr, nullptr, 0, &Y, &rode);
+  built->pad_ = 1;
+#else
   const int rc = trace_ahead(v, frame, ahead, out_depth, out_color, out_normals, stream, nullptr, nullptr, 0, &Y, &rode);
-  if (rc != VK_OK || !rode) return rc;      // (not ridden: Tracer::Trace as vk_trace_ahead makes it; the record stays invalid)
+  built->pad_ = 0;
+#endif
+  if (rc != VK_OK) return rc;
+  if (!rode)
+  {
+    // not ridden (vk_trace_ahead's launches; the record stays invalid) — the experiment's form owes the normal image then
+    if (!VK_TP_KEY_SIDE) return launch_normals(out_depth, &frame->depth_projection, out_normals, frame->width, frame->height, vk_s(stream));
+    return VK_OK;
+  }
   built->key_depths = out_depth;
   built->key_normals = out_normals;
   built->frame_depths = next->depths;
