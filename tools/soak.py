@@ -135,8 +135,15 @@ def main():
     reports, first_view = [], None
     t0 = time.time()
     window_from = 0
+    # the first 2 000 frames, every 100: what the CPU oracle's OWN tracked loop (tools/soak_oracle_leg.py,
+    # tests/golden/soak_oracle_drift.json) is compared with — is a slow creep of the pose the algorithm's or the device path's?
+    fine, fine_from = [], 0
     for i in range(n):
         loop.step(i)
+        if i < 2000 and (i + 1) % 100 == 0:
+            errs = [bench.pose_error(loop.tracked_poses[j], seq.truth[j]) for j in range(fine_from, i + 1)]
+            fine.append({"frame": i + 1, "translation_m": max(e[0] for e in errs), "rotation_deg": max(e[1] for e in errs)})
+            fine_from = i + 1
         if i + 1 == 300:
             first_view = raycast_from(api, loop, room)
         if (i + 1) % args.every == 0 or i + 1 == n:
@@ -171,6 +178,15 @@ def main():
             "pixels_both": int(both.sum()), "pixels_hit_at_300": int((first_view > 0).sum()), "pixels_hit_at_end": int((last_view > 0).sum()),
             "within_1mm_fraction": float((diff < 1e-3).mean()), "max_abs_m": float(diff.max()), "median_abs_m": float(np.median(diff))}
         soak["map_ok"] = bool(soak["map_from_the_first_pose"]["within_1mm_fraction"] >= 0.99)
+    drift_file = os.path.join(ROOT, "tests", "golden", "soak_oracle_drift.json")
+    if fine and os.path.exists(drift_file) and not args.excess and not args.max_weight:
+        oracle = {r["frame"]: r["pose_error_max"] for r in json.load(open(drift_file))["reports"]}
+        rows = [{"frame": f["frame"], "device_mm": 1e3 * f["translation_m"], "oracle_mm": 1e3 * oracle[f["frame"]]["translation_m"]}
+                for f in fine if f["frame"] in oracle]
+        soak["first_2000_frames_against_the_oracles_own_tracked_loop"] = {
+            "what": "largest translation error of every 100 frames, the device's loop and the CPU oracle's (restated reference kernels, "
+                    "float64 sums), same input: the creep of the tracked pose is the algorithm's, not the device path's",
+            "rows": rows, "largest_difference_mm": max(abs(r["device_mm"] - r["oracle_mm"]) for r in rows) if rows else None}
     doc["soak_leg"] = soak
     doc["total_seconds"] = time.time() - t_start
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
