@@ -106,10 +106,13 @@ NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
 TIME_BY_DISPATCH = os.environ.get("VK_BENCH_TIME_BY_DISPATCH", "1") != "0"
 ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
 # The headline's spread: WINDOWS consecutive windows of --steps frames (the sequence continues; `value` is the first window's).
-# The camera yaws 0.5 deg per frame and allocates new blocks every frame until it has turned once, so the windows stop short
-# of a full turn (SEQUENCE_FRAMES): a run with --steps 20 (the driver's) has all nine, the default --steps 200 has two.
+# The camera yaws 0.5 deg per frame and allocates ~60 new blocks every frame; the app's Volume(65024, 8192) takes that for
+# about 480 frames — then its EXCESS list (8 192 chained entries, ~36 k blocks in 65 024 buckets) is full, requests are
+# dropped and upstream's allocator drains the pool (profiles/r06_soak.json, finding 1) — so the windows and the roofline
+# sample stop at SEQUENCE_FRAMES: a run with --steps 20 (the driver's) has all nine windows, the default --steps 200 has one.
+# (A run that does cross the line says so: `error`, dropped_requests.)
 WINDOWS = int(os.environ.get("VK_BENCH_WINDOWS", "9"))
-SEQUENCE_FRAMES = 700
+SEQUENCE_FRAMES = 440
 
 
 def sphere_room_depth(k):

@@ -37,7 +37,7 @@ for i in range(30):
     integ.integrate(frame)
     tracer.trace(out)
 torch.cuda.synchronize()
-pl = C.CDLL(os.path.join(ROOT, "vulcan_amd", "lib", "libvk_probe.so"))
+pl = C.CDLL(os.environ.get("VK_PROBE_LIBRARY") or os.path.join(ROOT, "vulcan_amd", "lib", "libvk_probe.so"))   # (a variant build of the probe: experiments)
 tiles = (bench.W // 16) * (bench.H // 16)
 waves = 4 * tiles
 clocks = torch.zeros(2 * waves, dtype=torch.int64, device="cuda")

@@ -19,6 +19,13 @@
 // COUNT = true (tools/probe only) additionally marks every pool slot a ray reads.
 #pragma once
 
+#ifndef VK_MARCH_AHEAD
+#define VK_MARCH_AHEAD 0           // 4: the gated run-ahead through absent blocks (an experiment of round 6; see march_ray_nested)
+#endif
+#ifndef VK_MARCH_AHEAD_AFTER
+#define VK_MARCH_AHEAD_AFTER 12    // a wave takes the run-ahead path only past this many passes through its march loop
+#endif
+
 #include "vk_common.hpp"
 
 
@@ -512,7 +519,10 @@ __device__ __forceinline__ void march_ray_nested(const PointParams& P, int4* bdi
     bool refine = false;
     bool in_band = false;       // COUNT only (trip_log): the last trip took a sample
     int log_pass = 0;           // COUNT only
-    int absent_run = 0;         // COUNT only (trip_log): trips in a row through blocks that are not there
+    int absent_run = 0;         // trips in a row through blocks that are not there (trip_log; VK_MARCH_AHEAD)
+#if VK_MARCH_AHEAD > 0
+    int pass = 0;
+#endif
 
     for (;;)
     {
@@ -531,6 +541,74 @@ __device__ __forceinline__ void march_ray_nested(const PointParams& P, int4* bdi
           ++log_pass;
         }
       }
+#if VK_MARCH_AHEAD > 0
+      // Round 6, an EXPERIMENT behind -DVK_MARCH_AHEAD=4 [-DVK_MARCH_AHEAD_AFTER=n]: round 4's run-ahead
+      // through absent blocks — a ray on a run through empty space reads the table entries of its next VK_MARCH_AHEAD
+      // positions TOGETHER (they do not depend on what is read: p advances by dir * block_length per absent block) and takes
+      // the trips one after the other as far as the blocks are indeed not there: the same positions, the same checks, in
+      // the same order, so the same bits — but GATED: only a wave that is past its VK_MARCH_AHEAD_AFTER-th pass through
+      // this loop (a wave-uniform count; the mean wave is done in 6 passes, the slowest of the tracking scene take 46)
+      // executes it. Ungated it lost because every wave paid its instructions while the device was full (r04: 91.8 us).
+      ++pass;
+      if (__builtin_amdgcn_readfirstlane(pass) > VK_MARCH_AHEAD_AFTER && absent_run >= 2)
+      {
+        constexpr int kAhead = VK_MARCH_AHEAD;
+        int4 ahead[kAhead];
+        int qx[kAhead], qy[kAhead], qz[kAhead];
+        {
+          f3 q = p;
+#pragma unroll
+          for (int k = 0; k < kAhead; ++k)
+          {
+            qx[k] = f2i(floorf(div_uniform(q.x, P.inv_block_length)));
+            qy[k] = f2i(floorf(div_uniform(q.y, P.inv_block_length)));
+            qz[k] = f2i(floorf(div_uniform(q.z, P.inv_block_length)));
+            ahead[k] = reinterpret_cast<const int4*>(P.entries)[block_hash(qx[k], qy[k], qz[k], P.K)];
+            q = add3(q, scale3(dir, P.block_length));
+          }
+          // (all sixteen words are wanted HERE: left alone, the compiler reads an entry's y word only after its x word has
+          // matched — a second round trip per entry, one behind the other)
+#pragma unroll
+          for (int k = 0; k < kAhead; ++k)
+            asm volatile("" : "+v"(ahead[k].x), "+v"(ahead[k].y), "+v"(ahead[k].z), "+v"(ahead[k].w));
+        }
+        bool ended = false, stopped = false;
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k)
+        {
+          if (!stopped && !ended)
+          {
+            Entry entry;
+            entry.ox = (int16_t)(ahead[k].x & 0xffff);
+            entry.oy = (int16_t)((uint32_t)ahead[k].x >> 16);
+            entry.oz = (int16_t)(ahead[k].y & 0xffff);
+            entry.pad = 0;
+            entry.data = ahead[k].z;
+            entry.next = ahead[k].w;
+            for (int guard = 0; !entry_is(entry, qx[k], qy[k], qz[k]) && entry.next != -1 && guard < kMaxChain; ++guard)
+              entry = load_whole_entry(P.entries, (uint32_t)entry.next);
+            const bool is = entry_is(entry, qx[k], qy[k], qz[k]);
+            if (!is || entry.data == -1)
+            {
+              // the block is not there: the trip of the loop's last branch and its checks
+              p = add3(p, scale3(dir, P.block_length));
+              if (COUNT) ++trips;
+              const float depth = xform_point(P.Tcw, p).z;
+              if (++iters >= 500) { capped = true; ended = true; }
+              else if (!(depth < bound.y)) ended = true;
+            }
+            else
+            {
+              stopped = true;
+              cache.bx = qx[k]; cache.by = qy[k]; cache.bz = qz[k]; cache.data = entry.data; cache.valid = true;
+            }
+          }
+        }
+        if (ended) break;
+        if (stopped) absent_run = 0;
+        continue;
+      }
+#endif
       const int data = find_block(P, cache, bdir, bx, by, bz);
       absent_run = (data < 0 && !refine) ? absent_run + 1 : 0;
       if (COUNT) ++trips;

@@ -328,8 +328,13 @@ __device__ __forceinline__ void points_group(const PointParams& P, const int gro
   }
 }
 
+#ifdef VK_POINTS_WAVES_PER_EU      // experiments only: the kernel held to this many waves per SIMD (spills instead of registers)
+#define VK_POINTS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(VK_POINTS_WAVES_PER_EU)))
+#else
+#define VK_POINTS_OCCUPANCY
+#endif
 template <bool POOL32>
-__global__ __launch_bounds__(kPointsWaves * 64) void compute_points_kernel(PointParams P)
+__global__ __launch_bounds__(kPointsWaves * 64) VK_POINTS_OCCUPANCY void compute_points_kernel(PointParams P)
 {
   __shared__ int4 directories[kPointsWaves][kDirWords];
   points_group<POOL32, kPointsWaves>(P, (int)blockIdx.x, (int)gridDim.x, directories);
