@@ -104,15 +104,16 @@ NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
 # around the call, as until round 5 — that bracket also holds the events' own processing and the launch latency behind
 # the first of them (1.7 - 3.5 us of a 34 us launch: 0.555 where the trace says 0.58)
 TIME_BY_DISPATCH = os.environ.get("VK_BENCH_TIME_BY_DISPATCH", "1") != "0"
-ROOFLINE_SAMPLE_FRAMES = 120                                # untimed frames behind the timed region whose integrate launches are bracketed
+ROOFLINE_SAMPLE_FRAMES = 100                                # untimed frames behind the timed region whose integrate launches are bracketed
 # The headline's spread: WINDOWS consecutive windows of --steps frames (the sequence continues; `value` is the first window's).
-# The camera yaws 0.5 deg per frame and allocates ~60 new blocks every frame; the app's Volume(65024, 8192) takes that for
-# about 480 frames — then its EXCESS list (8 192 chained entries, ~36 k blocks in 65 024 buckets) is full, requests are
-# dropped and upstream's allocator drains the pool (profiles/r06_soak.json, finding 1) — so the windows and the roofline
-# sample stop at SEQUENCE_FRAMES: a run with --steps 20 (the driver's) has all nine windows, the default --steps 200 has one.
-# (A run that does cross the line says so: `error`, dropped_requests.)
+# The camera yaws 0.5 deg per frame and allocates ~62 new blocks every frame; the app's Volume(65024, 8192) takes that for
+# 307 frames — at frame 308 its EXCESS list (8 192 chained entries; the sphere's blocks cluster in the 65 024 buckets) is full
+# at 26 k blocks, requests are dropped and upstream's allocator drains the pool (profiles/r06_soak.json, finding 1; the
+# default --steps 200 run of rounds 4 and 5 crossed that line in its roofline sample: 20 233 dropped, unnoticed) — so the
+# windows and the roofline sample stay inside SEQUENCE_FRAMES: a run with --steps 20 --warmup 5 (the driver's) has all nine
+# windows (285 frames), the default --steps 150 has one (270 frames). A run that does cross the line says so: `error`.
 WINDOWS = int(os.environ.get("VK_BENCH_WINDOWS", "9"))
-SEQUENCE_FRAMES = 440
+SEQUENCE_FRAMES = 300
 
 
 def sphere_room_depth(k):
@@ -1242,7 +1243,7 @@ RIG_FAILED_EXIT = 4
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=150)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle sample budget (0 = skip)")
     ap.add_argument("--workload", default="rgbd", choices=["rgbd", "depth", "rgbd-icp"])
