@@ -1509,13 +1509,16 @@ def main():
         # Several sequences per GPU: replica volumes are 750 MB of 288 GB, and a tracked frame is a strict
         # chain that leaves the device idle in every tail. Aggregate frames/s of 2 and 4 independent sequences, beside the
         # single sequence measured the same way (MultiLoop with one sequence: the same host loop, one stream)
+        s_steps, s_warm = min(args.steps, 100), min(args.warmup, 10)      # (what the room sequence above was sized for)
         for name, count in (("rgbd-icp", 1), ("rgbd-icp", 2), ("rgbd-icp", 4), (wl if wl != "rgbd-icp" else "rgbd", 1),
                             (wl if wl != "rgbd-icp" else "rgbd", 2)):
             try:
-                o, multi = run_sequences(name, count, k_warm, k_steps, room=room)
+                o, multi = run_sequences(name, count, s_warm, s_steps, room=room)
                 del multi
             except Exception as e:     # noqa: BLE001  (reported next to the headline, never instead of it)
-                o = {"error": f"{type(e).__name__}: {e}"[:300]}
+                import traceback
+                where = traceback.extract_tb(e.__traceback__)[-1]
+                o = {"error": f"{type(e).__name__}: {e} ({os.path.basename(where.filename)}:{where.lineno} {where.line})"[:400]}
             torch.cuda.empty_cache()
             o["workload"] = names[name] + f" — {count} independent sequence(s) on one GPU, a replica volume and a stream each"
             others[f"{name} x{count}"] = o
