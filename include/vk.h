@@ -584,7 +584,8 @@ typedef struct vk_view_bounds {
   /* (ABI 6) The waiting normals workgroups' wait is BOUNDED (a launch whose counters were left behind by an aborted
    * one must not hang the device). A group whose wait expires stores nothing, sets a word behind the counters in
    * `scratch` and — when the caller gave one — `*late_host`: one int32 of pinned host memory (vk_malloc_host), zeroed by
-   * the caller once. The library looks at it, without synchronising anything, at the start of every vk_trace_ahead* call
+   * the caller once; the value stored is the number of the launch (1, 2, ... as this record counts them since its counters
+   * were last zeroed, never 0) whose group expired (round 6). The library looks at it, without synchronising anything, at the start of every vk_trace_ahead* call
    * with this record, and vk_trace_normals_settle does after synchronising; see there for what happens then. The
    * `last_*` fields say which images the riding normals of the last launch belong to (set by the library).
    * ONE stream at a time per record: the counters' target counts the launches in stream order, so two traces in
@@ -681,10 +682,12 @@ VK_API int vk_requests_ahead_cancel(const vk_volume* v, vk_requests_ahead* reque
  * counterpart; ref: include/vulcan/device.h:14-17 CUDA_ASSERT — the contract it keeps is upstream's "a failed device step
  * always surfaces" — and src/frame.cu:9-122 for the normals it recomputes). Synchronises `stream`, then looks at the expiry word (the pinned one,
  * or — without one — the word behind the counters, by a blocking copy). Nothing expired: VK_OK. Otherwise the riding
- * normals of the last launch are incomplete: the counters and both words are re-zeroed, the launch count starts over,
- * Frame::ComputeNormals of the last traced image is enqueued on `stream` as a launch of its own (ahead->last_*), and the
- * call returns VK_ERR_TIMEOUT: the normals are right once `stream` has drained, and the caller knows its counters had been
- * left in a bad state. Every vk_trace_ahead / vk_trace_ahead_requests call makes the same check first, on the pinned word
+ * normals of A launch since the last check are incomplete: the stream the counters counted on is drained, the counters and
+ * both words are re-zeroed, the launch count starts over, Frame::ComputeNormals of the LAST traced image is enqueued on
+ * `stream` as a launch of its own (ahead->last_*), and the call returns VK_ERR_TIMEOUT. What is guaranteed is the error: the
+ * caller knows its counters had been left in a bad state. The image repaired is the most recent one; a caller that runs
+ * several launches ahead of this check and kept an EARLIER image (the pinned word held the number of the launch that
+ * expired until this call zeroed it) recomputes that image's normals itself (vk_frame_compute_normals). Every vk_trace_ahead / vk_trace_ahead_requests call makes the same check first, on the pinned word
  * only and without synchronising; when it finds the word set it repairs in the same way, launches NOTHING of its own and
  * returns VK_ERR_TIMEOUT — the caller repeats the call. */
 VK_API int vk_trace_normals_settle(vk_view_bounds* ahead, void* stream);

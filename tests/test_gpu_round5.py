@@ -167,7 +167,7 @@ def test_expired_normals_wait_surfaces_and_is_repaired(api, orc):
         api.lib().vk_test_hooks_get(C.byref(hooks))
         assert hooks.force_normals_expiry == 0                # it fires once
     sync()
-    assert late.value == 1
+    assert late.value == 2                                    # the word names the launch that expired: this record's second (round 6)
     assert np.all(out.normals.cpu().numpy() == -7.0)          # an expired group stores nothing
     traced = out.depth.cpu().numpy()
     with pytest.raises(api.VkError, match=r"\[-6\]"):

@@ -62,6 +62,7 @@ struct PointParams
   // caller's pinned word or nullptr; normal_polls: how often a group looks before it gives up
   uint32_t* late_dev;
   int32_t* late_host;
+  uint32_t late_tag;           // what an expired group stores there: the record's launch number (never 0)
   int normal_polls;
 };
 

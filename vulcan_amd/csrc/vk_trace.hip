@@ -376,8 +376,10 @@ __device__ __forceinline__ void normals_group(const PointParams& P, float* __res
     *expired = late ? 1 : 0;
     if (late)
     {
-      __hip_atomic_store(P.late_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (P.late_host) __hip_atomic_store(P.late_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (the word names the LAUNCH whose wait expired — the record's launch count, never 0 — so that a host that is several
+      // launches ahead when it sees the word knows whether the image it can still repair is the one that expired: ADVICE r5)
+      __hip_atomic_store(P.late_dev, P.late_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.late_host) __hip_atomic_store(P.late_host, (int32_t)P.late_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
@@ -518,8 +520,10 @@ __device__ __forceinline__ bool ride_rows_complete(const PointParams& P, int fir
     *expired = late ? 1 : 0;
     if (late)
     {
-      __hip_atomic_store(P.late_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (P.late_host) __hip_atomic_store(P.late_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (the word names the LAUNCH whose wait expired — the record's launch count, never 0 — so that a host that is several
+      // launches ahead when it sees the word knows whether the image it can still repair is the one that expired: ADVICE r5)
+      __hip_atomic_store(P.late_dev, P.late_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (P.late_host) __hip_atomic_store(P.late_host, (int32_t)P.late_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
@@ -674,9 +678,10 @@ int launch_points(const vk_hash_entry* entries, const vk_voxel* voxels, const fl
     int image_width, int image_height, int bounds_width, int bounds_height, unsigned long long pool_bytes,
     hipStream_t s, float* normals = nullptr, uint32_t* rows_done = nullptr, uint32_t rows_target = 0,
     const RequestParams* next_requests = nullptr, const Retry* next_retry = nullptr, int next_prep = 0,
-    int32_t* late_host = nullptr, int normal_polls = kNormalWaitPolls, const PyramidRide* ride = nullptr)
+    int32_t* late_host = nullptr, int normal_polls = kNormalWaitPolls, const PyramidRide* ride = nullptr, uint32_t late_tag = 1)
 {
   PointParams P;
+  P.late_tag = late_tag ? late_tag : 1u;
   P.entries = entries;
   P.voxels = voxels;
   P.bounds = bounds;
@@ -903,10 +908,17 @@ static uint32_t* normals_counters(const vk_view_bounds* ahead)
 // launch count start over, and the normals of the last traced image are made by a launch of their own.
 static int normals_repair(vk_view_bounds* ahead, hipStream_t s)
 {
+  // (the launches the counters count ran on counted_stream: it is drained before the counters are zeroed under them)
+  if (ahead->counted_stream && ahead->counted_stream != (const void*)s)
+    VK_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(const_cast<void*>(ahead->counted_stream))));
   uint32_t* counters = normals_counters(ahead);
   if (counters) VK_CHECK(hipMemsetAsync(counters, 0, (kNormalRows * kNormalRowStride + kNormalLateWords) * sizeof(uint32_t), s));
   if (ahead->late_host) __atomic_store_n(ahead->late_host, 0, __ATOMIC_RELAXED);
   ahead->trace_launches = 0;
+  // What is guaranteed is the ERROR. The image that can still be repaired is the LAST launch's (last_*): in a pipelined loop
+  // the host may be several launches ahead when it sees the word, and the image whose groups expired (the word names its
+  // launch, vk.h) may be an earlier one — its riding normals are then incomplete and stay so; the caller that kept that
+  // image recomputes them (vk_frame_compute_normals).
   if (ahead->last_depths && ahead->last_normals && ahead->last_width > 0 && ahead->last_height > 0)
   {
     const int rc = launch_normals(ahead->last_depths, &ahead->last_projection, ahead->last_normals, ahead->last_width,
@@ -987,7 +999,7 @@ static int trace_ahead(const vk_volume* v, const vk_frame* frame, vk_view_bounds
            out_depth, out_color, frame->width, frame->height, ahead->bounds_width, ahead->bounds_height,
            (unsigned long long)(v->main_block_count + v->excess_block_count) * VK_BLOCK_VOXELS * sizeof(vk_voxel), s,
            normals_ride ? out_normals : nullptr, rows_done, rows_target, next_requests, next_retry, next_prep,
-           ahead->late_host, normal_polls, ride)) != VK_OK)
+           ahead->late_host, normal_polls, ride, (ahead->trace_launches + 1u) & 0x7fffffffu)) != VK_OK)
     return rc;
   if (normals_ride)
   {
