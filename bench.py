@@ -96,6 +96,12 @@ KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "
 # against 284.3 us per frame; with the frame side alone riding (nothing waits) the raycast launch still grows by 3.3 us and
 # the frame takes 286.2 against 282.3. Off in every reported run; "1": on (A/B).
 PYRAMID_AHEAD = os.environ.get("VK_BENCH_PYRAMID_AHEAD", "0") == "1"
+# rgbd-icp (round 6): the request pass of SetView(i) enqueued right behind Track(i), at the pose the tracker leaves ON THE DEVICE
+# (vk_volume_requests_at_device_pose), BEFORE the host waits for that pose; SetView(i) then launches its handle + visibility pass
+# only (vk_volume_set_view_rounds_ahead). The host's round trip for the pose — Tracker::EndSolve, then three calls that need it as
+# launch arguments: ~15 us with the device idle in every tracked frame — is spent under the request pass instead. Same requests,
+# same state, bit for bit (tests/test_gpu_round6.py). "0": the round trip in front of SetView, as until round 5 (A/B).
+REQUESTS_AT_DEVICE_POSE = os.environ.get("VK_BENCH_REQUESTS_AT_DEVICE_POSE", "1") != "0"
 # experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
 # makes them with launches of its own); never set in a reported run
 NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
@@ -351,6 +357,7 @@ class FrameLoop:
             self.pose_dev = C.c_void_p(t.pose.data_ptr())
             self.poll_words = (C.c_int32 * 4).from_address(t._poll_host.value)
             self.built = T.PyramidAhead() if PYRAMID_AHEAD else None
+            self.early = T.RequestsAhead() if REQUESTS_AT_DEVICE_POSE else None
             self.next_view = t._view(self.frame)
             self.pose_on_device = False
             self.current = T.Transform.from_buffer_copy(bytes(sequence.truth[0]))   # the first frame defines the map
@@ -472,6 +479,14 @@ class FrameLoop:
                     self.pose_on_device = True
                 else:
                     rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
+                if self.early is not None:
+                    # SetView(i)'s request pass at the pose Track(i) leaves on the device: enqueued now, behind the Track,
+                    # before the host waits for the pose (finish). The frame's content is named here, not in finish.
+                    self.fdesc.content_id += 2
+                    self.fdesc.depth_to_world = pose                   # the start pose: what a cancel would complete
+                    if self.mode == 2:
+                        self.prep.normals_out = None
+                    rc |= lib.vk_volume_requests_at_device_pose(self.vols[0]["vref"], self.fref, a[3], self.pprep, C.byref(self.early), s)
         self._begun = (i, n, rc, normals_in_set_view)
 
     def finish(self, i, ev=None, v=0, by_dispatch=None):
@@ -493,7 +508,9 @@ class FrameLoop:
             pose = self.poses[i]
         self.fdesc.depth_to_world = pose
         self.kdesc.depth_to_world = pose
-        self.fdesc.content_id += 2                 # this step's normals (and images): new content, odd ids
+        early = self.tracker is not None and self.early is not None and self.early.valid == 1
+        if not early:
+            self.fdesc.content_id += 2             # this step's normals (and images): new content, odd ids
         vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
         # volume.cu:430-437, three times (vulcan.cu:316-318), + light_integrator.cu:277-293
         if normals_in_set_view:
@@ -506,6 +523,8 @@ class FrameLoop:
                 rc |= lib.vk_stream_wait_event(sp["stream"], self.upload.slots[n % self.upload.SLOTS]["events"][0])   # the frame's images
             rc |= lib.vk_volume_set_view_rounds_split(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, sp["stream"], sp["requested"], s)
             sp["frames"] += 1
+        elif early:
+            rc |= lib.vk_volume_set_view_rounds_ahead(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, C.byref(self.early), s)
         elif self.ahead is not None:
             rc |= lib.vk_volume_set_view_rounds_ahead(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, self.aref, s)
         else:

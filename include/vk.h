@@ -658,6 +658,11 @@ typedef struct vk_requests_ahead {
                                       with the pass (next_prep->normals_out rode) — or, set by the class layer, by a launch of its
                                       own in front of the announce; 0 = the announce left the normals as they were. A caller
                                       whose next step is "ComputeNormals, then SetView" may skip the normals only on 1 */
+  int32_t       pose_on_device;    /* round 6: 1 = the pass was made by vk_volume_requests_at_device_pose — at the pose a tracker had
+                                      left on the device, which the host did not have yet; vk_volume_set_view_rounds_ahead then takes
+                                      the frame's pose on trust (the caller read it from that same device pose), and depth_to_world
+                                      above is the Track's START pose (what vk_requests_ahead_cancel completes after an aborted Track) */
+  int32_t       pad_;
 } vk_requests_ahead;
 
 VK_API int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bounds* ahead, float* out_depth,
@@ -665,6 +670,27 @@ VK_API int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_
     vk_requests_ahead* requests, void* stream);
 VK_API int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* frame, vk_light_prep* prep, int max_rounds,
     vk_requests_ahead* requests, void* stream);
+
+/* The request pass of a TRACKED frame's SetView without the host round trip in front of it (round 6; no reference counterpart;
+ * ref: src/volume.cu:430-437,497-518 Volume::SetView's first stage, apps/vulcan/vulcan.cu:300-318 for the loop). In the tracking
+ * loop the pose of frame i comes out of Tracker::Track, the host waits for it (Tracker::EndSolve), and only then can it enqueue
+ * SetView / Integrate / Trace — which need the pose as launch arguments: the device idles for the round trip, ~15 us of a 272 us
+ * frame (profiles/r06_tracked_frame_timeline.txt). The request pass is the first launch behind that gap, and it needs the pose
+ * for nothing but the rays' origin and direction: here it takes them from *pose_dev — the vk_transform the tracker's launches in
+ * front of it in `stream` leave on the device (vk_icp_track*'s Twc_dev) — so the host enqueues it RIGHT BEHIND the Track, before
+ * it waits, and has the whole pass (19 us) to pick up the pose and enqueue the rest:
+ *   vk_icp_pyramid_track_frame(.., Twc_dev, .., stream);                                 // Track(i), enqueued
+ *   vk_volume_requests_at_device_pose(&v, &frame, Twc_dev, &prep, &record, stream);      // requests(i), enqueued: no wait
+ *   vk_track_wait(&poll, stream);  frame.depth_to_world = *poll.host_pose;               // Tracker::EndSolve
+ *   vk_volume_set_view_rounds_ahead(&v, &frame, &prep, 3, &record, stream);              // handle + visibility only
+ * `frame`: as for vk_volume_set_view_prepare, its depth_to_world = the Track's start pose (ignored by the pass; kept in the
+ * record for vk_requests_ahead_cancel). `prep` rides as in SetView (the frame's normals must exist: normals_out is refused,
+ * VK_ERR_UNSUPPORTED). The same requests as SetView's own pass at the pose the host then reads: the same state, bit for bit
+ * (tests/test_gpu_round6.py). A Track that ends with VK_TRACK_ABORTED has left its start pose in *pose_dev: the record then
+ * announces a SetView at the start pose — vk_requests_ahead_cancel completes it (a state upstream reaches by calling SetView
+ * with the untracked frame), after which the staged Track and the frame's own SetView follow. */
+VK_API int vk_volume_requests_at_device_pose(const vk_volume* v, const vk_frame* frame, const vk_transform* pose_dev,
+    vk_light_prep* prep, vk_requests_ahead* requests, void* stream);
 
 /* A record that is still valid when vk_trace_ahead_requests is called again names a frame whose requests are in the volume
  * and whose SetView has not run: a second pass on top would mix two frames' requests, retry keys, posted list and touched

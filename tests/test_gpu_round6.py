@@ -285,3 +285,106 @@ def test_tracked_loop_with_the_pyramid_behind_the_raycast_equals_the_loop_withou
             assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), name
         else:
             assert torch.equal(x, y), name
+
+
+# --------------------------------- SetView's request pass at the pose on the device --
+
+def test_tracked_loop_with_requests_at_the_device_pose_equals_the_loop_without(api, monkeypatch):
+    """bench.FrameLoop('rgbd-icp') with SetView(i)'s request pass enqueued behind Track(i) at the pose the tracker leaves on
+    the device (vk_volume_requests_at_device_pose: before the host has that pose) and with the host's round trip in front of
+    SetView (VK_BENCH_REQUESTS_AT_DEVICE_POSE=0, the form the oracle's closed loop is held against in
+    tests/test_gpu_closed_loop.py): six frames, every tracked pose, the volume, the table, the visible list's size and the
+    raycast images, bit for bit."""
+    import torch
+    import bench
+    frames = 6
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    room = bench.RoomSequence(frames, k)
+    sync()
+    states = []
+    for early in (True, False):
+        monkeypatch.setattr(bench, "REQUESTS_AT_DEVICE_POSE", early)
+        monkeypatch.setattr(bench, "PYRAMID_AHEAD", False)
+        loop = bench.FrameLoop("rgbd-icp", room.truth, sequence=room)
+        assert (loop.early is not None) == early
+        for i in range(frames):
+            loop.begin(i)
+            if early and i > 0:
+                assert loop.early.valid == 1 and loop.early.pose_on_device == 1, "the request pass was not made behind the Track"
+            loop.finish(i)
+            if early:
+                assert loop.early.valid == 0                   # SetView used the record
+        sync()
+        vol = loop.vols[0]["vol"]
+        ctr = vol.read_counters()
+        states.append(([bytes(p) for p in loop.tracked_poses], list(loop.gn_steps), int(ctr[T.VK_CTR_VISIBLE]), int(ctr[T.VK_CTR_VOXEL_PTR]),
+                       vol.voxels.clone(), vol.hash_entries.clone(), vol.block_visibility.clone(), loop.key.depth.clone(),
+                       loop.key.color.clone(), loop.mask.clone(), loop.records.clone()))
+        del loop
+    a, b = states
+    assert a[0] == b[0], "tracked poses differ"
+    assert a[1:4] == b[1:4]
+    for x, y, name in zip(a[4:], b[4:], ("voxels", "table", "visibility", "key depth", "key colour", "mask", "records")):
+        assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), name
+
+
+def test_requests_at_the_device_pose_record_and_an_aborted_track(api):
+    """The record of vk_volume_requests_at_device_pose: it announces the frame (another frame is refused by SetView, a second
+    pass by the call itself), its pose is taken on trust (pose_on_device), and after a Track that ABORTED — the device pose
+    is then still the start pose — vk_requests_ahead_cancel completes the SetView at the start pose: the state of a plain
+    SetView with the untracked frame, bit for bit."""
+    import torch
+    lib = api.lib()
+    w, h = 320, 240
+    k, depth, color = _rgbd_inputs(w, h)
+    start = scenes.yaw(1.0)
+
+    def volume():
+        vol = api.Volume(16384, 4096, voxel_length=0.01, truncation_length=0.05)
+        f0 = api.Frame(depth, k, scenes.yaw(0.0), color=color)
+        f0.compute_normals()
+        vol.set_view(f0, rounds=3)
+        api.DepthIntegrator(vol).integrate(f0)
+        return vol
+
+    # the reference state: SetView of the frame at the start pose
+    want = volume()
+    f = api.Frame(depth, k, start, color=color)
+    f.compute_normals()
+    want.set_view(f, rounds=3)
+    sync()
+    # the early pass, reading the pose from device memory that holds the start pose (what an aborted Track leaves)
+    got = volume()
+    pose_dev = torch.from_numpy(np.frombuffer(bytes(start), dtype=np.uint8).copy()).cuda()
+    record = T.RequestsAhead()
+    g = api.Frame(depth, k, start, color=color)
+    g.compute_normals()
+    gd = g.desc()
+    api.check(lib.vk_volume_requests_at_device_pose(C.byref(got.desc()), C.byref(gd), pose_dev.data_ptr(), None, C.byref(record),
+                                                    api.stream()), "vk_volume_requests_at_device_pose")
+    assert record.valid == 1 and record.pose_on_device == 1
+    assert lib.vk_volume_requests_at_device_pose(C.byref(got.desc()), C.byref(gd), pose_dev.data_ptr(), None, C.byref(record),
+                                                 api.stream()) == -1                  # a second pass on top: refused
+    other = api.Frame(depth, k, scenes.yaw(5.0), color=color).desc()
+    assert lib.vk_volume_set_view_rounds_ahead(C.byref(got.desc()), C.byref(other), None, 3, C.byref(record), api.stream()) == -1
+    assert record.valid == 1                                                          # kept: cancel is the way out
+    api.check(lib.vk_requests_ahead_cancel(C.byref(got.desc()), C.byref(record), 3, api.stream()), "vk_requests_ahead_cancel")
+    sync()
+    assert record.valid == 0
+    for name in ("hash_entries", "block_visibility", "allocation_types"):
+        assert torch.equal(getattr(got, name), getattr(want, name)), name
+    cg, cw = got.read_counters(), want.read_counters()
+    for c in (T.VK_CTR_VISIBLE, T.VK_CTR_VOXEL_PTR, T.VK_CTR_EXCESS_PTR, T.VK_CTR_DROPPED):
+        assert cg[c] == cw[c]
+    n = int(cw[T.VK_CTR_VISIBLE])
+    assert n > 100 and torch.equal(got.visible_blocks[:n], want.visible_blocks[:n])
+    # the same pass with a pose the HOST has (trusted, pose_on_device): SetView takes the record for the frame
+    again = volume()
+    rec2 = T.RequestsAhead()
+    api.check(lib.vk_volume_requests_at_device_pose(C.byref(again.desc()), C.byref(gd), pose_dev.data_ptr(), None, C.byref(rec2),
+                                                    api.stream()), "vk_volume_requests_at_device_pose")
+    api.check(lib.vk_volume_set_view_rounds_ahead(C.byref(again.desc()), C.byref(gd), None, 3, C.byref(rec2), api.stream()),
+              "vk_volume_set_view_rounds_ahead")
+    sync()
+    assert rec2.valid == 0 and torch.equal(again.hash_entries, want.hash_entries)
+    assert again.read_counters()[T.VK_CTR_VISIBLE] == cw[T.VK_CTR_VISIBLE]

@@ -1057,6 +1057,7 @@ int vk_trace_ahead_requests(const vk_volume* v, const vk_frame* view, vk_view_bo
   requests->depth_to_world = next->depth_to_world;
   requests->content_id = next->content_id;
   requests->normals_made = with_prep == 2 ? 1 : 0;      // the pass wrote next->normals (prep->normals_out rode)
+  requests->pose_on_device = 0;
   requests->valid = 1;
   return VK_OK;
 }

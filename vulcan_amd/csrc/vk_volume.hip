@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
   requests_group<DEFER, PREP>(P, retry, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// The same pass at a pose that is still ON THE DEVICE when the launch is enqueued (vk_volume_requests_at_device_pose, round 6):
+// the tracked pose a Gauss-Newton loop launch in front of it in the stream leaves in *pose. Twelve uniform loads; the rest
+// is create_requests_kernel<true, PREP> to the instruction (make_rt's transposition of the column-major matrix).
+template <int PREP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void create_requests_at_kernel(RequestParams P, Retry retry,
+    const vk_transform* __restrict__ pose)
+{
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) P.Twd.r[r * 4 + c] = pose->m[c * 4 + r];
+  requests_group<true, PREP>(P, retry, (int)blockIdx.x, (int)blockIdx.y);
+}
+
 // --------------------------------------------------------- handle requests ----
 
 constexpr int kHandleThreads = 256;
@@ -1320,12 +1334,21 @@ int check_volume(const vk_volume* v)
 
 int launch_create_requests(const vk_volume* v, const float* depth, int width, int height,
     const vk_projection* projection, const vk_transform* Twd, bool deferred_reset, hipStream_t s,
-    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr, bool fused = false)
+    const vk_frame* prep_frame = nullptr, const vk_light_prep* prep = nullptr, bool fused = false,
+    const vk_transform* pose_dev = nullptr)
 {
   RequestParams P;
   Retry retry;
   const int with_prep = build_request_pass(P, retry, v, depth, width, height, projection, Twd, prep_frame, prep, fused);
   const dim3 grid((width + 63) / 64, (height + 3) / 4);
+  if (pose_dev)
+  {
+    if (with_prep == 2 || !deferred_reset) return VK_ERR_UNSUPPORTED;
+    if (with_prep == 1) hipLaunchKernelGGL((create_requests_at_kernel<1>), grid, dim3(256), 0, s, P, retry, pose_dev);
+    else hipLaunchKernelGGL((create_requests_at_kernel<0>), grid, dim3(256), 0, s, P, retry, pose_dev);
+    VK_LAUNCH_CHECK();
+    return VK_OK;
+  }
   if (with_prep == 2) hipLaunchKernelGGL((create_requests_kernel<true, 2>), grid, dim3(256), 0, s, P, retry);
   else if (with_prep == 1) hipLaunchKernelGGL((create_requests_kernel<true, 1>), grid, dim3(256), 0, s, P, retry);
   else if (deferred_reset) hipLaunchKernelGGL((create_requests_kernel<true, 0>), grid, dim3(256), 0, s, P, retry);
@@ -1479,7 +1502,7 @@ static bool requests_made_for(const vk_requests_ahead* r, const vk_volume* v, co
   return r && r->valid == 1 && r->counters == v->counters && r->depth == frame->depth && r->width == frame->width &&
       r->height == frame->height && frame->content_id != 0 && r->content_id == frame->content_id &&
       memcmp(&r->depth_projection, &frame->depth_projection, sizeof(vk_projection)) == 0 &&
-      memcmp(&r->depth_to_world, &frame->depth_to_world, sizeof(vk_transform)) == 0 &&
+      (r->pose_on_device == 1 || memcmp(&r->depth_to_world, &frame->depth_to_world, sizeof(vk_transform)) == 0) &&
       r->prep == (ride ? (const void*)prep : nullptr);
 }
 
@@ -1561,6 +1584,36 @@ int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* frame, v
     vk_requests_ahead* requests, void* stream)
 {
   return set_view(v, frame, prep, max_rounds, stream, nullptr, nullptr, requests);
+}
+
+int vk_volume_requests_at_device_pose(const vk_volume* v, const vk_frame* frame, const vk_transform* pose_dev, vk_light_prep* prep,
+    vk_requests_ahead* requests, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0 && pose_dev && requests && frame->content_id != 0);
+  // a record that still announces a frame: its requests are in the volume (vk_trace_ahead_requests refuses the same way)
+  if (requests->valid == 1) return VK_ERR_ARGUMENT;
+  // the frame's normals must exist: computing them on the way (normals_out) is SetView's own pass
+  if (prep && prep->normals_out) return VK_ERR_UNSUPPORTED;
+  const bool ride = prep_rides(prep, frame);
+  if (prep) prep->valid = 0;
+  const int rl = launch_create_requests(v, frame->depth, frame->width, frame->height, &frame->depth_projection, &frame->depth_to_world,
+      true, vk_s(stream), ride ? frame : nullptr, ride ? prep : nullptr, true, pose_dev);
+  if (rl != VK_OK) return rl;
+  if (ride) prep_note_made(prep, frame);
+  requests->counters = v->counters;
+  requests->depth = frame->depth;
+  requests->prep = ride ? prep : nullptr;
+  requests->width = frame->width;
+  requests->height = frame->height;
+  requests->depth_projection = frame->depth_projection;
+  requests->depth_to_world = frame->depth_to_world;      // the caller's best knowledge (the Track's start pose): what a cancel uses
+  requests->content_id = frame->content_id;
+  requests->normals_made = 0;
+  requests->pose_on_device = 1;
+  requests->valid = 1;
+  return VK_OK;
 }
 
 int vk_requests_ahead_cancel(const vk_volume* v, vk_requests_ahead* requests, int max_rounds, void* stream)

@@ -194,7 +194,7 @@ class RequestsAhead(C.Structure):
     """vk_requests_ahead (vk.h): the frame a request pass was made for ahead of its SetView"""
     _fields_ = [("counters", C.c_void_p), ("depth", C.c_void_p), ("prep", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32),
                 ("depth_projection", Projection), ("depth_to_world", Transform), ("content_id", C.c_uint64),
-                ("valid", C.c_int32), ("normals_made", C.c_int32)]
+                ("valid", C.c_int32), ("normals_made", C.c_int32), ("pose_on_device", C.c_int32), ("pad_", C.c_int32)]
 
 
 class PyramidAhead(C.Structure):
