@@ -377,7 +377,8 @@ def test_requests_at_the_device_pose_record_and_an_aborted_track(api):
     for c in (T.VK_CTR_VISIBLE, T.VK_CTR_VOXEL_PTR, T.VK_CTR_EXCESS_PTR, T.VK_CTR_DROPPED):
         assert cg[c] == cw[c]
     n = int(cw[T.VK_CTR_VISIBLE])
-    assert n > 100 and torch.equal(got.visible_blocks[:n], want.visible_blocks[:n])
+    # (the visible list's ORDER is the compaction's; its content is the state)
+    assert n > 100 and torch.equal(torch.sort(got.visible_blocks[:n]).values, torch.sort(want.visible_blocks[:n]).values)
     # the same pass with a pose the HOST has (trusted, pose_on_device): SetView takes the record for the frame
     again = volume()
     rec2 = T.RequestsAhead()
