@@ -358,6 +358,9 @@ class FrameLoop:
             self.poll_words = (C.c_int32 * 4).from_address(t._poll_host.value)
             self.built = T.PyramidAhead() if PYRAMID_AHEAD else None
             self.early = T.RequestsAhead() if REQUESTS_AT_DEVICE_POSE else None
+            self._pose_host = t._pose_host
+            self._fpose_at = C.addressof(self.fdesc) + T.Frame.depth_to_world.offset
+            self._kpose_at = C.addressof(self.kdesc) + T.Frame.depth_to_world.offset
             self.next_view = t._view(self.frame)
             self.pose_on_device = False
             self.current = T.Transform.from_buffer_copy(bytes(sequence.truth[0]))   # the first frame defines the map
@@ -494,20 +497,20 @@ class FrameLoop:
         by_dispatch = TIME_BY_DISPATCH if by_dispatch is None else by_dispatch
         begun, n, rc, normals_in_set_view = self._begun
         assert begun == i, "finish(i) follows begin(i)"
-        if self.tracker is not None:
-            pose = self.current
-            if i > 0:
-                rc |= lib.vk_track_wait(self.track_args[-1], s)     # Tracker::EndSolve: the pose, from pinned memory
-                if rc:
-                    raise self.api.VkError(f"frame {i}: tracking returned {rc}")
-                pose = self.T.Transform.from_buffer_copy(C.string_at(self.tracker.tracker._pose_host, 128))
-                self.current = pose
-                self.gn_steps.append(int(self.poll_words[0]))
-            self.tracked_poses.append(pose)
+        tracked = self.tracker is not None and i > 0
+        if tracked:
+            # Tracker::EndSolve: the pose, from pinned memory — straight into the two descriptors; the host is on the frame's
+            # critical path from here to the SetView call below (the request pass enqueued in begin covers 16 us of it), so
+            # the loop's own book-keeping (tracked_poses, gn_steps) waits until the frame's launches are out
+            rc |= lib.vk_track_wait(self.track_args[-1], s)
+            if rc:
+                raise self.api.VkError(f"frame {i}: tracking returned {rc}")
+            C.memmove(self._fpose_at, self._pose_host, 128)
+            C.memmove(self._kpose_at, self._pose_host, 128)
         else:
-            pose = self.poses[i]
-        self.fdesc.depth_to_world = pose
-        self.kdesc.depth_to_world = pose
+            pose = self.current if self.tracker is not None else self.poses[i]
+            self.fdesc.depth_to_world = pose
+            self.kdesc.depth_to_world = pose
         early = self.tracker is not None and self.early is not None and self.early.valid == 1
         if not early:
             self.fdesc.content_id += 2             # this step's normals (and images): new content, odd ids
@@ -582,6 +585,11 @@ class FrameLoop:
             lib.vk_event_record(ev[3], s)
         for _ in range(EXTRA_NORMALS):      # experiment: what one more launch-floor kernel costs the frame
             rc |= lib.vk_frame_compute_normals(self.out_ptrs[0], self.kproj, self.n_ptr, W, H, s)
+        if self.tracker is not None:
+            if tracked:
+                self.current = self.T.Transform.from_buffer_copy(bytes(self.fdesc.depth_to_world))
+                self.gn_steps.append(int(self.poll_words[0]))
+            self.tracked_poses.append(self.current)
         if rc:
             raise self.api.VkError(f"frame {i}: C ABI returned {rc}")
 

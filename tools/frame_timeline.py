@@ -38,4 +38,4 @@ for j, k in enumerate(shape):
     print(f"{k:4s}   {sum(dur[j]) / len(dur[j]) / 1e3:7.1f}  {g:7.1f}")
 print(json.dumps({"frames": len(same), "shape": shape, "period_us": sum(period) / len(period) / 1e3,
                   "sum_kernels_us": sum(sum(dur[j]) / len(dur[j]) for j in range(len(shape))) / 1e3,
-                  "sum_gaps_us": sum(sum(gap[j]) / len(gap[j]) for j in gap) / 1e3}))
+                  "sum_gaps_us": sum(sum(g) / len(g) for g in gap.values() if g) / 1e3}))
