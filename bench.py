@@ -96,12 +96,13 @@ KEY_NORMALS_WITH_PYRAMID = os.environ.get("VK_BENCH_KEY_NORMALS_WITH_PYRAMID", "
 # against 284.3 us per frame; with the frame side alone riding (nothing waits) the raycast launch still grows by 3.3 us and
 # the frame takes 286.2 against 282.3. Off in every reported run; "1": on (A/B).
 PYRAMID_AHEAD = os.environ.get("VK_BENCH_PYRAMID_AHEAD", "0") == "1"
-# rgbd-icp (round 6): the request pass of SetView(i) enqueued right behind Track(i), at the pose the tracker leaves ON THE DEVICE
-# (vk_volume_requests_at_device_pose), BEFORE the host waits for that pose; SetView(i) then launches its handle + visibility pass
-# only (vk_volume_set_view_rounds_ahead). The host's round trip for the pose — Tracker::EndSolve, then three calls that need it as
-# launch arguments: ~15 us with the device idle in every tracked frame — is spent under the request pass instead. Same requests,
-# same state, bit for bit (tests/test_gpu_round6.py). "0": the round trip in front of SetView, as until round 5 (A/B).
-REQUESTS_AT_DEVICE_POSE = os.environ.get("VK_BENCH_REQUESTS_AT_DEVICE_POSE", "1") != "0"
+# rgbd-icp (round 6): SetView(i) enqueued right behind Track(i), at the pose the tracker leaves ON THE DEVICE, BEFORE the host
+# waits for that pose: VK_BENCH_SET_VIEW_AT_DEVICE_POSE = "2" (default) the whole SetView (vk_volume_set_view_at_device_pose:
+# request pass + handle / visibility), "1" its request pass only (vk_volume_requests_at_device_pose; SetView(i) then launches its
+# handle + visibility pass once the host has the pose), "0" neither — the host's round trip for the pose in front of SetView, as
+# until round 5 (Tracker::EndSolve, then calls that need the pose as launch arguments: ~15 us with the device idle in every
+# tracked frame). Same state, bit for bit, in all three (tests/test_gpu_round6.py).
+SET_VIEW_AT_DEVICE_POSE = int(os.environ.get("VK_BENCH_SET_VIEW_AT_DEVICE_POSE", "2"))
 # experiment only (profiles/r05_integrate_ring.txt): the integrate launch WITHOUT the raycast bounds riding in it (the tracer then
 # makes them with launches of its own); never set in a reported run
 NO_BOUNDS_AHEAD = os.environ.get("VK_BENCH_NO_BOUNDS_AHEAD", "0") == "1"
@@ -357,7 +358,9 @@ class FrameLoop:
             self.pose_dev = C.c_void_p(t.pose.data_ptr())
             self.poll_words = (C.c_int32 * 4).from_address(t._poll_host.value)
             self.built = T.PyramidAhead() if PYRAMID_AHEAD else None
-            self.early = T.RequestsAhead() if REQUESTS_AT_DEVICE_POSE else None
+            self.early = T.RequestsAhead() if SET_VIEW_AT_DEVICE_POSE == 1 else None
+            self.set_view_early = SET_VIEW_AT_DEVICE_POSE == 2
+            self.set_view_done = False
             self._pose_host = t._pose_host
             self._fpose_at = C.addressof(self.fdesc) + T.Frame.depth_to_world.offset
             self._kpose_at = C.addressof(self.kdesc) + T.Frame.depth_to_world.offset
@@ -482,14 +485,19 @@ class FrameLoop:
                     self.pose_on_device = True
                 else:
                     rc |= lib.vk_icp_pyramid_track_frame(a[0], C.byref(pose), a[2], a[3], C.byref(pose), due, *a[4:], s)
-                if self.early is not None:
-                    # SetView(i)'s request pass at the pose Track(i) leaves on the device: enqueued now, behind the Track,
-                    # before the host waits for the pose (finish). The frame's content is named here, not in finish.
+                if self.early is not None or self.set_view_early:
+                    # SetView(i) — or its request pass — at the pose Track(i) leaves on the device: enqueued now, behind the
+                    # Track, before the host waits for the pose (finish). The frame's content is named here, not in finish.
                     self.fdesc.content_id += 2
                     self.fdesc.depth_to_world = pose                   # the start pose: what a cancel would complete
                     if self.mode == 2:
                         self.prep.normals_out = None
-                    rc |= lib.vk_volume_requests_at_device_pose(self.vols[0]["vref"], self.fref, a[3], self.pprep, C.byref(self.early), s)
+                    if self.set_view_early:
+                        self.vols[0]["tracer"].view_bounds.valid = 0   # Volume::SetView: new visible list
+                        rc |= lib.vk_volume_set_view_at_device_pose(self.vols[0]["vref"], self.fref, a[3], self.pprep, SET_VIEW_ROUNDS, s)
+                        self.set_view_done = True
+                    else:
+                        rc |= lib.vk_volume_requests_at_device_pose(self.vols[0]["vref"], self.fref, a[3], self.pprep, C.byref(self.early), s)
         self._begun = (i, n, rc, normals_in_set_view)
 
     def finish(self, i, ev=None, v=0, by_dispatch=None):
@@ -512,9 +520,13 @@ class FrameLoop:
             self.fdesc.depth_to_world = pose
             self.kdesc.depth_to_world = pose
         early = self.tracker is not None and self.early is not None and self.early.valid == 1
-        if not early:
+        done = self.tracker is not None and self.set_view_done      # the whole SetView was enqueued in begin
+        if self.tracker is not None:
+            self.set_view_done = False
+        if not early and not done:
             self.fdesc.content_id += 2             # this step's normals (and images): new content, odd ids
-        vv["tracer"].view_bounds.valid = 0                                          # Volume::SetView: new visible list
+        if not done:
+            vv["tracer"].view_bounds.valid = 0                                      # Volume::SetView: new visible list
         # volume.cu:430-437, three times (vulcan.cu:316-318), + light_integrator.cu:277-293
         if normals_in_set_view:
             self.prep.normals_out = self.n_ptr.value
@@ -526,6 +538,8 @@ class FrameLoop:
                 rc |= lib.vk_stream_wait_event(sp["stream"], self.upload.slots[n % self.upload.SLOTS]["events"][0])   # the frame's images
             rc |= lib.vk_volume_set_view_rounds_split(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, sp["stream"], sp["requested"], s)
             sp["frames"] += 1
+        elif done:
+            pass
         elif early:
             rc |= lib.vk_volume_set_view_rounds_ahead(vv["vref"], self.fref, self.pprep, SET_VIEW_ROUNDS, C.byref(self.early), s)
         elif self.ahead is not None:

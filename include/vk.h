@@ -692,6 +692,18 @@ VK_API int vk_volume_set_view_rounds_ahead(const vk_volume* v, const vk_frame* f
 VK_API int vk_volume_requests_at_device_pose(const vk_volume* v, const vk_frame* frame, const vk_transform* pose_dev,
     vk_light_prep* prep, vk_requests_ahead* requests, void* stream);
 
+/* ref: src/volume.cu:430-437 Volume::SetView (x max_rounds, as vk_volume_set_view_rounds) — the WHOLE call at the pose on the
+ * device: the request pass as above and the handle + visibility launch with its frustum test's world -> depth transform taken
+ * from pose_dev->inv. Nothing of SetView then waits for the host: a tracking loop enqueues it right behind the Track and has
+ * both launches (28 us) to pick the pose up (vk_track_wait) for Integrate and Trace — which found the device idle for 6 us even
+ * behind the request pass alone (profiles/r06_tracked_frame_timeline.txt). `frame->depth_to_world` is ignored. No record: there
+ * is no later SetView call to match. After a Track that ABORTED the volume has seen SetView(frame at the Track's start pose) —
+ * a state upstream reaches — and the caller's staged Track and the frame's own SetView follow. VK_ERR_UNSUPPORTED (nothing
+ * launched): prep->normals_out set, or vk_test_hooks.set_view_unfused. Same state as vk_volume_set_view_rounds with the pose
+ * the host then reads, bit for bit (tests/test_gpu_round6.py). */
+VK_API int vk_volume_set_view_at_device_pose(const vk_volume* v, const vk_frame* frame, const vk_transform* pose_dev,
+    vk_light_prep* prep, int max_rounds, void* stream);
+
 /* A record that is still valid when vk_trace_ahead_requests is called again names a frame whose requests are in the volume
  * and whose SetView has not run: a second pass on top would mix two frames' requests, retry keys, posted list and touched
  * bits — the state vk_volume_set_view_rounds_ahead refuses. vk_trace_ahead_requests therefore returns VK_ERR_ARGUMENT for a

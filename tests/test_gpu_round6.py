@@ -266,6 +266,7 @@ def test_tracked_loop_with_the_pyramid_behind_the_raycast_equals_the_loop_withou
     states = []
     for ahead in (True, False):
         monkeypatch.setattr(bench, "PYRAMID_AHEAD", ahead)
+        monkeypatch.setattr(bench, "SET_VIEW_AT_DEVICE_POSE", 0)
         loop = bench.FrameLoop("rgbd-icp", room.truth, sequence=room)
         assert (loop.built is not None) == ahead
         for i in range(frames):
@@ -289,12 +290,13 @@ def test_tracked_loop_with_the_pyramid_behind_the_raycast_equals_the_loop_withou
 
 # --------------------------------- SetView's request pass at the pose on the device --
 
-def test_tracked_loop_with_requests_at_the_device_pose_equals_the_loop_without(api, monkeypatch):
-    """bench.FrameLoop('rgbd-icp') with SetView(i)'s request pass enqueued behind Track(i) at the pose the tracker leaves on
-    the device (vk_volume_requests_at_device_pose: before the host has that pose) and with the host's round trip in front of
-    SetView (VK_BENCH_REQUESTS_AT_DEVICE_POSE=0, the form the oracle's closed loop is held against in
-    tests/test_gpu_closed_loop.py): six frames, every tracked pose, the volume, the table, the visible list's size and the
-    raycast images, bit for bit."""
+def test_tracked_loop_with_set_view_at_the_device_pose_equals_the_loop_without(api, monkeypatch):
+    """bench.FrameLoop('rgbd-icp') with SetView(i) enqueued behind Track(i) at the pose the tracker leaves on the device — the
+    whole call (vk_volume_set_view_at_device_pose, bench.py's default) or its request pass only
+    (vk_volume_requests_at_device_pose) — and with the host's round trip in front of SetView
+    (VK_BENCH_SET_VIEW_AT_DEVICE_POSE=0, the form the oracle's closed loop is held against in tests/test_gpu_closed_loop.py):
+    six frames, every tracked pose, the volume, the table, the visibility bytes, the visible list's size and the raycast and
+    light-preparation images, bit for bit."""
     import torch
     import bench
     frames = 6
@@ -302,17 +304,19 @@ def test_tracked_loop_with_requests_at_the_device_pose_equals_the_loop_without(a
     room = bench.RoomSequence(frames, k)
     sync()
     states = []
-    for early in (True, False):
-        monkeypatch.setattr(bench, "REQUESTS_AT_DEVICE_POSE", early)
+    for mode in (2, 1, 0):
+        monkeypatch.setattr(bench, "SET_VIEW_AT_DEVICE_POSE", mode)
         monkeypatch.setattr(bench, "PYRAMID_AHEAD", False)
         loop = bench.FrameLoop("rgbd-icp", room.truth, sequence=room)
-        assert (loop.early is not None) == early
+        assert (loop.early is not None) == (mode == 1) and loop.set_view_early == (mode == 2)
         for i in range(frames):
             loop.begin(i)
-            if early and i > 0:
+            if mode == 1 and i > 0:
                 assert loop.early.valid == 1 and loop.early.pose_on_device == 1, "the request pass was not made behind the Track"
+            if mode == 2 and i > 0:
+                assert loop.set_view_done
             loop.finish(i)
-            if early:
+            if mode == 1:
                 assert loop.early.valid == 0                   # SetView used the record
         sync()
         vol = loop.vols[0]["vol"]
@@ -321,11 +325,12 @@ def test_tracked_loop_with_requests_at_the_device_pose_equals_the_loop_without(a
                        vol.voxels.clone(), vol.hash_entries.clone(), vol.block_visibility.clone(), loop.key.depth.clone(),
                        loop.key.color.clone(), loop.mask.clone(), loop.records.clone()))
         del loop
-    a, b = states
-    assert a[0] == b[0], "tracked poses differ"
-    assert a[1:4] == b[1:4]
-    for x, y, name in zip(a[4:], b[4:], ("voxels", "table", "visibility", "key depth", "key colour", "mask", "records")):
-        assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), name
+    for a in states[:2]:
+        b = states[2]
+        assert a[0] == b[0], "tracked poses differ"
+        assert a[1:4] == b[1:4]
+        for x, y, name in zip(a[4:], b[4:], ("voxels", "table", "visibility", "key depth", "key colour", "mask", "records")):
+            assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), name
 
 
 def test_requests_at_the_device_pose_record_and_an_aborted_track(api):

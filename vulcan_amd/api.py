@@ -122,6 +122,7 @@ _SIGNATURES = {
     "vk_test_hooks_loop_count": ([_P, _P, _P], _I),
     "vk_trace_ahead_pyramid": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
     "vk_volume_requests_at_device_pose": ([_P, _P, _P, _P, _P, _P], _I),
+    "vk_volume_set_view_at_device_pose": ([_P, _P, _P, _P, _I, _P], _I),
     "vk_icp_pyramid_track_built": ([_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -1091,7 +1091,7 @@ __device__ __forceinline__ unsigned long long visibility_quads(const VisibilityP
   return before_us;
 }
 
-__global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(FusedParams P)
+__device__ __forceinline__ void handle_visibility_body(const FusedParams& P)
 {
   __shared__ unsigned long long arrived, added;
   __shared__ int range[2];
@@ -1317,6 +1317,23 @@ __global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(Fused
   }
 }
 
+__global__ __launch_bounds__(kHandleThreads) void handle_visibility_kernel(FusedParams P)
+{
+  handle_visibility_body(P);
+}
+
+// The same launch with the view's pose taken from the DEVICE (vk_volume_set_view_at_device_pose, round 6): the frustum test's
+// world -> depth transform is the inverse a tracker's launch in front of this one left in *pose. Twelve uniform loads; the
+// rest is handle_visibility_kernel to the instruction (make_rt's transposition of the column-major matrix).
+__global__ __launch_bounds__(kHandleThreads) void handle_visibility_at_kernel(FusedParams P, const vk_transform* __restrict__ pose)
+{
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) P.vis.Tdw.r[r * 4 + c] = pose->inv[c * 4 + r];
+  handle_visibility_body(P);
+}
+
 int check_volume(const vk_volume* v)
 {
   if (!v) return VK_ERR_ARGUMENT;
@@ -1462,7 +1479,7 @@ int vk_light_prepared(const vk_light_prep* prep, const vk_frame* frame, float de
 // SetView's second launch — the handle pass, the visibility pass and the later rounds (volume.cu:520-535, :473-495): what
 // follows a request pass, whoever made it and when. `Tdw`: the 16 floats of depth_to_world's cached inverse.
 static int launch_handle_visibility(const vk_volume* v, int width, int height, const vk_projection& k, const float* Tdw,
-    int max_rounds, hipStream_t s)
+    int max_rounds, hipStream_t s, const vk_transform* pose_dev = nullptr)
 {
   const int handle_groups = (v->main_block_count + kHandlePerGroup - 1) / kHandlePerGroup;
   const int vis_groups = (v->main_block_count + v->excess_block_count + kVisPerGroup - 1) / kVisPerGroup;
@@ -1481,10 +1498,12 @@ static int launch_handle_visibility(const vk_volume* v, int width, int height, c
     F.max_rounds = max_rounds;
     F.retry_capacity = retry_capacity();
     F.posted_capacity = posted_capacity();
-    hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
+    if (pose_dev) hipLaunchKernelGGL(handle_visibility_at_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F, pose_dev);
+    else hipLaunchKernelGGL(handle_visibility_kernel, dim3(F.handle_wgs + vis_groups), dim3(kHandleThreads), 0, s, F);
     VK_LAUNCH_CHECK();
     return VK_OK;
   }
+  if (pose_dev) return VK_ERR_UNSUPPORTED;
   // the three-launch form (vk_test_hooks.set_view_unfused: kept for comparison and as the reference for the fused one)
   hipLaunchKernelGGL(handle_rounds_kernel, dim3(handle_groups), dim3(kHandleThreads), 0, s, *v, max_rounds, retry_capacity());
   VK_LAUNCH_CHECK();  // also zeroes counters[VK_CTR_VISIBLE]; pointers are folded in by the next kernel
@@ -1614,6 +1633,23 @@ int vk_volume_requests_at_device_pose(const vk_volume* v, const vk_frame* frame,
   requests->pose_on_device = 1;
   requests->valid = 1;
   return VK_OK;
+}
+
+int vk_volume_set_view_at_device_pose(const vk_volume* v, const vk_frame* frame, const vk_transform* pose_dev, vk_light_prep* prep,
+    int max_rounds, void* stream)
+{
+  const int rc = check_volume(v);
+  if (rc != VK_OK) return rc;
+  VK_REQUIRE(frame && frame->depth && frame->width > 0 && frame->height > 0 && pose_dev && max_rounds >= 1);
+  if ((prep && prep->normals_out) || set_view_unfused(v)) return VK_ERR_UNSUPPORTED;
+  const bool ride = prep_rides(prep, frame);
+  if (prep) prep->valid = 0;
+  int rl = launch_create_requests(v, frame->depth, frame->width, frame->height, &frame->depth_projection, &frame->depth_to_world,
+      true, vk_s(stream), ride ? frame : nullptr, ride ? prep : nullptr, true, pose_dev);
+  if (rl != VK_OK) return rl;
+  if (ride) prep_note_made(prep, frame);
+  return launch_handle_visibility(v, frame->width, frame->height, frame->depth_projection, frame->depth_to_world.inv, max_rounds,
+      vk_s(stream), pose_dev);
 }
 
 int vk_requests_ahead_cancel(const vk_volume* v, vk_requests_ahead* requests, int max_rounds, void* stream)
