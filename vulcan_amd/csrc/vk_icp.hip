@@ -9,6 +9,8 @@
 // fixed order (bit-reproducible, independent of the device), and the 6x6 solve + SE(3)
 // update run on the device: Track() is one launch for the whole loop (track_loop_kernel).
 #include "vk_gauss_newton.hpp"
+
+#include <time.h>
 #include "vk_rig_protocol.h"
 
 #include <string.h>
@@ -1195,11 +1197,27 @@ int vk_track_wait(const vk_track_poll* poll, void* stream)
   const int32_t tag = host[2];
   if (tag == 0) return VK_ERR_UNSUPPORTED;      // no Track has been issued with this block (tags are never 0)
   hipStream_t s = vk_s(stream);
+  // The word is watched without a pause; the stream is asked whether it has drained (the safety net for a Track that left no
+  // pose) only every quarter of a millisecond. Until round 6 it was asked every 1 024 looks — a hipStreamQuery takes
+  // microseconds, so the caller spent half its wait inside it and saw the pose up to a query late: 20 us of the tracked
+  // frame's host round trip (profiles/r06_tracked_frame_timeline.txt).
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  long long next_query_ns = 250000;
   for (unsigned spin = 0;; ++spin)
   {
     if (host[3] == tag) return VK_OK;
-    if ((spin & 1023u) == 1023u && hipStreamQuery(s) != hipErrorNotReady)
-      return host[3] == tag ? VK_OK : VK_ERR_UNSUPPORTED;      // drained: whatever is there is final
+    if ((spin & 255u) == 255u)
+    {
+      timespec t;
+      clock_gettime(CLOCK_MONOTONIC, &t);
+      const long long waited = (long long)(t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec);
+      if (waited >= next_query_ns)
+      {
+        if (hipStreamQuery(s) != hipErrorNotReady) return host[3] == tag ? VK_OK : VK_ERR_UNSUPPORTED;   // drained: final
+        next_query_ns = waited + 250000;
+      }
+    }
   }
 }
 
