@@ -1348,8 +1348,9 @@ def main():
     windows = max(1, min(WINDOWS, (SEQUENCE_FRAMES - args.warmup - ROOFLINE_SAMPLE_FRAMES) // max(1, args.steps)))
     timed_frames = args.steps * windows
     total = args.warmup + timed_frames + ROOFLINE_SAMPLE_FRAMES
-    # every rank walks the same arc, offset so ranks do not share poses
-    poses = [scenes.orbit_pose(i + rank * 7, YAW_STEP) for i in range(total)]
+    # every rank walks the same arc, offset so ranks do not share poses (one degree per rank: the last rank of eight still
+    # stays inside the frames the app's pool takes, SEQUENCE_FRAMES)
+    poses = [scenes.orbit_pose(i + rank * 2, YAW_STEP) for i in range(total)]
     wl = args.workload
     res, loop = run_workload(wl, poses, args.warmup, args.steps, vd, with_roofline=True, sample_frames=ROOFLINE_SAMPLE_FRAMES,
                              windows=windows)

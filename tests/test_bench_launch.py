@@ -121,3 +121,43 @@ def test_recorded_past_l3_trace_adds_up():
         assert 20.0 < d["avg_launch_us"] < 80.0 and d["launches"] >= 48
         assert d["frac"] < 1.0
     assert bench.recorded_past_l3("rgbd-icp") is None
+
+
+def test_recorded_round6_bench_line_is_complete():
+    """the driver-run line carries every BASELINE config and a spread. The newest line on file
+    (profiles/r06_*_bench.json, written by tools/round_run.sh on the GPU box) must hold: the nine-window spread; frac_hbm beside
+    frac, and what `frac` is; the bracket figure beside the dispatch figure; configs[3] (pyramid-icp) at three sizes; configs[0]
+    on the device beside the CPU's; the multi-sequence legs; dropped_requests in every entry and no `error` anywhere."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_*_bench.json")))
+    assert files, "no round-6 bench line recorded under profiles/"
+    d = json.load(open(files[-1]))
+    assert "error" not in d
+    w = d["windows"]
+    assert w["count"] >= 1 and len(w["frames_per_s"]) == w["count"] and w["min"] <= w["median"] <= w["max"]
+    assert w["frames_per_s"][0] == d["value"]
+    roof = d["roofline"]
+    assert 0.0 < roof["frac_hbm"] < roof["frac"] < 1.0 and "cache-assisted" in roof["frac_is"]
+    assert roof["frac_hbm"] == roof["frac_past_l3"]
+    assert roof["timed_by"] == "dispatch" and 0.0 < roof["by_bracket"]["frac"] <= roof["frac"] * 1.02
+    others = d["other_workloads"]
+    for name in ("depth", "rgbd-icp", "rgbd-requests-inside-set-view", "rgbd-icp x1", "rgbd-icp x2", "rgbd-icp x4", "rgbd x1", "rgbd x2"):
+        assert name in others, name
+        assert "error" not in others[name], (name, others[name].get("error"))
+        dropped = others[name]["dropped_requests"]
+        assert dropped == 0 or (isinstance(dropped, list) and not any(dropped)), name
+    for name in ("rgbd-icp x2", "rgbd-icp x4", "rgbd x2"):
+        assert others[name]["aggregate_over_single"] > 0.9 and others[name]["single_sequence_value"] > 0
+    pyr = others["pyramid-icp"]
+    assert "error" not in pyr
+    for size in ("320x240", "640x480", "1280x960"):
+        for case in ("same surface", "two views"):
+            e = pyr["sizes"][size][case]
+            assert "error" not in e and 20.0 < e["us_per_track"] < 2000.0
+            assert e["steps_run"]["half_resolution"] >= 1 and e["steps_run"]["full_resolution"] >= 1
+            assert e["pose_error_after_track"]["translation_m"] < 2e-4 and e["algorithmic_GBps"] > 0 and e["frac_of_8TBps"] < 1.0
+    dense = d["cpu_baseline"]["configs0_dense_128"]
+    gpu = dense["gpu"]
+    assert gpu["voxels"] == dense["voxels"] == 128 ** 3 and dense["same_voxels_updated"] is True
+    assert 0.001 < gpu["ms"] < 1.0 and 0.0 < gpu["past_l3"]["frac_of_8TBps"] < 1.0 and "frac_of_8TBps" not in gpu
+    assert dense["gpu_over_cpu"]["1_core"] > 10
