@@ -175,6 +175,9 @@ int main(int argc, char** argv)
 
   // the same loop without its cold start (frame 0 allocates the whole first view: a 200 us request pass, the table's first
   // fill): an event behind frame `warm - 1` and one behind the last frame, on the classes' stream
+  // mode 1: SetView enqueued behind the Track at the pose on the device (round 6); the environment switch is read once, here
+  const bool set_view_with_track = mode == 1 && !(std::getenv("VK_APP_SET_VIEW_AFTER_TRACK") && std::getenv("VK_APP_SET_VIEW_AFTER_TRACK")[0] == '1');
+  bool set_view_done = false;
   const int warm = 20;
   void* steady_from = nullptr;
   void* steady_to = nullptr;
@@ -211,6 +214,9 @@ int main(int argc, char** argv)
       if (mode == 3) { app_tracker.SetKeyframe(keyframe); app_tracker.Track(frame); run = app_tracker.GetIterationsRun(); }
       else if (mode == 2) { light_tracker.SetKeyframe(keyframe); light_tracker.Track(frame); run = light_tracker.GetTracker()->GetIterationsRun(); }
       // (mode 1: the raycast below leaves its normal image to this call — Tracer::TraceWithoutNormals — one launch less per frame)
+      // (round 6: and the SetView below is enqueued behind the Track, at the pose on the device — ComputeNormalsTrackAndSetView;
+      // VK_APP_SET_VIEW_AFTER_TRACK=1: the three calls, as until round 5)
+      else if (set_view_with_track) { depth_tracker.SetKeyframe(keyframe); depth_tracker.ComputeNormalsTrackAndSetView(frame, *volume, 3, true); run = depth_tracker.GetTracker()->GetIterationsRun(); set_view_done = true; }
       else { depth_tracker.SetKeyframe(keyframe); depth_tracker.ComputeNormalsAndTrack(frame, true); run = depth_tracker.GetTracker()->GetIterationsRun(); }
       steps_run.push_back(run);
       if (run >= 0 && run < 64) ++steps_histogram[run];
@@ -223,7 +229,8 @@ int main(int argc, char** argv)
       frame.depth_to_world_transform = truth[i];
     }
 
-    volume->SetView(frame, 3);         // vulcan.cu:316-318: three SetView calls
+    if (!set_view_done) volume->SetView(frame, 3);         // vulcan.cu:316-318: three SetView calls
+    set_view_done = false;
     if (photometric) light_integrator.Integrate(frame); else depth_integrator.Integrate(frame);   // :321
     if (stream_input) uploader->Release();         // the frame's images have no reader after Integrate
     keyframe->depth_to_world_transform = frame.depth_to_world_transform;

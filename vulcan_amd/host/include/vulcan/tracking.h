@@ -115,7 +115,11 @@ class DepthTracker : public Tracker
     // `normals_due`: frame.normal_image is still to be computed (Frame::ComputeNormals) and is, by the pyramid's launch
     // `keyframe_normals_due`: the KEYFRAME's normal image is still to be computed too (Tracer::TraceWithoutNormals left it
     // out) and is, by the same launch
-    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due = false, bool keyframe_normals_due = false);
+    // `set_view_of` (round 6): Volume::SetView(frame, set_view_rounds) is enqueued BEHIND the Track at the pose the loop leaves
+    // on the device, before this call waits for that pose (Volume::SetViewAtDevicePose); *set_view_done says whether it was
+    // (false: the caller calls SetView itself — also after a Track that aborted and was repeated stage by stage)
+    void TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due = false, bool keyframe_normals_due = false,
+        class Volume* set_view_of = nullptr, int set_view_rounds = 1, bool* set_view_done = nullptr);
 
   protected:
     int GetResidualCount(const Frame& frame) const override;
@@ -227,6 +231,12 @@ class PyramidTracker
     // `keyframe_normals_due` (DepthTracker): the keyframe came from Tracer::TraceWithoutNormals — its normal image is computed by
     // the same launch as well (other trackers: keyframe normals are computed first, by a launch of their own)
     void ComputeNormalsAndTrack(Frame& frame, bool keyframe_normals_due = false);
+    // frame.ComputeNormals(); Track(frame); volume.SetView(frame, rounds) — the head of the reference's frame loop
+    // (vulcan.cu:297-318) — in one call, not upstream (round 6): with a DepthTracker SetView is enqueued BEHIND the Track at the
+    // pose the loop leaves on the device, before the host waits for that pose, so the device does not idle for the host's
+    // round trip (Volume::SetViewAtDevicePose; ~5 us of a 280 us frame, profiles/r06_tracked_frame_timeline.txt). The same
+    // state as the three calls, bit for bit. Other trackers, and a volume that cannot take the call: the three calls.
+    void ComputeNormalsTrackAndSetView(Frame& frame, class Volume& volume, int rounds = 1, bool keyframe_normals_due = false);
 
   protected:
     void TrackLevels(Frame& frame);   // the generic two-level loop (pyramid_tracker.cpp:52-90)

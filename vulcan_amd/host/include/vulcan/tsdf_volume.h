@@ -80,6 +80,12 @@ class Volume
     // pointer itself keeps falling once the pool is empty (upstream's does too, src/volume.cu:352-356): VK_CTR_DROPPED
     // counts the requests that found it empty.
     int GetAllocatedBlockCount() const;
+    // Not upstream (round 6): SetView(frame, rounds) at a pose that is still ON THE DEVICE — the vk_transform a tracker's
+    // launches in front of this call leave there — so that a tracking loop can enqueue SetView behind its Track before it waits
+    // for the pose (vk_volume_set_view_at_device_pose; PyramidTracker<DepthTracker>::ComputeNormalsTrackAndSetView uses it).
+    // frame.depth_to_world_transform is ignored. false: not possible in this state (a frame announced by Tracer::Trace, a
+    // request stream, the three-launch test form) — nothing was launched, the caller calls SetView once it has the pose.
+    bool SetViewAtDevicePose(const Frame& frame, const vk_transform* pose_device, int rounds = 1);
 
     // Raycast bounds prepared ahead of time (vk_view_bounds, not upstream): a Tracer
     // registers its scratch buffer and settings here, the integrators then compute

@@ -4,6 +4,7 @@
 #include <vulcan/tracking.h>
 #include <vulcan/exception.h>
 #include <vulcan/observation.h>
+#include <vulcan/tsdf_volume.h>
 
 namespace vulcan
 {
@@ -242,8 +243,10 @@ void DepthTracker::TrackOnDevice(Frame& frame)
       DeviceHook(), &adapter, &poll_, Device::GetStream()));
 }
 
-void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due, bool keyframe_normals_due)
+void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& frame, bool normals_due, bool keyframe_normals_due,
+    Volume* set_view_of, int set_view_rounds, bool* set_view_done)
 {
+  if (set_view_done) *set_view_done = false;
   if (normals_due)
   {
     VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
@@ -275,8 +278,18 @@ void DepthTracker::TrackPyramid(std::shared_ptr<const Frame> keyframe, Frame& fr
         pyramid_.GetData(), workspace_.GetData(), system_.GetData(), state_.GetData(), update_.GetData(), DeviceHook(), &adapter,
         &poll_, Device::GetStream()));
     iteration_ = max_iterations_;
-    if (FinishSolve(frame, attempt == 1)) break;
-    frame.depth_to_world_transform = start;      // aborted: again, one launch per stage (Tracker::Track)
+    // Volume::SetView at the pose this Track leaves on the device, enqueued before the host waits for it (first attempt only;
+    // a reduce hook's loop is enqueued in chunks and is not covered)
+    bool early = false;
+    if (attempt == 0 && set_view_of && !reduce_hook_) early = set_view_of->SetViewAtDevicePose(frame, pose_.GetData(), set_view_rounds);
+    if (FinishSolve(frame, attempt == 1))
+    {
+      if (set_view_done) *set_view_done = early;
+      break;
+    }
+    // aborted: again, one launch per stage (Tracker::Track). An early SetView has then run at the START pose (the aborted
+    // loop leaves it on the device): a state upstream reaches; the caller's own SetView follows the repeated Track.
+    frame.depth_to_world_transform = start;
     staged_only_ = true;
   }
   staged_only_ = false;
@@ -665,6 +678,23 @@ void PyramidTracker<DepthTracker>::ComputeNormalsAndTrack(Frame& frame, bool key
   VULCAN_DEBUG(keyframe_);
   tracker_->TrackPyramid(keyframe_, frame, true, keyframe_normals_due);
   ++iter_;
+}
+
+template <typename Tracker>
+void PyramidTracker<Tracker>::ComputeNormalsTrackAndSetView(Frame& frame, Volume& volume, int rounds, bool keyframe_normals_due)
+{
+  ComputeNormalsAndTrack(frame, keyframe_normals_due);
+  volume.SetView(frame, rounds);
+}
+
+template <>
+void PyramidTracker<DepthTracker>::ComputeNormalsTrackAndSetView(Frame& frame, Volume& volume, int rounds, bool keyframe_normals_due)
+{
+  VULCAN_DEBUG(keyframe_);
+  bool done = false;
+  tracker_->TrackPyramid(keyframe_, frame, true, keyframe_normals_due, &volume, rounds, &done);
+  ++iter_;
+  if (!done) volume.SetView(frame, rounds);
 }
 
 // the photometric trackers run both levels without a host round trip in between

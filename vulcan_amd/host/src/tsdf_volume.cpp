@@ -183,6 +183,24 @@ void Volume::SetView(const Frame& frame, int rounds)
   empty_ = false;
 }
 
+bool Volume::SetViewAtDevicePose(const Frame& frame, const vk_transform* pose_device, int rounds)
+{
+  VULCAN_ASSERT_MSG(frame.depth_image, "missing depth image");
+  VULCAN_ASSERT_MSG(rounds >= 1 && pose_device, "SetViewAtDevicePose needs a device pose and at least one round");
+  if (request_stream_ || requests_ahead_.valid == 1) return false;
+  const vk_volume v = ToVk();
+  const vk_frame f = frame.ToVk();
+  vk_light_prep* prep = GetLightPreparation();
+  if (prep && prep->normals_out) return false;
+  const int code = vk_volume_set_view_at_device_pose(&v, &f, pose_device, prep, rounds, Device::GetStream());
+  if (code == VK_ERR_UNSUPPORTED) return false;
+  VK_ASSERT(code);
+  view_bounds_.valid = 0;   // the visible list has changed
+  visible_count_stale_ = true;
+  empty_ = false;
+  return true;
+}
+
 void Volume::EnableRequestStream()
 {
   if (request_stream_) return;

@@ -1685,6 +1685,67 @@ TEST(Tracer, TraceWithoutNormalsLeavesThemToTheNextTrack)
   ASSERT_TRUE(with_normal > 10000);
 }
 
+// Round 6: frame.ComputeNormals(); tracker.Track(frame); volume.SetView(frame, 3) as ONE call whose SetView is enqueued behind
+// the Track at the pose the loop leaves on the device, before the host waits for it (Volume::SetViewAtDevicePose). The same
+// pose, the same table, visible list and voxels as the three calls — with a LightIntegrator's preparation riding in both.
+TEST(PyramidTracker, ComputeNormalsTrackAndSetViewEqualsTheThreeCalls)
+{
+  const int w = 160, h = 120;
+  Light light;
+  light.SetIntensity(2.0f);
+  light.SetPosition(0.025f, 0.08f, 0.0f);
+  std::vector<Voxel> voxels[2];
+  std::vector<HashEntry> entries[2];
+  Transform tracked[2];
+  int visible[2] = {0, 0};
+  for (int variant = 0; variant < 2; ++variant)
+  {
+    Frame frame;
+    frame.depth_projection.SetFocalLength(136, 136);
+    frame.depth_projection.SetCenterPoint(80, 60);
+    frame.color_projection = frame.depth_projection;
+    frame.depth_image = MakeDepth(w, h, [&](int x, int y) { return float(1.4 + 0.08 * cos(5.0 * x / w) * sin(4.0 * y / h + 0.3)); });
+    frame.color_image = MakeColor(w, h, [](int x, int y) { return Vector3f(0.2f + 0.003f * x, 0.3f + 0.004f * y, 0.4f); });
+    auto volume = std::make_shared<Volume>(8192, 2048);
+    volume->SetVoxelLength(0.008f);
+    LightIntegrator integrator(volume);
+    integrator.SetLight(light);
+    Tracer tracer(volume);
+    auto keyframe = std::make_shared<Frame>();
+    keyframe->depth_projection = keyframe->color_projection = frame.depth_projection;
+    keyframe->depth_image = std::make_shared<Image>(w, h);
+    volume->ComputeNormalsAndSetView(frame, 3);
+    integrator.Integrate(frame);
+    tracer.TraceWithoutNormals(*keyframe);
+    Frame next = frame;
+    next.normal_image = std::make_shared<ColorImage>(w, h);
+    next.depth_to_world_transform = Transform::Translate(0.002f, -0.001f, 0.0015f) * Transform::Rotate(0.999995f, 0.002f, -0.0015f, 0.001f);
+    PyramidTracker<DepthTracker> tracker;
+    tracker.SetKeyframe(keyframe);
+    if (variant == 0)
+    {
+      tracker.ComputeNormalsAndTrack(next, true);
+      volume->SetView(next, 3);
+    }
+    else tracker.ComputeNormalsTrackAndSetView(next, *volume, 3, true);
+    tracked[variant] = next.depth_to_world_transform;
+    integrator.Integrate(next);
+    voxels[variant] = Download(volume->GetVoxels());
+    entries[variant] = Download(volume->GetHashEntries());
+    int32_t counters[VK_CTR_PUBLIC];
+    volume->GetCounters(counters);
+    visible[variant] = counters[VK_CTR_VISIBLE];
+  }
+  const Matrix4f A = tracked[0].GetMatrix(), B = tracked[1].GetMatrix();
+  ASSERT_TRUE(std::memcmp(&A, &B, sizeof(A)) == 0);
+  ASSERT_EQ(visible[0], visible[1]);
+  ASSERT_TRUE(visible[0] > 100);
+  ASSERT_EQ(entries[0].size(), entries[1].size());
+  ASSERT_TRUE(std::memcmp(entries[0].data(), entries[1].data(), entries[0].size() * sizeof(HashEntry)) == 0);
+  ASSERT_EQ(voxels[0].size(), voxels[1].size());
+  ASSERT_TRUE(std::memcmp(voxels[0].data(), voxels[1].data(), voxels[0].size() * sizeof(Voxel)) == 0);
+}
+
 // ---- FrameUploader (upload.h): no upstream test — upstream uploads with a blocking copy (image.h:100-123) ----
 
 TEST(FrameUploader, DeliversEveryFrameInOrderThroughTwoSlots)
