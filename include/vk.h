@@ -230,7 +230,9 @@ VK_API int vk_test_hooks_get(vk_test_hooks* out);
  * about ten minutes of tracking. The library keeps the repeat from ever being seen: a tracker's `workspace` is cleared
  * in front of a launch whenever it is new to the library, was last cleared 2^21 or more launches ago, or was written by
  * a launch-per-stage loop in between (vulcan_amd/csrc/vk_runtime.hip, vk_loop_epoch_begin). What the caller owes: nothing
- * but the library writes a workspace between two calls that use it. This entry point lets a test put the count right
+ * but the library writes a workspace between two calls that use it, and a workspace made of memory that has been back at an
+ * allocator since the library last saw that address is zeroed by the caller first (vk_memset) — the library knows areas by
+ * their address and cannot see a free (the host layers zero a workspace when they allocate it). This entry point lets a test put the count right
  * in front of a repeat instead of tracking for ten minutes: `set_to` (may be NULL) replaces the count, `count_now` and
  * `clears` (may be NULL) receive the count and the number of clears enqueued so far. No reference counterpart (upstream's
  * loop, src/tracker.cpp:53-63, has no launch tags). */

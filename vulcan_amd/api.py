@@ -846,7 +846,9 @@ class DepthTracker(_PollMixin):
         import torch
         n = int(lib().vk_icp_workspace_floats(frame.width, frame.height))
         if self.workspace is None or self.workspace.numel() < n:
-            self.workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+            # zeroed: memory that comes back from the allocator may hold anything, and the library — which clears a workspace
+            # only when it is new to it, old, grown or overwritten by a staged loop (vk.h) — cannot see that
+            self.workspace = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self.workspace
 
     def compute_residuals(self, frame):      # depth_tracker.cu:272-300
@@ -973,7 +975,9 @@ class ColorTracker(_PollMixin):
         import torch
         n = int(lib().vk_icp_workspace_floats(self._keyframe.width, self._keyframe.height))
         if self.workspace is None or self.workspace.numel() < n:
-            self.workspace = torch.empty(n, dtype=torch.float32, device=self.device)
+            # zeroed: memory that comes back from the allocator may hold anything, and the library — which clears a workspace
+            # only when it is new to it, old, grown or overwritten by a staged loop (vk.h) — cannot see that
+            self.workspace = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self.workspace
 
     def compute_residuals(self, frame):      # color_tracker.cu:296-344

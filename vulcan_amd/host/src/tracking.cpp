@@ -197,7 +197,13 @@ void Tracker::ValidateFrame(const Frame& frame) const
 void Tracker::ResizeBuffers(const Frame& frame)
 {
   const size_t floats = vk_icp_workspace_floats(frame.depth_image->GetWidth(), frame.depth_image->GetHeight());
-  if (floats > workspace_.GetSize()) workspace_.Resize(floats);
+  if (floats > workspace_.GetSize())
+  {
+    // zeroed: memory that comes back from an allocator may hold anything, and the library — which clears a workspace only
+    // when it is new to it, old, grown or overwritten by a staged loop (vk.h) — cannot see that
+    workspace_.Resize(floats);
+    VK_ASSERT(vk_memset(workspace_.GetData(), 0, floats * sizeof(float), Device::GetStream()));
+  }
 }
 
 int Tracker::GetParameterCount() const { return translation_enabled_ ? 6 : 3; }
@@ -377,7 +383,13 @@ void ColorTracker::BeginOnDevice(const Frame& frame, Image* mask, bool upload_po
       upload_pose ? &pose : nullptr, upload_pose ? color_pose_.GetData() : nullptr, state_.GetData(), Device::GetStream()));
   // the residuals are per KEYFRAME pixel (color_tracker.cpp:27-32)
   const size_t floats = vk_icp_workspace_floats(keyframe_->depth_image->GetWidth(), keyframe_->depth_image->GetHeight());
-  if (floats > workspace_.GetSize()) workspace_.Resize(floats);
+  if (floats > workspace_.GetSize())
+  {
+    // zeroed: memory that comes back from an allocator may hold anything, and the library — which clears a workspace only
+    // when it is new to it, old, grown or overwritten by a staged loop (vk.h) — cannot see that
+    workspace_.Resize(floats);
+    VK_ASSERT(vk_memset(workspace_.GetData(), 0, floats * sizeof(float), Device::GetStream()));
+  }
 }
 
 void ColorTracker::TrackCoarseToFine(std::shared_ptr<const Frame> half_keyframe, Frame& half_frame,
