@@ -11,6 +11,7 @@ light_packed|vk_integrate.hip|-DVK_LIGHT_PACKED=1|tests/test_gpu_parity.py tests
 integrate_ring|vk_integrate.hip|-DVK_INTEGRATE_RING=1|tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_weights.py tests/test_gpu_fuzz.py tests/test_gpu_round5.py tests/test_gpu_banded_lists.py
 handle_fenced|vk_volume.hip|-DVK_HANDLE_ALWAYS_FENCED=1|tests/test_gpu_parity.py tests/test_gpu_set_view_rounds.py tests/test_gpu_banded_lists.py tests/test_gpu_edge_cases.py tests/test_gpu_round5.py
 atomic_exchange|vk_icp.hip|-DVK_LOOP_ATOMIC_EXCHANGE|tests/test_gpu_closed_loop.py tests/test_gpu_loop_abort.py
+march_ahead|vk_trace.hip|-DVK_MARCH_AHEAD=4 -DVK_POINTS_WAVES_PER_EU=6 -DVK_MARCH_AHEAD_AFTER=6|tests/test_gpu_parity.py tests/test_gpu_golden.py tests/test_gpu_round5.py tests/test_gpu_fuzz.py tests/test_gpu_closed_loop.py
 "
 if [ "$1" = build ]; then
   echo "$table" | while IFS='|' read name src flags tests; do
