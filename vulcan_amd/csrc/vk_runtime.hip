@@ -57,6 +57,8 @@ struct LoopAreas
 LoopAreas& loop_areas() { static LoopAreas a; return a; }
 }
 
+void vk_loop_area_written(const void* area);
+
 int vk_loop_epoch_begin(void* area, size_t bytes, hipStream_t s, uint32_t* epoch)
 {
   LoopAreas& A = loop_areas();
@@ -75,7 +77,17 @@ int vk_loop_epoch_begin(void* area, size_t bytes, hipStream_t s, uint32_t* epoch
     }
   }
 #ifndef VK_LOOP_EPOCH_UNGUARDED
-  if (clear) VK_CHECK(hipMemsetAsync(area, 0, bytes, s));
+  if (clear)
+  {
+    const hipError_t e = hipMemsetAsync(area, 0, bytes, s);
+    if (e != hipSuccess)
+    {
+      // the clear was not enqueued: the area is not what the registry says — it is cleared at its next launch
+      (void)hipGetLastError();
+      vk_loop_area_written(area);
+      return (int)e;
+    }
+  }
 #endif
   return VK_OK;
 }
