@@ -394,3 +394,58 @@ def test_requests_at_the_device_pose_record_and_an_aborted_track(api):
     sync()
     assert rec2.valid == 0 and torch.equal(again.hash_entries, want.hash_entries)
     assert again.read_counters()[T.VK_CTR_VISIBLE] == cw[T.VK_CTR_VISIBLE]
+
+
+@pytest.mark.parametrize("with_prep", [False, True], ids=["no preparation", "light preparation rides"])
+def test_set_view_at_the_device_pose_equals_set_view_rounds(api, with_prep):
+    """vk_volume_set_view_at_device_pose against vk_volume_set_view_rounds with the same pose as a launch argument, from an EMPTY
+    volume (7 k blocks requested at once: buckets are contested, the later rounds run inside the handle + visibility launch) and
+    once more from the state that leaves: table, visibility bytes, request flags, the visible set, the pool pointers, the rounds
+    run — and, with a LightIntegrator's preparation riding, its mask and records — bit for bit."""
+    import torch
+    import bench
+    lib = api.lib()
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    depth = bench.sphere_room_depth(k)
+    color = scenes.checker_color(bench.W, bench.H, 0.1, 0.9)
+    poses = [scenes.orbit_pose(0, bench.YAW_STEP), scenes.orbit_pose(9, bench.YAW_STEP)]
+    states = []
+    for at_device in (False, True):
+        vol = api.Volume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+        frame = api.Frame(depth, k, poses[0], color=color)
+        frame.compute_normals()
+        prep = pprep = None
+        if with_prep:
+            mask = torch.full((bench.H, bench.W), -1.0, dtype=torch.float32, device="cuda")
+            records = torch.full((bench.H, bench.W, 4), -1.0, dtype=torch.float32, device="cuda")
+            prep = T.LightPrep()
+            prep.depth_threshold, prep.mask, prep.records, prep.capacity = 0.2, mask.data_ptr(), records.data_ptr(), bench.W * bench.H
+            pprep = C.byref(prep)
+        rounds = []
+        for pose in poses:
+            frame.depth_to_world = pose
+            frame.touch()
+            fd = frame.desc()
+            if at_device:
+                fd.depth_to_world = T.Transform.identity()             # ignored: the pose comes from the device
+                pose_dev = torch.from_numpy(np.frombuffer(bytes(pose), dtype=np.uint8).copy()).cuda()
+                api.check(lib.vk_volume_set_view_at_device_pose(C.byref(vol.desc()), C.byref(fd), pose_dev.data_ptr(), pprep, 3, api.stream()),
+                          "vk_volume_set_view_at_device_pose")
+            else:
+                api.check(lib.vk_volume_set_view_rounds(C.byref(vol.desc()), C.byref(fd), pprep, 3, api.stream()), "vk_volume_set_view_rounds")
+            sync()
+            if with_prep:
+                assert prep.valid == 1
+            rounds.append(int(vol.read_counters()[T.VK_CTR_ROUNDS]))
+        ctr = vol.read_counters()
+        n = int(ctr[T.VK_CTR_VISIBLE])
+        state = {"table": vol.hash_entries.clone(), "visibility": vol.block_visibility.clone(), "request flags": vol.allocation_types.clone(),
+                 "request words": vol.allocation_blocks.clone(), "visible set": torch.sort(vol.visible_blocks[:n]).values.clone(),
+                 "counters": torch.tensor([int(ctr[c]) for c in (T.VK_CTR_VISIBLE, T.VK_CTR_VOXEL_PTR, T.VK_CTR_EXCESS_PTR, T.VK_CTR_DROPPED,
+                                                                 T.VK_CTR_REQUESTS)] + rounds)}
+        if with_prep:
+            state["mask"], state["records"] = mask.clone(), records.clone()
+        states.append(state)
+        assert n > 5000 and rounds[0] > 1, "the first SetView from an empty volume runs more than one round"
+    for name in states[0]:
+        assert torch.equal(states[0][name], states[1][name]), name
