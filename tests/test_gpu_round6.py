@@ -449,3 +449,51 @@ def test_set_view_at_the_device_pose_equals_set_view_rounds(api, with_prep):
         assert n > 5000 and rounds[0] > 1, "the first SetView from an empty volume runs more than one round"
     for name in states[0]:
         assert torch.equal(states[0][name], states[1][name]), name
+
+
+def test_python_track_with_set_view_equals_the_two_calls(api):
+    """api.PyramidTracker.track(frame, set_view_of=volume, rounds=3) — the Python mirror of
+    PyramidTracker<DepthTracker>::ComputeNormalsTrackAndSetView — against track() followed by Volume.set_view(): the same pose,
+    table, visibility bytes and visible set; and under a forced loop abort the call still ends with the frame's SetView."""
+    import torch
+    import bench
+    k = T.Projection.make(*scenes.APP_INTRINSICS)
+    poses = [scenes.room_pose(30), scenes.room_pose(31)]
+    inputs = [scenes.room_frame(k, p, bench.W, bench.H, light=bench.LIGHT) for p in poses]
+    states = []
+    for combined in (False, True, "aborted"):
+        vol = api.Volume(bench.MAIN, bench.EXCESS, voxel_length=bench.VOXEL, truncation_length=bench.TRUNC)
+        integ, tracer = api.LightIntegrator(vol), api.Tracer(vol)
+        integ.light = T.Light.make(*bench.LIGHT)
+        f0 = api.Frame(inputs[0][0], k, poses[0], color=inputs[0][1])
+        vol.set_view(f0, rounds=3, compute_normals=True)
+        integ.integrate(f0)
+        key = api.Frame(torch.zeros((bench.H, bench.W), dtype=torch.float32, device="cuda"), k, poses[0])
+        tracer.trace(key)
+        f1 = api.Frame(inputs[1][0], k, poses[0], color=inputs[1][1])
+        tracker = api.PyramidTracker()
+        tracker.keyframe = key
+        if combined is False:
+            pose = tracker.track(f1, compute_normals=True)
+            vol.set_view(f1, rounds=3)
+        elif combined is True:
+            pose = tracker.track(f1, compute_normals=True, set_view_of=vol, rounds=3)
+            assert tracker._set_view_done, "SetView was not enqueued behind the Track"
+        else:
+            with api.test_hooks(force_loop_abort=1):
+                pose = tracker.track(f1, compute_normals=True, set_view_of=vol, rounds=3)
+            assert not tracker._set_view_done
+        integ.integrate(f1)
+        sync()
+        ctr = vol.read_counters()
+        n = int(ctr[T.VK_CTR_VISIBLE])
+        states.append((bytes(pose), vol.hash_entries.clone(), vol.block_visibility.clone(), torch.sort(vol.visible_blocks[:n]).values.clone(), n))
+    a, b, c = states
+    assert a[0] == b[0] and a[4] == b[4] > 1000
+    for x, y in zip(a[1:4], b[1:4]):
+        assert torch.equal(x, y)
+    # aborted: the staged Track gives the oracle-level pose (within the loop forms' tolerance) and the frame's own SetView ran
+    # after an extra SetView at the start pose: at least the blocks of the plain sequence are visible
+    pa, pc = T.Transform.from_buffer_copy(a[0]), T.Transform.from_buffer_copy(c[0])
+    assert np.abs(pa.matrix() - pc.matrix()).max() < 2e-5
+    assert c[4] >= a[4]

@@ -440,6 +440,23 @@ class Volume:
         if stale_prep:
             self.light_prep.valid = 0
 
+    def set_view_at_device_pose(self, frame, pose_dev, rounds=1):
+        """Volume::SetViewAtDevicePose (not upstream, round 6): SetView(frame, rounds) at the pose in `pose_dev` (a device
+        vk_transform: what a tracker's launches in front of this call leave there), enqueued before the host has that pose.
+        frame.depth_to_world is ignored. False: not possible in this state (an announced frame, the three-launch test form,
+        normals still due) — nothing was launched, call set_view once the pose is known."""
+        if self.requests_ahead is not None and self.requests_ahead.valid == 1:
+            return False
+        prep = _ref(self.light_prep) if self.light_prep is not None else None
+        if self.light_prep is not None and self.light_prep.normals_out:
+            return False
+        rc = lib().vk_volume_set_view_at_device_pose(_ref(self.desc()), _ref(frame.desc()), _ptr(pose_dev), prep, int(rounds), stream())
+        if rc == T.VK_ERR_UNSUPPORTED:
+            return False
+        check(rc, "vk_volume_set_view_at_device_pose")
+        self._view_changed()
+        return True
+
     def cancel_requests_ahead(self, rounds=1):
         """vk_requests_ahead_cancel: the way out of an announced frame that will not be fused as announced — its SetView is
         completed from the record (handle + visibility pass), after which any frame may follow."""
@@ -1122,10 +1139,22 @@ class PyramidTracker:
         self.tracker = tracker or DepthTracker(device)
         self.keyframe = None
 
-    def track(self, frame, compute_normals=False, keyframe_normals_due=False):
+    def track(self, frame, compute_normals=False, keyframe_normals_due=False, set_view_of=None, rounds=1):
         """`compute_normals` (not upstream): frame.compute_normals() is still due; with a DepthTracker it is done by the launch
         that builds the pyramid (vk_icp_pyramid_track_frame). `keyframe_normals_due`: the key frame came from
-        Tracer.trace(.., normals=False); its normal image is computed by the same launch."""
+        Tracer.trace(.., normals=False); its normal image is computed by the same launch. `set_view_of` (round 6;
+        PyramidTracker<DepthTracker>::ComputeNormalsTrackAndSetView): a Volume whose set_view(frame, rounds) follows this Track
+        — with a DepthTracker it is enqueued BEHIND the Track at the pose the loop leaves on the device, before this call waits
+        for that pose (Volume.set_view_at_device_pose); otherwise, and after a Track that aborted, it is called afterwards."""
+        if set_view_of is not None:
+            self._set_view_of, self._set_view_rounds, self._set_view_done = set_view_of, int(rounds), False
+            try:
+                pose = self.track(frame, compute_normals, keyframe_normals_due)
+            finally:
+                done, self._set_view_of = self._set_view_done, None
+            if not done:
+                set_view_of.set_view(frame, rounds=rounds)
+            return pose
         t = self.tracker
         if keyframe_normals_due and not isinstance(t, DepthTracker):
             self.keyframe.compute_normals()
@@ -1174,7 +1203,15 @@ class PyramidTracker:
                                                _ptr(t._workspace(frame)), _ptr(t.system), _ptr(t.state), _ptr(t.update),
                                                *t._c_hook(), t._poll(), stream()),
               "vk_icp_pyramid_track_frame")
+        # (round 6) the caller's SetView at the pose this Track leaves on the device, enqueued before the host waits for it;
+        # the first attempt only: after an aborted loop the staged Track follows and the caller's own SetView after it
+        volume = getattr(self, "_set_view_of", None)
+        early = False
+        if volume is not None and not t._staged and t.reduce_hook is None and t.comm is None:
+            early = volume.set_view_at_device_pose(frame, t.pose, self._set_view_rounds)
         out = t._wait_pose()
+        if volume is not None:
+            self._set_view_done = early
         frame.depth_to_world = out
         return out
 

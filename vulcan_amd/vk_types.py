@@ -19,6 +19,7 @@ VK_CTR_BANDED, VK_BANDS, VK_BAND_SLOTS = 20, 8, 16384
 VK_CTR_COUNT = (VK_CTR_PUBLIC + 2 * 2 * VK_RETRY_SLOTS + 2 * VK_RETRY_KEYS + 2 * VK_POSTED_SLOTS
                 + VK_BANDS + VK_BANDS * VK_BAND_SLOTS)
 VK_TRACK_ABORTED = -1
+VK_ERR_UNSUPPORTED = -2                  # include/vk.h vk_status
 VISIBILITY_UNKNOWN, VISIBILITY_FALSE, VISIBILITY_TRUE = 0, 1, 2
 ALLOC_NONE, ALLOC_MAIN, ALLOC_EXCESS = 0, 1, 2
 BLOCK_RESOLUTION, BLOCK_VOXELS, PATCH_MAX_SIZE = 8, 512, 16
