@@ -84,7 +84,11 @@ int main(int argc, char** argv)
   }
 
   // app defaults: vulcan.cu:12-13 (65024 + 8192 blocks), :283-287 intrinsics, 5 mm voxels
-  auto volume = std::make_shared<Volume>(65024, 8192);
+  // apps/vulcan/vulcan.cu:12-13: Volume(65024, 8192). A 7th argument gives the EXCESS block count instead (round 6,
+  // profiles/r06_soak.json finding 1: the app's 8 192 chained entries are what runs out first — at 26 to 33 k allocated
+  // blocks — and upstream's allocator then drains the pool; 65 536 entries cost 590 MB of the GPU's 288 GB)
+  const int excess_blocks = argc > 6 && std::atoi(argv[6]) > 0 ? std::atoi(argv[6]) : 8192;
+  auto volume = std::make_shared<Volume>(65024, excess_blocks);
   volume->SetVoxelLength(0.005f);
   volume->SetTruncationLength(0.04f);
   if (split_streams) volume->EnableRequestStream();
@@ -254,7 +258,7 @@ int main(int argc, char** argv)
   volume->GetCounters(counters);
   // blocks of the pool in use: the free-slot pointer keeps falling below -1 once the pool is empty (as upstream's,
   // src/volume.cu:352-356), so capacity - 1 - pointer overshoots the capacity by the dropped requests; VERDICT r5 weak #9
-  const int capacity = 65024 + 8192;
+  const int capacity = 65024 + excess_blocks;
   const int allocated = std::min(capacity, capacity - 1 - counters[VK_CTR_VOXEL_PTR]);
   const bool pool_exhausted = counters[VK_CTR_DROPPED] > 0;
   if (pool_exhausted)
