@@ -1,19 +1,19 @@
 #!/usr/bin/env python3
-"""The CPU oracle's OWN tracked loop over the soak's sequence (tools/soak.py leg 2, the looped room sequence), for as many
+"""(Test infrastructure: a fixture generator — it runs the oracle, like make_fixtures.py.) The CPU oracle's OWN tracked loop over the soak's sequence (tools/soak.py leg 2, the looped room sequence), for as many
 frames as one cares to wait for: ComputeNormals -> PyramidTracker<DepthTracker>::Track against the previous raycast ->
 SetView x3 -> depth + shaded colour -> Trace at the TRACKED pose (apps/vulcan/vulcan.cu:297-325) — the restated reference
 kernels, float64 sums, no GPU. Prints the pose error against the ground truth every --every frames and writes
 tests/golden/soak_oracle_drift.json: what the soak's drift is compared with (is the slow creep of the tracked pose the
 algorithm's, or the device path's?).
 
-  python3 tools/soak_oracle_leg.py --frames 1500 --every 100       (about 0.35 s per frame on 8 cores)"""
+  python3 tests/golden/make_soak_oracle_drift.py --frames 2000 --every 100       (about 0.35 s per frame on 8 cores)"""
 import argparse
 import json
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -60,7 +60,7 @@ def main():
             print(json.dumps(reports[-1]), flush=True)
             worst = (0.0, 0.0)
             with open(args.out, "w") as f:
-                json.dump({"what": "tools/soak_oracle_leg.py: the CPU oracle's tracked loop on the soak's sequence (pose_error_max: "
+                json.dump({"what": "tests/golden/make_soak_oracle_drift.py: the CPU oracle's tracked loop on the soak's sequence (pose_error_max: "
                                    "over the frames since the previous report)", "threads": args.threads, "reports": reports}, f, indent=1)
 
 

@@ -135,7 +135,7 @@ def main():
     reports, first_view = [], None
     t0 = time.time()
     window_from = 0
-    # the first 2 000 frames, every 100: what the CPU oracle's OWN tracked loop (tools/soak_oracle_leg.py,
+    # the first 2 000 frames, every 100: what the CPU oracle's OWN tracked loop (tests/golden/make_soak_oracle_drift.py,
     # tests/golden/soak_oracle_drift.json) is compared with — is a slow creep of the pose the algorithm's or the device path's?
     fine, fine_from = [], 0
     for i in range(n):
