@@ -75,3 +75,24 @@ def test_oracle_reproduces_the_soak_fixtures_first_checkpoint(orc):
     assert all(golden[n]["dropped"] == 0 for n in golden)
     assert golden["240"]["entries_sha256"] == golden["2000"]["entries_sha256"] != golden["20"]["entries_sha256"]
     assert golden["240"]["voxels_sha256"] != golden["2000"]["voxels_sha256"]
+
+
+def test_oracle_reproduces_the_soak_drift_fixtures_first_report(orc):
+    """tests/golden/soak_oracle_drift.json (make_soak_oracle_drift.py: the oracle's OWN tracked loop over the soak's sequence —
+    what tools/soak.py compares the device's creeping pose with, profiles/r06_soak.json finding 2): the first 100 frames of that
+    loop still give the file's first report, to the bit (30 s of oracle; the whole file took ten minutes, once)."""
+    import json
+    import subprocess
+    path = os.path.join(os.path.dirname(mf.SOAK_FILE), "soak_oracle_drift.json")
+    golden = json.load(open(path))["reports"]
+    assert [r["frame"] for r in golden][:3] == [100, 200, 300] and golden[-1]["frame"] == 2000
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "soak_drift_check.json")
+    script = os.path.join(os.path.dirname(mf.SOAK_FILE), "make_soak_oracle_drift.py")
+    subprocess.run([sys.executable, script, "--frames", "100", "--every", "100", "--out", out], check=True, stdout=subprocess.DEVNULL,
+                   timeout=600)
+    got = json.load(open(out))["reports"][0]
+    for key in ("pose_error_max", "pose_error_last", "allocated_blocks", "dropped_requests"):
+        assert got[key] == golden[0][key], key
+    # and what the file says: the error grows steadily (the algorithm's creep), nothing is dropped in 2 000 frames
+    assert golden[-1]["pose_error_max"]["translation_m"] > 1.8 * golden[0]["pose_error_max"]["translation_m"]
+    assert all(r["dropped_requests"] == 0 for r in golden)
